@@ -1,0 +1,240 @@
+/* llmrec_hip.h - C ABI of the MI355X (gfx950) hot path of LLMRec Stage 2.
+ *
+ * The reference (HKUDS/LLMRec) has no plugin / FFI layer: every FLOP on its hot path is an ATen
+ * call made from Python. Each entry point below replaces one group of those call
+ * sites; the reference file:line it stands in for is cited on the declaration. The Python host
+ * (llmrec_amd/ops.py) binds these with ctypes and passes raw device pointers
+ * (tensor.data_ptr()) plus the hipStream_t of torch's current stream; INTEGRATION.md shows the
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = LLMREC_OK, negative = error (llmrec_status_string());
+ *     llmrec_last_error() gives the thread-local detail message. Nothing throws.
+ *   - all pointers are DEVICE pointers unless the name ends in _host; matrices are row-major fp32
+ *     with an explicit leading dimension in ELEMENTS (ld >= number of columns).
+ *   - no entry point allocates, frees or synchronises: scratch comes from the caller
+ *     (sizes from the matching *_workspace_bytes query), so every call is hipGraph-capturable.
+ *     The two exceptions are the one-time set-up routines llmrec_csr_build and
+ *     llmrec_spmm_plan_count, which synchronise the stream to return a count to the host.
+ *   - indices: COO input int64 (torch's sparse layout, reference main.py:131); CSR row pointers
+ *     and column indices int32 (nnz < 2^31 in every BASELINE.json config); byte/element offsets
+ *     into X/Y are computed in 64 bit inside the kernels (50 M rows x 128 floats > 2^31).
+ */
+#ifndef LLMREC_HIP_H
+#define LLMREC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LLMREC_ABI_VERSION 1
+
+enum {
+    LLMREC_OK = 0,
+    LLMREC_EINVAL = -1,        /* bad argument (null pointer, negative size, misaligned ld ...) */
+    LLMREC_EHIP = -2,          /* a HIP runtime call or kernel launch failed */
+    LLMREC_EWORKSPACE = -3,    /* caller workspace smaller than the *_workspace_bytes answer */
+    LLMREC_EUNSUPPORTED = -4   /* shape outside the compiled kernel family */
+};
+
+typedef void* llmrec_stream_t; /* hipStream_t */
+
+int llmrec_abi_version(void);
+const char* llmrec_status_string(int status);
+const char* llmrec_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * R1  graph ingest: COO -> CSR.          replaces scipy csr_norm + matrix_to_tensor and the
+ *                                        COO->CSR conversion torch.sparse.mm does per call
+ *                                        (reference main.py:84-93,114-134)
+ * Sorts (row, col) pairs (radix sort, 64-bit keys) so each CSR row has ascending columns;
+ * duplicate (row, col) entries are kept (torch.sparse.mm sums them too). val may be NULL
+ * (pattern-only). Passing (col, row) builds the CSR of the transpose.
+ * ------------------------------------------------------------------------------------------ */
+int64_t llmrec_csr_build_workspace_bytes(int64_t n_rows, int64_t nnz);
+int llmrec_csr_build(int64_t n_rows, int64_t n_cols, int64_t nnz,
+                     const int64_t* coo_row, const int64_t* coo_col, const float* coo_val,
+                     int32_t* rowptr /* n_rows+1 */, int32_t* colidx /* nnz */, float* val /* nnz or NULL */,
+                     void* workspace, int64_t workspace_bytes, llmrec_stream_t stream);
+
+/* scale[r] = fp32((deg_r + 1e-8)^-1/2), 0 for empty rows     (reference main.py:115-117) */
+int llmrec_degree_scale(int64_t n_rows, const int32_t* rowptr, float* scale, llmrec_stream_t stream);
+
+/* flag_out[0] = 1 if every row's values are one constant (then row_const[r] = that constant,
+ * 0 for empty rows) else 0. Lets the SpMM drop the 4 B/nnz value stream: the reference's
+ * normalised adjacency is diag(s) * R with binary R (reference main.py:123-126). */
+int llmrec_csr_row_constant(int64_t n_rows, const int32_t* rowptr, const float* val,
+                            float* row_const, int32_t* flag_out, llmrec_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * R2  SpMM  Y = diag(row_scale) * (P (.) val) * diag(col_scale) * X
+ *                                        replaces torch.sparse.mm / torch.mm(sparse, dense)
+ *                                        (reference Models.py:57-61 and its 20 call sites
+ *                                        :153-157,162-163,166-167,176-180) and, with col_scale,
+ *                                        the transposed SpMM autograd runs for dX = A^T dY.
+ * val, row_scale, col_scale may each be NULL (= all ones). d = columns of X and Y.
+ * Rows longer than LLMREC_SPMM_LONG_ROW are cut into segments handled by whole wavefronts and
+ * summed by a second pass in a fixed order (results are run-to-run deterministic); the segment
+ * lists come from the plan calls below and `partials` is caller scratch of
+ * plan.n_segments * d floats.
+ * ------------------------------------------------------------------------------------------ */
+#define LLMREC_SPMM_LONG_ROW 128   /* rows with more nnz are split              */
+#define LLMREC_SPMM_SEGMENT 256    /* ... into segments of this many nnz         */
+
+/* counts_host[0] = number of long rows, counts_host[1] = number of segments (synchronises). */
+int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t* scratch2 /* device, 2 ints */,
+                           int32_t* counts_host, llmrec_stream_t stream);
+int llmrec_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, int32_t* scratch2,
+                          int32_t* long_rows /* n_long */, int32_t* long_seg_begin /* n_long */,
+                          int32_t* seg_long /* n_seg: index into long_rows */, llmrec_stream_t stream);
+
+int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
+                    const int32_t* rowptr, const int32_t* colidx, const float* val,
+                    const float* row_scale, const float* col_scale,
+                    const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t d,
+                    int32_t n_long, const int32_t* long_rows, const int32_t* long_seg_begin,
+                    int32_t n_seg, const int32_t* seg_long, float* partials,
+                    llmrec_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * R4  side-feature projection            replaces nn.Linear forward / weight-grad
+ *                                        (reference Models.py:30-37,145-150; aten::addmm, aten::mm)
+ * Y[M x N] = X[M x K] * W[N x K]^T + b     (fp32 MFMA v_mfma_f32_16x16x4_f32, exact fp32)
+ * dW[N x K] (+)= dY[M x N]^T * X[M x K],  db[N] (+)= column sums of dY.  The inputs X are
+ * constants in the reference, so no dX is ever needed.
+ * N must be a multiple of 16 and <= 128; K a multiple of 4.
+ * ------------------------------------------------------------------------------------------ */
+int llmrec_linear_fwd_f32(int64_t M, int32_t N, int32_t K, const float* X, int64_t ldx,
+                          const float* W, int64_t ldw, const float* bias,
+                          float* Y, int64_t ldy, llmrec_stream_t stream);
+int64_t llmrec_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K);
+int llmrec_linear_wgrad_f32(int64_t M, int32_t N, int32_t K, const float* dY, int64_t lddy,
+                            const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,
+                            int32_t accumulate, void* workspace, int64_t workspace_bytes,
+                            llmrec_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * R3  last-layer row softmax + mean over the L+1 layer outputs
+ *                                        replaces nn.Softmax(dim=-1) and stack+mean
+ *                                        (reference Models.py:176-177,185-186)
+ * ------------------------------------------------------------------------------------------ */
+int llmrec_softmax_rows_fwd_f32(int64_t rows, int32_t d, const float* Z, int64_t ldz,
+                                float* Y, int64_t ldy, llmrec_stream_t stream);
+/* dZ = Y (.) (dY - <dY, Y>_row) */
+int llmrec_softmax_rows_bwd_f32(int64_t rows, int32_t d, const float* Y, int64_t ldy,
+                                const float* dY, int64_t lddy, float* dZ, int64_t lddz,
+                                llmrec_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * R6  fusion  out = scale * sum_t mean_terms[t] + sum_t rates[t] * normalize(terms[t])
+ *                                        replaces torch.mean(torch.stack(..)) + the 16
+ *                                        F.normalize / scaled-add calls (reference Models.py:185-197)
+ * normalize(x) = x / max(||x||_2, 1e-12) row-wise. Term pointer/ld/rate tables live on the HOST
+ * (<= LLMREC_MAX_TERMS each) and are passed by value to the kernel.
+ * bwd: d_mean (shared by all mean terms) = scale * dOut is NOT written (the caller scales);
+ *      d_terms[t] (+)= rates[t] * (dOut - n <n, dOut>) / max(||x||, 1e-12)
+ * ------------------------------------------------------------------------------------------ */
+#define LLMREC_MAX_TERMS 12
+int llmrec_fuse_fwd_f32(int64_t rows, int32_t d, float mean_scale,
+                        int32_t n_mean, const float* const* mean_terms_host, const int64_t* mean_ld_host,
+                        int32_t n_norm, const float* const* norm_terms_host, const int64_t* norm_ld_host,
+                        const float* rates_host, float* out, int64_t ldo, llmrec_stream_t stream);
+int llmrec_fuse_bwd_f32(int64_t rows, int32_t d, const float* dOut, int64_t lddo,
+                        int32_t n_norm, const float* const* norm_terms_host, const int64_t* norm_ld_host,
+                        const float* rates_host, float* const* d_terms_host, const int64_t* d_ld_host,
+                        int32_t accumulate, llmrec_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * R7  fused BPR + prune loss             replaces the 3 gathers, mul/sum, logsigmoid, the
+ *                                        D2H argsort of prune_loss and its backward
+ *                                        (reference main.py:158-165,232-254,330-342)
+ * For sample b < B:  s_b = <Eu[u_b], Ei[p_b]> - <Eu[u_b], Ei[q_b]>,  m_b = logsigmoid(s_b + 1e-8)
+ * keep = the k = (int)(remember_rate * B) samples with the SMALLEST m_b (ties: lower b first)
+ * out[0] = mf  = -(1/k) * sum_keep m_b
+ * out[1] = emb = decay / batch_size_flag * (1/(2 Su + 1e-8) + 1/(2 Sp + 1e-8) + 1/(2 Sq + 1e-8)),
+ *          S* = squared Frobenius norms of the three gathered B x d blocks
+ * The same launch stores what backward needs (per-sample ds_b and the three norms) in `saved`
+ * (B + 4 floats). B may come from device memory (n_valid_dev != NULL) so a captured graph can
+ * replay with a varying number of augmented triples; B_max bounds it (<= LLMREC_BPR_MAX_B).
+ * ------------------------------------------------------------------------------------------ */
+#define LLMREC_BPR_MAX_B 4096
+int llmrec_bpr_prune_fwd_f32(const float* Eu, int64_t ldu, const float* Ei, int64_t ldi, int32_t d,
+                             const int64_t* users, const int64_t* pos, const int64_t* neg,
+                             int32_t B_max, const int32_t* n_valid_dev,
+                             double remember_rate, float decay, float batch_size_flag,
+                             float* out2, float* saved, llmrec_stream_t stream);
+/* dEu[u_b] += g_mf * ds_b * (Ei[p_b] - Ei[q_b]) + g_emb * c_u * Eu[u_b]   (atomic scatter-add)
+ * dEi[p_b] += g_mf * ds_b * Eu[u_b] + g_emb * c_p * Ei[p_b] ; dEi[q_b] likewise with -ds_b, c_q
+ * g_mf / g_emb are upstream gradients read from device memory (grads2[0], grads2[1]). */
+int llmrec_bpr_prune_bwd_f32(const float* Eu, int64_t ldu, const float* Ei, int64_t ldi, int32_t d,
+                             const int64_t* users, const int64_t* pos, const int64_t* neg,
+                             int32_t B_max, const int32_t* n_valid_dev,
+                             float decay, float batch_size_flag,
+                             const float* saved, const float* grads2,
+                             float* dEu, int64_t lddu, float* dEi, int64_t lddi, llmrec_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * R8  feature regulariser, optimiser     replaces (x**2).sum() x4 (reference main.py:151-156)
+ *                                        and torch.optim.AdamW.step (main.py:100-104,278)
+ * ------------------------------------------------------------------------------------------ */
+/* out[0] (+)= coef * sum of squares of the rows x d block (deterministic two-level reduction) */
+int64_t llmrec_sumsq_workspace_bytes(int64_t rows, int32_t d);
+int llmrec_sumsq_f32(int64_t rows, int32_t d, const float* X, int64_t ldx, float coef, int32_t accumulate,
+                     float* out, void* workspace, int64_t workspace_bytes, llmrec_stream_t stream);
+/* Y (+)= alpha_dev[0] * alpha * X   (gradient of the regulariser; alpha_dev may be NULL = 1) */
+int llmrec_axpy_f32(int64_t rows, int32_t d, float alpha, const float* alpha_dev, const float* X, int64_t ldx,
+                    float* Y, int64_t ldy, int32_t accumulate, llmrec_stream_t stream);
+
+/* state[0] = step count (as float bits of an int32), state[1] = lr / (1 - b1^t), state[2] = sqrt(1 - b2^t).
+ * llmrec_adamw_advance increments t on the device and refreshes state[1..2]. */
+int llmrec_adamw_advance(float* state3, float lr, float beta1, float beta2, llmrec_stream_t stream);
+/* decoupled weight decay, then Adam (torch.optim.AdamW, amsgrad=False, maximize=False) */
+int llmrec_adamw_f32(int64_t n, float* p, const float* g, float* m, float* v, const float* state3,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, llmrec_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * R9/R10  full-rank scoring + masked top-K + hit vectors
+ *                                        replaces torch.matmul(E_u[blk], E_i^T), the D2H copy of
+ *                                        the 2048 x I score block and the per-user Python
+ *                                        set-difference + heapq.nlargest
+ *                                        (reference utility/batch_test.py:21-36,83-109,149-157)
+ * For each listed user: scores over all items (fp32 MFMA), train items removed (CSR row of the
+ * user, ascending columns), top K by (score desc, item id asc). The U x I matrix is never
+ * written. Missing entries (fewer than K candidates) are -1 / -inf.
+ * K <= LLMREC_TOPK_MAX. d a multiple of 16 and <= 128.
+ * ------------------------------------------------------------------------------------------ */
+#define LLMREC_TOPK_MAX 64
+int llmrec_score_topk_f32(int32_t n_query, const int64_t* query_users,
+                          const float* Eu, int64_t ldu, const float* Ei, int64_t ldi,
+                          int64_t n_items, int32_t d,
+                          const int32_t* train_rowptr, const int32_t* train_colidx,
+                          int32_t K, int32_t* out_idx /* n_query x K */, float* out_score /* n_query x K */,
+                          llmrec_stream_t stream);
+/* debug / test entry: the full score block with the same MFMA arithmetic as above */
+int llmrec_scores_f32(int32_t n_query, const int64_t* query_users,
+                      const float* Eu, int64_t ldu, const float* Ei, int64_t ldi,
+                      int64_t n_items, int32_t d, float* S, int64_t lds, llmrec_stream_t stream);
+/* hits[q, j] = 1 if topk_idx[q, j] is in the held-out CSR row of query_users[q]
+ * (reference batch_test.py:29-34) */
+int llmrec_topk_hits(int32_t n_query, const int64_t* query_users, int32_t K, const int32_t* topk_idx,
+                     const int32_t* test_rowptr, const int32_t* test_colidx, uint8_t* hits,
+                     llmrec_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * R11  on-device BPR sampler             replaces Data.sample (reference
+ *                                        utility/load_data.py:157-195): B distinct users
+ *                                        (keyed permutation of the users that have train items),
+ *                                        one uniform positive from the user's CSR row, one
+ *                                        uniform negative rejected while it is in that row.
+ * Counter-based (Philox4x32-10) on (seed, step): reproducible and order-free.
+ * ------------------------------------------------------------------------------------------ */
+int llmrec_sample_bpr(uint64_t seed, uint64_t step, int64_t n_exist_users, const int64_t* exist_users,
+                      int64_t n_items, const int32_t* train_rowptr, const int32_t* train_colidx,
+                      int32_t B, int64_t* users, int64_t* pos, int64_t* neg, llmrec_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLMREC_HIP_H */

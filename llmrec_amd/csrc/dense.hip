@@ -1,0 +1,296 @@
+// dense.hip - R4: side-feature projection  Y = X W^T + b  and its weight gradient, fp32.
+// Replaces nn.Linear forward (aten::addmm) and the autograd weight-grad GEMM (aten::mm) at
+// reference Models.py:30-37,145-150. The inputs X are constant feature matrices, so dX never
+// exists.
+//
+// Arithmetic: v_mfma_f32_16x16x4_f32 (exact fp32, a k-ordered fma chain) - at N = 64 the
+// projection needs 32 flop per streamed byte, above the 19.7 flop/B ridge of 157 TFLOP/s over
+// 8 TB/s, so it is matrix-pipe-bound, not HBM-bound.
+//
+// Operand feed without LDS: the MFMA A/B operands are ONE float per lane per instruction, and a
+// dot product may visit its k's in any order as long as A and B agree. So every lane loads a
+// float4 along the contiguous dimension and feeds component s to the s-th of four consecutive
+// MFMAs; the wave's 16 lanes x 16 B cover whole 64..256-byte row segments (coalesced), e.g.
+//   forward : lane l holds X[row0 + (l&15)][kb + 4*(l>>4) + s] and W[n0 + (l&15)][kb + 4*(l>>4) + s]
+//   wgrad   : lane l holds dY[m][4*(l&15) + q] / X[m][k0 + 4*(l&15) + q] with m = m0 + (l>>4) + 4s';
+//             component q selects one of four INTERLEAVED 16-wide tiles (n = 4 i + q, k = k0 + 4 j + q).
+#include "common.h"
+
+namespace llmrec {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 load4_guard(const float* row, int k, int K, bool vec_ok) {
+    // elements [k, k+4) of a row of length K; zero beyond K
+    if (vec_ok && k + 3 < K) return *reinterpret_cast<const float4*>(row + k);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < K) r.x = row[k];
+    if (k + 1 < K) r.y = row[k + 1];
+    if (k + 2 < K) r.z = row[k + 2];
+    if (k + 3 < K) r.w = row[k + 3];
+    return r;
+}
+
+__device__ __forceinline__ float comp(const float4& v, int s) {
+    return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w));
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: each wave computes RT*16 rows x NT*16 columns; block = 4 waves
+// ---------------------------------------------------------------------------------------------
+template <int NT, int RT>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(int64_t M, int N, int K, const float* __restrict__ X, int64_t ldx,
+                                                         const float* __restrict__ W, int64_t ldw,
+                                                         const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy,
+                                                         int vec_ok) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * (RT * 16);
+    if (row0 >= M) return;
+    const float* xrow[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        int64_t r = row0 + t * 16 + li;
+        if (r > M - 1) r = M - 1;
+        xrow[t] = X + r * ldx;
+    }
+    const float* wrow[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        int c = n * 16 + li;
+        if (c > N - 1) c = N - 1;
+        wrow[n] = W + (int64_t)c * ldw;
+    }
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 xa[RT], wb[NT], xa_n[RT], wb_n[NT];
+    const int koff = 4 * lq;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) xa[t] = load4_guard(xrow[t], koff, K, vec_ok);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) wb[n] = load4_guard(wrow[n], koff, K, vec_ok);
+    for (int kb = 0; kb < K; kb += 16) {
+        const int kn = kb + 16 + koff;
+        if (kb + 16 < K) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) xa_n[t] = load4_guard(xrow[t], kn, K, vec_ok);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) wb_n[n] = load4_guard(wrow[n], kn, K, vec_ok);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(xa[t], s), comp(wb[n], s), acc[t][n], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) xa[t] = xa_n[t];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wb[n] = wb_n[n];
+    }
+    // D layout: lane holds D[row = lq*4 + r][col = li]
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int c = n * 16 + li;
+        if (c >= N) continue;
+        const float b = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + t * 16 + lq * 4 + r;
+                if (row < M) Y[row * ldy + c] = acc[t][n][r] + b;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: wave tile = 64 n (interleaved tiles q) x 64 k (interleaved tiles p), over a
+// chunk of MC rows; partial[chunk][n][k] then reduced in chunk order (deterministic).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(int64_t M, int N, int K, const float* __restrict__ dY, int64_t lddy,
+                                                           const float* __restrict__ X, int64_t ldx,
+                                                           float* __restrict__ partial, float* __restrict__ partial_db,
+                                                           int64_t MC, int n_kslab, int vec_ok) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;          // (chunk, kslab) flattened, kslab fastest
+    const int64_t chunk = wid / n_kslab;
+    const int kslab = (int)(wid % n_kslab);
+    const int nblk = blockIdx.y;                                 // 64-wide block of output rows n
+    const int64_t m_begin = chunk * MC;
+    if (m_begin >= M) return;
+    const int64_t m_end = (m_begin + MC < M) ? m_begin + MC : M;
+    const int n_base = nblk * 64 + 4 * li;                       // this lane's 4 n's: n_base + q
+    const int k_base = kslab * 64 + 4 * li;                      // this lane's 4 k's: k_base + p
+
+    f32x4 acc[4][4];                                             // [q][p]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[q][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int64_t m0 = m_begin; m0 < m_end; m0 += 16) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                            // 4 MFMA k-steps of 4 rows each
+            const int64_t m = m0 + 4 * s + lq;
+            if (m < m_end) {
+                a[s] = load4_guard(dY + m * lddy, n_base, N, vec_ok);
+                b[s] = load4_guard(X + m * ldx, k_base, K, vec_ok);
+            } else {
+                a[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+                b[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            dbs.x += a[s].x; dbs.y += a[s].y; dbs.z += a[s].z; dbs.w += a[s].w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    acc[q][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(a[s], q), comp(b[s], p), acc[q][p], 0, 0, 0);
+        }
+    }
+    // D[q][p]: lane holds rows i = lq*4 + r (n = nblk*64 + 4 i + q), col j = li (k = kslab*64 + 4 j + p)
+    float* pw = partial + chunk * (int64_t)N * K;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nblk * 64 + 4 * (lq * 4 + r) + q;
+            if (n >= N) continue;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int k = kslab * 64 + 4 * li + p;
+                if (k < K) pw[(int64_t)n * K + k] = acc[q][p][r];
+            }
+        }
+    if (kslab == 0 && partial_db) {
+        // column sums of dY over this chunk: combine the 4 row groups (lq) in a fixed order
+        dbs.x += __shfl_xor(dbs.x, 16, 64); dbs.y += __shfl_xor(dbs.y, 16, 64);
+        dbs.z += __shfl_xor(dbs.z, 16, 64); dbs.w += __shfl_xor(dbs.w, 16, 64);
+        dbs.x += __shfl_xor(dbs.x, 32, 64); dbs.y += __shfl_xor(dbs.y, 32, 64);
+        dbs.z += __shfl_xor(dbs.z, 32, 64); dbs.w += __shfl_xor(dbs.w, 32, 64);
+        if (lq == 0) {
+            float* pd = partial_db + chunk * (int64_t)N;
+            if (n_base + 0 < N) pd[n_base + 0] = dbs.x;
+            if (n_base + 1 < N) pd[n_base + 1] = dbs.y;
+            if (n_base + 2 < N) pd[n_base + 2] = dbs.z;
+            if (n_base + 3 < N) pd[n_base + 3] = dbs.w;
+        }
+    }
+}
+
+__global__ void reduce_chunks_kernel(int64_t n_elem, int64_t n_chunks, const float* __restrict__ partial,
+                                     float* __restrict__ out, int64_t ld_out, int row_len, int accumulate) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elem; e += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int64_t c = 0; c < n_chunks; ++c) s += partial[c * n_elem + e];
+        const int64_t r = e / row_len, col = e % row_len;
+        float* o = out + r * ld_out + col;
+        *o = accumulate ? (*o + s) : s;
+    }
+}
+
+static void wgrad_geometry(int64_t M, int K, int64_t* MC, int64_t* n_chunks, int* n_kslab) {
+    *n_kslab = (int)ceil_div(K, 64);
+    // aim for ~4096 waves; chunks are multiples of 16 rows
+    int64_t want_chunks = ceil_div(4096, *n_kslab);
+    int64_t mc = align_up(ceil_div(M, want_chunks), 16);
+    if (mc < 64) mc = 64;
+    *MC = mc;
+    *n_chunks = ceil_div(M, mc);
+}
+
+}  // namespace llmrec
+
+using namespace llmrec;
+
+extern "C" {
+
+int llmrec_linear_fwd_f32(int64_t M, int32_t N, int32_t K, const float* X, int64_t ldx,
+                          const float* W, int64_t ldw, const float* bias,
+                          float* Y, int64_t ldy, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear_fwd: bad sizes");
+    if (M == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(X && W && Y && ldx >= K && ldw >= K && ldy >= N, "linear_fwd: null pointer or ld too small");
+    if (N > 128) { set_error("linear_fwd: N = %d > 128", N); return LLMREC_EUNSUPPORTED; }
+    const int vec_ok = (ldx % 4 == 0) && (ldw % 4 == 0) && (((uintptr_t)X | (uintptr_t)W) % 16 == 0);
+    const int NT = (N + 15) / 16;
+    // 32-row wave tiles once there is enough work to fill 1024 SIMDs twice, else 16-row tiles
+    const bool big = M >= 32 * 2048;
+#define LAUNCH_FWD(NT_, RT_)                                                                          \
+    linear_fwd_kernel<NT_, RT_><<<(int)ceil_div(M, 4 * 16 * RT_), 256, 0, stream>>>(M, N, K, X, ldx, W, ldw, bias, Y, ldy, vec_ok)
+    switch (NT) {
+        case 1: if (big) LAUNCH_FWD(1, 2); else LAUNCH_FWD(1, 1); break;
+        case 2: if (big) LAUNCH_FWD(2, 2); else LAUNCH_FWD(2, 1); break;
+        case 3: if (big) LAUNCH_FWD(3, 2); else LAUNCH_FWD(3, 1); break;
+        case 4: if (big) LAUNCH_FWD(4, 2); else LAUNCH_FWD(4, 1); break;
+        case 5: LAUNCH_FWD(5, 1); break;
+        case 6: LAUNCH_FWD(6, 1); break;
+        case 7: LAUNCH_FWD(7, 1); break;
+        default: LAUNCH_FWD(8, 1); break;
+    }
+#undef LAUNCH_FWD
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int64_t llmrec_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+    if (M < 0 || N <= 0 || K <= 0) return -1;
+    int64_t MC, n_chunks; int n_kslab;
+    wgrad_geometry(M > 0 ? M : 1, K, &MC, &n_chunks, &n_kslab);
+    return align_up(4 * n_chunks * (int64_t)N * K, 256) + align_up(4 * n_chunks * (int64_t)N, 256);
+}
+
+int llmrec_linear_wgrad_f32(int64_t M, int32_t N, int32_t K, const float* dY, int64_t lddy,
+                            const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,
+                            int32_t accumulate, void* workspace, int64_t workspace_bytes,
+                            llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear_wgrad: bad sizes");
+    LLMREC_CHECK_ARG(dW && lddw >= K && (M == 0 || (dY && X && lddy >= N && ldx >= K)), "linear_wgrad: null pointer or ld too small");
+    if (M == 0) {
+        if (!accumulate) {
+            LLMREC_HIP(hipMemset2DAsync(dW, 4 * lddw, 0, 4 * (size_t)K, N, stream));
+            if (db) LLMREC_HIP(hipMemsetAsync(db, 0, 4 * (size_t)N, stream));
+        }
+        return LLMREC_OK;
+    }
+    if (workspace_bytes < llmrec_linear_wgrad_workspace_bytes(M, N, K) || !workspace) {
+        set_error("linear_wgrad: workspace %lld < %lld", (long long)workspace_bytes,
+                  (long long)llmrec_linear_wgrad_workspace_bytes(M, N, K));
+        return LLMREC_EWORKSPACE;
+    }
+    int64_t MC, n_chunks; int n_kslab;
+    wgrad_geometry(M, K, &MC, &n_chunks, &n_kslab);
+    float* partial = (float*)workspace;
+    float* partial_db = (float*)((char*)workspace + align_up(4 * n_chunks * (int64_t)N * K, 256));
+    const int vec_ok = (lddy % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)dY | (uintptr_t)X) % 16 == 0);
+    const int64_t n_waves = n_chunks * n_kslab;
+    dim3 grid((unsigned)ceil_div(n_waves, 4), (unsigned)ceil_div(N, 64));
+    // waves past n_waves in the last block compute chunk >= n_chunks and exit (m_begin >= M)
+    linear_wgrad_kernel<<<grid, 256, 0, stream>>>(M, N, K, dY, lddy, X, ldx, partial, db ? partial_db : nullptr, MC, n_kslab, vec_ok);
+    LLMREC_LAUNCH_CHECK();
+    const int64_t ne = (int64_t)N * K;
+    reduce_chunks_kernel<<<grid_for(ne, 256), 256, 0, stream>>>(ne, n_chunks, partial, dW, lddw, K, accumulate);
+    LLMREC_LAUNCH_CHECK();
+    if (db) {
+        reduce_chunks_kernel<<<1, 128, 0, stream>>>(N, n_chunks, partial_db, db, N, N, accumulate);
+        LLMREC_LAUNCH_CHECK();
+    }
+    return LLMREC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+// graph.hip - R1: device-side graph ingest (COO -> CSR), degree scales, SpMM long-row plan.
+// Replaces the host scipy normalisation + COO tensor of reference main.py:84-93,114-134.
+// These run once per graph (set-up), so the sort is rocPRIM's radix sort via hipCUB; the
+// hand-written kernels are the ones on the per-step path (spmm.hip etc.).
+#include "common.h"
+#include <hipcub/hipcub.hpp>
+
+namespace llmrec {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+__global__ void pack_keys_kernel(int64_t nnz, const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                                 uint64_t* __restrict__ keys) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * blockDim.x)
+        keys[j] = ((uint64_t)row[j] << 32) | (uint64_t)(uint32_t)col[j];
+}
+
+// sorted keys -> colidx and rowptr. Position j opens every row in (row(j-1), row(j)].
+__global__ void unpack_keys_kernel(int64_t nnz, int64_t n_rows, const uint64_t* __restrict__ keys,
+                                   int32_t* __restrict__ colidx, int32_t* __restrict__ rowptr) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j <= nnz; j += stride) {
+        int64_t r_prev = (j == 0) ? -1 : (int64_t)(keys[j - 1] >> 32);
+        int64_t r_cur = (j == nnz) ? n_rows : (int64_t)(keys[j] >> 32);
+        if (j < nnz) colidx[j] = (int32_t)(uint32_t)(keys[j] & 0xffffffffull);
+        for (int64_t r = r_prev + 1; r <= r_cur; ++r) rowptr[r] = (int32_t)j;
+    }
+}
+
+__global__ void degree_scale_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, float* __restrict__ scale) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
+        int32_t deg = rowptr[r + 1] - rowptr[r];
+        // reference main.py:115-117: np.power(rowsum + 1e-8, -0.5), inf -> 0, on fp32 row sums.
+        // In fp32, deg + 1e-8 == deg for deg >= 1; deg == 0 gives 1e-8^-0.5 = 1e4 in the
+        // reference, multiplied into an empty row (no effect), so 0 is equivalent.
+        scale[r] = deg > 0 ? (float)(1.0 / sqrt((double)deg)) : 0.0f;
+    }
+}
+
+__global__ void row_constant_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, const float* __restrict__ val,
+                                    float* __restrict__ row_const, int32_t* __restrict__ not_const) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
+        int32_t s = rowptr[r], e = rowptr[r + 1];
+        float c = (e > s) ? val[s] : 0.0f;
+        bool bad = false;
+        for (int32_t j = s + 1; j < e; ++j) bad |= (val[j] != c);
+        row_const[r] = c;
+        if (bad) atomicOr(not_const, 1);
+    }
+}
+
+__global__ void flag_finish_kernel(int32_t* flag) { flag[0] = flag[0] ? 0 : 1; }
+
+__device__ __forceinline__ int32_t n_segments_of(int32_t deg) {
+    return deg > LLMREC_SPMM_LONG_ROW ? (deg + LLMREC_SPMM_SEGMENT - 1) / LLMREC_SPMM_SEGMENT : 0;
+}
+
+__global__ void plan_count_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t* __restrict__ counts) {
+    int32_t nl = 0, ns = 0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
+        int32_t k = n_segments_of(rowptr[r + 1] - rowptr[r]);
+        if (k) { nl += 1; ns += k; }
+    }
+    if (nl) { atomicAdd(&counts[0], nl); atomicAdd(&counts[1], ns); }
+}
+
+__global__ void plan_fill_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t* __restrict__ cursors,
+                                 int32_t* __restrict__ long_rows, int32_t* __restrict__ long_seg_begin,
+                                 int32_t* __restrict__ seg_long) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
+        int32_t k = n_segments_of(rowptr[r + 1] - rowptr[r]);
+        if (!k) continue;
+        int32_t slot = atomicAdd(&cursors[0], 1);
+        int32_t base = atomicAdd(&cursors[1], k);
+        long_rows[slot] = (int32_t)r;
+        long_seg_begin[slot] = base;
+        for (int32_t s = 0; s < k; ++s) seg_long[base + s] = slot;
+    }
+}
+
+}  // namespace llmrec
+
+using namespace llmrec;
+
+extern "C" {
+
+int llmrec_abi_version(void) { return LLMREC_ABI_VERSION; }
+
+const char* llmrec_status_string(int status) {
+    switch (status) {
+        case LLMREC_OK: return "ok";
+        case LLMREC_EINVAL: return "invalid argument";
+        case LLMREC_EHIP: return "HIP runtime error";
+        case LLMREC_EWORKSPACE: return "workspace too small";
+        case LLMREC_EUNSUPPORTED: return "unsupported shape";
+        default: return "unknown status";
+    }
+}
+
+const char* llmrec_last_error(void) { return g_err; }
+
+int64_t llmrec_csr_build_workspace_bytes(int64_t n_rows, int64_t nnz) {
+    (void)n_rows;
+    if (nnz < 0) return -1;
+    // two key buffers (8 B each) + alternate value buffer (4 B) + rocPRIM temp storage bound
+    return align_up(8 * nnz, 256) * 2 + align_up(4 * nnz, 256) + align_up(nnz + (32ll << 20), 256);
+}
+
+int llmrec_csr_build(int64_t n_rows, int64_t n_cols, int64_t nnz,
+                     const int64_t* coo_row, const int64_t* coo_col, const float* coo_val,
+                     int32_t* rowptr, int32_t* colidx, float* val,
+                     void* workspace, int64_t workspace_bytes, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "csr_build: negative size");
+    LLMREC_CHECK_ARG(n_rows < (1ll << 31) && n_cols < (1ll << 32) && nnz < (1ll << 31),
+                     "csr_build: sizes exceed the int32 CSR range (rows %lld cols %lld nnz %lld)",
+                     (long long)n_rows, (long long)n_cols, (long long)nnz);
+    LLMREC_CHECK_ARG(rowptr && (nnz == 0 || (coo_row && coo_col && colidx)), "csr_build: null pointer");
+    LLMREC_CHECK_ARG((coo_val == nullptr) == (val == nullptr), "csr_build: coo_val and val must both be set or both NULL");
+    if (workspace_bytes < llmrec_csr_build_workspace_bytes(n_rows, nnz) || (nnz > 0 && !workspace)) {
+        set_error("csr_build: workspace %lld < %lld", (long long)workspace_bytes,
+                  (long long)llmrec_csr_build_workspace_bytes(n_rows, nnz));
+        return LLMREC_EWORKSPACE;
+    }
+    char* ws = (char*)workspace;
+    uint64_t* keys_a = (uint64_t*)ws;
+    uint64_t* keys_b = (uint64_t*)(ws + align_up(8 * nnz, 256));
+    float* val_alt = (float*)(ws + 2 * align_up(8 * nnz, 256));
+    void* temp = ws + 2 * align_up(8 * nnz, 256) + align_up(4 * nnz, 256);
+    size_t temp_avail = (size_t)align_up(nnz + (32ll << 20), 256);
+
+    if (nnz > 0) {
+        pack_keys_kernel<<<grid_for(nnz, 256), 256, 0, stream>>>(nnz, coo_row, coo_col, keys_a);
+        LLMREC_LAUNCH_CHECK();
+        int row_bits = 1;
+        while ((1ll << row_bits) < n_rows) ++row_bits;
+        int end_bit = 32 + row_bits;
+        hipcub::DoubleBuffer<uint64_t> kbuf(keys_a, keys_b);
+        size_t need = 0;
+        if (coo_val) {
+            LLMREC_HIP(hipMemcpyAsync(val, coo_val, 4 * nnz, hipMemcpyDeviceToDevice, stream));
+            hipcub::DoubleBuffer<float> vbuf(val, val_alt);
+            LLMREC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, kbuf, vbuf, (int)nnz, 0, end_bit, stream));
+            if (need > temp_avail) { set_error("csr_build: rocPRIM needs %zu B temp > %zu", need, temp_avail); return LLMREC_EWORKSPACE; }
+            LLMREC_HIP(hipcub::DeviceRadixSort::SortPairs(temp, need, kbuf, vbuf, (int)nnz, 0, end_bit, stream));
+            if (vbuf.Current() != val)
+                LLMREC_HIP(hipMemcpyAsync(val, vbuf.Current(), 4 * nnz, hipMemcpyDeviceToDevice, stream));
+        } else {
+            LLMREC_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, need, kbuf, (int)nnz, 0, end_bit, stream));
+            if (need > temp_avail) { set_error("csr_build: rocPRIM needs %zu B temp > %zu", need, temp_avail); return LLMREC_EWORKSPACE; }
+            LLMREC_HIP(hipcub::DeviceRadixSort::SortKeys(temp, need, kbuf, (int)nnz, 0, end_bit, stream));
+        }
+        unpack_keys_kernel<<<grid_for(nnz + 1, 256), 256, 0, stream>>>(nnz, n_rows, kbuf.Current(), colidx, rowptr);
+        LLMREC_LAUNCH_CHECK();
+    } else {
+        LLMREC_HIP(hipMemsetAsync(rowptr, 0, 4 * (n_rows + 1), stream));
+    }
+    return LLMREC_OK;
+}
+
+int llmrec_degree_scale(int64_t n_rows, const int32_t* rowptr, float* scale, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_rows >= 0 && rowptr && (scale || n_rows == 0), "degree_scale: bad argument");
+    if (n_rows == 0) return LLMREC_OK;
+    degree_scale_kernel<<<grid_for(n_rows, 256), 256, 0, (hipStream_t)stream_>>>(n_rows, rowptr, scale);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_csr_row_constant(int64_t n_rows, const int32_t* rowptr, const float* val,
+                            float* row_const, int32_t* flag_out, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(n_rows >= 0 && rowptr && flag_out && (n_rows == 0 || (val && row_const)), "csr_row_constant: bad argument");
+    LLMREC_HIP(hipMemsetAsync(flag_out, 0, 4, stream));
+    if (n_rows > 0) {
+        row_constant_kernel<<<grid_for(n_rows, 256), 256, 0, stream>>>(n_rows, rowptr, val, row_const, flag_out);
+        LLMREC_LAUNCH_CHECK();
+    }
+    flag_finish_kernel<<<1, 1, 0, stream>>>(flag_out);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t* scratch2, int32_t* counts_host,
+                           llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(n_rows >= 0 && rowptr && scratch2 && counts_host, "spmm_plan_count: bad argument");
+    LLMREC_HIP(hipMemsetAsync(scratch2, 0, 8, stream));
+    if (n_rows > 0) {
+        plan_count_kernel<<<grid_for(n_rows, 256), 256, 0, stream>>>(n_rows, rowptr, scratch2);
+        LLMREC_LAUNCH_CHECK();
+    }
+    LLMREC_HIP(hipMemcpyAsync(counts_host, scratch2, 8, hipMemcpyDeviceToHost, stream));
+    LLMREC_HIP(hipStreamSynchronize(stream));
+    return LLMREC_OK;
+}
+
+int llmrec_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, int32_t* scratch2,
+                          int32_t* long_rows, int32_t* long_seg_begin, int32_t* seg_long, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(n_rows >= 0 && rowptr && scratch2 && long_rows && long_seg_begin && seg_long, "spmm_plan_fill: bad argument");
+    LLMREC_HIP(hipMemsetAsync(scratch2, 0, 8, stream));
+    if (n_rows > 0) {
+        plan_fill_kernel<<<grid_for(n_rows, 256), 256, 0, stream>>>(n_rows, rowptr, scratch2, long_rows, long_seg_begin, seg_long);
+        LLMREC_LAUNCH_CHECK();
+    }
+    return LLMREC_OK;
+}
+
+}  // extern "C"

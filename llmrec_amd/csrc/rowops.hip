@@ -1,0 +1,428 @@
+// rowops.hip - R3/R6/R8: row-wise kernels (softmax, normalise-and-add fusion, squared-norm
+// regulariser, axpy, AdamW). All HBM-bound elementwise/row-reduction work; one 16-lane group per
+// row with 16-byte accesses, so a wavefront instruction touches 4 complete 256-B rows at d = 64.
+// Replaces nn.Softmax / torch.mean(torch.stack) / F.normalize + scaled adds (reference
+// Models.py:176-177,185-197), (x**2).sum() (main.py:151-156) and AdamW.step (main.py:100-104,278).
+#include "common.h"
+#include <type_traits>
+
+namespace llmrec {
+
+constexpr int RL = 16;                 // lanes per row
+constexpr int ROWS_PER_BLOCK = 256 / RL;
+
+// A row held in registers: lane gl owns elements {(k*RL + gl)*VEC + q}, k < NCHUNK, q < VEC.
+template <int VEC, int NCHUNK>
+struct RowReg {
+    float x[NCHUNK][VEC];
+    __device__ __forceinline__ void load(const float* row, int gl, int d) {
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k) {
+            const int c = (k * RL + gl) * VEC;
+            if (VEC == 4) {
+                float4 v = (c < d) ? *reinterpret_cast<const float4*>(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                x[k][0] = v.x; x[k][1 % VEC] = v.y; x[k][2 % VEC] = v.z; x[k][3 % VEC] = v.w;
+            } else {
+                x[k][0] = (c < d) ? row[c] : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* row, int gl, int d) const {
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k) {
+            const int c = (k * RL + gl) * VEC;
+            if (c < d) {
+                if (VEC == 4) *reinterpret_cast<float4*>(row + c) = make_float4(x[k][0], x[k][1 % VEC], x[k][2 % VEC], x[k][3 % VEC]);
+                else row[c] = x[k][0];
+            }
+        }
+    }
+    __device__ __forceinline__ void fill(float v) {
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) x[k][q] = v;
+    }
+    __device__ __forceinline__ float dot(const RowReg& o) const {      // full-row dot (all lanes get it)
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) s = fmaf(x[k][q], o.x[k][q], s);
+        return group_sum<RL>(s);
+    }
+};
+
+#define ROW_LOOP_HEADER                                                                           \
+    const int gl = threadIdx.x & (RL - 1);                                                        \
+    const int64_t row_stride = (int64_t)gridDim.x * ROWS_PER_BLOCK;                               \
+    for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + threadIdx.x / RL; row < rows; row += row_stride)
+
+// ---------------------------------------------------------------------------------------------
+// softmax over d
+// ---------------------------------------------------------------------------------------------
+template <int VEC, int NCHUNK>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(int64_t rows, int d, const float* __restrict__ Z, int64_t ldz,
+                                                          float* __restrict__ Y, int64_t ldy) {
+    ROW_LOOP_HEADER {
+        RowReg<VEC, NCHUNK> z;
+        z.load(Z + row * ldz, gl, d);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+            for (int q = 0; q < VEC; ++q)
+                if ((k * RL + gl) * VEC + q < d) mx = fmaxf(mx, z.x[k][q]);
+        mx = group_max<RL>(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const bool in = (k * RL + gl) * VEC + q < d;
+                z.x[k][q] = in ? expf(z.x[k][q] - mx) : 0.f;
+                s += z.x[k][q];
+            }
+        s = group_sum<RL>(s);
+        const float inv = 1.0f / s;
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) z.x[k][q] *= inv;
+        z.store(Y + row * ldy, gl, d);
+    }
+}
+
+template <int VEC, int NCHUNK>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(int64_t rows, int d, const float* __restrict__ Y, int64_t ldy,
+                                                          const float* __restrict__ dY, int64_t lddy,
+                                                          float* __restrict__ dZ, int64_t lddz) {
+    ROW_LOOP_HEADER {
+        RowReg<VEC, NCHUNK> y, g;
+        y.load(Y + row * ldy, gl, d);
+        g.load(dY + row * lddy, gl, d);
+        const float dot = y.dot(g);
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) g.x[k][q] = y.x[k][q] * (g.x[k][q] - dot);
+        g.store(dZ + row * lddz, gl, d);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fusion
+// ---------------------------------------------------------------------------------------------
+struct FuseArgs {
+    const float* mean_terms[LLMREC_MAX_TERMS];
+    int64_t mean_ld[LLMREC_MAX_TERMS];
+    const float* norm_terms[LLMREC_MAX_TERMS];
+    int64_t norm_ld[LLMREC_MAX_TERMS];
+    float* d_terms[LLMREC_MAX_TERMS];
+    int64_t d_ld[LLMREC_MAX_TERMS];
+    float rates[LLMREC_MAX_TERMS];
+    int n_mean, n_norm;
+    float mean_scale;
+};
+
+template <int VEC, int NCHUNK>
+__global__ __launch_bounds__(256) void fuse_fwd_kernel(int64_t rows, int d, FuseArgs a, float* __restrict__ out, int64_t ldo) {
+    ROW_LOOP_HEADER {
+        RowReg<VEC, NCHUNK> acc, t;
+        acc.fill(0.f);
+        for (int i = 0; i < a.n_mean; ++i) {
+            t.load(a.mean_terms[i] + row * a.mean_ld[i], gl, d);
+#pragma unroll
+            for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc.x[k][q] += t.x[k][q];
+        }
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc.x[k][q] *= a.mean_scale;
+        for (int i = 0; i < a.n_norm; ++i) {
+            t.load(a.norm_terms[i] + row * a.norm_ld[i], gl, d);
+            const float nrm = fmaxf(sqrtf(t.dot(t)), 1e-12f);           // F.normalize eps
+            const float w = a.rates[i] / nrm;
+#pragma unroll
+            for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc.x[k][q] = fmaf(w, t.x[k][q], acc.x[k][q]);
+        }
+        acc.store(out + row * ldo, gl, d);
+    }
+}
+
+template <int VEC, int NCHUNK>
+__global__ __launch_bounds__(256) void fuse_bwd_kernel(int64_t rows, int d, FuseArgs a, const float* __restrict__ dOut,
+                                                       int64_t lddo, int accumulate) {
+    ROW_LOOP_HEADER {
+        RowReg<VEC, NCHUNK> g, t, o;
+        g.load(dOut + row * lddo, gl, d);
+        for (int i = 0; i < a.n_norm; ++i) {
+            t.load(a.norm_terms[i] + row * a.norm_ld[i], gl, d);
+            const float nn = sqrtf(t.dot(t));
+            float* dst = a.d_terms[i] + row * a.d_ld[i];
+            if (accumulate) o.load(dst, gl, d); else o.fill(0.f);
+            if (nn >= 1e-12f) {
+                const float inv = 1.0f / nn;
+                const float proj = t.dot(g) * inv * inv;                 // <n, g> / ||x||
+                const float w = a.rates[i] * inv;
+#pragma unroll
+                for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) o.x[k][q] += w * (g.x[k][q] - t.x[k][q] * proj);
+            } else {                                                     // clamp active: x / eps
+                const float w = a.rates[i] * 1e12f;
+#pragma unroll
+                for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) o.x[k][q] += w * g.x[k][q];
+            }
+            o.store(dst, gl, d);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sum of squares (two-level, fixed order), axpy
+// ---------------------------------------------------------------------------------------------
+constexpr int SUMSQ_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(int64_t rows, int d, const float* __restrict__ X, int64_t ldx,
+                                                            float* __restrict__ partial) {
+    __shared__ float red[256];
+    float s = 0.f;
+    const int64_t n = rows * d;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const float v = X[(e / d) * ldx + (e % d)];
+        s = fmaf(v, v, s);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(int n_partial, const float* __restrict__ partial, float coef,
+                                                          int accumulate, float* __restrict__ out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_partial; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + coef * red[0];
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(int64_t rows, int d, float alpha, const float* __restrict__ alpha_dev,
+                                                   const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy,
+                                                   int accumulate) {
+    const float a = alpha * (alpha_dev ? alpha_dev[0] : 1.0f);
+    const int64_t n = rows * d;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / d, c = e % d;
+        const float v = a * X[r * ldx + c];
+        float* y = Y + r * ldy + c;
+        *y = accumulate ? (*y + v) : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// AdamW
+// ---------------------------------------------------------------------------------------------
+__global__ void adamw_advance_kernel(float* state, float lr, float b1, float b2) {
+    int t = __float_as_int(state[0]) + 1;
+    state[0] = __int_as_float(t);
+    const double bc1 = 1.0 - pow((double)b1, (double)t);
+    const double bc2 = 1.0 - pow((double)b2, (double)t);
+    state[1] = (float)((double)lr / bc1);
+    state[2] = (float)sqrt(bc2);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    const float* __restrict__ state, float decay_mul, float b1, float b2, float eps) {
+    const float step_size = state[1], bc2s = state[2];
+    const float w1 = 1.0f - b1, w2 = 1.0f - b2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        float pi = p[i] * decay_mul;                                   // p.mul_(1 - lr * wd)
+        const float mi = m[i] + w1 * (gi - m[i]);                      // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = fmaf(w2 * gi, gi, v[i] * b2);                 // mul_(beta2).addcmul_(g, g, 1 - beta2)
+        const float denom = sqrtf(vi) / bc2s + eps;
+        pi = pi - step_size * (mi / denom);                            // addcdiv_(exp_avg, denom, -step_size)
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
+template <typename F4, typename F1>
+static int dispatch_rows(int d, bool vec4, F4 f4, F1 f1) {
+    if (vec4) {
+        if (d <= 64) return f4(std::integral_constant<int, 1>());
+        if (d <= 128) return f4(std::integral_constant<int, 2>());
+        if (d <= 256) return f4(std::integral_constant<int, 4>());
+        if (d <= 512) return f4(std::integral_constant<int, 8>());
+    } else {
+        if (d <= 16) return f1(std::integral_constant<int, 1>());
+        if (d <= 64) return f1(std::integral_constant<int, 4>());
+        if (d <= 128) return f1(std::integral_constant<int, 8>());
+        if (d <= 256) return f1(std::integral_constant<int, 16>());
+    }
+    set_error("row kernel: d = %d outside the compiled family (vec4 = %d)", d, (int)vec4);
+    return LLMREC_EUNSUPPORTED;
+}
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+}  // namespace llmrec
+
+using namespace llmrec;
+
+extern "C" {
+
+int llmrec_softmax_rows_fwd_f32(int64_t rows, int32_t d, const float* Z, int64_t ldz, float* Y, int64_t ldy,
+                                llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(rows >= 0 && d > 0, "softmax_fwd: bad sizes");
+    if (rows == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(Z && Y && ldz >= d && ldy >= d, "softmax_fwd: null pointer or ld < d");
+    const bool vec4 = d % 4 == 0 && ldz % 4 == 0 && ldy % 4 == 0 && aligned16(Z) && aligned16(Y);
+    const int grid = grid_for(rows, ROWS_PER_BLOCK);
+    int rc = dispatch_rows(d, vec4,
+        [&](auto nc) { softmax_fwd_kernel<4, decltype(nc)::value><<<grid, 256, 0, stream>>>(rows, d, Z, ldz, Y, ldy); return 0; },
+        [&](auto nc) { softmax_fwd_kernel<1, decltype(nc)::value><<<grid, 256, 0, stream>>>(rows, d, Z, ldz, Y, ldy); return 0; });
+    if (rc) return rc;
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_softmax_rows_bwd_f32(int64_t rows, int32_t d, const float* Y, int64_t ldy, const float* dY, int64_t lddy,
+                                float* dZ, int64_t lddz, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(rows >= 0 && d > 0, "softmax_bwd: bad sizes");
+    if (rows == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(Y && dY && dZ && ldy >= d && lddy >= d && lddz >= d, "softmax_bwd: null pointer or ld < d");
+    const bool vec4 = d % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && lddz % 4 == 0 && aligned16(Y) && aligned16(dY) && aligned16(dZ);
+    const int grid = grid_for(rows, ROWS_PER_BLOCK);
+    int rc = dispatch_rows(d, vec4,
+        [&](auto nc) { softmax_bwd_kernel<4, decltype(nc)::value><<<grid, 256, 0, stream>>>(rows, d, Y, ldy, dY, lddy, dZ, lddz); return 0; },
+        [&](auto nc) { softmax_bwd_kernel<1, decltype(nc)::value><<<grid, 256, 0, stream>>>(rows, d, Y, ldy, dY, lddy, dZ, lddz); return 0; });
+    if (rc) return rc;
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_fuse_fwd_f32(int64_t rows, int32_t d, float mean_scale,
+                        int32_t n_mean, const float* const* mean_terms, const int64_t* mean_ld,
+                        int32_t n_norm, const float* const* norm_terms, const int64_t* norm_ld,
+                        const float* rates, float* out, int64_t ldo, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(rows >= 0 && d > 0 && n_mean >= 0 && n_norm >= 0, "fuse_fwd: bad sizes");
+    LLMREC_CHECK_ARG(n_mean <= LLMREC_MAX_TERMS && n_norm <= LLMREC_MAX_TERMS, "fuse_fwd: more than %d terms", LLMREC_MAX_TERMS);
+    if (rows == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(out && ldo >= d, "fuse_fwd: null out or ld < d");
+    FuseArgs a = {};
+    bool vec4 = d % 4 == 0 && ldo % 4 == 0 && aligned16(out);
+    a.n_mean = n_mean; a.n_norm = n_norm; a.mean_scale = mean_scale;
+    for (int i = 0; i < n_mean; ++i) {
+        LLMREC_CHECK_ARG(mean_terms[i] && mean_ld[i] >= d, "fuse_fwd: bad mean term %d", i);
+        a.mean_terms[i] = mean_terms[i]; a.mean_ld[i] = mean_ld[i];
+        vec4 = vec4 && mean_ld[i] % 4 == 0 && aligned16(mean_terms[i]);
+    }
+    for (int i = 0; i < n_norm; ++i) {
+        LLMREC_CHECK_ARG(norm_terms[i] && norm_ld[i] >= d, "fuse_fwd: bad norm term %d", i);
+        a.norm_terms[i] = norm_terms[i]; a.norm_ld[i] = norm_ld[i]; a.rates[i] = rates[i];
+        vec4 = vec4 && norm_ld[i] % 4 == 0 && aligned16(norm_terms[i]);
+    }
+    const int grid = grid_for(rows, ROWS_PER_BLOCK);
+    int rc = dispatch_rows(d, vec4,
+        [&](auto nc) { fuse_fwd_kernel<4, decltype(nc)::value><<<grid, 256, 0, stream>>>(rows, d, a, out, ldo); return 0; },
+        [&](auto nc) { fuse_fwd_kernel<1, decltype(nc)::value><<<grid, 256, 0, stream>>>(rows, d, a, out, ldo); return 0; });
+    if (rc) return rc;
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_fuse_bwd_f32(int64_t rows, int32_t d, const float* dOut, int64_t lddo,
+                        int32_t n_norm, const float* const* norm_terms, const int64_t* norm_ld,
+                        const float* rates, float* const* d_terms, const int64_t* d_ld,
+                        int32_t accumulate, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(rows >= 0 && d > 0 && n_norm >= 0 && n_norm <= LLMREC_MAX_TERMS, "fuse_bwd: bad sizes");
+    if (rows == 0 || n_norm == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(dOut && lddo >= d, "fuse_bwd: null dOut or ld < d");
+    FuseArgs a = {};
+    bool vec4 = d % 4 == 0 && lddo % 4 == 0 && aligned16(dOut);
+    a.n_norm = n_norm;
+    for (int i = 0; i < n_norm; ++i) {
+        LLMREC_CHECK_ARG(norm_terms[i] && d_terms[i] && norm_ld[i] >= d && d_ld[i] >= d, "fuse_bwd: bad term %d", i);
+        a.norm_terms[i] = norm_terms[i]; a.norm_ld[i] = norm_ld[i]; a.rates[i] = rates[i];
+        a.d_terms[i] = d_terms[i]; a.d_ld[i] = d_ld[i];
+        vec4 = vec4 && norm_ld[i] % 4 == 0 && d_ld[i] % 4 == 0 && aligned16(norm_terms[i]) && aligned16(d_terms[i]);
+    }
+    const int grid = grid_for(rows, ROWS_PER_BLOCK);
+    int rc = dispatch_rows(d, vec4,
+        [&](auto nc) { fuse_bwd_kernel<4, decltype(nc)::value><<<grid, 256, 0, stream>>>(rows, d, a, dOut, lddo, accumulate); return 0; },
+        [&](auto nc) { fuse_bwd_kernel<1, decltype(nc)::value><<<grid, 256, 0, stream>>>(rows, d, a, dOut, lddo, accumulate); return 0; });
+    if (rc) return rc;
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int64_t llmrec_sumsq_workspace_bytes(int64_t rows, int32_t d) {
+    (void)rows; (void)d;
+    return 4 * SUMSQ_BLOCKS;
+}
+
+int llmrec_sumsq_f32(int64_t rows, int32_t d, const float* X, int64_t ldx, float coef, int32_t accumulate,
+                     float* out, void* workspace, int64_t workspace_bytes, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(rows >= 0 && d >= 0 && out, "sumsq: bad argument");
+    LLMREC_CHECK_ARG(rows * d == 0 || (X && ldx >= d), "sumsq: null X or ld < d");
+    if (workspace_bytes < 4 * SUMSQ_BLOCKS || !workspace) { set_error("sumsq: workspace too small"); return LLMREC_EWORKSPACE; }
+    const int nb = rows * d == 0 ? 1 : grid_for(rows * d, 256 * 8, SUMSQ_BLOCKS);
+    sumsq_partial_kernel<<<nb, 256, 0, stream>>>(rows, d > 0 ? d : 1, X, ldx, (float*)workspace);
+    LLMREC_LAUNCH_CHECK();
+    sumsq_final_kernel<<<1, 256, 0, stream>>>(nb, (const float*)workspace, coef, accumulate, out);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_axpy_f32(int64_t rows, int32_t d, float alpha, const float* alpha_dev, const float* X, int64_t ldx,
+                    float* Y, int64_t ldy, int32_t accumulate, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(rows >= 0 && d >= 0, "axpy: bad sizes");
+    if (rows * d == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(X && Y && ldx >= d && ldy >= d, "axpy: null pointer or ld < d");
+    axpy_kernel<<<grid_for(rows * d, 256 * 4), 256, 0, stream>>>(rows, d, alpha, alpha_dev, X, ldx, Y, ldy, accumulate);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_adamw_advance(float* state3, float lr, float beta1, float beta2, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(state3, "adamw_advance: null state");
+    adamw_advance_kernel<<<1, 1, 0, (hipStream_t)stream_>>>(state3, lr, beta1, beta2);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_adamw_f32(int64_t n, float* p, const float* g, float* m, float* v, const float* state3,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n >= 0 && state3, "adamw: bad argument");
+    if (n == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(p && g && m && v, "adamw: null pointer");
+    const float decay_mul = (float)(1.0 - (double)lr * (double)weight_decay);
+    adamw_kernel<<<grid_for(n, 256 * 4), 256, 0, (hipStream_t)stream_>>>(n, p, g, m, v, state3, decay_mul, beta1, beta2, eps);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,535 @@
+"""Host side of the C ABI: device-CSR operands and torch.autograd Functions over the HIP kernels.
+
+Everything here is plumbing: tensors stay torch-owned, kernels receive ``tensor.data_ptr()`` and
+the hipStream_t of torch's current stream (so launches are ordered with torch's own work and can
+be captured in a HIP graph). No function in this module computes on the CPU or falls back to
+torch math: if the HIP library is missing or a tensor is not on the GPU, it raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import weakref
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+CONST = _lib.CONST
+_c = ctypes
+
+
+def _stream():
+    return _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else _c.c_void_p(t.data_ptr())
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("llmrec_amd: the HIP path needs GPU tensors; got a %s tensor "
+                               "(there is no CPU fallback)" % t.device)
+
+
+def _rowmajor(t: torch.Tensor) -> torch.Tensor:
+    """2-D fp32 view whose inner stride is 1 (copy only if it is not)."""
+    if t.dtype != torch.float32:
+        raise RuntimeError("llmrec_amd: fp32 expected, got %s" % t.dtype)
+    if t.dim() != 2:
+        raise RuntimeError("llmrec_amd: 2-D tensor expected")
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+# ---------------------------------------------------------------------------------------------
+# R1: CSR operands
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class SpmmPlan:
+    """Long-row segment lists for one rowptr (include/llmrec_hip.h, llmrec_spmm_plan_*)."""
+    n_long: int
+    n_seg: int
+    long_rows: Optional[torch.Tensor]
+    long_seg_begin: Optional[torch.Tensor]
+    seg_long: Optional[torch.Tensor]
+
+    @staticmethod
+    def build(rowptr: torch.Tensor) -> "SpmmPlan":
+        n_rows = rowptr.numel() - 1
+        scratch = torch.zeros(2, dtype=torch.int32, device=rowptr.device)
+        counts = (_c.c_int32 * 2)()
+        _lib.call("llmrec_spmm_plan_count", n_rows, _p(rowptr), _p(scratch), counts, _stream())
+        n_long, n_seg = int(counts[0]), int(counts[1])
+        if n_long == 0:
+            return SpmmPlan(0, 0, None, None, None)
+        lr = torch.empty(n_long, dtype=torch.int32, device=rowptr.device)
+        lb = torch.empty(n_long, dtype=torch.int32, device=rowptr.device)
+        sl = torch.empty(n_seg, dtype=torch.int32, device=rowptr.device)
+        _lib.call("llmrec_spmm_plan_fill", n_rows, _p(rowptr), _p(scratch), _p(lr), _p(lb), _p(sl), _stream())
+        return SpmmPlan(n_long, n_seg, lr, lb, sl)
+
+
+@dataclass
+class Csr:
+    """One SpMM operand: Y = diag(row_scale) (P . val) diag(col_scale) X."""
+    n_rows: int
+    n_cols: int
+    rowptr: torch.Tensor            # int32 [n_rows + 1]
+    colidx: torch.Tensor            # int32 [nnz]
+    val: Optional[torch.Tensor]     # fp32 [nnz] or None (pattern only)
+    row_scale: Optional[torch.Tensor]
+    col_scale: Optional[torch.Tensor]
+    plan: SpmmPlan
+
+    @property
+    def nnz(self) -> int:
+        return self.colidx.numel()
+
+
+def csr_from_coo(rows: torch.Tensor, cols: torch.Tensor, vals: Optional[torch.Tensor], n_rows: int, n_cols: int):
+    """Device COO (int64) -> (rowptr, colidx, val) with ascending columns per row."""
+    _need_gpu(rows, cols, vals)
+    nnz = rows.numel()
+    dev = rows.device
+    rows = rows.to(torch.int64).contiguous()
+    cols = cols.to(torch.int64).contiguous()
+    if vals is not None:
+        vals = vals.to(torch.float32).contiguous()
+    rowptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+    colidx = torch.empty(nnz, dtype=torch.int32, device=dev)
+    val = torch.empty(nnz, dtype=torch.float32, device=dev) if vals is not None else None
+    ws_bytes = _lib.query("llmrec_csr_build_workspace_bytes", n_rows, nnz)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.call("llmrec_csr_build", n_rows, n_cols, nnz, _p(rows), _p(cols), _p(vals), _p(rowptr), _p(colidx), _p(val),
+              _p(ws), ws_bytes, _stream())
+    return rowptr, colidx, val
+
+
+def degree_scale(rowptr: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(rowptr.numel() - 1, dtype=torch.float32, device=rowptr.device)
+    _lib.call("llmrec_degree_scale", out.numel(), _p(rowptr), _p(out), _stream())
+    return out
+
+
+@dataclass
+class SparseOperand:
+    """A sparse matrix A prepared for Y = A X (``fwd``) and dX = A^T dY (``bwd``)."""
+    fwd: Csr
+    bwd: Csr
+
+    @property
+    def shape(self):
+        return (self.fwd.n_rows, self.fwd.n_cols)
+
+    @staticmethod
+    def from_coo(rows, cols, vals, n_rows: int, n_cols: int) -> "SparseOperand":
+        """General path (any values). If every row's values are one constant - the reference's
+        normalised adjacency diag(s) R, main.py:123-126 - the 4 B/nnz value stream is dropped."""
+        rowptr, colidx, val = csr_from_coo(rows, cols, vals, n_rows, n_cols)
+        t_rowptr, t_colidx, t_val = csr_from_coo(cols, rows, vals, n_cols, n_rows)
+        row_const = None
+        if val is not None:
+            rc = torch.empty(n_rows, dtype=torch.float32, device=rowptr.device)
+            flag = torch.zeros(1, dtype=torch.int32, device=rowptr.device)
+            _lib.call("llmrec_csr_row_constant", n_rows, _p(rowptr), _p(val), _p(rc), _p(flag), _stream())
+            if int(flag.item()) == 1:
+                row_const = rc
+        plan_f, plan_b = SpmmPlan.build(rowptr), SpmmPlan.build(t_rowptr)
+        if val is None or row_const is not None:
+            fwd = Csr(n_rows, n_cols, rowptr, colidx, None, row_const, None, plan_f)
+            bwd = Csr(n_cols, n_rows, t_rowptr, t_colidx, None, None, row_const, plan_b)
+        else:
+            fwd = Csr(n_rows, n_cols, rowptr, colidx, val, None, None, plan_f)
+            bwd = Csr(n_cols, n_rows, t_rowptr, t_colidx, t_val, None, None, plan_b)
+        return SparseOperand(fwd, bwd)
+
+
+_operand_cache = {}
+
+
+def operand_from_sparse_tensor(t: torch.Tensor) -> SparseOperand:
+    """Drop-in entry: accepts the torch sparse COO tensor the reference passes to
+    MM_Model.forward (reference main.py:128-134) and caches the device CSR on tensor identity."""
+    key = id(t)
+    hit = _operand_cache.get(key)
+    if hit is not None and hit[0]() is t:
+        return hit[1]
+    if not t.is_sparse:
+        raise RuntimeError("llmrec_amd: expected a torch sparse COO tensor")
+    _need_gpu(t)
+    idx = t._indices()
+    op = SparseOperand.from_coo(idx[0], idx[1], t._values(), t.shape[0], t.shape[1])
+    _operand_cache[key] = (weakref.ref(t), op)
+    return op
+
+
+@dataclass
+class BipartiteGraph:
+    """User-item interaction pattern R with the reference's one-sided normalisation:
+    A_ui = diag(s_u) R, A_iu = diag(s_i) R^T (reference main.py:84-91). Holds two pattern-only
+    CSRs (by user, by item) shared by the four SpMM directions."""
+    n_users: int
+    n_items: int
+    ui: SparseOperand
+    iu: SparseOperand
+    by_user: Csr            # pattern of R (train items per user, ascending) - also the eval mask
+    s_u: torch.Tensor
+    s_i: torch.Tensor
+
+    @staticmethod
+    def from_edges(users: torch.Tensor, items: torch.Tensor, n_users: int, n_items: int) -> "BipartiteGraph":
+        ru, cu, _ = csr_from_coo(users, items, None, n_users, n_items)
+        ri, ci, _ = csr_from_coo(items, users, None, n_items, n_users)
+        s_u, s_i = degree_scale(ru), degree_scale(ri)
+        pu, pi = SpmmPlan.build(ru), SpmmPlan.build(ri)
+        ui = SparseOperand(Csr(n_users, n_items, ru, cu, None, s_u, None, pu), Csr(n_items, n_users, ri, ci, None, None, s_u, pi))
+        iu = SparseOperand(Csr(n_items, n_users, ri, ci, None, s_i, None, pi), Csr(n_users, n_items, ru, cu, None, None, s_i, pu))
+        return BipartiteGraph(n_users, n_items, ui, iu, ui.fwd, s_u, s_i)
+
+
+# ---------------------------------------------------------------------------------------------
+# R2: SpMM
+# ---------------------------------------------------------------------------------------------
+def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_gpu(X, a.rowptr)
+    X = _rowmajor(X)
+    if X.shape[0] != a.n_cols:
+        raise RuntimeError("spmm: X has %d rows, operand has %d columns" % (X.shape[0], a.n_cols))
+    d = X.shape[1]
+    Y = out if out is not None else torch.empty(a.n_rows, d, dtype=torch.float32, device=X.device)
+    pl = a.plan
+    partials = torch.empty(pl.n_seg * d, dtype=torch.float32, device=X.device) if pl.n_long else None
+    _lib.call("llmrec_spmm_f32", a.n_rows, a.n_cols, _p(a.rowptr), _p(a.colidx), _p(a.val), _p(a.row_scale),
+              _p(a.col_scale), _p(X), _ld(X), _p(Y), _ld(Y), d, pl.n_long, _p(pl.long_rows), _p(pl.long_seg_begin),
+              pl.n_seg, _p(pl.seg_long), _p(partials), _stream())
+    return Y
+
+
+class _SpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, op: SparseOperand, X):
+        ctx.op = op
+        return spmm_raw(op.fwd, X)
+
+    @staticmethod
+    def backward(ctx, dY):
+        return None, spmm_raw(ctx.op.bwd, dY)
+
+
+def spmm(op, X: torch.Tensor) -> torch.Tensor:
+    """Y = A X with autograd (dX = A^T dY). ``op``: SparseOperand or a torch sparse COO tensor."""
+    if isinstance(op, torch.Tensor):
+        op = operand_from_sparse_tensor(op)
+    return _SpMM.apply(op, X)
+
+
+# ---------------------------------------------------------------------------------------------
+# R4: projection
+# ---------------------------------------------------------------------------------------------
+def linear_fwd_raw(X, W, b, out=None):
+    _need_gpu(X, W, b)
+    X, W = _rowmajor(X), _rowmajor(W)
+    M, K = X.shape
+    N = W.shape[0]
+    Y = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=X.device)
+    _lib.call("llmrec_linear_fwd_f32", M, N, K, _p(X), _ld(X), _p(W), _ld(W), _p(b), _p(Y), _ld(Y), _stream())
+    return Y
+
+
+def linear_wgrad_raw(dY, X, dW, db, accumulate: bool):
+    dY, X = _rowmajor(dY), _rowmajor(X)
+    M, K = X.shape
+    N = dY.shape[1]
+    ws_bytes = _lib.query("llmrec_linear_wgrad_workspace_bytes", M, N, K)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
+    _lib.call("llmrec_linear_wgrad_f32", M, N, K, _p(dY), _ld(dY), _p(X), _ld(X), _p(dW), _ld(dW), _p(db),
+              1 if accumulate else 0, _p(ws), ws_bytes, _stream())
+
+
+class _Linear(torch.autograd.Function):
+    """Y = X W^T + b for CONSTANT X (the reference's feature matrices): no dX."""
+
+    @staticmethod
+    def forward(ctx, X, W, b):
+        ctx.save_for_backward(X)
+        return linear_fwd_raw(X, W, b)
+
+    @staticmethod
+    def backward(ctx, dY):
+        (X,) = ctx.saved_tensors
+        dW = torch.empty(dY.shape[1], X.shape[1], dtype=torch.float32, device=X.device)
+        db = torch.empty(dY.shape[1], dtype=torch.float32, device=X.device)
+        linear_wgrad_raw(dY, X, dW, db, accumulate=False)
+        return None, dW, db
+
+
+def linear(X, W, b):
+    return _Linear.apply(X, W, b)
+
+
+class _LinearMulti(torch.autograd.Function):
+    """Several constant inputs through ONE shared Linear (the reference's item_trans for its 5
+    attribute keys, Models.py:33,150): n outputs, one accumulated weight gradient."""
+
+    @staticmethod
+    def forward(ctx, W, b, *Xs):
+        ctx.Xs = Xs
+        return tuple(linear_fwd_raw(X, W, b) for X in Xs)
+
+    @staticmethod
+    def backward(ctx, *dYs):
+        Xs = ctx.Xs
+        N = Xs and dYs[0].shape[1]
+        dW = torch.empty(N, Xs[0].shape[1], dtype=torch.float32, device=dYs[0].device)
+        db = torch.empty(N, dtype=torch.float32, device=dYs[0].device)
+        for k, (X, dY) in enumerate(zip(Xs, dYs)):
+            linear_wgrad_raw(dY, X, dW, db, accumulate=k > 0)
+        return (dW, db) + (None,) * len(Xs)
+
+
+def linear_multi(W, b, Xs: Sequence[torch.Tensor]):
+    return _LinearMulti.apply(W, b, *Xs)
+
+
+# ---------------------------------------------------------------------------------------------
+# R3: softmax over d
+# ---------------------------------------------------------------------------------------------
+class _SoftmaxRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Z):
+        _need_gpu(Z)
+        Z = _rowmajor(Z)
+        Y = torch.empty(Z.shape, dtype=torch.float32, device=Z.device)
+        _lib.call("llmrec_softmax_rows_fwd_f32", Z.shape[0], Z.shape[1], _p(Z), _ld(Z), _p(Y), _ld(Y), _stream())
+        ctx.save_for_backward(Y)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        (Y,) = ctx.saved_tensors
+        dY = _rowmajor(dY)
+        dZ = torch.empty_like(Y)
+        _lib.call("llmrec_softmax_rows_bwd_f32", Y.shape[0], Y.shape[1], _p(Y), _ld(Y), _p(dY), _ld(dY), _p(dZ), _ld(dZ), _stream())
+        return dZ
+
+
+def softmax_rows(Z):
+    return _SoftmaxRows.apply(Z)
+
+
+# ---------------------------------------------------------------------------------------------
+# R6: fusion
+# ---------------------------------------------------------------------------------------------
+def _ptr_table(ts: Sequence[torch.Tensor]):
+    n = len(ts)
+    return (_c.c_void_p * max(n, 1))(*[t.data_ptr() for t in ts]), (_c.c_int64 * max(n, 1))(*[_ld(t) for t in ts])
+
+
+class _Fuse(torch.autograd.Function):
+    """out = mean_scale * sum(mean_terms) + sum_t rate_t * normalize(norm_terms[t])."""
+
+    @staticmethod
+    def forward(ctx, mean_scale, n_mean, rates, *terms):
+        _need_gpu(*terms)
+        terms = [_rowmajor(t) for t in terms]
+        mean_terms, norm_terms = terms[:n_mean], terms[n_mean:]
+        rows, d = terms[0].shape
+        out = torch.empty(rows, d, dtype=torch.float32, device=terms[0].device)
+        mp, ml = _ptr_table(mean_terms)
+        npt, nl = _ptr_table(norm_terms)
+        r = (_c.c_float * max(len(rates), 1))(*rates)
+        _lib.call("llmrec_fuse_fwd_f32", rows, d, float(mean_scale), len(mean_terms), mp, ml, len(norm_terms), npt, nl, r,
+                  _p(out), _ld(out), _stream())
+        ctx.mean_scale, ctx.n_mean, ctx.rates = float(mean_scale), n_mean, list(rates)
+        ctx.save_for_backward(*norm_terms)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        norm_terms = ctx.saved_tensors
+        dOut = _rowmajor(dOut)
+        rows, d = dOut.shape
+        d_mean = None
+        if ctx.n_mean:
+            d_mean = torch.empty(rows, d, dtype=torch.float32, device=dOut.device)
+            _lib.call("llmrec_axpy_f32", rows, d, ctx.mean_scale, None, _p(dOut), _ld(dOut), _p(d_mean), _ld(d_mean), 0, _stream())
+        d_terms = [torch.empty(rows, d, dtype=torch.float32, device=dOut.device) for _ in norm_terms]
+        if norm_terms:
+            npt, nl = _ptr_table(norm_terms)
+            dp, dl = _ptr_table(d_terms)
+            r = (_c.c_float * len(ctx.rates))(*ctx.rates)
+            _lib.call("llmrec_fuse_bwd_f32", rows, d, _p(dOut), _ld(dOut), len(norm_terms), npt, nl, r, dp, dl, 0, _stream())
+        return (None, None, None) + (d_mean,) * ctx.n_mean + tuple(d_terms)
+
+
+def fuse(mean_terms: List[torch.Tensor], norm_terms: List[torch.Tensor], rates: List[float]):
+    """Layer mean + normalise-and-add (reference Models.py:185-197)."""
+    if len(mean_terms) > CONST["LLMREC_MAX_TERMS"] or len(norm_terms) > CONST["LLMREC_MAX_TERMS"]:
+        raise RuntimeError("fuse: too many terms")
+    return _Fuse.apply(1.0 / max(len(mean_terms), 1), len(mean_terms), list(rates), *mean_terms, *norm_terms)
+
+
+# ---------------------------------------------------------------------------------------------
+# R7: BPR + prune
+# ---------------------------------------------------------------------------------------------
+class _BprPrune(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Eu, Ei, users, pos, neg, remember_rate, decay, batch_size_flag, n_valid):
+        _need_gpu(Eu, Ei, users, pos, neg)
+        Eu, Ei = _rowmajor(Eu), _rowmajor(Ei)
+        B = users.numel()
+        d = Eu.shape[1]
+        out = torch.empty(2, dtype=torch.float32, device=Eu.device)
+        saved = torch.empty(B + 4, dtype=torch.float32, device=Eu.device)
+        _lib.call("llmrec_bpr_prune_fwd_f32", _p(Eu), _ld(Eu), _p(Ei), _ld(Ei), d, _p(users), _p(pos), _p(neg), B, _p(n_valid),
+                  float(remember_rate), float(decay), float(batch_size_flag), _p(out), _p(saved), _stream())
+        ctx.save_for_backward(Eu, Ei, users, pos, neg, saved)
+        ctx.n_valid, ctx.decay, ctx.bsz = n_valid, float(decay), float(batch_size_flag)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Eu, Ei, users, pos, neg, saved = ctx.saved_tensors
+        g = g.contiguous()
+        dEu, dEi = torch.zeros_like(Eu), torch.zeros_like(Ei)
+        _lib.call("llmrec_bpr_prune_bwd_f32", _p(Eu), _ld(Eu), _p(Ei), _ld(Ei), Eu.shape[1], _p(users), _p(pos), _p(neg),
+                  users.numel(), _p(ctx.n_valid), ctx.decay, ctx.bsz, _p(saved), _p(g), _p(dEu), _ld(dEu), _p(dEi), _ld(dEi), _stream())
+        return dEu, dEi, None, None, None, None, None, None, None
+
+
+def bpr_prune(Eu, Ei, users, pos, neg, drop_rate: float, decay: float, batch_size_flag: float, n_valid=None):
+    """Returns a 2-vector [mf_loss, emb_loss] (reference main.py:330-342 with prune_loss :158-165).
+    users/pos/neg: int64 device vectors indexing rows of Eu / Ei."""
+    if users.dtype != torch.int64 or pos.dtype != torch.int64 or neg.dtype != torch.int64:
+        raise RuntimeError("bpr_prune: int64 index tensors expected")
+    if users.numel() > CONST["LLMREC_BPR_MAX_B"]:
+        raise RuntimeError("bpr_prune: batch of %d exceeds LLMREC_BPR_MAX_B" % users.numel())
+    remember = 1 - drop_rate                                       # python float, as main.py:161
+    return _BprPrune.apply(Eu, Ei, users, pos, neg, remember, decay, batch_size_flag, n_valid)
+
+
+# ---------------------------------------------------------------------------------------------
+# R8: regulariser
+# ---------------------------------------------------------------------------------------------
+class _SumSq(torch.autograd.Function):
+    """coef * sum_t ||X_t||_F^2 as a 1-element tensor."""
+
+    @staticmethod
+    def forward(ctx, coef, *Xs):
+        _need_gpu(*Xs)
+        Xs = [_rowmajor(x) for x in Xs]
+        out = torch.empty(1, dtype=torch.float32, device=Xs[0].device)
+        ws_bytes = _lib.query("llmrec_sumsq_workspace_bytes", 0, 0)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=Xs[0].device)
+        for k, x in enumerate(Xs):
+            _lib.call("llmrec_sumsq_f32", x.shape[0], x.shape[1], _p(x), _ld(x), float(coef), 1 if k else 0, _p(out), _p(ws), ws_bytes, _stream())
+        ctx.coef = float(coef)
+        ctx.save_for_backward(*Xs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        outs = []
+        for x in ctx.saved_tensors:
+            dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            _lib.call("llmrec_axpy_f32", x.shape[0], x.shape[1], 2.0 * ctx.coef, _p(g), _p(x), _ld(x), _p(dx), _ld(dx), 0, _stream())
+            outs.append(dx)
+        return (None,) + tuple(outs)
+
+
+def sumsq(coef: float, Xs: Sequence[torch.Tensor]):
+    return _SumSq.apply(coef, *Xs)
+
+
+# ---------------------------------------------------------------------------------------------
+# R8: AdamW
+# ---------------------------------------------------------------------------------------------
+class FusedAdamW:
+    """torch.optim.AdamW(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01) semantics as built
+    at reference main.py:100-104, one HIP launch per parameter, bias corrections kept on device
+    (graph-capturable). Parameters without a gradient are skipped, as torch does."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        self.params = [p for p in params]
+        self.lr, self.betas, self.eps, self.wd = float(lr), betas, float(eps), float(weight_decay)
+        self.state = {}
+        self.dev_state = None
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        live = [p for p in self.params if p.grad is not None]
+        if not live:
+            return
+        _need_gpu(*live)
+        if self.dev_state is None:
+            self.dev_state = torch.zeros(3, dtype=torch.float32, device=live[0].device)
+        _lib.call("llmrec_adamw_advance", _p(self.dev_state), self.lr, self.betas[0], self.betas[1], _stream())
+        for p in live:
+            st = self.state.get(p)
+            if st is None:
+                st = self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
+            if not p.is_contiguous():
+                raise RuntimeError("FusedAdamW: contiguous parameters expected")
+            g = p.grad.contiguous()
+            _lib.call("llmrec_adamw_f32", p.numel(), _p(p), _p(g), _p(st[0]), _p(st[1]), _p(self.dev_state), self.lr,
+                      self.betas[0], self.betas[1], self.eps, self.wd, _stream())
+
+
+# ---------------------------------------------------------------------------------------------
+# R9/R10: scoring + top-K, R11: sampler
+# ---------------------------------------------------------------------------------------------
+def score_topk(Eu, Ei, query_users: torch.Tensor, train: Optional[Csr], K: int):
+    """Masked top-K item ids (int32 [n_query, K], -1 = none) and scores for the listed users."""
+    _need_gpu(Eu, Ei, query_users)
+    Eu, Ei = _rowmajor(Eu.detach()), _rowmajor(Ei.detach())
+    q = query_users.to(torch.int64).contiguous()
+    n = q.numel()
+    idx = torch.empty(n, K, dtype=torch.int32, device=Eu.device)
+    sc = torch.empty(n, K, dtype=torch.float32, device=Eu.device)
+    _lib.call("llmrec_score_topk_f32", n, _p(q), _p(Eu), _ld(Eu), _p(Ei), _ld(Ei), Ei.shape[0], Eu.shape[1],
+              _p(train.rowptr) if train is not None else None, _p(train.colidx) if train is not None else None,
+              K, _p(idx), _p(sc), _stream())
+    return idx, sc
+
+
+def scores(Eu, Ei, query_users: torch.Tensor):
+    _need_gpu(Eu, Ei, query_users)
+    Eu, Ei = _rowmajor(Eu.detach()), _rowmajor(Ei.detach())
+    q = query_users.to(torch.int64).contiguous()
+    S = torch.empty(q.numel(), Ei.shape[0], dtype=torch.float32, device=Eu.device)
+    _lib.call("llmrec_scores_f32", q.numel(), _p(q), _p(Eu), _ld(Eu), _p(Ei), _ld(Ei), Ei.shape[0], Eu.shape[1], _p(S), _ld(S), _stream())
+    return S
+
+
+def topk_hits(topk_idx: torch.Tensor, query_users: torch.Tensor, test_rowptr: torch.Tensor, test_colidx: torch.Tensor):
+    q = query_users.to(torch.int64).contiguous()
+    hits = torch.empty(topk_idx.shape, dtype=torch.uint8, device=topk_idx.device)
+    _lib.call("llmrec_topk_hits", q.numel(), _p(q), topk_idx.shape[1], _p(topk_idx), _p(test_rowptr), _p(test_colidx), _p(hits), _stream())
+    return hits
+
+
+def sample_bpr(seed: int, step: int, exist_users: torch.Tensor, n_items: int, train: Csr, B: int):
+    dev = exist_users.device
+    u = torch.empty(B, dtype=torch.int64, device=dev)
+    p = torch.empty(B, dtype=torch.int64, device=dev)
+    n = torch.empty(B, dtype=torch.int64, device=dev)
+    _lib.call("llmrec_sample_bpr", seed, step, exist_users.numel(), _p(exist_users), n_items, _p(train.rowptr), _p(train.colidx),
+              B, _p(u), _p(p), _p(n), _stream())
+    return u, p, n

@@ -1,0 +1,285 @@
+"""Stage-2 driver with the reference's CLI, Trainer surface and log lines (reference main.py),
+running on the gfx950 HIP kernels of llmrec_amd.
+
+    python main.py --dataset netflix_valid_item --data_path ./data/ [reference flags ...]
+
+What differs from the reference, by design (results are unchanged):
+  * the graph is turned into device CSR once; the hot loop never touches COO tensors;
+  * each of the 8 BPR + prune losses per step is ONE kernel with on-device selection - the
+    reference copies the scores to the host and argsorts them there (main.py:159), 8 syncs/step;
+  * losses are accumulated on the device and read once per epoch (the reference calls float()
+    on four tensors every step, main.py:280-283);
+  * augmented_sample_dict is unpickled once, not every step (main.py:216);
+  * the two pickles the reference re-writes into the dataset directory at start-up
+    (main.py:66,78) are not written.
+Environment: LLMREC_DEVICE_SAMPLER=1 switches Data.sample() to the HIP sampler (not
+stream-compatible with the reference's host RNG; default keeps the reference's sample stream).
+"""
+from datetime import datetime
+import math
+import os
+import pickle
+import random
+import sys
+from time import time
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from utility.parser import parse_args
+from Models import MM_Model, Decoder
+from utility.batch_test import *          # data_generator, test_torch, Ks, ... (reference main.py:28)
+from utility.logging import Logger
+from llmrec_amd import engine, ops
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+args = parse_args()
+
+ATTRIBUTE_KEYS = {                                         # reference main.py:69-72
+    'preprocessed_raw_MovieLens': ['title', 'genre', 'director', 'country', 'language'],
+    'netflix_valid_item': ['year', 'title', 'director', 'country', 'language'],
+}
+
+
+def _progress(it):
+    try:
+        from tqdm import tqdm
+        return tqdm(it)
+    except Exception:
+        return it
+
+
+class Trainer(object):
+    def __init__(self, data_config):
+        self.task_name = "%s_%s_%s" % (datetime.now().strftime('%Y-%m-%d %H:%M:%S'), args.dataset, args.cf_model,)
+        self.logger = Logger(filename=self.task_name, is_debug=args.debug)
+        self.logger.logging("PID: %d" % os.getpid())
+        self.logger.logging(str(args))
+
+        self.mess_dropout = eval(args.mess_dropout)
+        self.lr = args.lr
+        self.emb_dim = args.embed_size
+        self.batch_size = args.batch_size
+        self.weight_size = eval(args.weight_size)
+        self.n_layers = len(self.weight_size)
+        self.regs = eval(args.regs)
+        self.decay = self.regs[0]
+
+        root = args.data_path + args.dataset
+        self.image_feats = np.load(root + '/image_feat.npy')
+        self.text_feats = np.load(root + '/text_feat.npy')
+        self.image_feat_dim = self.image_feats.shape[-1]
+        self.text_feat_dim = self.text_feats.shape[-1]
+        with open(root + '/train_mat', 'rb') as f:
+            self.ui_graph = self.ui_graph_raw = pickle.load(f)
+        with open(root + '/augmented_user_init_embedding', 'rb') as f:
+            user_emb = pickle.load(f)
+        self.user_init_embedding = np.array([user_emb[i] for i in range(len(user_emb))])
+        if args.dataset not in ATTRIBUTE_KEYS:             # the reference dies with a NameError here
+            raise ValueError("--dataset must be one of %s" % sorted(ATTRIBUTE_KEYS))
+        with open(root + '/augmented_atttribute_embedding_dict', 'rb') as f:
+            attr = pickle.load(f)
+        self.item_attribute_embedding = {key: [] for key in ATTRIBUTE_KEYS[args.dataset]}
+        for key in attr.keys():
+            self.item_attribute_embedding[key] = np.array([attr[key][i] for i in range(len(attr[key]))])
+        with open(root + '/augmented_sample_dict', 'rb') as f:
+            self.augmented_sample_dict = pickle.load(f)
+
+        self.n_users, self.n_items = self.ui_graph.shape
+        self.iu_graph = self.ui_graph.T
+        self.ui_graph = self.matrix_to_tensor(self.csr_norm(self.ui_graph, mean_flag=True))
+        self.iu_graph = self.matrix_to_tensor(self.csr_norm(self.iu_graph, mean_flag=True))
+        self.image_ui_graph = self.text_ui_graph = self.ui_graph
+        self.image_iu_graph = self.text_iu_graph = self.iu_graph
+
+        self.model_mm = MM_Model(self.n_users, self.n_items, self.emb_dim, self.weight_size, self.mess_dropout,
+                                 self.image_feats, self.text_feats, self.user_init_embedding, self.item_attribute_embedding)
+        self.model_mm = self.model_mm.to(device)
+        self.decoder = Decoder(self.user_init_embedding.shape[1]).to(device)
+
+        # torch.optim.AdamW(lr) defaults (betas .9/.999, eps 1e-8, weight_decay 0.01), fused HIP kernel
+        self.optimizer = ops.FusedAdamW(self.model_mm.parameters(), lr=self.lr)
+        self.de_optimizer = torch.optim.AdamW([{'params': self.decoder.parameters()}], lr=args.de_lr)   # never stepped
+        self.hyper = engine.Hyper.from_args(args)
+        self._on_bpr = None                                   # test hook: called with (mf, emb) of each BPR call
+        self._device_sampler = os.environ.get("LLMREC_DEVICE_SAMPLER", "0") == "1"
+        self._global_step = 0
+
+    # -- graph helpers (same arithmetic as the reference, host side, once) -----------------------
+    def csr_norm(self, csr_mat, mean_flag=False):
+        def inv_sqrt(total):
+            s = np.power(np.array(total) + 1e-8, -0.5).flatten()
+            s[np.isinf(s)] = 0.
+            return sp.diags(s)
+        left = inv_sqrt(csr_mat.sum(1))
+        if mean_flag:
+            return left * csr_mat
+        return left * csr_mat * inv_sqrt(csr_mat.sum(0))
+
+    def matrix_to_tensor(self, cur_matrix):
+        coo = cur_matrix if isinstance(cur_matrix, sp.coo_matrix) else cur_matrix.tocoo()
+        indices = torch.from_numpy(np.vstack((coo.row, coo.col)).astype(np.int64))
+        values = torch.from_numpy(coo.data)
+        return torch.sparse_coo_tensor(indices, values, torch.Size(coo.shape)).to(torch.float32).to(device)
+
+    # -- losses -----------------------------------------------------------------------------------
+    def feat_reg_loss_calculation(self, g_item_image, g_item_text, g_user_image, g_user_text):
+        coef = args.feat_reg_decay * 0.5 / self.n_items
+        return ops.sumsq(coef, [g_item_image, g_item_text, g_user_image, g_user_text])[0]
+
+    def prune_loss(self, pred, drop_rate):
+        """Mean of the int((1-drop)*B) smallest entries. The training loop does not call this:
+        selection is fused into the BPR kernel (ops.bpr_prune). Kept for the reference surface."""
+        keep = int((1 - drop_rate) * len(pred))
+        order = torch.argsort(pred.detach(), stable=True)
+        return pred[order[:keep]].mean()
+
+    def _bpr(self, user_table, item_table, users, pos_items, neg_items):
+        mf, emb = engine.bpr(self.hyper, user_table, item_table, users, pos_items, neg_items)
+        return mf, emb, 0.0
+
+    def bpr_loss(self, users, pos_items, neg_items):
+        """Reference signature: three gathered [B, d] blocks -> (mf_loss, emb_loss, reg_loss)."""
+        B = users.shape[0]
+        idx = torch.arange(B, dtype=torch.int64, device=users.device)
+        return self._bpr(users, torch.cat([pos_items, neg_items], dim=0), idx, idx, idx + B)
+
+    def sce_criterion(self, x, y, alpha=1):
+        x, y = F.normalize(x, p=2, dim=-1), F.normalize(y, p=2, dim=-1)
+        return (1 - (x * y).sum(dim=-1)).pow_(alpha).mean()
+
+    def mse_criterion(self, x, y, alpha=3):
+        return F.mse_loss(F.normalize(x, p=2, dim=-1), F.normalize(y, p=2, dim=-1))
+
+    # -- evaluation -------------------------------------------------------------------------------
+    def test(self, users_to_test, is_val):
+        self.model_mm.eval()
+        with torch.no_grad():
+            ua_embeddings, ia_embeddings, *rest = self.model_mm(self.ui_graph, self.iu_graph, self.image_ui_graph,
+                                                                self.image_iu_graph, self.text_ui_graph, self.text_iu_graph)
+        return test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val)
+
+    # -- one step ---------------------------------------------------------------------------------
+    def sample_batch(self):
+        """(users, pos, neg) int64 device tensors incl. the LLM-augmented triples (main.py:213-224)."""
+        if self._device_sampler:
+            u, p, n = data_generator.sample_device(args.seed, self._global_step, device)
+            users = u.tolist()
+        else:
+            users, pos_items, neg_items = data_generator.sample()
+        aug = self.augmented_sample_dict
+        users_aug = random.sample(users, int(len(users) * args.aug_sample_rate))
+        users_aug = [u_ for u_ in users_aug if (aug[u_][0] < self.n_items and aug[u_][1] < self.n_items)]
+        self.new_batch_size = len(users_aug)
+        pos_aug = [aug[u_][0] for u_ in users_aug]
+        neg_aug = [aug[u_][1] for u_ in users_aug]
+        if self._device_sampler:
+            extra = torch.tensor([users_aug, pos_aug, neg_aug], dtype=torch.int64).reshape(3, -1).to(device)
+            return torch.cat([u, extra[0]]), torch.cat([p, extra[1]]), torch.cat([n, extra[2]])
+        packed = torch.tensor([users + users_aug, pos_items + pos_aug, neg_items + neg_aug], dtype=torch.int64).to(device)
+        return packed[0], packed[1], packed[2]
+
+    def train_step(self, users, pos_items, neg_items, n_valid=None):
+        """Forward, the 8 BPR(+prune) losses, feature regulariser, backward, AdamW
+        (llmrec_amd/engine.py). Returns the device scalars (batch_loss, mf_loss, emb_loss)."""
+        out = engine.train_step(self.model_mm, self.optimizer, self.ui_graph, self.iu_graph, users, pos_items, neg_items,
+                                self.hyper, n_valid=n_valid, on_bpr=self._on_bpr,
+                                extra_loss=self._mask_loss if args.mask else None)
+        # (the reference calls clip_grad_norm_ before zero_grad(), on gradients that are then
+        #  discarded, main.py:274-275 - it has no effect on the update and is omitted)
+        self._global_step += 1
+        return out
+
+    def _mask_loss(self, fw):
+        """Attribute-restoration term (reference main.py:258-271); off unless --mask."""
+        user_prof_feat, item_att_feats, i_mask_nodes, u_mask_nodes = fw[8], fw[11], fw[12], fw[13]
+        input_i = {value: item_att_feats[value][i_mask_nodes] for value in item_att_feats.keys()}
+        decoded_u, decoded_i = self.decoder(user_prof_feat[u_mask_nodes], input_i)
+        crit = self.mse_criterion if args.feat_loss_type == 'mse' else self.sce_criterion
+        loss = crit(decoded_u, torch.as_tensor(self.user_init_embedding[u_mask_nodes]).float().to(device), alpha=args.alpha_l)
+        for index, value in enumerate(item_att_feats.keys()):
+            target = torch.as_tensor(self.item_attribute_embedding[value][i_mask_nodes]).float().to(device)
+            loss = loss + crit(decoded_i[index], target, alpha=args.alpha_l)
+        return args.att_re_rate * loss
+
+    def train(self):
+        now_time = datetime.now()
+        run_time = datetime.strftime(now_time, '%Y_%m_%d__%H_%M_%S')
+        training_time_list = []
+        stopping_step = 0
+        best_recall = 0
+        test_ret = None
+        for epoch in range(args.epoch):
+            t1 = time()
+            n_batch = data_generator.n_train // args.batch_size + 1
+            sums = torch.zeros(3, dtype=torch.float64, device=device)
+            sample_time = 0.
+            for idx in _progress(range(n_batch)):
+                sample_t1 = time()
+                users, pos_items, neg_items = self.sample_batch()
+                sample_time += time() - sample_t1
+                parts = self.train_step(users, pos_items, neg_items)
+                sums += torch.stack(parts).double()
+            loss, mf_loss, emb_loss = (float(x) for x in sums.cpu())     # one sync per epoch
+            reg_loss, contrastive_loss = 0., 0.
+
+            if math.isnan(loss):
+                self.logger.logging('ERROR: loss is nan.')
+                sys.exit()
+
+            if (epoch + 1) % args.verbose != 0:
+                perf_str = 'Epoch %d [%.1fs]: train==[%.5f=%.5f + %.5f + %.5f  + %.5f]' % (
+                    epoch, time() - t1, loss, mf_loss, emb_loss, reg_loss, contrastive_loss)
+                training_time_list.append(time() - t1)
+                self.logger.logging(perf_str)
+
+            t2 = time()
+            users_to_test = list(data_generator.test_set.keys())
+            ret = self.test(users_to_test, is_val=False)
+            training_time_list.append(t2 - t1)
+            t3 = time()
+
+            if args.verbose > 0:
+                perf_str = 'Epoch %d [%.1fs + %.1fs]: train==[%.5f=%.5f + %.5f + %.5f], recall=[%.5f, %.5f, %.5f, %.5f], ' \
+                           'precision=[%.5f, %.5f, %.5f, %.5f], hit=[%.5f, %.5f, %.5f, %.5f], ndcg=[%.5f, %.5f, %.5f, %.5f]' % \
+                           (epoch, t2 - t1, t3 - t2, loss, mf_loss, emb_loss, reg_loss,
+                            ret['recall'][0], ret['recall'][1], ret['recall'][2], ret['recall'][-1],
+                            ret['precision'][0], ret['precision'][1], ret['precision'][2], ret['precision'][-1],
+                            ret['hit_ratio'][0], ret['hit_ratio'][1], ret['hit_ratio'][2], ret['hit_ratio'][-1],
+                            ret['ndcg'][0], ret['ndcg'][1], ret['ndcg'][2], ret['ndcg'][-1])
+                self.logger.logging(perf_str)
+
+            if ret['recall'][1] > best_recall:
+                best_recall = ret['recall'][1]
+                test_ret = self.test(users_to_test, is_val=False)
+                self.logger.logging("Test_Recall@%d: %.5f,  precision=[%.5f], ndcg=[%.5f]" % (
+                    eval(args.Ks)[1], test_ret['recall'][1], test_ret['precision'][1], test_ret['ndcg'][1]))
+                stopping_step = 0
+            elif stopping_step < args.early_stopping_patience:
+                stopping_step += 1
+                self.logger.logging('#####Early stopping steps: %d #####' % stopping_step)
+            else:
+                self.logger.logging('#####Early stop! #####')
+                break
+        self.logger.logging(str(test_ret))
+        return best_recall, run_time
+
+
+def set_seed(seed):
+    np.random.seed(seed)
+    random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+if __name__ == '__main__':
+    set_seed(args.seed)
+    config = dict()
+    config['n_users'] = data_generator.n_users
+    config['n_items'] = data_generator.n_items
+    trainer = Trainer(data_config=config)
+    trainer.train()

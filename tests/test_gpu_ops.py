@@ -1,0 +1,370 @@
+"""GPU parity: every HIP entry point (called through the C ABI via llmrec_amd.ops) against the
+CPU oracle (oracle/oracle.py) or the ATen op the reference calls, on the same seeded inputs.
+Tolerances: fp32 results 1e-4 relative (north_star) - asserted tighter where the arithmetic
+allows; index lists bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from llmrec_amd import ops as _ops
+    return _ops
+
+
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def rand_graph(rng, n_rows, n_cols, degs):
+    rows = np.repeat(np.arange(n_rows), degs)
+    cols = np.concatenate([rng.choice(n_cols, size=d, replace=False) for d in degs]) if rows.size else np.zeros(0, dtype=np.int64)
+    return rows.astype(np.int64), cols.astype(np.int64)
+
+
+def degree_mix(rng, n_rows, n_cols):
+    """Empty rows, short rows, rows just around the long-row / segment boundaries, hubs."""
+    degs = rng.integers(0, 12, size=n_rows)
+    special = [0, 1, 127, 128, 129, 255, 256, 257, 511, 513, min(n_cols, 1500)]
+    for k, d in enumerate(special):
+        degs[(k * 7) % n_rows] = min(d, n_cols)
+    return degs
+
+
+# ------------------------------------------------------------------------------------------
+# R1 graph ingest
+# ------------------------------------------------------------------------------------------
+def test_csr_build_matches_scipy(ops):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(0)
+    n_rows, n_cols = 300, 2000
+    rows, cols = rand_graph(rng, n_rows, n_cols, degree_mix(rng, n_rows, n_cols))
+    perm = rng.permutation(rows.size)                    # unsorted COO in
+    rows, cols = rows[perm], cols[perm]
+    vals = rng.standard_normal(rows.size).astype(np.float32)
+    rp, ci, v = ops.csr_from_coo(torch.from_numpy(rows).to(DEV), torch.from_numpy(cols).to(DEV), torch.from_numpy(vals).to(DEV), n_rows, n_cols)
+    ref = sp.csr_matrix((vals, (rows, cols)), shape=(n_rows, n_cols))
+    ref.sort_indices()
+    assert np.array_equal(rp.cpu().numpy(), ref.indptr)
+    assert np.array_equal(ci.cpu().numpy(), ref.indices)
+    assert np.array_equal(v.cpu().numpy(), ref.data)
+    # pattern-only, with duplicate edges kept, and the transpose via swapped arguments
+    rows2 = np.concatenate([rows, rows[:50]]); cols2 = np.concatenate([cols, cols[:50]])
+    rp2, ci2, _ = ops.csr_from_coo(torch.from_numpy(cols2).to(DEV), torch.from_numpy(rows2).to(DEV), None, n_cols, n_rows)
+    order = np.lexsort((rows2, cols2))
+    assert np.array_equal(ci2.cpu().numpy(), rows2[order])
+    assert np.array_equal(rp2.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(cols2, minlength=n_cols))]))
+    # empty graph
+    rp3, ci3, _ = ops.csr_from_coo(torch.zeros(0, dtype=torch.int64, device=DEV), torch.zeros(0, dtype=torch.int64, device=DEV), None, 5, 5)
+    assert rp3.cpu().tolist() == [0] * 6 and ci3.numel() == 0
+
+
+def test_degree_scale_matches_reference_formula(ops):
+    degs = np.array([0, 1, 2, 3, 7, 100, 12345], dtype=np.int64)
+    rp = torch.tensor(np.concatenate([[0], np.cumsum(degs)]), dtype=torch.int32, device=DEV)
+    got = ops.degree_scale(rp).cpu().numpy()
+    want = np.power(degs.astype(np.float32) + 1e-8, -0.5).astype(np.float32)     # reference main.py:115-116 on fp32 sums
+    want[degs == 0] = 0
+    assert np.allclose(got, want, rtol=1.3e-7, atol=0)
+
+
+# ------------------------------------------------------------------------------------------
+# R2 SpMM forward / backward
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [64, 16, 128, 448, 20, 4])
+def test_spmm_forward_backward_vs_torch_sparse(ops, d):
+    rng = np.random.default_rng(d)
+    n_rows, n_cols = 257, 1600
+    rows, cols = rand_graph(rng, n_rows, n_cols, degree_mix(rng, n_rows, n_cols))
+    deg = np.bincount(rows, minlength=n_rows)
+    s = np.where(deg > 0, 1.0 / np.sqrt(np.maximum(deg, 1)), 0).astype(np.float32)
+    vals = s[rows]                                           # the reference's diag(s) R
+    A_cpu = torch.sparse_coo_tensor(torch.tensor(np.vstack([rows, cols])), torch.tensor(vals), (n_rows, n_cols))
+    X_cpu = torch.tensor(rng.standard_normal((n_cols, d)).astype(np.float32), requires_grad=True)
+    Y_cpu = torch.sparse.mm(A_cpu, X_cpu)
+    G = torch.tensor(rng.standard_normal((n_rows, d)).astype(np.float32))
+    Y_cpu.backward(G)
+
+    A = A_cpu.to(DEV)
+    op = ops.operand_from_sparse_tensor(A)
+    assert op.fwd.val is None and op.fwd.row_scale is not None      # row-constant values detected
+    assert op.fwd.plan.n_long >= 5
+    X = X_cpu.detach().to(DEV).requires_grad_(True)
+    Y = ops.spmm(A, X)
+    Y.backward(G.to(DEV))
+    assert rel_err(Y.detach().cpu(), Y_cpu.detach()) < 2e-6
+    assert rel_err(X.grad.cpu(), X_cpu.grad) < 2e-6
+    # deterministic run to run (no float atomics in the SpMM)
+    assert torch.equal(ops.spmm(A, X).detach(), Y.detach())
+
+
+def test_spmm_general_values_and_strided_operands(ops):
+    rng = np.random.default_rng(5)
+    n_rows, n_cols, d = 120, 900, 64
+    rows, cols = rand_graph(rng, n_rows, n_cols, degree_mix(rng, n_rows, n_cols))
+    vals = rng.standard_normal(rows.size).astype(np.float32)
+    A_cpu = torch.sparse_coo_tensor(torch.tensor(np.vstack([rows, cols])), torch.tensor(vals), (n_rows, n_cols))
+    big = torch.tensor(rng.standard_normal((n_cols, 3 * d)).astype(np.float32))
+    X_cpu = big[:, d:2 * d].clone().requires_grad_(True)
+    Y_cpu = torch.sparse.mm(A_cpu, X_cpu)
+    Y_cpu.sum().backward()
+    op = ops.operand_from_sparse_tensor(A_cpu.to(DEV))
+    assert op.fwd.val is not None
+    Xg = big.to(DEV)[:, d:2 * d]                              # ld = 3 d view, no copy
+    Xg.requires_grad_(True)
+    Y = ops.spmm(op, Xg)
+    Y.sum().backward()
+    assert rel_err(Y.detach().cpu(), Y_cpu.detach()) < 2e-6
+    assert rel_err(Xg.grad.cpu(), X_cpu.grad) < 2e-6
+
+
+def test_bipartite_graph_matches_oracle_normalisation(ops):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(9)
+    U, I, d = 150, 400, 64
+    rows, cols = rand_graph(rng, U, I, rng.integers(0, 30, size=U))
+    R = sp.csr_matrix((np.ones(rows.size, dtype=np.float32), (rows, cols)), shape=(U, I))
+    a_ui, a_iu = O.normalized_graphs(R)
+    g = ops.BipartiteGraph.from_edges(torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV), U, I)
+    Xi = torch.tensor(rng.standard_normal((I, d)).astype(np.float32))
+    Xu = torch.tensor(rng.standard_normal((U, d)).astype(np.float32))
+    assert rel_err(ops.spmm(g.ui, Xi.to(DEV)).cpu(), torch.sparse.mm(a_ui, Xi)) < 2e-6
+    assert rel_err(ops.spmm(g.iu, Xu.to(DEV)).cpu(), torch.sparse.mm(a_iu, Xu)) < 2e-6
+    assert rel_err(ops.spmm_raw(g.ui.bwd, Xu.to(DEV)).cpu(), torch.sparse.mm(a_ui.t(), Xu)) < 2e-6
+    assert rel_err(ops.spmm_raw(g.iu.bwd, Xi.to(DEV)).cpu(), torch.sparse.mm(a_iu.t(), Xi)) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------
+# R4 projection
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N", [(1000, 512, 64), (333, 24, 64), (97, 56, 16), (70000, 64, 64), (50, 1536, 64), (129, 40, 128)])
+def test_linear_forward_and_weight_grad(ops, M, K, N):
+    rng = np.random.default_rng(M + K)
+    X = torch.tensor(rng.standard_normal((M, K)).astype(np.float32))
+    W = torch.tensor((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32), requires_grad=True)
+    b = torch.tensor(rng.standard_normal(N).astype(np.float32), requires_grad=True)
+    G = torch.tensor(rng.standard_normal((M, N)).astype(np.float32))
+    Y = F.linear(X, W, b)
+    Y.backward(G)
+    Wg = W.detach().to(DEV).requires_grad_(True)
+    bg = b.detach().to(DEV).requires_grad_(True)
+    Yg = ops.linear(X.to(DEV), Wg, bg)
+    Yg.backward(G.to(DEV))
+    assert rel_err(Yg.detach().cpu(), Y.detach()) < 5e-6
+    assert rel_err(Wg.grad.cpu(), W.grad) < 2e-5
+    assert rel_err(bg.grad.cpu(), b.grad) < 2e-5
+
+
+def test_linear_multi_shares_one_weight(ops):
+    rng = np.random.default_rng(3)
+    M, K, N = 300, 56, 64
+    Xs = [torch.tensor(rng.standard_normal((M, K)).astype(np.float32)) for _ in range(5)]
+    W = torch.tensor(rng.standard_normal((N, K)).astype(np.float32), requires_grad=True)
+    b = torch.tensor(rng.standard_normal(N).astype(np.float32), requires_grad=True)
+    Gs = [torch.tensor(rng.standard_normal((M, N)).astype(np.float32)) for _ in range(5)]
+    sum((F.linear(x, W, b) * g).sum() for x, g in zip(Xs, Gs)).backward()
+    Wg = W.detach().to(DEV).requires_grad_(True); bg = b.detach().to(DEV).requires_grad_(True)
+    outs = ops.linear_multi(Wg, bg, [x.to(DEV) for x in Xs])
+    sum((o * g.to(DEV)).sum() for o, g in zip(outs, Gs)).backward()
+    assert rel_err(Wg.grad.cpu(), W.grad) < 2e-5
+    assert rel_err(bg.grad.cpu(), b.grad) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------
+# R3 / R6 row ops
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [64, 16, 128, 20])
+def test_softmax_rows(ops, d):
+    rng = np.random.default_rng(d)
+    Z = torch.tensor((rng.standard_normal((211, d)) * 3).astype(np.float32), requires_grad=True)
+    G = torch.tensor(rng.standard_normal((211, d)).astype(np.float32))
+    Y = torch.softmax(Z, dim=-1); Y.backward(G)
+    Zg = Z.detach().to(DEV).requires_grad_(True)
+    Yg = ops.softmax_rows(Zg); Yg.backward(G.to(DEV))
+    assert rel_err(Yg.detach().cpu(), Y.detach()) < 2e-6
+    assert rel_err(Zg.grad.cpu(), Z.grad) < 1e-5
+
+
+@pytest.mark.parametrize("d", [64, 16, 128])
+def test_fuse_mean_normalize_add(ops, d):
+    rng = np.random.default_rng(d + 1)
+    rows = 203
+    means = [torch.tensor(rng.standard_normal((rows, d)).astype(np.float32), requires_grad=True) for _ in range(3)]
+    norms = [torch.tensor(rng.standard_normal((rows, d)).astype(np.float32), requires_grad=True) for _ in range(8)]
+    with torch.no_grad():
+        norms[2][5] = 0.0                                   # a zero row: F.normalize's eps clamp
+    rates = [0.02, 0.02, 2.8] + [0.005] * 5
+    G = torch.tensor(rng.standard_normal((rows, d)).astype(np.float32))
+    out = torch.mean(torch.stack(means), dim=0)
+    for r, t in zip(rates, norms):
+        out = out + r * F.normalize(t, p=2, dim=1)
+    out.backward(G)
+    mg = [m.detach().to(DEV).requires_grad_(True) for m in means]
+    ng = [n.detach().to(DEV).requires_grad_(True) for n in norms]
+    og = ops.fuse(mg, ng, rates)
+    og.backward(G.to(DEV))
+    assert rel_err(og.detach().cpu(), out.detach()) < 2e-6
+    for a, b in zip(mg + ng, means + norms):
+        assert rel_err(a.grad.cpu(), b.grad) < 2e-5
+
+
+def test_sumsq_and_adamw(ops):
+    rng = np.random.default_rng(2)
+    Xs = [torch.tensor(rng.standard_normal(s).astype(np.float32), requires_grad=True) for s in [(100, 64), (333, 64), (7, 16)]]
+    coef = 1e-5 * 0.5 / 80
+    ref = sum(coef * (x ** 2).sum() for x in Xs); ref.backward()
+    Xg = [x.detach().to(DEV).requires_grad_(True) for x in Xs]
+    got = ops.sumsq(coef, Xg)[0]; got.backward()
+    assert abs(float(got) - float(ref)) <= 2e-6 * abs(float(ref))
+    for a, b in zip(Xg, Xs):
+        assert rel_err(a.grad.cpu(), b.grad) < 1e-6
+    # AdamW: 5 steps against torch.optim.AdamW with the reference's construction (lr only)
+    p_ref = torch.nn.Parameter(torch.tensor(rng.standard_normal((50, 64)).astype(np.float32)))
+    p_gpu = torch.nn.Parameter(p_ref.detach().clone().to(DEV))
+    o_ref = torch.optim.AdamW([{'params': [p_ref]}], lr=1e-4)
+    o_gpu = ops.FusedAdamW([p_gpu], lr=1e-4)
+    for step in range(5):
+        g = torch.tensor(rng.standard_normal((50, 64)).astype(np.float32)) * (10.0 ** (step - 2))
+        p_ref.grad = g.clone(); p_gpu.grad = g.to(DEV)
+        o_ref.step(); o_gpu.step()
+        assert rel_err(p_gpu.detach().cpu(), p_ref.detach()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------
+# R7 BPR + prune
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("drop,B,d", [(0.71, 1126, 64), (0.0, 1024, 64), (0.71, 35, 16), (0.5, 2048, 128), (0.999, 40, 64)])
+def test_bpr_prune_forward_backward(ops, drop, B, d):
+    rng = np.random.default_rng(B)
+    U, I = 300, 500
+    Eu = torch.tensor((rng.standard_normal((U, d)) * 0.3).astype(np.float32), requires_grad=True)
+    Ei = torch.tensor((rng.standard_normal((I, d)) * 0.3).astype(np.float32), requires_grad=True)
+    users = torch.tensor(rng.integers(0, U, size=B)); pos = torch.tensor(rng.integers(0, I, size=B)); neg = torch.tensor(rng.integers(0, I, size=B))
+    cfg = O.Config(batch_size=1024, decay=1e-5, prune_loss_drop_rate=drop)
+    mf, emb = O.bpr_loss(Eu[users], Ei[pos], Ei[neg], cfg)
+    (0.7 * mf + 1.3 * emb).backward()
+    Eug = Eu.detach().to(DEV).requires_grad_(True); Eig = Ei.detach().to(DEV).requires_grad_(True)
+    out = ops.bpr_prune(Eug, Eig, users.to(DEV), pos.to(DEV), neg.to(DEV), drop, 1e-5, 1024)
+    (0.7 * out[0] + 1.3 * out[1]).backward()
+    if int((1 - drop) * B) == 0:
+        assert np.isnan(float(out[0])) and np.isnan(float(mf))
+        return
+    assert abs(float(out[0]) - float(mf)) < 2e-6 * abs(float(mf))
+    assert abs(float(out[1]) - float(emb)) < 2e-6 * abs(float(emb))
+    assert rel_err(Eug.grad.cpu(), Eu.grad) < 2e-5
+    assert rel_err(Eig.grad.cpu(), Ei.grad) < 2e-5
+
+
+def test_bpr_device_batch_count(ops):
+    """n_valid on the device (graph-replay path): padding entries beyond it are ignored."""
+    rng = np.random.default_rng(4)
+    U, I, d, B, Bmax = 100, 120, 64, 70, 96
+    Eu = torch.tensor(rng.standard_normal((U, d)).astype(np.float32) * 0.2)
+    Ei = torch.tensor(rng.standard_normal((I, d)).astype(np.float32) * 0.2)
+    idx = [torch.tensor(rng.integers(0, n, size=Bmax)) for n in (U, I, I)]
+    cfg = O.Config(batch_size=64, decay=1e-5, prune_loss_drop_rate=0.71)
+    mf, emb = O.bpr_loss(Eu[idx[0][:B]], Ei[idx[1][:B]], Ei[idx[2][:B]], cfg)
+    nv = torch.tensor([B], dtype=torch.int32, device=DEV)
+    out = ops.bpr_prune(Eu.to(DEV), Ei.to(DEV), idx[0].to(DEV), idx[1].to(DEV), idx[2].to(DEV), 0.71, 1e-5, 64, n_valid=nv)
+    assert abs(float(out[0]) - float(mf)) < 2e-6 * abs(float(mf))
+    assert abs(float(out[1]) - float(emb)) < 2e-6 * abs(float(emb))
+
+
+# ------------------------------------------------------------------------------------------
+# R9/R10 scoring + top-K
+# ------------------------------------------------------------------------------------------
+def _train_csr(ops, train_items, U, I):
+    rows = np.concatenate([np.full(len(v), u) for u, v in train_items.items()] + [np.zeros(0)]).astype(np.int64)
+    cols = np.concatenate([np.asarray(v) for v in train_items.values()] + [np.zeros(0)]).astype(np.int64)
+    rp, ci, _ = ops.csr_from_coo(torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV), None, U, I)
+    return ops.Csr(U, I, rp, ci, None, None, None, ops.SpmmPlan(0, 0, None, None, None))
+
+
+@pytest.mark.parametrize("U,I,d,K", [(150, 1000, 64, 50), (70, 130, 16, 50), (33, 64, 64, 20), (200, 777, 128, 64), (10, 45, 64, 50)])
+def test_score_topk_lists_bit_exact(ops, U, I, d, K):
+    rng = np.random.default_rng(U + I)
+    Eu = rng.standard_normal((U, d)).astype(np.float32)
+    Ei = rng.standard_normal((I, d)).astype(np.float32)
+    train_items = {u: sorted(rng.choice(I, size=int(rng.integers(0, min(I - 1, 40))), replace=False).tolist()) for u in range(U)}
+    train_items[0] = sorted(rng.choice(I, size=I - 7, replace=False).tolist())        # fewer than K candidates
+    train_items[1] = []
+    users = rng.permutation(U)[: U - 3]
+    Eug, Eig = torch.tensor(Eu).to(DEV), torch.tensor(Ei).to(DEV)
+    q = torch.tensor(users).to(DEV)
+    S = ops.scores(Eug, Eig, q).cpu().numpy()
+    # the MFMA scores are the documented k-ordered fp32 fma chain
+    chain = O.scores_fma_chain(Eu[users], Ei, order="mfma16x16x4")
+    assert np.array_equal(S, chain), "MFMA score arithmetic differs from the documented fma chain"
+    assert rel_err(S, Eu[users].astype(np.float64) @ Ei.astype(np.float64).T) < 1e-5
+    idx, sc = ops.score_topk(Eug, Eig, q, _train_csr(ops, train_items, U, I), K)
+    idx, sc = idx.cpu().numpy(), sc.cpu().numpy()
+    for row, u in enumerate(users):
+        want = O.rank_topk_np(S[row], train_items[u], K)
+        got = idx[row][idx[row] >= 0]
+        assert np.array_equal(got, want), (row, u)
+        assert np.array_equal(sc[row][: len(want)], S[row][want])
+        assert np.all(idx[row][len(want):] == -1)
+
+
+def test_score_topk_exact_ties_follow_reference_rule(ops):
+    """Integer-valued embeddings: every score is exact in any summation order, so ties are real
+    and the list must equal the reference's heapq ranking (score desc, item id asc)."""
+    rng = np.random.default_rng(11)
+    U, I, d, K = 64, 500, 64, 50
+    Eu = rng.integers(-2, 3, size=(U, d)).astype(np.float32)
+    Ei = rng.integers(-1, 2, size=(I, d)).astype(np.float32)
+    train_items = {u: sorted(rng.choice(I, size=20, replace=False).tolist()) for u in range(U)}
+    S_ref = (torch.tensor(Eu) @ torch.tensor(Ei).t()).numpy()                     # the reference's GEMM, exact here
+    idx, _ = ops.score_topk(torch.tensor(Eu).to(DEV), torch.tensor(Ei).to(DEV), torch.arange(U).to(DEV),
+                            _train_csr(ops, train_items, U, I), K)
+    idx = idx.cpu().numpy()
+    for u in range(U):
+        assert idx[u].tolist() == O.rank_topk(S_ref[u], train_items[u], K), u
+
+
+def test_topk_hits(ops):
+    rng = np.random.default_rng(1)
+    U, I, K = 40, 300, 50
+    test = {u: sorted(rng.choice(I, size=int(rng.integers(1, 5)), replace=False).tolist()) for u in range(U)}
+    topk = np.stack([rng.permutation(I)[:K] for _ in range(U)]).astype(np.int32)
+    topk[3, 40:] = -1
+    csr = _train_csr(ops, test, U, I)
+    hits = ops.topk_hits(torch.tensor(topk).to(DEV), torch.arange(U).to(DEV), csr.rowptr, csr.colidx).cpu().numpy()
+    want = np.array([[1 if (i >= 0 and i in set(test[u])) else 0 for i in topk[u]] for u in range(U)])
+    assert np.array_equal(hits, want)
+
+
+# ------------------------------------------------------------------------------------------
+# R11 device sampler
+# ------------------------------------------------------------------------------------------
+def test_device_sampler_properties(ops):
+    rng = np.random.default_rng(6)
+    U, I, B = 500, 300, 256
+    train_items = {u: sorted(rng.choice(I, size=int(rng.integers(1, 60)), replace=False).tolist()) for u in range(0, U, 2)}
+    csr = _train_csr(ops, train_items, U, I)
+    exist = torch.tensor(sorted(train_items), dtype=torch.int64, device=DEV)
+    seen_users = set()
+    for step in range(4):
+        u, p, n = (t.cpu().tolist() for t in ops.sample_bpr(2022, step, exist, I, csr, B))
+        assert len(set(u)) == B                                # without replacement (rd.sample)
+        for uu, pp, nn_ in zip(u, p, n):
+            assert uu in train_items and pp in train_items[uu] and nn_ not in train_items[uu] and 0 <= nn_ < I
+        seen_users.update(u)
+    assert len(seen_users) >= len(train_items) - 5             # 4 x 256 draws from 250 users covers ~all of them
+    a = ops.sample_bpr(2022, 1, exist, I, csr, B); b = ops.sample_bpr(2022, 1, exist, I, csr, B)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))       # counter-based: reproducible
+    # B > n_exist -> with replacement
+    u, _, _ = ops.sample_bpr(1, 0, exist[:50], I, csr, 128)
+    assert u.numel() == 128 and set(u.cpu().tolist()) <= set(exist[:50].cpu().tolist())

@@ -1,0 +1,93 @@
+"""CPU tests of the host side: C-ABI symbols, CLI surface, dataset container, metrics,
+drop-in initialisation (no compute call is made without a GPU)."""
+import ctypes
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from llmrec_amd import _lib
+from tests._dropin import load_dropin, golden_argv
+
+
+def test_library_exports_every_header_symbol():
+    protos = _lib.parse_header()
+    assert len(protos) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(lib, name), name
+    lib2 = _lib.load()
+    assert lib2.llmrec_abi_version() == _lib.CONST["LLMREC_ABI_VERSION"]
+    assert lib2.llmrec_status_string(-3) == b"workspace too small"
+
+
+def test_workspace_queries_run_without_gpu():
+    assert _lib.query("llmrec_csr_build_workspace_bytes", 10, 1000) > 16 * 1000
+    assert _lib.query("llmrec_linear_wgrad_workspace_bytes", 1000, 64, 512) >= 4 * 64 * 512
+    assert _lib.query("llmrec_sumsq_workspace_bytes", 10, 10) > 0
+
+
+def test_argument_errors_are_reported_not_thrown():
+    lib = _lib.load()
+    st = lib.llmrec_spmm_f32(4, 4, None, None, None, None, None, None, 8, None, 8, 8, 0, None, None, 0, None, None, None)
+    assert st == -1 and b"spmm" in lib.llmrec_last_error()
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        _lib.call("llmrec_degree_scale", -1, None, None, None)
+
+
+def test_ops_refuse_cpu_tensors():
+    from llmrec_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.softmax_rows(torch.zeros(4, 8))
+
+
+def test_dropin_init_matches_reference_init(golden):
+    """Same seed -> bit-identical initial parameters and the same sample stream as the reference."""
+    m = load_dropin(golden_argv(golden))
+    m.set_seed(golden.args["seed"])
+    tr = m.Trainer(data_config={})
+    init = golden.init_params()
+    sd = tr.model_mm.state_dict()
+    assert set(init) == set(sd)
+    for k, v in init.items():
+        assert np.array_equal(sd[k].cpu().numpy(), v), k
+    if not torch.cuda.is_available():
+        # sample stream (host sampler + aug triples), identical to the reference's
+        for s in range(golden.n_steps):
+            u, p, n = (t.tolist() for t in tr.sample_batch())
+            assert u == golden.z["step%d/users" % s].tolist()
+            assert p == golden.z["step%d/pos" % s].tolist()
+            assert n == golden.z["step%d/neg" % s].tolist()
+    assert m.data_generator.n_users == golden.meta["config"]["n_users"]
+    assert m.data_generator.n_items == golden.meta["config"]["n_items"]
+    assert (tr.n_users, tr.n_items) == (m.data_generator.n_users, m.data_generator.n_items)
+    # graph tensors: values are diag(deg^-1/2) R
+    ui = tr.ui_graph.coalesce()
+    deg = torch.bincount(ui.indices()[0], minlength=tr.n_users).float()
+    assert torch.allclose(ui.values(), deg[ui.indices()[0]].rsqrt(), rtol=1e-6)
+
+
+def test_metrics_vectorised_equals_scalar():
+    import utility.metrics as M
+    rng = np.random.default_rng(0)
+    hits = (rng.random((40, 50)) < 0.08).astype(np.uint8)
+    hits[3] = 0
+    n_pos = rng.integers(1, 6, size=40)
+    Ks = [10, 20, 50]
+    vec = M.metrics_from_hit_matrix(hits, n_pos, Ks)
+    for u in range(40):
+        r = hits[u].tolist()
+        for j, K in enumerate(Ks):
+            assert vec["precision"][u, j] == pytest.approx(M.precision_at_k(r, K), abs=1e-15)
+            assert vec["recall"][u, j] == pytest.approx(M.recall_at_k(r, K, n_pos[u]), abs=1e-15)
+            assert vec["ndcg"][u, j] == pytest.approx(M.ndcg_at_k(r, K), abs=1e-15)
+            assert vec["hit_ratio"][u, j] == M.hit_at_k(r, K)
+
+
+def test_synth_generator_exact_and_duplicate_free():
+    from llmrec_amd.synth import bipartite_edges
+    r, c = bipartite_edges(300, 200, 2500, seed=1, max_deg=150)
+    assert r.size == 2500 and np.unique(r * 200 + c).size == 2500
+    assert np.bincount(r, minlength=300).min() >= 1

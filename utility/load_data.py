@@ -1,0 +1,120 @@
+"""Dataset container with the reference's attributes and sampling semantics
+(reference utility/load_data.py:10-92,157-195).
+
+``sample()`` draws from python's ``random`` and ``np.random`` global streams in exactly the
+reference's call order, so the same seed yields the same (users, pos, neg) triples as the
+reference (tests/test_oracle_golden.py::test_host_sampler_stream_matches_reference).
+``sample_device()`` is the MI355X-native alternative: Philox-keyed sampling in one HIP launch
+(llmrec_sample_bpr), distribution-equivalent but not stream-equivalent."""
+import json
+import random as rd
+
+import numpy as np
+
+from utility.parser import parse_args
+
+args = parse_args()
+
+
+class Data(object):
+    def __init__(self, path, batch_size):
+        self.path = path
+        self.batch_size = batch_size
+        with open(path + '/train.json') as f:
+            train = json.load(f)
+        with open(path + '/test.json') as f:
+            test = json.load(f)
+        with open(path + '/val.json') as f:
+            val = json.load(f)
+
+        self.neg_pools = {}
+        self.exist_users = []
+        self.train_items, self.test_set, self.val_set = {}, {}, {}
+        self.n_train = self.n_test = self.n_val = 0
+        max_uid = 0
+        for uid, items in train.items():
+            if len(items) == 0:
+                continue
+            uid = int(uid)
+            self.exist_users.append(uid)
+            max_uid = max(max_uid, uid)
+            self.n_train += len(items)
+            self.train_items[uid] = items
+        for uid, items in test.items():
+            if len(items):
+                self.test_set[int(uid)] = items
+                self.n_test += len(items)
+        for uid, items in val.items():
+            if len(items):
+                self.val_set[int(uid)] = items
+                self.n_val += len(items)
+        self.n_users = max_uid + 1                                   # from train.json only, as the reference
+        # the item count is defined by the text-feature matrix (reference load_data.py:57-58)
+        self.n_items = np.load(args.data_path + args.dataset + '/text_feat.npy', mmap_mode='r').shape[0]
+        self._train_sets = {u: set(v) for u, v in self.train_items.items()}
+        self._R = None
+        self._device_state = None
+        self.print_statistics()
+
+    @property
+    def R(self):
+        """User x item interaction matrix (scipy); built on first use (the reference fills a DOK
+        matrix element by element at import, load_data.py:63-72, and then never reads it)."""
+        if self._R is None:
+            import scipy.sparse as sp
+            rows = np.concatenate([np.full(len(v), u, dtype=np.int64) for u, v in self.train_items.items()])
+            cols = np.concatenate([np.asarray(v, dtype=np.int64) for v in self.train_items.values()])
+            self._R = sp.csr_matrix((np.ones(rows.size, dtype=np.float32), (rows, cols)),
+                                    shape=(self.n_users, self.n_items)).todok()
+        return self._R
+
+    def sample(self):
+        if self.batch_size <= self.n_users:
+            users = rd.sample(self.exist_users, self.batch_size)
+        else:
+            users = [rd.choice(self.exist_users) for _ in range(self.batch_size)]
+        pos_items, neg_items = [], []
+        for u in users:
+            mine = self.train_items[u]
+            pos_items.append(mine[np.random.randint(low=0, high=len(mine), size=1)[0]])
+            seen = self._train_sets[u]
+            while True:
+                neg_id = np.random.randint(low=0, high=self.n_items, size=1)[0]
+                if neg_id not in seen:
+                    neg_items.append(neg_id)
+                    break
+        return users, pos_items, neg_items
+
+    # -- device-side state (train CSR etc.), shared by the sampler and the evaluator ------------
+    def device_state(self, device):
+        import torch
+        from llmrec_amd import ops
+        if self._device_state is not None and self._device_state["device"] == device:
+            return self._device_state
+
+        def csr_of(d):
+            if not d:
+                z = torch.zeros(self.n_users + 1, dtype=torch.int32, device=device)
+                return z, torch.zeros(0, dtype=torch.int32, device=device)
+            rows = np.concatenate([np.full(len(v), u, dtype=np.int64) for u, v in d.items()])
+            cols = np.concatenate([np.asarray(v, dtype=np.int64) for v in d.values()])
+            rp, ci, _ = ops.csr_from_coo(torch.from_numpy(rows).to(device), torch.from_numpy(cols).to(device), None,
+                                         self.n_users, self.n_items)
+            return rp, ci
+        tr = csr_of(self.train_items)
+        train = ops.Csr(self.n_users, self.n_items, tr[0], tr[1], None, None, None, ops.SpmmPlan(0, 0, None, None, None))
+        self._device_state = {"device": device, "train": train, "test": csr_of(self.test_set), "val": csr_of(self.val_set),
+                              "exist_users": torch.tensor(self.exist_users, dtype=torch.int64, device=device)}
+        return self._device_state
+
+    def sample_device(self, seed, step, device):
+        """(users, pos, neg) int64 device tensors from the HIP sampler."""
+        from llmrec_amd import ops
+        st = self.device_state(device)
+        return ops.sample_bpr(seed, step, st["exist_users"], self.n_items, st["train"], self.batch_size)
+
+    def print_statistics(self):
+        print('n_users=%d, n_items=%d' % (self.n_users, self.n_items))
+        print('n_interactions=%d' % (self.n_train + self.n_test))
+        print('n_train=%d, n_test=%d, sparsity=%.5f' % (self.n_train, self.n_test,
+                                                        (self.n_train + self.n_test) / (self.n_users * self.n_items)))
