@@ -165,6 +165,17 @@ int llmrec_bpr_prune_fwd_f32(const float* Eu, int64_t ldu, const float* Ei, int6
                              int32_t B_max, const int32_t* n_valid_dev,
                              double remember_rate, float decay, float batch_size_flag,
                              float* out2, float* saved, llmrec_stream_t stream);
+/* User-sharded batch: every rank holds B_local samples of a global batch of
+ * global_B. Pass 1 (scores_only = 1) writes the local m_b to saved[0..B_local) and the local
+ * squared norms to saved[B_local..B_local+2]; the host all-gathers the m_b (RCCL) and calls
+ * pass 2 with them: selection ranks against the GLOBAL batch (ties: lower global index), out2[0]
+ * is this rank's share -(1/k) * sum_{kept local} m_b (all-reduce it), and saved is ready for
+ * llmrec_bpr_prune_bwd_f32 once saved[B_local..B_local+2] hold the all-reduced norms. */
+int llmrec_bpr_prune_fwd_sharded_f32(const float* Eu, int64_t ldu, const float* Ei, int64_t ldi, int32_t d,
+                                     const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                     int32_t B_local, double remember_rate, float decay, float batch_size_flag,
+                                     const float* global_m, int32_t global_B, int32_t my_offset, int32_t scores_only,
+                                     float* out2, float* saved, llmrec_stream_t stream);
 /* dEu[u_b] += g_mf * ds_b * (Ei[p_b] - Ei[q_b]) + g_emb * c_u * Eu[u_b]   (atomic scatter-add)
  * dEi[p_b] += g_mf * ds_b * Eu[u_b] + g_emb * c_p * Ei[p_b] ; dEi[q_b] likewise with -ds_b, c_q
  * g_mf / g_emb are upstream gradients read from device memory (grads2[0], grads2[1]). */

@@ -63,6 +63,10 @@ def load():
     global _lib, _protos
     if _lib is not None:
         return _lib
+    # torch bundles its own ROCm runtime (torch/lib/libamdhip64.so); it must be the one in the
+    # process before this library resolves libamdhip64.so.7, or two HIP runtimes get loaded and
+    # launches fail with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "llmrec_amd: %s is missing. Build it with `python -m llmrec_amd.build` (hipcc, gfx950). "

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_fwd_kernel(const float* __res
                                                               const int64_t* __restrict__ neg, int B_max,
                                                               const int32_t* __restrict__ n_valid_dev, double remember_rate,
                                                               float decay, float bsz, float* __restrict__ out2,
-                                                              float* __restrict__ saved) {
+                                                              float* __restrict__ saved, const float* __restrict__ global_m,
+                                                              int global_B, int my_offset, int scores_only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* m_s = reinterpret_cast<float*>(smem);                       // [B_max] logsigmoid values
     float* sg_s = m_s + B_max;                                         // [B_max] sigmoid(-(s + 1e-8))
@@ -57,17 +58,33 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_fwd_kernel(const float* __res
     if (gl == 0) { nrm[grp * 3 + 0] = su; nrm[grp * 3 + 1] = sp; nrm[grp * 3 + 2] = sq; }
     __syncthreads();
 
-    // phase 2: keep the k smallest m_b (ties: lower b first) by rank counting
-    const int k = (int)(remember_rate * (double)B);                    // int((1 - drop) * len) of main.py:161-162
+    if (scores_only) {
+        // sharded batch, pass 1: publish the local log-sigmoids and squared norms; the caller
+        // all-gathers them and calls again with global_m (pass 2)
+        for (int b = threadIdx.x; b < B_max; b += BPR_THREADS) saved[b] = b < B ? m_s[b] : INFINITY;
+        if (threadIdx.x == 0) {
+            float Su = 0.f, Sp = 0.f, Sq = 0.f;
+            for (int g = 0; g < BPR_GROUPS; ++g) { Su += nrm[g * 3]; Sp += nrm[g * 3 + 1]; Sq += nrm[g * 3 + 2]; }
+            saved[B_max + 0] = Su; saved[B_max + 1] = Sp; saved[B_max + 2] = Sq; saved[B_max + 3] = 0.f;
+        }
+        return;
+    }
+
+    // phase 2: keep the k smallest m_b (ties: lower global index first) by rank counting; with a
+    // sharded batch the ranking runs against the all-gathered m of every rank
+    const int Bg = global_m ? global_B : B;
+    const float* mg = global_m ? global_m : m_s;
+    const int k = (int)(remember_rate * (double)Bg);                   // int((1 - drop) * len) of main.py:161-162
     float part = 0.f;
     for (int b = threadIdx.x; b < B; b += BPR_THREADS) {
         const float mb = m_s[b];
         bool keep = true;
-        if (k < B) {
+        if (k < Bg) {
             int rank = 0;
-            for (int j = 0; j < B; ++j) {
-                const float mj = m_s[j];
-                rank += (mj < mb) || (mj == mb && j < b);
+            const int me = my_offset + b;
+            for (int j = 0; j < Bg; ++j) {
+                const float mj = mg[j];
+                rank += (mj < mb) || (mj == mb && j < me);
             }
             keep = rank < k;
         }
@@ -219,7 +236,26 @@ int llmrec_bpr_prune_fwd_f32(const float* Eu, int64_t ldu, const float* Ei, int6
     LLMREC_CHECK_ARG(B_max == 0 || (Eu && Ei && users && pos && neg && ldu >= d && ldi >= d), "bpr_fwd: null pointer or ld < d");
     const size_t shmem = sizeof(float) * ((size_t)2 * B_max + BPR_THREADS + BPR_GROUPS * 3);
     bpr_fwd_kernel<<<1, BPR_THREADS, shmem, stream>>>(Eu, ldu, Ei, ldi, d, users, pos, neg, B_max, n_valid_dev,
-                                                     remember_rate, decay, batch_size_flag, out2, saved);
+                                                     remember_rate, decay, batch_size_flag, out2, saved, nullptr, 0, 0, 0);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_bpr_prune_fwd_sharded_f32(const float* Eu, int64_t ldu, const float* Ei, int64_t ldi, int32_t d,
+                                     const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                     int32_t B_local, double remember_rate, float decay, float batch_size_flag,
+                                     const float* global_m, int32_t global_B, int32_t my_offset, int32_t scores_only,
+                                     float* out2, float* saved, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(B_local >= 0 && d > 0 && out2 && saved, "bpr_fwd_sharded: bad argument");
+    if (B_local > LLMREC_BPR_MAX_B) { set_error("bpr_fwd_sharded: B_local %d > %d", B_local, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
+    LLMREC_CHECK_ARG(B_local == 0 || (Eu && Ei && users && pos && neg && ldu >= d && ldi >= d), "bpr_fwd_sharded: null pointer or ld < d");
+    LLMREC_CHECK_ARG(scores_only || (global_m && global_B >= B_local && my_offset >= 0 && my_offset + B_local <= global_B),
+                     "bpr_fwd_sharded: pass 2 needs the gathered scores and a valid offset");
+    const size_t shmem = sizeof(float) * ((size_t)2 * B_local + BPR_THREADS + BPR_GROUPS * 3);
+    bpr_fwd_kernel<<<1, BPR_THREADS, shmem, stream>>>(Eu, ldu, Ei, ldi, d, users, pos, neg, B_local, nullptr,
+                                                     remember_rate, decay, batch_size_flag, out2, saved,
+                                                     scores_only ? nullptr : global_m, global_B, my_offset, scores_only);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

@@ -1,0 +1,308 @@
+"""User-sharded propagation over several GPUs of one node.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI). Users are partitioned
+into contiguous blocks; rank r owns
+  * the edges of its users (two pattern-only CSRs: by local user, by item),
+  * its slice of the user-side tensors (user_id_embedding rows, their AdamW state),
+  * a REPLICA of every item-side tensor (I x d: 256 MB at cfg 4, 2.56 GB at cfg 5).
+Per propagation layer there is exactly one exchange, an all-reduce (sum, fp32) of an I x d array:
+  forward   I^{l+1} = sum_r A_iu[:, blk_r] U^{l+1}[blk_r]        (ShardedIU.forward)
+  backward  dI^{l}  = sum_r A_ui[blk_r, :]^T dU^{l+1}[blk_r]     (ShardedUI.backward)
+U^{l+1}[blk] = A_ui[blk, :] I^l and its mirror in backward are local. The BPR batch is sharded by
+user owner; the prune selection ranks against the all-gathered log-sigmoids of the whole batch
+(B floats), so the result equals the single-GPU step.
+
+The local kernels come from a ``backend`` object (default: the HIP library through
+llmrec_amd.ops). tests/test_dist_cpu.py injects a torch-CPU backend to check the partitioning and
+the placement of the collectives with gloo, world_size 2, against the single-process oracle.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+
+class Comm:
+    """Thin view of torch.distributed (identity when the world has one rank)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.world = self.dist.get_world_size() if self.dist else 1
+
+    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
+        if self.dist and self.world > 1:
+            self.dist.all_reduce(t)
+        return t
+
+    def all_gather_cat(self, t: torch.Tensor) -> torch.Tensor:
+        if not (self.dist and self.world > 1):
+            return t
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, t.contiguous())
+        return out
+
+
+def user_block(n_users: int, rank: int, world: int):
+    """Contiguous user partition: [u0, u1) of rank."""
+    per = (n_users + world - 1) // world
+    return min(rank * per, n_users), min((rank + 1) * per, n_users)
+
+
+class HipBackend:
+    """Local kernels = the C-ABI HIP library."""
+
+    def __init__(self):
+        from . import ops
+        self.ops = ops
+
+    def pattern_csr(self, rows, cols, n_rows, n_cols):
+        rp, ci, _ = self.ops.csr_from_coo(rows, cols, None, n_rows, n_cols)
+        return self.ops.Csr(n_rows, n_cols, rp, ci, None, None, None, self.ops.SpmmPlan.build(rp))
+
+    def with_scales(self, csr, row_scale, col_scale):
+        o = self.ops
+        return o.Csr(csr.n_rows, csr.n_cols, csr.rowptr, csr.colidx, None, row_scale, col_scale, csr.plan)
+
+    def degrees(self, csr) -> torch.Tensor:
+        return (csr.rowptr[1:] - csr.rowptr[:-1]).to(torch.float32)
+
+    def spmm(self, csr, X):
+        return self.ops.spmm_raw(csr, X)
+
+    def softmax_rows(self, Z):
+        return self.ops.softmax_rows(Z)
+
+    def layer_mean(self, terms):
+        return self.ops.fuse(list(terms), [], [])
+
+    def bpr_fwd(self, Eu, Ei, u, p, n, remember, decay, bsz, global_m, global_B, offset, scores_only):
+        o = self.ops
+        Eu, Ei = o._rowmajor(Eu), o._rowmajor(Ei)
+        B = u.numel()
+        out = torch.empty(2, dtype=torch.float32, device=Eu.device)
+        saved = torch.empty(B + 4, dtype=torch.float32, device=Eu.device)
+        o._lib.call("llmrec_bpr_prune_fwd_sharded_f32", o._p(Eu), o._ld(Eu), o._p(Ei), o._ld(Ei), Eu.shape[1], o._p(u), o._p(p), o._p(n),
+                    B, float(remember), float(decay), float(bsz), o._p(global_m), int(global_B), int(offset), 1 if scores_only else 0,
+                    o._p(out), o._p(saved), o._stream())
+        return out, saved
+
+    def bpr_bwd(self, Eu, Ei, u, p, n, decay, bsz, saved, grads2):
+        o = self.ops
+        Eu, Ei = o._rowmajor(Eu), o._rowmajor(Ei)
+        dEu, dEi = torch.zeros_like(Eu), torch.zeros_like(Ei)
+        o._lib.call("llmrec_bpr_prune_bwd_f32", o._p(Eu), o._ld(Eu), o._p(Ei), o._ld(Ei), Eu.shape[1], o._p(u), o._p(p), o._p(n),
+                    u.numel(), None, float(decay), float(bsz), o._p(saved), o._p(grads2.contiguous()), o._p(dEu), o._ld(dEu),
+                    o._p(dEi), o._ld(dEi), o._stream())
+        return dEu, dEi
+
+    def sample(self, seed, step, exist_users, n_items, by_user, B):
+        return self.ops.sample_bpr(seed, step, exist_users, n_items, by_user, B)
+
+    def optimizer(self, params, lr):
+        return self.ops.FusedAdamW(params, lr=lr)
+
+
+@dataclass
+class ShardedGraph:
+    """This rank's slice of the bipartite graph, ready for the four SpMM directions."""
+    n_users_local: int
+    n_items: int
+    u0: int
+    ui_fwd: object      # A_ui[blk, :]        rows = local users, row_scale = s_u
+    ui_bwd: object      # A_ui[blk, :]^T      rows = items, col_scale = s_u        (partial -> all-reduce)
+    iu_fwd: object      # A_iu[:, blk]        rows = items, row_scale = s_i(global) (partial -> all-reduce)
+    iu_bwd: object      # A_iu[:, blk]^T      rows = local users, col_scale = s_i
+    by_user: object
+    s_i: torch.Tensor
+
+    @staticmethod
+    def build(local_users: torch.Tensor, items: torch.Tensor, n_users_local: int, n_items: int, u0: int,
+              comm: Comm, backend) -> "ShardedGraph":
+        """local_users: user ids RELATIVE to this rank's block."""
+        by_user = backend.pattern_csr(local_users, items, n_users_local, n_items)
+        by_item = backend.pattern_csr(items, local_users, n_items, n_users_local)
+        deg_u = backend.degrees(by_user)
+        deg_i = comm.all_reduce_(backend.degrees(by_item).clone())           # global item degrees
+        inv = lambda deg: torch.where(deg > 0, (1.0 / torch.sqrt(deg.double())).float(), torch.zeros_like(deg))
+        s_u, s_i = inv(deg_u), inv(deg_i)                                     # reference main.py:115-117
+        return ShardedGraph(n_users_local, n_items, u0,
+                            backend.with_scales(by_user, s_u, None), backend.with_scales(by_item, None, s_u),
+                            backend.with_scales(by_item, s_i, None), backend.with_scales(by_user, None, s_i),
+                            by_user, s_i)
+
+
+def _fn_ui(graph: ShardedGraph, comm: Comm, backend):
+    class ShardedUI(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, Xi):
+            return backend.spmm(graph.ui_fwd, Xi)
+
+        @staticmethod
+        def backward(ctx, dYu):
+            return comm.all_reduce_(backend.spmm(graph.ui_bwd, dYu))
+    return ShardedUI.apply
+
+
+def _fn_iu(graph: ShardedGraph, comm: Comm, backend):
+    class ShardedIU(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, Xu):
+            return comm.all_reduce_(backend.spmm(graph.iu_fwd, Xu))
+
+        @staticmethod
+        def backward(ctx, dYi):
+            return backend.spmm(graph.iu_bwd, dYi)
+    return ShardedIU.apply
+
+
+def _fn_replicated(comm: Comm):
+    class ReplicatedGrad(torch.autograd.Function):
+        """Identity on a replicated tensor whose consumers differ per rank: the true gradient is
+        the sum of the per-rank gradients."""
+        @staticmethod
+        def forward(ctx, x):
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, g):
+            return comm.all_reduce_(g.contiguous().clone())
+    return ReplicatedGrad.apply
+
+
+def _fn_bpr(comm: Comm, backend, remember: float, decay: float, bsz: float):
+    class ShardedBpr(torch.autograd.Function):
+        """[mf, emb] of the GLOBAL batch from this rank's share of the samples."""
+        @staticmethod
+        def forward(ctx, Eu, Ei, u, p, n):
+            B = u.numel()
+            _, s1 = backend.bpr_fwd(Eu, Ei, u, p, n, remember, decay, bsz, None, 0, 0, True)
+            global_m = comm.all_gather_cat(s1[:B].contiguous())
+            out, saved = backend.bpr_fwd(Eu, Ei, u, p, n, remember, decay, bsz, global_m, global_m.numel(), comm.rank * B, False)
+            norms = comm.all_reduce_(saved[B:B + 3].clone())
+            saved[B:B + 3] = norms
+            mf = comm.all_reduce_(out[:1].clone())
+            reg = (1.0 / (2.0 * norms + 1e-8)).sum()
+            emb = (decay * (reg / bsz)).reshape(1)
+            ctx.save_for_backward(Eu, Ei, u, p, n, saved)
+            return torch.cat([mf, emb])
+
+        @staticmethod
+        def backward(ctx, g):
+            Eu, Ei, u, p, n, saved = ctx.saved_tensors
+            dEu, dEi = backend.bpr_bwd(Eu, Ei, u, p, n, decay, bsz, saved, g)
+            return dEu, dEi, None, None, None
+    return ShardedBpr.apply
+
+
+class ShardedIDModel(nn.Module):
+    """The ID-embedding block of the reference (Models.py:169-186) over a sharded graph:
+    user rows local, item rows replicated. E_u[blk], E_i = mean over the L+1 layer outputs, row
+    softmax on the last layer, items of layer l+1 from the NEW users."""
+
+    def __init__(self, graph: ShardedGraph, comm: Comm, backend, d: int, n_layers: int, n_users_global: int, seed: int):
+        super().__init__()
+        self.graph, self.comm, self.backend, self.n_layers = graph, comm, backend, n_layers
+        dev = graph.s_i.device
+        g = torch.Generator(device="cpu"); g.manual_seed(seed)
+        # xavier_uniform over the GLOBAL table shapes (reference Models.py:39-42); the item table is
+        # drawn identically on every rank, the user table per rank
+        bi = math.sqrt(6.0 / (graph.n_items + d))
+        self.item_id_embedding = nn.Parameter(((torch.rand(graph.n_items, d, generator=g) * 2 - 1) * bi).to(dev))
+        bu = math.sqrt(6.0 / (n_users_global + d))
+        gu = torch.Generator(device="cpu"); gu.manual_seed(seed * 7919 + 1 + comm.rank)
+        self.user_id_embedding = nn.Parameter(((torch.rand(graph.n_users_local, d, generator=gu) * 2 - 1) * bu).to(dev))
+        self.ui = _fn_ui(graph, comm, backend)
+        self.iu = _fn_iu(graph, comm, backend)
+        self.replicated = _fn_replicated(comm)
+
+    def forward(self):
+        u, i = self.user_id_embedding, self.item_id_embedding
+        us, is_ = [u], [i]
+        for layer in range(self.n_layers):
+            last = layer == self.n_layers - 1
+            u = self.ui(i)
+            if last:
+                u = self.backend.softmax_rows(u)
+            i = self.iu(u)
+            if last:
+                i = self.backend.softmax_rows(i)
+            us.append(u); is_.append(i)
+        e_u = self.backend.layer_mean(us)
+        e_i = self.replicated(self.backend.layer_mean(is_))
+        return e_u, e_i
+
+
+class ShardedTrainer:
+    """One synchronous training step of the sharded ID model: sample B_local users from the local
+    block on the device, sharded BPR + prune over the global batch, backward, AdamW (user rows
+    local; the item table's gradient is already complete on every rank, so its update is
+    replicated without a further collective)."""
+
+    def __init__(self, model: ShardedIDModel, lr: float, batch_local: int, drop_rate: float, decay: float, seed: int):
+        self.model, self.comm, self.backend = model, model.comm, model.backend
+        self.B = batch_local
+        self.opt = self.backend.optimizer(list(model.parameters()), lr)
+        bsz_flag = float(batch_local * self.comm.world)
+        self.bpr = _fn_bpr(self.comm, self.backend, 1 - drop_rate, decay, bsz_flag)
+        g = model.graph
+        deg = self.backend.degrees(g.by_user)
+        self.exist = torch.nonzero(deg > 0).reshape(-1).to(torch.int64)
+        self.seed = seed * 1000003 + self.comm.rank
+        self.step_id = 0
+
+    def sample(self):
+        g = self.model.graph
+        return self.backend.sample(self.seed, self.step_id, self.exist, g.n_items, g.by_user, self.B)
+
+    def step(self, triples=None):
+        u, p, n = triples if triples is not None else self.sample()
+        self.step_id += 1
+        e_u, e_i = self.model()
+        out = self.bpr(e_u, e_i, u, p, n)
+        loss = out[0] + out[1]
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        return loss.detach(), out.detach()
+
+
+class ShardedBench:
+    """bench.py --workload synth: cfg-4-shaped synthetic graph, `users_per_gpu` users and
+    `edges_per_gpu` edges per rank (weak scaling), items replicated; at 8 GPUs the defaults give
+    10 M users x 1 M items x 200 M edges, d = 64, 2 layers, batch 1024 per GPU."""
+
+    def __init__(self, users_per_gpu, n_items, edges_per_gpu, seed, device, rank, world, d=64, n_layers=2, batch_local=1024):
+        from . import synth
+        self.comm = Comm()
+        self.backend = HipBackend()
+        self.device, self.world = device, world
+        rows, cols = synth.bipartite_edges_device(users_per_gpu, n_items, edges_per_gpu, seed * 131 + rank, device)
+        self.nnz_local = int(rows.numel())
+        self.graph = ShardedGraph.build(rows, cols, users_per_gpu, n_items, rank * users_per_gpu, self.comm, self.backend)
+        del rows, cols
+        self.model = ShardedIDModel(self.graph, self.comm, self.backend, d, n_layers, users_per_gpu * world, seed)
+        self.trainer = ShardedTrainer(self.model, 1e-4, batch_local, 0.71, 1e-5, seed)
+        self.units_per_step = batch_local * world
+        self.cfg = {"workload": "synthetic_user_sharded_id_path_cfg4_shape", "users_per_gpu": users_per_gpu, "n_items": n_items,
+                    "edges_per_gpu": self.nnz_local, "embed_size": d, "prop_layers": n_layers, "batch_per_gpu": batch_local,
+                    "global_batch": batch_local * world, "prune_loss_drop_rate": 0.71,
+                    "parallelism": "user-sharded x%d, item table replicated, 1 all-reduce(I x d) per layer fwd + bwd" % world}
+
+    def step(self):
+        return self.trainer.step()
+
+    def config(self):
+        return self.cfg
+
+    def extras(self):
+        nnz = torch.tensor([self.nnz_local], dtype=torch.float64, device=self.device)
+        self.comm.all_reduce_(nnz)
+        L = self.model.n_layers
+        return {"propagated_edges_per_step": float(nnz.item()) * 4 * L,
+                "allreduce_bytes_per_step": 4.0 * self.graph.n_items * self.model.item_id_embedding.shape[1] * (2 * L + 1)}

@@ -1,0 +1,73 @@
+"""TEST-ONLY torch-CPU stand-in for llmrec_amd.dist.HipBackend, so the sharding logic and the
+placement of the collectives in llmrec_amd/dist.py can run under gloo without a GPU. It follows
+the C ABI's contracts (saved-buffer layout of llmrec_bpr_prune_fwd_sharded_f32 etc.)."""
+import torch
+import torch.nn.functional as F
+
+
+class _Pattern:
+    def __init__(self, rows, cols, n_rows, n_cols, row_scale=None, col_scale=None):
+        self.rows, self.cols, self.n_rows, self.n_cols = rows, cols, n_rows, n_cols
+        self.row_scale, self.col_scale = row_scale, col_scale
+
+
+class CpuBackend:
+    def pattern_csr(self, rows, cols, n_rows, n_cols):
+        return _Pattern(rows.long(), cols.long(), n_rows, n_cols)
+
+    def with_scales(self, p, row_scale, col_scale):
+        return _Pattern(p.rows, p.cols, p.n_rows, p.n_cols, row_scale, col_scale)
+
+    def degrees(self, p):
+        return torch.bincount(p.rows, minlength=p.n_rows).float()
+
+    def spmm(self, p, X):
+        X = X if p.col_scale is None else X * p.col_scale[:, None]
+        A = torch.sparse_coo_tensor(torch.stack([p.rows, p.cols]), torch.ones(p.rows.numel()), (p.n_rows, p.n_cols))
+        Y = torch.sparse.mm(A, X)
+        return Y if p.row_scale is None else Y * p.row_scale[:, None]
+
+    def softmax_rows(self, Z):
+        return torch.softmax(Z, dim=-1)
+
+    def layer_mean(self, terms):
+        return torch.mean(torch.stack(list(terms)), dim=0)
+
+    def bpr_fwd(self, Eu, Ei, u, p, n, remember, decay, bsz, global_m, global_B, offset, scores_only):
+        B = u.numel()
+        eu, ep, en = Eu[u], Ei[p], Ei[n]
+        x = (eu * ep).sum(1) - (eu * en).sum(1) + 1e-8
+        m = F.logsigmoid(x)
+        sg = torch.sigmoid(-x)
+        norms = torch.stack([(eu ** 2).sum(), (ep ** 2).sum(), (en ** 2).sum()])
+        saved = torch.zeros(B + 4)
+        if scores_only:
+            saved[:B] = m
+            saved[B:B + 3] = norms
+            return torch.zeros(2), saved
+        k = int(remember * global_B)
+        gidx = torch.arange(global_B)
+        me = offset + torch.arange(B)
+        rank = ((global_m[None, :] < m[:, None]) | ((global_m[None, :] == m[:, None]) & (gidx[None, :] < me[:, None]))).sum(1)
+        keep = rank < k
+        saved[:B] = torch.where(keep, -sg / k, torch.zeros(B))
+        saved[B:B + 3] = norms
+        saved[B + 3] = k
+        out = torch.stack([-(m[keep].sum() / k), torch.tensor(0.0)])
+        return out, saved
+
+    def bpr_bwd(self, Eu, Ei, u, p, n, decay, bsz, saved, grads2):
+        B = u.numel()
+        ds = grads2[0] * saved[:B]
+        Su, Sp, Sq = saved[B], saved[B + 1], saved[B + 2]
+        base = -4.0 * decay / bsz * grads2[1]
+        cu, cp, cq = (base / (2 * S + 1e-8) ** 2 for S in (Su, Sp, Sq))
+        dEu, dEi = torch.zeros_like(Eu), torch.zeros_like(Ei)
+        eu, ep, en = Eu[u], Ei[p], Ei[n]
+        dEu.index_add_(0, u, ds[:, None] * (ep - en) + cu * eu)
+        dEi.index_add_(0, p, ds[:, None] * eu + cp * ep)
+        dEi.index_add_(0, n, -ds[:, None] * eu + cq * en)
+        return dEu, dEi
+
+    def optimizer(self, params, lr):
+        return torch.optim.AdamW([{"params": params}], lr=lr)

@@ -1,0 +1,112 @@
+"""CPU, gloo, world_size 2: the user-sharded path of llmrec_amd/dist.py (partitioning, global
+item degrees, one all-reduce per layer forward/backward, sharded BPR + prune over the global
+batch) reproduces the single-process oracle after optimiser steps. The local kernels are the
+torch stand-ins of tests/_cpu_backend.py; the HIP kernels themselves are checked on the GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import oracle as O
+
+U, I, D, L, B_LOCAL, STEPS = 60, 45, 16, 2, 12, 3
+DROP, DECAY, LR = 0.71, 1e-5, 1e-2
+
+
+def _problem():
+    rng = np.random.default_rng(0)
+    rows = np.repeat(np.arange(U), rng.integers(1, 9, size=U))
+    cols = np.concatenate([rng.choice(I, size=c, replace=False) for c in np.bincount(rows)])
+    u_tab = (rng.standard_normal((U, D)) * 0.1).astype(np.float32)
+    i_tab = (rng.standard_normal((I, D)) * 0.1).astype(np.float32)
+    batches = []
+    for s in range(STEPS):
+        per_rank = []
+        for r in range(2):
+            u0, u1 = r * (U // 2), (r + 1) * (U // 2)
+            us = rng.integers(u0, u1, size=B_LOCAL)
+            per_rank.append((us, rng.integers(0, I, size=B_LOCAL), rng.integers(0, I, size=B_LOCAL)))
+        batches.append(per_rank)
+    return rows, cols, u_tab, i_tab, batches
+
+
+def _oracle_run():
+    import scipy.sparse as sp
+    rows, cols, u_tab, i_tab, batches = _problem()
+    R = sp.csr_matrix((np.ones(rows.size, dtype=np.float32), (rows, cols)), shape=(U, I))
+    a_ui, a_iu = O.normalized_graphs(R)
+    pu = torch.tensor(u_tab, requires_grad=True); pi = torch.tensor(i_tab, requires_grad=True)
+    opt = torch.optim.AdamW([{"params": [pu, pi]}], lr=LR)
+    cfg = O.Config(batch_size=2 * B_LOCAL, decay=DECAY, prune_loss_drop_rate=DROP)
+    losses = []
+    for per_rank in batches:
+        us = np.concatenate([b[0] for b in per_rank]); ps = np.concatenate([b[1] for b in per_rank]); ns = np.concatenate([b[2] for b in per_rank])
+        u, i = pu, pi
+        ul, il = [u], [i]
+        for l in range(L):
+            u = torch.sparse.mm(a_ui, i)
+            if l == L - 1: u = torch.softmax(u, -1)
+            i = torch.sparse.mm(a_iu, u)
+            if l == L - 1: i = torch.softmax(i, -1)
+            ul.append(u); il.append(i)
+        eu, ei = torch.mean(torch.stack(ul), 0), torch.mean(torch.stack(il), 0)
+        mf, emb = O.bpr_loss(eu[torch.tensor(us)], ei[torch.tensor(ps)], ei[torch.tensor(ns)], cfg)
+        loss = mf + emb
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(float(loss))
+    return pu.detach().numpy(), pi.detach().numpy(), losses
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from llmrec_amd import dist as ld
+    from tests._cpu_backend import CpuBackend
+    rows, cols, u_tab, i_tab, batches = _problem()
+    comm, be = ld.Comm(), CpuBackend()
+    u0, u1 = ld.user_block(U, rank, world)
+    sel = (rows >= u0) & (rows < u1)
+    g = ld.ShardedGraph.build(torch.tensor(rows[sel] - u0), torch.tensor(cols[sel]), u1 - u0, I, u0, comm, be)
+    model = ld.ShardedIDModel(g, comm, be, D, L, U, seed=1)
+    with torch.no_grad():
+        model.user_id_embedding.copy_(torch.tensor(u_tab[u0:u1])); model.item_id_embedding.copy_(torch.tensor(i_tab))
+    tr = ld.ShardedTrainer(model, LR, B_LOCAL, DROP, DECAY, seed=1)
+    losses = []
+    for per_rank in batches:
+        us, ps, ns = per_rank[rank]
+        loss, _ = tr.step((torch.tensor(us - u0), torch.tensor(ps), torch.tensor(ns)))
+        losses.append(float(loss))
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), users=model.user_id_embedding.detach().numpy(),
+             items=model.item_id_embedding.detach().numpy(), losses=np.array(losses))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_sharded_training_matches_single_process_oracle(tmp_path):
+    ref_u, ref_i, ref_losses = _oracle_run()
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    got_u = np.concatenate([r0["users"], r1["users"]])
+    assert np.allclose(r0["items"], r1["items"], rtol=0, atol=0)              # replicas stay identical
+    assert np.allclose(r0["losses"], ref_losses, rtol=1e-5)
+    assert np.allclose(r1["losses"], ref_losses, rtol=1e-5)
+    assert np.abs(got_u - ref_u).max() <= 1e-4 * np.abs(ref_u).max()
+    assert np.abs(r0["items"] - ref_i).max() <= 1e-4 * np.abs(ref_i).max()
+
+
+def test_user_block_partition_covers_all_users():
+    from llmrec_amd.dist import user_block
+    for n, w in ((10, 3), (8, 8), (5, 8), (1000003, 8)):
+        blocks = [user_block(n, r, w) for r in range(w)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))

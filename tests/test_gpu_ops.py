@@ -351,7 +351,7 @@ def test_topk_hits(ops):
 # ------------------------------------------------------------------------------------------
 def test_device_sampler_properties(ops):
     rng = np.random.default_rng(6)
-    U, I, B = 500, 300, 256
+    U, I, B = 500, 300, 200
     train_items = {u: sorted(rng.choice(I, size=int(rng.integers(1, 60)), replace=False).tolist()) for u in range(0, U, 2)}
     csr = _train_csr(ops, train_items, U, I)
     exist = torch.tensor(sorted(train_items), dtype=torch.int64, device=DEV)
@@ -362,7 +362,7 @@ def test_device_sampler_properties(ops):
         for uu, pp, nn_ in zip(u, p, n):
             assert uu in train_items and pp in train_items[uu] and nn_ not in train_items[uu] and 0 <= nn_ < I
         seen_users.update(u)
-    assert len(seen_users) >= len(train_items) - 5             # 4 x 256 draws from 250 users covers ~all of them
+    assert len(seen_users) >= len(train_items) - 5             # 4 x 200 draws from 250 users covers ~all of them
     a = ops.sample_bpr(2022, 1, exist, I, csr, B); b = ops.sample_bpr(2022, 1, exist, I, csr, B)
     assert all(torch.equal(x, y) for x, y in zip(a, b))       # counter-based: reproducible
     # B > n_exist -> with replacement

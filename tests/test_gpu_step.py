@@ -90,3 +90,54 @@ def test_device_sampler_epoch_runs(golden):
         assert np.isfinite(float(loss))
     finally:
         os.environ.pop("LLMREC_DEVICE_SAMPLER", None)
+
+
+def test_sharded_trainer_single_rank_matches_oracle():
+    """llmrec_amd/dist.py on the HIP backend with a world of one rank (collectives are identities):
+    the two-pass sharded BPR and the sharded SpMM operands must reproduce the oracle's steps."""
+    import scipy.sparse as sp
+    from oracle import oracle as O
+    from llmrec_amd import dist as ld
+    rng = np.random.default_rng(3)
+    U, I, D, L, B, STEPS = 700, 500, 64, 2, 256, 3
+    deg = rng.integers(1, 40, size=U); deg[5] = 300
+    rows = np.repeat(np.arange(U), deg)
+    cols = np.concatenate([rng.choice(I, size=c, replace=False) for c in deg])
+    u_tab = (rng.standard_normal((U, D)) * 0.1).astype(np.float32)
+    i_tab = (rng.standard_normal((I, D)) * 0.1).astype(np.float32)
+    batches = [(rng.integers(0, U, size=B), rng.integers(0, I, size=B), rng.integers(0, I, size=B)) for _ in range(STEPS)]
+    # oracle
+    R = sp.csr_matrix((np.ones(rows.size, dtype=np.float32), (rows, cols)), shape=(U, I))
+    a_ui, a_iu = O.normalized_graphs(R)
+    pu = torch.tensor(u_tab, requires_grad=True); pi = torch.tensor(i_tab, requires_grad=True)
+    opt = torch.optim.AdamW([{"params": [pu, pi]}], lr=1e-3)
+    cfg = O.Config(batch_size=B, decay=1e-5, prune_loss_drop_rate=0.71)
+    ref_losses = []
+    for us, ps, ns in batches:
+        u, i = pu, pi
+        ul, il = [u], [i]
+        for l in range(L):
+            u = torch.sparse.mm(a_ui, i)
+            if l == L - 1: u = torch.softmax(u, -1)
+            i = torch.sparse.mm(a_iu, u)
+            if l == L - 1: i = torch.softmax(i, -1)
+            ul.append(u); il.append(i)
+        eu, ei = torch.mean(torch.stack(ul), 0), torch.mean(torch.stack(il), 0)
+        mf, emb = O.bpr_loss(eu[torch.tensor(us)], ei[torch.tensor(ps)], ei[torch.tensor(ns)], cfg)
+        opt.zero_grad(); (mf + emb).backward(); opt.step()
+        ref_losses.append(float(mf + emb))
+    # HIP, sharded code path, one rank
+    comm, be = ld.Comm(), ld.HipBackend()
+    g = ld.ShardedGraph.build(torch.tensor(rows).cuda(), torch.tensor(cols).cuda(), U, I, 0, comm, be)
+    model = ld.ShardedIDModel(g, comm, be, D, L, U, seed=1)
+    with torch.no_grad():
+        model.user_id_embedding.copy_(torch.tensor(u_tab)); model.item_id_embedding.copy_(torch.tensor(i_tab))
+    tr = ld.ShardedTrainer(model, 1e-3, B, 0.71, 1e-5, seed=1)
+    for (us, ps, ns), want in zip(batches, ref_losses):
+        loss, _ = tr.step((torch.tensor(us).cuda(), torch.tensor(ps).cuda(), torch.tensor(ns).cuda()))
+        assert abs(float(loss) - want) <= 1e-5 * abs(want)
+    assert rel(model.user_id_embedding.detach().cpu().numpy(), pu.detach().numpy()) < RTOL
+    assert rel(model.item_id_embedding.detach().cpu().numpy(), pi.detach().numpy()) < RTOL
+    # the device sampler path of the trainer
+    loss, _ = tr.step()
+    assert np.isfinite(float(loss))

@@ -80,7 +80,8 @@ def test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val, drop_flag=Fa
         rp, ci = st["val"] if is_val else st["test"]
         hits = ops.topk_hits(idx, q, rp, ci).cpu().numpy()
         n_pos = np.array([len(held[u]) for u in test_users], dtype=np.float64)
-        per_user = metrics.metrics_from_hit_matrix(hits, n_pos, Ks)
+        list_len = (idx >= 0).sum(1).cpu().numpy()
+        per_user = metrics.metrics_from_hit_matrix(hits, n_pos, Ks, list_len)
         for k in ('precision', 'recall', 'ndcg', 'hit_ratio'):
             result[k] = (per_user[k] / n_test_users).sum(0)
         return result

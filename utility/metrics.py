@@ -62,13 +62,16 @@ def auc(ground_truth, prediction):
         return 0.
 
 
-def metrics_from_hit_matrix(hits, n_pos, Ks):
-    """Vectorised over users: ``hits`` [n, Kmax] 0/1, ``n_pos`` [n] held-out counts.
+def metrics_from_hit_matrix(hits, n_pos, Ks, list_len=None):
+    """Vectorised over users: ``hits`` [n, Kmax] 0/1, ``n_pos`` [n] held-out counts,
+    ``list_len`` [n] number of ranked items actually available (< Kmax only when a user has fewer
+    than Kmax candidate items; the reference's precision is then a mean over the shorter list).
     Returns dict of per-user arrays [n, len(Ks)] for precision / recall / ndcg / hit_ratio,
     equal to calling the scalar functions above per user (reference batch_test.py:70-80)."""
     hits = np.asarray(hits, dtype=np.float64)
     n_pos = np.asarray(n_pos, dtype=np.float64)
     n, kmax = hits.shape
+    list_len = np.full(n, kmax, dtype=np.float64) if list_len is None else np.asarray(list_len, dtype=np.float64)
     disc = 1.0 / np.log2(np.arange(2, kmax + 2))
     ideal = -np.sort(-hits, axis=1)                    # sorted(r, reverse=True)
     out = {k: np.zeros((n, len(Ks))) for k in ("precision", "recall", "ndcg", "hit_ratio")}
@@ -76,7 +79,7 @@ def metrics_from_hit_matrix(hits, n_pos, Ks):
         K = min(K, kmax)
         h = hits[:, :K]
         s = h.sum(1)
-        out["precision"][:, j] = h.mean(1)
+        out["precision"][:, j] = s / np.maximum(np.minimum(list_len, K), 1)      # np.mean(r[:K]) over the real list
         out["recall"][:, j] = np.where(n_pos > 0, s / np.maximum(n_pos, 1), 0.0)
         dcg = (h * disc[:K]).sum(1)
         idcg = (ideal[:, :K] * disc[:K]).sum(1)
