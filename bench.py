@@ -119,8 +119,23 @@ class NetflixShaped:
         self.engine, self.ops, self.device = engine, ops, device
         self.step_id = 0
         self.units_per_step = self.hp.batch_size
+        # the fused step (hand-written backward, 7-stream SpMM operands, multi-BPR) replayed from a HIP graph
+        from llmrec_amd.fused import FusedStep
+        a = self.args
+        self.fused = FusedStep(self.model, self.graph, self.hp, (a.model_cat_rate, a.user_cat_rate, a.item_cat_rate), self.opt,
+                               self.hp.batch_size + self.batcher.n_aug)
+        self.use_graph = os.environ.get("LLMREC_GRAPH", "1") == "1"
 
     def step(self):
+        u, p, n, nv = self.batcher.next(self.step_id)
+        self.step_id += 1
+        if self.use_graph and self.fused.graph_exec is None:
+            self.fused.capture(u, p, n, nv)
+            return self.fused.scal[1:4]
+        return self.fused.step(u, p, n, nv)
+
+    def step_modular(self):
+        """The same step through torch.autograd over the per-op Functions (reference-shaped path)."""
         u, p, n, nv = self.batcher.next(self.step_id)
         self.step_id += 1
         return self.engine.train_step(self.model, self.opt, self.graph.ui, self.graph.iu, u, p, n, self.hp, n_valid=nv)
@@ -136,7 +151,8 @@ class NetflixShaped:
                 "embed_size": self.args.embed_size, "prop_layers": len(eval(self.args.weight_size)),
                 "batch_size": self.hp.batch_size, "aug_sample_rate": self.hp.aug_sample_rate,
                 "prune_loss_drop_rate": self.hp.prune_loss_drop_rate, "side_features": "image512+text768+llm1536x(1+5)",
-                "sampler": "device (llmrec_sample_bpr)", "parallelism": "single GPU"}
+                "sampler": "device (llmrec_sample_bpr)", "parallelism": "single GPU",
+                "step": "fused (llmrec_amd/fused.py)" + (" + HIP graph replay" if self.use_graph else "")}
 
     # ---- per-kernel roofline (dominant kernels of this workload, timed in isolation) -------------
     def kernel_rooflines(self):

@@ -80,8 +80,8 @@ int llmrec_csr_row_constant(int64_t n_rows, const int32_t* rowptr, const float* 
  * lists come from the plan calls below and `partials` is caller scratch of
  * plan.n_segments * d floats.
  * ------------------------------------------------------------------------------------------ */
-#define LLMREC_SPMM_LONG_ROW 128   /* rows with more nnz are split              */
-#define LLMREC_SPMM_SEGMENT 256    /* ... into segments of this many nnz         */
+#define LLMREC_SPMM_LONG_ROW 32    /* rows with more nnz are split              */
+#define LLMREC_SPMM_SEGMENT 128    /* ... into segments of this many nnz         */
 
 /* counts_host[0] = number of long rows, counts_host[1] = number of segments (synchronises). */
 int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t* scratch2 /* device, 2 ints */,
@@ -96,7 +96,7 @@ int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
                     const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t d,
                     int32_t n_long, const int32_t* long_rows, const int32_t* long_seg_begin,
                     int32_t n_seg, const int32_t* seg_long, float* partials,
-                    llmrec_stream_t stream);
+                    int32_t accumulate /* 1: Y += result */, llmrec_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * R4  side-feature projection            replaces nn.Linear forward / weight-grad
@@ -155,11 +155,13 @@ int llmrec_fuse_bwd_f32(int64_t rows, int32_t d, const float* dOut, int64_t lddo
  * out[0] = mf  = -(1/k) * sum_keep m_b
  * out[1] = emb = decay / batch_size_flag * (1/(2 Su + 1e-8) + 1/(2 Sp + 1e-8) + 1/(2 Sq + 1e-8)),
  *          S* = squared Frobenius norms of the three gathered B x d blocks
- * The same launch stores what backward needs (per-sample ds_b and the three norms) in `saved`
- * (B + 4 floats). B may come from device memory (n_valid_dev != NULL) so a captured graph can
+ * The forward stores what backward needs (per-sample ds_b, the three norms, and per-sample
+ * scratch) in `saved` (LLMREC_BPR_SAVED_FLOATS(B_max) floats). B may come from device memory (n_valid_dev != NULL) so a captured graph can
  * replay with a varying number of augmented triples; B_max bounds it (<= LLMREC_BPR_MAX_B).
  * ------------------------------------------------------------------------------------------ */
 #define LLMREC_BPR_MAX_B 4096
+#define LLMREC_BPR_MAX_PROBLEMS 8
+#define LLMREC_BPR_SAVED_FLOATS(B) (6 * (B) + 8)   /* floats of `saved` per problem */
 int llmrec_bpr_prune_fwd_f32(const float* Eu, int64_t ldu, const float* Ei, int64_t ldi, int32_t d,
                              const int64_t* users, const int64_t* pos, const int64_t* neg,
                              int32_t B_max, const int32_t* n_valid_dev,
@@ -167,7 +169,8 @@ int llmrec_bpr_prune_fwd_f32(const float* Eu, int64_t ldu, const float* Ei, int6
                              float* out2, float* saved, llmrec_stream_t stream);
 /* User-sharded batch: every rank holds B_local samples of a global batch of
  * global_B. Pass 1 (scores_only = 1) writes the local m_b to saved[0..B_local) and the local
- * squared norms to saved[B_local..B_local+2]; the host all-gathers the m_b (RCCL) and calls
+ * squared norms per sample to the scratch part of saved (m_b at saved[B_local + 4 + b]); the
+ * host all-gathers the m_b (RCCL) and calls
  * pass 2 with them: selection ranks against the GLOBAL batch (ties: lower global index), out2[0]
  * is this rank's share -(1/k) * sum_{kept local} m_b (all-reduce it), and saved is ready for
  * llmrec_bpr_prune_bwd_f32 once saved[B_local..B_local+2] hold the all-reduced norms. */
@@ -176,6 +179,23 @@ int llmrec_bpr_prune_fwd_sharded_f32(const float* Eu, int64_t ldu, const float* 
                                      int32_t B_local, double remember_rate, float decay, float batch_size_flag,
                                      const float* global_m, int32_t global_B, int32_t my_offset, int32_t scores_only,
                                      float* out2, float* saved, llmrec_stream_t stream);
+/* Several (user table, item table) pairs over ONE batch in two launches - the reference computes
+ * 8 such losses per step (main.py:232-254). out: [n_problems][2], saved: n_problems blocks of
+ * LLMREC_BPR_SAVED_FLOATS(B_max). The backward takes the loss weights from the (host) problem
+ * table (g_mf, g_emb) and scatter-adds into dEu / dEi, which the caller zero-initialises. */
+typedef struct {
+    const float* Eu; int64_t ldu; const float* Ei; int64_t ldi;
+    float* dEu; int64_t lddu; float* dEi; int64_t lddi;
+    float g_mf, g_emb;
+} llmrec_bpr_problem_t;
+int llmrec_bpr_multi_fwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
+                             const int64_t* users, const int64_t* pos, const int64_t* neg,
+                             int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
+                             float batch_size_flag, float* out, float* saved, llmrec_stream_t stream);
+int llmrec_bpr_multi_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
+                             const int64_t* users, const int64_t* pos, const int64_t* neg,
+                             int32_t B_max, const int32_t* n_valid_dev, float decay, float batch_size_flag,
+                             const float* saved, llmrec_stream_t stream);
 /* dEu[u_b] += g_mf * ds_b * (Ei[p_b] - Ei[q_b]) + g_emb * c_u * Eu[u_b]   (atomic scatter-add)
  * dEi[p_b] += g_mf * ds_b * Eu[u_b] + g_emb * c_p * Ei[p_b] ; dEi[q_b] likewise with -ds_b, c_q
  * g_mf / g_emb are upstream gradients read from device memory (grads2[0], grads2[1]). */

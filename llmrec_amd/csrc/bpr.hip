@@ -15,96 +15,150 @@ __device__ __forceinline__ float logsigmoid_f(float x) {
     return fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
 }
 
-// saved layout: [0, B_max) per-sample d(mf)/d(s_b); [B_max + 0..2] = Su, Sp, Sq; [B_max + 3] = k
-__global__ __launch_bounds__(BPR_THREADS) void bpr_fwd_kernel(const float* __restrict__ Eu, int64_t ldu,
-                                                              const float* __restrict__ Ei, int64_t ldi, int d,
-                                                              const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
-                                                              const int64_t* __restrict__ neg, int B_max,
-                                                              const int32_t* __restrict__ n_valid_dev, double remember_rate,
-                                                              float decay, float bsz, float* __restrict__ out2,
-                                                              float* __restrict__ saved, const float* __restrict__ global_m,
-                                                              int global_B, int my_offset, int scores_only) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* m_s = reinterpret_cast<float*>(smem);                       // [B_max] logsigmoid values
-    float* sg_s = m_s + B_max;                                         // [B_max] sigmoid(-(s + 1e-8))
-    float* red = sg_s + B_max;                                         // [BPR_THREADS]
-    float* nrm = red + BPR_THREADS;                                    // [BPR_GROUPS * 3]
+// ---------------------------------------------------------------------------------------------
+// Forward = two launches over up to LLMREC_BPR_MAX_PROBLEMS (user table, item table) pairs that
+// share one (users, pos, neg) batch - the reference evaluates 8 such losses per step
+// (main.py:232-254):
+//   bpr_scores_kernel  one 16-lane group per (problem, sample): the three row gathers, both dot
+//                      products, log-sigmoid, its derivative and the three squared row norms;
+//   bpr_select_kernel  one 1024-thread block per problem: rank counting over the B log-sigmoids
+//                      held in LDS (keep the k smallest, ties by lower index), the kept mean and
+//                      the norm sums by fixed-order trees (deterministic).
+// saved layout per problem (LLMREC_BPR_SAVED_FLOATS(B) floats):
+//   [0, B) d(mf)/d(s_b) | [B..B+2] Su, Sp, Sq | [B+3] k | [B+4 + {0..4} * B + b] m, sg, nu, np, nq
+// ---------------------------------------------------------------------------------------------
+struct BprTables {
+    const float* Eu[LLMREC_BPR_MAX_PROBLEMS];
+    const float* Ei[LLMREC_BPR_MAX_PROBLEMS];
+    int64_t ldu[LLMREC_BPR_MAX_PROBLEMS];
+    int64_t ldi[LLMREC_BPR_MAX_PROBLEMS];
+    float* dEu[LLMREC_BPR_MAX_PROBLEMS];
+    float* dEi[LLMREC_BPR_MAX_PROBLEMS];
+    int64_t lddu[LLMREC_BPR_MAX_PROBLEMS];
+    int64_t lddi[LLMREC_BPR_MAX_PROBLEMS];
+    float g_mf[LLMREC_BPR_MAX_PROBLEMS];
+    float g_emb[LLMREC_BPR_MAX_PROBLEMS];
+};
+
+__device__ __forceinline__ int bpr_batch(const int32_t* n_valid_dev, int B_max) {
     int B = n_valid_dev ? n_valid_dev[0] : B_max;
-    if (B > B_max) B = B_max;
-    if (B < 0) B = 0;
-    const int gl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    return B > B_max ? B_max : (B < 0 ? 0 : B);
+}
 
-    // phase 1: scores, log-sigmoids, squared norms
-    float su = 0.f, sp = 0.f, sq = 0.f;
-    for (int b = grp; b < B; b += BPR_GROUPS) {
-        const float* u = Eu + users[b] * ldu;
-        const float* p = Ei + pos[b] * ldi;
-        const float* q = Ei + neg[b] * ldi;
-        float dp = 0.f, dn = 0.f, nu = 0.f, np_ = 0.f, nq = 0.f;
-        for (int c = gl; c < d; c += 16) {
-            const float uu = u[c], pp = p[c], qq = q[c];
-            dp = fmaf(uu, pp, dp); dn = fmaf(uu, qq, dn);
-            nu = fmaf(uu, uu, nu); np_ = fmaf(pp, pp, np_); nq = fmaf(qq, qq, nq);
-        }
-        dp = group_sum<16>(dp); dn = group_sum<16>(dn);
-        nu = group_sum<16>(nu); np_ = group_sum<16>(np_); nq = group_sum<16>(nq);
-        su += nu; sp += np_; sq += nq;
-        if (gl == 0) {
-            const float x = (dp - dn) + 1e-8f;
-            m_s[b] = logsigmoid_f(x);
-            sg_s[b] = 1.0f / (1.0f + expf(x));                        // sigmoid(-x) = d logsigmoid / dx
-        }
+__global__ __launch_bounds__(256) void bpr_scores_kernel(BprTables t, int d, const int64_t* __restrict__ users,
+                                                         const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
+                                                         int B_max, const int32_t* __restrict__ n_valid_dev,
+                                                         float* __restrict__ saved_all, int saved_stride) {
+    const int B = bpr_batch(n_valid_dev, B_max);
+    const int prob = blockIdx.y;
+    const int gl = threadIdx.x & 15;
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (b >= B) return;
+    float* sc = saved_all + (int64_t)prob * saved_stride + B_max + 4;
+    const float* u = t.Eu[prob] + users[b] * t.ldu[prob];
+    const float* p = t.Ei[prob] + pos[b] * t.ldi[prob];
+    const float* q = t.Ei[prob] + neg[b] * t.ldi[prob];
+    float dp = 0.f, dn = 0.f, nu = 0.f, np_ = 0.f, nq = 0.f;
+    for (int c = gl; c < d; c += 16) {
+        const float uu = u[c], pp = p[c], qq = q[c];
+        dp = fmaf(uu, pp, dp); dn = fmaf(uu, qq, dn);
+        nu = fmaf(uu, uu, nu); np_ = fmaf(pp, pp, np_); nq = fmaf(qq, qq, nq);
     }
-    if (gl == 0) { nrm[grp * 3 + 0] = su; nrm[grp * 3 + 1] = sp; nrm[grp * 3 + 2] = sq; }
-    __syncthreads();
+    dp = group_sum<16>(dp); dn = group_sum<16>(dn);
+    nu = group_sum<16>(nu); np_ = group_sum<16>(np_); nq = group_sum<16>(nq);
+    if (gl == 0) {
+        const float x = (dp - dn) + 1e-8f;
+        sc[b] = logsigmoid_f(x);
+        sc[B_max + b] = 1.0f / (1.0f + expf(x));                      // sigmoid(-x) = d logsigmoid / dx
+        sc[2 * B_max + b] = nu; sc[3 * B_max + b] = np_; sc[4 * B_max + b] = nq;
+    }
+}
 
-    if (scores_only) {
-        // sharded batch, pass 1: publish the local log-sigmoids and squared norms; the caller
-        // all-gathers them and calls again with global_m (pass 2)
-        for (int b = threadIdx.x; b < B_max; b += BPR_THREADS) saved[b] = b < B ? m_s[b] : INFINITY;
-        if (threadIdx.x == 0) {
-            float Su = 0.f, Sp = 0.f, Sq = 0.f;
-            for (int g = 0; g < BPR_GROUPS; ++g) { Su += nrm[g * 3]; Sp += nrm[g * 3 + 1]; Sq += nrm[g * 3 + 2]; }
-            saved[B_max + 0] = Su; saved[B_max + 1] = Sp; saved[B_max + 2] = Sq; saved[B_max + 3] = 0.f;
-        }
-        return;
-    }
-
-    // phase 2: keep the k smallest m_b (ties: lower global index first) by rank counting; with a
-    // sharded batch the ranking runs against the all-gathered m of every rank
-    const int Bg = global_m ? global_B : B;
-    const float* mg = global_m ? global_m : m_s;
-    const int k = (int)(remember_rate * (double)Bg);                   // int((1 - drop) * len) of main.py:161-162
-    float part = 0.f;
-    for (int b = threadIdx.x; b < B; b += BPR_THREADS) {
-        const float mb = m_s[b];
-        bool keep = true;
-        if (k < Bg) {
-            int rank = 0;
-            const int me = my_offset + b;
-            for (int j = 0; j < Bg; ++j) {
-                const float mj = mg[j];
-                rank += (mj < mb) || (mj == mb && j < me);
-            }
-            keep = rank < k;
-        }
-        if (keep) part += mb;
-        saved[b] = keep ? (-1.0f / (float)k) * sg_s[b] : 0.f;
-    }
-    for (int b = B + threadIdx.x; b < B_max; b += BPR_THREADS) saved[b] = 0.f;
-    red[threadIdx.x] = part;
+__device__ __forceinline__ float block_tree_sum(float v, float* red) {
+    red[threadIdx.x] = v;
     __syncthreads();
     for (int off = BPR_THREADS / 2; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(BPR_THREADS) void bpr_select_kernel(int B_max, const int32_t* __restrict__ n_valid_dev,
+                                                                 double remember_rate, float decay, float bsz,
+                                                                 float* __restrict__ out_all, float* __restrict__ saved_all,
+                                                                 int saved_stride, const float* __restrict__ global_m,
+                                                                 int global_B, int my_offset) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* m_s = reinterpret_cast<float*>(smem);                       // [Bg] log-sigmoids ranked against
+    float* red = m_s + (global_m ? global_B : B_max);                  // [BPR_THREADS]
+    const int B = bpr_batch(n_valid_dev, B_max);
+    const int prob = blockIdx.x;
+    float* saved = saved_all + (int64_t)prob * saved_stride;
+    const float* sc = saved + B_max + 4;
+    const int Bg = global_m ? global_B : B;
+    for (int j = threadIdx.x; j < Bg; j += BPR_THREADS) m_s[j] = global_m ? global_m[j] : sc[j];
+    __syncthreads();
+    const int k = (int)(remember_rate * (double)Bg);                   // int((1 - drop) * len) of main.py:161-162
+    float part = 0.f, su = 0.f, sp = 0.f, sq = 0.f;
+    for (int b = threadIdx.x; b < B; b += BPR_THREADS) {
+        const float mb = sc[b];
+        bool keep = true;
+        if (k < Bg) {
+            int rank = 0;
+            const int me = my_offset + b;
+            for (int j = 0; j < Bg; ++j) {
+                const float mj = m_s[j];
+                rank += (mj < mb) || (mj == mb && j < me);
+            }
+            keep = rank < k;
+        }
+        if (keep) part += mb;
+        saved[b] = keep ? (-1.0f / (float)k) * sc[B_max + b] : 0.f;
+        su += sc[2 * B_max + b]; sp += sc[3 * B_max + b]; sq += sc[4 * B_max + b];
+    }
+    for (int b = B + threadIdx.x; b < B_max; b += BPR_THREADS) saved[b] = 0.f;
+    const float kept = block_tree_sum(part, red);
+    const float Su = block_tree_sum(su, red), Sp = block_tree_sum(sp, red), Sq = block_tree_sum(sq, red);
     if (threadIdx.x == 0) {
-        float Su = 0.f, Sp = 0.f, Sq = 0.f;
-        for (int g = 0; g < BPR_GROUPS; ++g) { Su += nrm[g * 3]; Sp += nrm[g * 3 + 1]; Sq += nrm[g * 3 + 2]; }
-        out2[0] = -(red[0] / (float)k);                                // k == 0 -> nan, as torch's empty mean
+        out_all[prob * 2 + 0] = -(kept / (float)k);                    // k == 0 -> nan, as torch's empty mean
         const float reg = 1.0f / (2.0f * Su + 1e-8f) + 1.0f / (2.0f * Sp + 1e-8f) + 1.0f / (2.0f * Sq + 1e-8f);
-        out2[1] = decay * (reg / bsz);
+        out_all[prob * 2 + 1] = decay * (reg / bsz);
         saved[B_max + 0] = Su; saved[B_max + 1] = Sp; saved[B_max + 2] = Sq; saved[B_max + 3] = (float)k;
+    }
+}
+
+// backward for several problems with HOST loss weights (fused step): grid.y = problem
+__global__ __launch_bounds__(256) void bpr_bwd_multi_kernel(BprTables t, int d, const int64_t* __restrict__ users,
+                                                            const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
+                                                            int B_max, const int32_t* __restrict__ n_valid_dev, float decay, float bsz,
+                                                            const float* __restrict__ saved_all, int saved_stride) {
+    const int B = bpr_batch(n_valid_dev, B_max);
+    const int prob = blockIdx.y;
+    const float* saved = saved_all + (int64_t)prob * saved_stride;
+    const float g_mf = t.g_mf[prob], g_emb = t.g_emb[prob];
+    const float Su = saved[B_max], Sp = saved[B_max + 1], Sq = saved[B_max + 2];
+    const float base = -4.0f * decay / bsz * g_emb;
+    const float du_ = 2.0f * Su + 1e-8f, dp_ = 2.0f * Sp + 1e-8f, dq_ = 2.0f * Sq + 1e-8f;
+    const float cu = base / (du_ * du_), cp = base / (dp_ * dp_), cq = base / (dq_ * dq_);
+    const int gl = threadIdx.x & 15;
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (b >= B) return;
+    const int64_t ui = users[b], pi = pos[b], qi = neg[b];
+    const float ds = g_mf * saved[b];
+    const float* u = t.Eu[prob] + ui * t.ldu[prob];
+    const float* p = t.Ei[prob] + pi * t.ldi[prob];
+    const float* q = t.Ei[prob] + qi * t.ldi[prob];
+    float* du = t.dEu[prob] + ui * t.lddu[prob];
+    float* dpp = t.dEi[prob] + pi * t.lddi[prob];
+    float* dqq = t.dEi[prob] + qi * t.lddi[prob];
+    for (int c = gl; c < d; c += 16) {
+        const float uu = u[c], pp = p[c], qq = q[c];
+        atomicAdd(du + c, fmaf(ds, pp - qq, cu * uu));
+        atomicAdd(dpp + c, fmaf(ds, uu, cp * pp));
+        atomicAdd(dqq + c, fmaf(-ds, uu, cq * qq));
     }
 }
 
@@ -225,20 +279,37 @@ using namespace llmrec;
 
 extern "C" {
 
+static int launch_bpr_fwd(const BprTables& t, int n_prob, int d, const int64_t* users, const int64_t* pos, const int64_t* neg,
+                          int B_max, const int32_t* n_valid_dev, double remember_rate, float decay, float bsz,
+                          float* out, float* saved, const float* global_m, int global_B, int my_offset,
+                          bool do_scores, bool do_select, hipStream_t stream) {
+    const int stride = LLMREC_BPR_SAVED_FLOATS(B_max);
+    if (do_scores && B_max > 0) {
+        dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_prob);
+        bpr_scores_kernel<<<grid, 256, 0, stream>>>(t, d, users, pos, neg, B_max, n_valid_dev, saved, stride);
+        LLMREC_LAUNCH_CHECK();
+    }
+    if (do_select) {
+        const size_t shmem = sizeof(float) * ((size_t)(global_m ? global_B : B_max) + BPR_THREADS);
+        bpr_select_kernel<<<n_prob, BPR_THREADS, shmem, stream>>>(B_max, n_valid_dev, remember_rate, decay, bsz, out, saved, stride,
+                                                                  global_m, global_B, my_offset);
+        LLMREC_LAUNCH_CHECK();
+    }
+    return LLMREC_OK;
+}
+
 int llmrec_bpr_prune_fwd_f32(const float* Eu, int64_t ldu, const float* Ei, int64_t ldi, int32_t d,
                              const int64_t* users, const int64_t* pos, const int64_t* neg,
                              int32_t B_max, const int32_t* n_valid_dev,
                              double remember_rate, float decay, float batch_size_flag,
                              float* out2, float* saved, llmrec_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
     LLMREC_CHECK_ARG(B_max >= 0 && d > 0 && out2 && saved, "bpr_fwd: bad argument");
     if (B_max > LLMREC_BPR_MAX_B) { set_error("bpr_fwd: B_max %d > %d", B_max, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
     LLMREC_CHECK_ARG(B_max == 0 || (Eu && Ei && users && pos && neg && ldu >= d && ldi >= d), "bpr_fwd: null pointer or ld < d");
-    const size_t shmem = sizeof(float) * ((size_t)2 * B_max + BPR_THREADS + BPR_GROUPS * 3);
-    bpr_fwd_kernel<<<1, BPR_THREADS, shmem, stream>>>(Eu, ldu, Ei, ldi, d, users, pos, neg, B_max, n_valid_dev,
-                                                     remember_rate, decay, batch_size_flag, out2, saved, nullptr, 0, 0, 0);
-    LLMREC_LAUNCH_CHECK();
-    return LLMREC_OK;
+    BprTables t = {};
+    t.Eu[0] = Eu; t.Ei[0] = Ei; t.ldu[0] = ldu; t.ldi[0] = ldi;
+    return launch_bpr_fwd(t, 1, d, users, pos, neg, B_max, n_valid_dev, remember_rate, decay, batch_size_flag, out2, saved,
+                          nullptr, 0, 0, true, true, (hipStream_t)stream_);
 }
 
 int llmrec_bpr_prune_fwd_sharded_f32(const float* Eu, int64_t ldu, const float* Ei, int64_t ldi, int32_t d,
@@ -246,16 +317,56 @@ int llmrec_bpr_prune_fwd_sharded_f32(const float* Eu, int64_t ldu, const float* 
                                      int32_t B_local, double remember_rate, float decay, float batch_size_flag,
                                      const float* global_m, int32_t global_B, int32_t my_offset, int32_t scores_only,
                                      float* out2, float* saved, llmrec_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
     LLMREC_CHECK_ARG(B_local >= 0 && d > 0 && out2 && saved, "bpr_fwd_sharded: bad argument");
-    if (B_local > LLMREC_BPR_MAX_B) { set_error("bpr_fwd_sharded: B_local %d > %d", B_local, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
+    if (B_local > LLMREC_BPR_MAX_B || global_B > 3 * LLMREC_BPR_MAX_B) { set_error("bpr_fwd_sharded: batch too large"); return LLMREC_EUNSUPPORTED; }
     LLMREC_CHECK_ARG(B_local == 0 || (Eu && Ei && users && pos && neg && ldu >= d && ldi >= d), "bpr_fwd_sharded: null pointer or ld < d");
     LLMREC_CHECK_ARG(scores_only || (global_m && global_B >= B_local && my_offset >= 0 && my_offset + B_local <= global_B),
                      "bpr_fwd_sharded: pass 2 needs the gathered scores and a valid offset");
-    const size_t shmem = sizeof(float) * ((size_t)2 * B_local + BPR_THREADS + BPR_GROUPS * 3);
-    bpr_fwd_kernel<<<1, BPR_THREADS, shmem, stream>>>(Eu, ldu, Ei, ldi, d, users, pos, neg, B_local, nullptr,
-                                                     remember_rate, decay, batch_size_flag, out2, saved,
-                                                     scores_only ? nullptr : global_m, global_B, my_offset, scores_only);
+    BprTables t = {};
+    t.Eu[0] = Eu; t.Ei[0] = Ei; t.ldu[0] = ldu; t.ldi[0] = ldi;
+    // pass 1 writes the per-sample scratch (m at saved[B_local + 4 ...)); pass 2 only selects
+    return launch_bpr_fwd(t, 1, d, users, pos, neg, B_local, nullptr, remember_rate, decay, batch_size_flag, out2, saved,
+                          global_m, global_B, my_offset, scores_only != 0, scores_only == 0, (hipStream_t)stream_);
+}
+
+static int fill_tables(BprTables& t, int n, const llmrec_bpr_problem_t* p, int d, bool need_grads) {
+    for (int i = 0; i < n; ++i) {
+        if (!p[i].Eu || !p[i].Ei || p[i].ldu < d || p[i].ldi < d) return 1;
+        if (need_grads && (!p[i].dEu || !p[i].dEi || p[i].lddu < d || p[i].lddi < d)) return 1;
+        t.Eu[i] = p[i].Eu; t.Ei[i] = p[i].Ei; t.ldu[i] = p[i].ldu; t.ldi[i] = p[i].ldi;
+        t.dEu[i] = p[i].dEu; t.dEi[i] = p[i].dEi; t.lddu[i] = p[i].lddu; t.lddi[i] = p[i].lddi;
+        t.g_mf[i] = p[i].g_mf; t.g_emb[i] = p[i].g_emb;
+    }
+    return 0;
+}
+
+int llmrec_bpr_multi_fwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
+                             const int64_t* users, const int64_t* pos, const int64_t* neg,
+                             int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
+                             float batch_size_flag, float* out, float* saved, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && problems_host && d > 0 && out && saved,
+                     "bpr_multi_fwd: bad argument");
+    if (B_max > LLMREC_BPR_MAX_B) { set_error("bpr_multi_fwd: B_max %d > %d", B_max, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
+    LLMREC_CHECK_ARG(B_max == 0 || (users && pos && neg), "bpr_multi_fwd: null index pointer");
+    BprTables t = {};
+    LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, false), "bpr_multi_fwd: bad problem table");
+    return launch_bpr_fwd(t, n_problems, d, users, pos, neg, B_max, n_valid_dev, remember_rate, decay, batch_size_flag, out, saved,
+                          nullptr, 0, 0, true, true, (hipStream_t)stream_);
+}
+
+int llmrec_bpr_multi_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
+                             const int64_t* users, const int64_t* pos, const int64_t* neg,
+                             int32_t B_max, const int32_t* n_valid_dev, float decay, float batch_size_flag,
+                             const float* saved, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && problems_host && d > 0 && saved,
+                     "bpr_multi_bwd: bad argument");
+    if (B_max == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(users && pos && neg, "bpr_multi_bwd: null index pointer");
+    BprTables t = {};
+    LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, true), "bpr_multi_bwd: bad problem table");
+    dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_problems);
+    bpr_bwd_multi_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(t, d, users, pos, neg, B_max, n_valid_dev, decay, batch_size_flag,
+                                                                saved, LLMREC_BPR_SAVED_FLOATS(B_max));
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

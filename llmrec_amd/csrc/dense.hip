@@ -38,16 +38,24 @@ __device__ __forceinline__ float comp(const float4& v, int s) {
 // ---------------------------------------------------------------------------------------------
 // forward: each wave computes RT*16 rows x NT*16 columns; block = 4 waves
 // ---------------------------------------------------------------------------------------------
-template <int NT, int RT>
+// SPLITK = false: the block's 4 waves take 4 different row tiles and the whole K range.
+// SPLITK = true : the 4 waves share ONE row tile and split K in four; partial tiles are combined
+//                 through LDS in wave order (deterministic). Used when M alone gives too few
+//                 waves to hide the operand-load latency (M = 17366 -> 1086 row tiles for 1024 SIMDs).
+template <int NT, int RT, bool SPLITK>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(int64_t M, int N, int K, const float* __restrict__ X, int64_t ldx,
                                                          const float* __restrict__ W, int64_t ldw,
                                                          const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy,
                                                          int vec_ok) {
+    extern __shared__ __attribute__((aligned(16))) float part_lds[];   // SPLITK: [4][RT*16][NT*16]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * (RT * 16);
-    if (row0 >= M) return;
+    const int64_t row0 = SPLITK ? (int64_t)blockIdx.x * (RT * 16) : ((int64_t)blockIdx.x * 4 + wave) * (RT * 16);
+    if (!SPLITK && row0 >= M) return;
+    const int kq = SPLITK ? (((K + 3) / 4 + 15) / 16) * 16 : K;        // K range of this wave
+    const int k_begin = SPLITK ? wave * kq : 0;
+    const int k_end = SPLITK ? min(K, k_begin + kq) : K;
     const float* xrow[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
@@ -71,16 +79,16 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(int64_t M, int N, int K
     float4 xa[RT], wb[NT], xa_n[RT], wb_n[NT];
     const int koff = 4 * lq;
 #pragma unroll
-    for (int t = 0; t < RT; ++t) xa[t] = load4_guard(xrow[t], koff, K, vec_ok);
+    for (int t = 0; t < RT; ++t) xa[t] = load4_guard(xrow[t], k_begin + koff, k_end, vec_ok);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) wb[n] = load4_guard(wrow[n], koff, K, vec_ok);
-    for (int kb = 0; kb < K; kb += 16) {
+    for (int n = 0; n < NT; ++n) wb[n] = load4_guard(wrow[n], k_begin + koff, k_end, vec_ok);
+    for (int kb = k_begin; kb < k_end; kb += 16) {
         const int kn = kb + 16 + koff;
-        if (kb + 16 < K) {
+        if (kb + 16 < k_end) {
 #pragma unroll
-            for (int t = 0; t < RT; ++t) xa_n[t] = load4_guard(xrow[t], kn, K, vec_ok);
+            for (int t = 0; t < RT; ++t) xa_n[t] = load4_guard(xrow[t], kn, k_end, vec_ok);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) wb_n[n] = load4_guard(wrow[n], kn, K, vec_ok);
+            for (int n = 0; n < NT; ++n) wb_n[n] = load4_guard(wrow[n], kn, k_end, vec_ok);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -93,6 +101,29 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(int64_t M, int N, int K
         for (int t = 0; t < RT; ++t) xa[t] = xa_n[t];
 #pragma unroll
         for (int n = 0; n < NT; ++n) wb[n] = wb_n[n];
+    }
+    if (SPLITK) {
+        constexpr int R = RT * 16, C = NT * 16;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    part_lds[(wave * R + t * 16 + lq * 4 + r) * C + n * 16 + li] = acc[t][n][r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < R * C; e += 256) {
+            const int r = e / C, c = e % C;
+            const int64_t row = row0 + r;
+            if (row < M && c < N) {
+                float v = part_lds[e];
+                v += part_lds[R * C + e];
+                v += part_lds[2 * R * C + e];
+                v += part_lds[3 * R * C + e];
+                Y[row * ldy + c] = v + (bias ? bias[c] : 0.f);
+            }
+        }
+        return;
     }
     // D layout: lane holds D[row = lq*4 + r][col = li]
 #pragma unroll
@@ -138,19 +169,23 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int64_t M, int N, int
         for (int p = 0; p < 4; ++p) acc[q][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    for (int64_t m0 = m_begin; m0 < m_end; m0 += 16) {
-        float4 a[4], b[4];
+    float4 a[4], b[4], an[4], bn[4];
+    auto load_tile = [&](int64_t m0, float4 (&aa)[4], float4 (&bb)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {                            // 4 MFMA k-steps of 4 rows each
             const int64_t m = m0 + 4 * s + lq;
             if (m < m_end) {
-                a[s] = load4_guard(dY + m * lddy, n_base, N, vec_ok);
-                b[s] = load4_guard(X + m * ldx, k_base, K, vec_ok);
+                aa[s] = load4_guard(dY + m * lddy, n_base, N, vec_ok);
+                bb[s] = load4_guard(X + m * ldx, k_base, K, vec_ok);
             } else {
-                a[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-                b[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+                aa[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+                bb[s] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+    };
+    load_tile(m_begin, a, b);
+    for (int64_t m0 = m_begin; m0 < m_end; m0 += 16) {
+        if (m0 + 16 < m_end) load_tile(m0 + 16, an, bn);         // register double buffer
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             dbs.x += a[s].x; dbs.y += a[s].y; dbs.z += a[s].z; dbs.w += a[s].w;
@@ -160,6 +195,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int64_t M, int N, int
                 for (int p = 0; p < 4; ++p)
                     acc[q][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(a[s], q), comp(b[s], p), acc[q][p], 0, 0, 0);
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { a[s] = an[s]; b[s] = bn[s]; }
     }
     // D[q][p]: lane holds rows i = lq*4 + r (n = nblk*64 + 4 i + q), col j = li (k = kslab*64 + 4 j + p)
     float* pw = partial + chunk * (int64_t)N * K;
@@ -194,8 +231,16 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int64_t M, int N, int
 __global__ void reduce_chunks_kernel(int64_t n_elem, int64_t n_chunks, const float* __restrict__ partial,
                                      float* __restrict__ out, int64_t ld_out, int row_len, int accumulate) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elem; e += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int64_t c = 0; c < n_chunks; ++c) s += partial[c * n_elem + e];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int64_t c = 0;
+        for (; c + 4 <= n_chunks; c += 4) {                      // 4 independent loads in flight
+            s0 += partial[c * n_elem + e];
+            s1 += partial[(c + 1) * n_elem + e];
+            s2 += partial[(c + 2) * n_elem + e];
+            s3 += partial[(c + 3) * n_elem + e];
+        }
+        for (; c < n_chunks; ++c) s0 += partial[c * n_elem + e];
+        const float s = (s0 + s1) + (s2 + s3);
         const int64_t r = e / row_len, col = e % row_len;
         float* o = out + r * ld_out + col;
         *o = accumulate ? (*o + s) : s;
@@ -204,10 +249,11 @@ __global__ void reduce_chunks_kernel(int64_t n_elem, int64_t n_chunks, const flo
 
 static void wgrad_geometry(int64_t M, int K, int64_t* MC, int64_t* n_chunks, int* n_kslab) {
     *n_kslab = (int)ceil_div(K, 64);
-    // aim for ~4096 waves; chunks are multiples of 16 rows
-    int64_t want_chunks = ceil_div(4096, *n_kslab);
+    // aim for ~2048 waves (2 per SIMD); chunks are multiples of 16 rows, at least 128 rows each so
+    // the partial slabs (n_chunks x N x K floats) stay small next to the X stream
+    int64_t want_chunks = ceil_div(2048, *n_kslab);
     int64_t mc = align_up(ceil_div(M, want_chunks), 16);
-    if (mc < 64) mc = 64;
+    if (mc < 128) mc = 128;
     *MC = mc;
     *n_chunks = ceil_div(M, mc);
 }
@@ -228,21 +274,25 @@ int llmrec_linear_fwd_f32(int64_t M, int32_t N, int32_t K, const float* X, int64
     if (N > 128) { set_error("linear_fwd: N = %d > 128", N); return LLMREC_EUNSUPPORTED; }
     const int vec_ok = (ldx % 4 == 0) && (ldw % 4 == 0) && (((uintptr_t)X | (uintptr_t)W) % 16 == 0);
     const int NT = (N + 15) / 16;
-    // 32-row wave tiles once there is enough work to fill 1024 SIMDs twice, else 16-row tiles
-    const bool big = M >= 32 * 2048;
-#define LAUNCH_FWD(NT_, RT_)                                                                          \
-    linear_fwd_kernel<NT_, RT_><<<(int)ceil_div(M, 4 * 16 * RT_), 256, 0, stream>>>(M, N, K, X, ldx, W, ldw, bias, Y, ldy, vec_ok)
+    // enough row tiles to keep >= 2 waves per SIMD busy -> row mode (32-row tiles); otherwise the
+    // 4 waves of a block split K over one 16-row tile
+    const bool rows_mode = M >= 32 * 2048;
+#define LAUNCH_ROWS(NT_, RT_)                                                                         \
+    linear_fwd_kernel<NT_, RT_, false><<<(int)ceil_div(M, 4 * 16 * RT_), 256, 0, stream>>>(M, N, K, X, ldx, W, ldw, bias, Y, ldy, vec_ok)
+#define LAUNCH_SPLITK(NT_)                                                                            \
+    linear_fwd_kernel<NT_, 1, true><<<(int)ceil_div(M, 16), 256, sizeof(float) * 4 * 16 * 16 * NT_, stream>>>(M, N, K, X, ldx, W, ldw, bias, Y, ldy, vec_ok)
     switch (NT) {
-        case 1: if (big) LAUNCH_FWD(1, 2); else LAUNCH_FWD(1, 1); break;
-        case 2: if (big) LAUNCH_FWD(2, 2); else LAUNCH_FWD(2, 1); break;
-        case 3: if (big) LAUNCH_FWD(3, 2); else LAUNCH_FWD(3, 1); break;
-        case 4: if (big) LAUNCH_FWD(4, 2); else LAUNCH_FWD(4, 1); break;
-        case 5: LAUNCH_FWD(5, 1); break;
-        case 6: LAUNCH_FWD(6, 1); break;
-        case 7: LAUNCH_FWD(7, 1); break;
-        default: LAUNCH_FWD(8, 1); break;
+        case 1: if (rows_mode) LAUNCH_ROWS(1, 2); else LAUNCH_SPLITK(1); break;
+        case 2: if (rows_mode) LAUNCH_ROWS(2, 2); else LAUNCH_SPLITK(2); break;
+        case 3: if (rows_mode) LAUNCH_ROWS(3, 2); else LAUNCH_SPLITK(3); break;
+        case 4: if (rows_mode) LAUNCH_ROWS(4, 2); else LAUNCH_SPLITK(4); break;
+        case 5: if (rows_mode) LAUNCH_ROWS(5, 1); else LAUNCH_SPLITK(5); break;
+        case 6: if (rows_mode) LAUNCH_ROWS(6, 1); else LAUNCH_SPLITK(6); break;
+        case 7: if (rows_mode) LAUNCH_ROWS(7, 1); else LAUNCH_SPLITK(7); break;
+        default: if (rows_mode) LAUNCH_ROWS(8, 1); else LAUNCH_SPLITK(8); break;
     }
-#undef LAUNCH_FWD
+#undef LAUNCH_ROWS
+#undef LAUNCH_SPLITK
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

@@ -19,7 +19,7 @@
 
 namespace llmrec {
 
-constexpr int UNROLL = 4;
+constexpr int UNROLL = 8;
 
 template <int VEC> struct Vec;
 template <> struct Vec<4> {
@@ -60,6 +60,7 @@ struct SpmmArgs {
     float* Y;
     int64_t ldy;
     int32_t d;
+    int32_t accumulate;          // 1: Y += result
     int32_t skip_long;           // 1: rows longer than LLMREC_SPMM_LONG_ROW are left to the segment pass
     const int32_t* long_rows;
     const int32_t* long_seg_begin;
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
         const int col = (k * LPR + gl) * VEC;
         if (col < a.d) {
             if (a.row_scale) acc[k].scale(rs);
+            if (a.accumulate) { Vec<VEC> old; old.load(yr + col); acc[k].add(old); }
             acc[k].store(yr + col);
         }
     }
@@ -170,25 +172,56 @@ __global__ __launch_bounds__(256) void spmm_segments_kernel(SpmmArgs a, int32_t 
     }
 }
 
-// one block per long row: column c is summed over the row's segment partials in ascending order
+// one block per long row: the 256/LPR lane groups each add every (256/LPR)-th segment partial
+// (ascending), then the groups are combined through LDS in group order - a fixed summation tree
+template <int LPR, int NCHUNK, int VEC>
 __global__ __launch_bounds__(256) void spmm_finalize_kernel(SpmmArgs a) {
+    constexpr int G = 256 / LPR;
+    extern __shared__ __attribute__((aligned(16))) float fin_lds[];   // [G][NCHUNK * LPR * VEC]
+    constexpr int ROWW = NCHUNK * LPR * VEC;
+    const int gl = threadIdx.x & (LPR - 1), g = threadIdx.x / LPR;
     const int32_t slot = blockIdx.x;
     const int32_t row = a.long_rows[slot];
     const int32_t deg = a.rowptr[row + 1] - a.rowptr[row];
     const int32_t nseg = (deg + LLMREC_SPMM_SEGMENT - 1) / LLMREC_SPMM_SEGMENT;
     const float* pr = a.partials + (int64_t)a.long_seg_begin[slot] * a.d;
-    const float rs = a.row_scale ? a.row_scale[row] : 1.0f;
-    for (int c = threadIdx.x; c < a.d; c += blockDim.x) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int k = 0;
-        for (; k + 4 <= nseg; k += 4) {
-            s0 += pr[(int64_t)(k + 0) * a.d + c];
-            s1 += pr[(int64_t)(k + 1) * a.d + c];
-            s2 += pr[(int64_t)(k + 2) * a.d + c];
-            s3 += pr[(int64_t)(k + 3) * a.d + c];
+    Vec<VEC> acc[NCHUNK];
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
+    for (int s0 = g; s0 < nseg; s0 += 4 * G) {
+        Vec<VEC> v[4][NCHUNK];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int sidx = s0 + u * G;
+#pragma unroll
+            for (int k = 0; k < NCHUNK; ++k) {
+                const int col = (k * LPR + gl) * VEC;
+                if (sidx < nseg && col < a.d) v[u][k].load(pr + (int64_t)sidx * a.d + col);
+                else v[u][k].zero();
+            }
         }
-        for (; k < nseg; ++k) s0 += pr[(int64_t)k * a.d + c];
-        a.Y[(int64_t)row * a.ldy + c] = ((s0 + s1) + (s2 + s3)) * rs;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < NCHUNK; ++k) acc[k].add(v[u][k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) acc[k].store(fin_lds + g * ROWW + (k * LPR + gl) * VEC);
+    __syncthreads();
+    if (g == 0) {
+        const float rs = a.row_scale ? a.row_scale[row] : 1.0f;
+        float* yr = a.Y + (int64_t)row * a.ldy;
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k) {
+            const int col = (k * LPR + gl) * VEC;
+            if (col >= a.d) continue;
+            Vec<VEC> t;
+            t.zero();
+            for (int gg = 0; gg < G; ++gg) { Vec<VEC> o; o.load(fin_lds + gg * ROWW + col); t.add(o); }
+            if (a.row_scale) t.scale(rs);
+            if (a.accumulate) { Vec<VEC> old; old.load(yr + col); t.add(old); }
+            t.store(yr + col);
+        }
     }
 }
 
@@ -208,7 +241,7 @@ static int launch_spmm(const SpmmArgs& a, int32_t n_long, int32_t n_seg, hipStre
         if (weighted) spmm_segments_kernel<LPR, NCHUNK, VEC, true><<<sb, 256, 0, stream>>>(a, n_seg);
         else spmm_segments_kernel<LPR, NCHUNK, VEC, false><<<sb, 256, 0, stream>>>(a, n_seg);
         LLMREC_LAUNCH_CHECK();
-        spmm_finalize_kernel<<<n_long, 256, 0, stream>>>(a);
+        spmm_finalize_kernel<LPR, NCHUNK, VEC><<<n_long, 256, sizeof(float) * (256 / LPR) * NCHUNK * LPR * VEC, stream>>>(a);
         LLMREC_LAUNCH_CHECK();
     }
     return LLMREC_OK;
@@ -224,7 +257,7 @@ extern "C" int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
                                const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t d,
                                int32_t n_long, const int32_t* long_rows, const int32_t* long_seg_begin,
                                int32_t n_seg, const int32_t* seg_long, float* partials,
-                               llmrec_stream_t stream_) {
+                               int32_t accumulate, llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LLMREC_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && d >= 0, "spmm: negative size");
     if (n_rows == 0 || d == 0) return LLMREC_OK;
@@ -234,7 +267,7 @@ extern "C" int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
     SpmmArgs a;
     a.n_rows = n_rows; a.rowptr = rowptr; a.colidx = colidx; a.val = val; a.row_scale = row_scale;
     a.col_scale = col_scale; a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.d = d;
-    a.skip_long = n_long > 0; a.long_rows = long_rows; a.long_seg_begin = long_seg_begin;
+    a.accumulate = accumulate; a.skip_long = n_long > 0; a.long_rows = long_rows; a.long_seg_begin = long_seg_begin;
     a.seg_long = seg_long; a.partials = partials;
     const bool vec4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
                       (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)partials) % 16 == 0);

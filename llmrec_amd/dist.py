@@ -60,6 +60,11 @@ class HipBackend:
     def __init__(self):
         from . import ops
         self.ops = ops
+        self._saved = None
+
+    def bpr_local_m(self, saved, B):
+        """The local log-sigmoids pass 1 left in the scratch part of `saved`."""
+        return saved[B + 4: 2 * B + 4]
 
     def pattern_csr(self, rows, cols, n_rows, n_cols):
         rp, ci, _ = self.ops.csr_from_coo(rows, cols, None, n_rows, n_cols)
@@ -86,7 +91,9 @@ class HipBackend:
         Eu, Ei = o._rowmajor(Eu), o._rowmajor(Ei)
         B = u.numel()
         out = torch.empty(2, dtype=torch.float32, device=Eu.device)
-        saved = torch.empty(B + 4, dtype=torch.float32, device=Eu.device)
+        saved = self._saved if (not scores_only and self._saved is not None and self._saved.numel() == o.bpr_saved_floats(B)) \
+            else torch.empty(o.bpr_saved_floats(B), dtype=torch.float32, device=Eu.device)
+        self._saved = saved if scores_only else None        # pass 2 reuses pass 1's per-sample scratch
         o._lib.call("llmrec_bpr_prune_fwd_sharded_f32", o._p(Eu), o._ld(Eu), o._p(Ei), o._ld(Ei), Eu.shape[1], o._p(u), o._p(p), o._p(n),
                     B, float(remember), float(decay), float(bsz), o._p(global_m), int(global_B), int(offset), 1 if scores_only else 0,
                     o._p(out), o._p(saved), o._stream())
@@ -182,7 +189,7 @@ def _fn_bpr(comm: Comm, backend, remember: float, decay: float, bsz: float):
         def forward(ctx, Eu, Ei, u, p, n):
             B = u.numel()
             _, s1 = backend.bpr_fwd(Eu, Ei, u, p, n, remember, decay, bsz, None, 0, 0, True)
-            global_m = comm.all_gather_cat(s1[:B].contiguous())
+            global_m = comm.all_gather_cat(backend.bpr_local_m(s1, B).contiguous())
             out, saved = backend.bpr_fwd(Eu, Ei, u, p, n, remember, decay, bsz, global_m, global_m.numel(), comm.rank * B, False)
             norms = comm.all_reduce_(saved[B:B + 3].clone())
             saved[B:B + 3] = norms

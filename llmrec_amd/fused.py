@@ -1,0 +1,285 @@
+"""Fused training step: the whole Stage-2 step as a fixed sequence of ~50 HIP launches over
+preallocated buffers, with the backward pass written out by hand (no autograd graph), optionally
+captured into one HIP graph.
+
+Same arithmetic as the modular path (Models.MM_Model.forward + llmrec_amd.engine.train_step,
+i.e. reference Models.py:127-199 + main.py:228-278); what changes is the organisation:
+  * the seven item-side streams (image, text, 5 attributes) travel as ONE [rows, 7d] operand, so
+    the 16 side-feature SpMMs of the reference (Models.py:152-167) become 4 (+4 in backward) and the
+    adjacency indices are read once per direction instead of seven times;
+  * the 8 BPR + prune losses (main.py:232-254) are two launches (llmrec_bpr_multi_fwd_f32) and
+    their backward one (llmrec_bpr_multi_bwd_f32), scattering straight into the gradient buffers;
+  * gradients are written into preallocated .grad tensors; AdamW reads them in place;
+  * nothing allocates or synchronises, so the step can be replayed from a HIP graph
+    (``capture()``), removing the per-launch host cost that dominates at Netflix scale.
+Falls outside its scope (use the modular path): dropout > 0 and the --mask branch.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import torch
+
+from . import _lib, ops
+from .engine import Hyper
+
+_p, _ld, _c = ops._p, ops._ld, ctypes
+
+
+def _call(name, *a):
+    _lib.call(name, *a, ops._stream())
+
+
+class FusedStep:
+    def __init__(self, model, graph, hp: Hyper, rates, optimizer: ops.FusedAdamW, b_max: int):
+        """model: Models.MM_Model (parameters + constant feature tensors); graph: ops.BipartiteGraph
+        or any object with .ui/.iu SparseOperands; rates: (model_cat, user_cat, item_cat)."""
+        self.m, self.hp, self.opt = model, hp, optimizer
+        self.ui, self.iu = graph.ui, graph.iu
+        self.U, self.I = model.n_users, model.n_items
+        self.d = d = model.embedding_dim
+        self.L = model.n_ui_layers
+        self.keys = list(model.item_feats.keys())
+        self.S = S = 2 + len(self.keys)                      # item-side streams: image, text, attributes
+        self.c_m, self.c_u, self.c_a = rates
+        self.b_max = b_max
+        dev = model.item_id_embedding.weight.device
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        U, I = self.U, self.I
+        # forward buffers
+        self.P_cat, self.U_cat, self.I_cat = f(I, S * d), f(U, S * d), f(I, S * d)
+        self.P_usr, self.prof_i, self.prof_u = f(U, d), f(I, d), f(U, d)
+        self.Ul = [f(U, d) for _ in range(self.L)]
+        self.Il = [f(I, d) for _ in range(self.L)]
+        self.E_u, self.E_i = f(U, d), f(I, d)
+        # backward buffers
+        self.dE_u, self.dE_i = f(U, d), f(I, d)
+        self.dU_cat, self.dI_cat, self.dP_cat = f(U, S * d), f(I, S * d), f(I, S * d)
+        self.dprof_u, self.dprof_i, self.dP_usr = f(U, d), f(I, d), f(U, d)
+        self.bufU, self.bufI, self.tmpU, self.tmpI = f(U, d), f(I, d), f(U, d), f(I, d)
+        self.out = f(8, 2)
+        self.saved = f(8 * ops.bpr_saved_floats(b_max))
+        self.scal = f(4)                                     # [feat_reg, loss, mf, emb]
+        self.ws_sumsq = torch.empty(_lib.query("llmrec_sumsq_workspace_bytes", 0, 0), dtype=torch.uint8, device=dev)
+        feats = [model.image_feats, model.text_feats, model.user_feats] + [model.item_feats[k] for k in self.keys]
+        ws = max(_lib.query("llmrec_linear_wgrad_workspace_bytes", x.shape[0], d, x.shape[1]) for x in feats)
+        self.ws_wgrad = torch.empty(ws, dtype=torch.uint8, device=dev)
+        self._partials = {}
+        for p in model.parameters():
+            if p.requires_grad and p.grad is None and p is not model.batch_norm.weight and p is not model.batch_norm.bias:
+                p.grad = torch.zeros_like(p)
+        # loss weights of the 8 BPR problems (main.py:273): main (mf + emb), image/text (mm_mf_rate), attributes (aug_mf_rate)
+        self.w_mf = [1.0, hp.mm_mf_rate, hp.mm_mf_rate] + [hp.aug_mf_rate] * len(self.keys)
+        self.w_emb = [1.0] + [0.0] * (S)
+        self.n_prob = 1 + S
+        if self.n_prob > _lib.CONST["LLMREC_BPR_MAX_PROBLEMS"]:
+            raise RuntimeError("FusedStep: %d BPR problems exceed LLMREC_BPR_MAX_PROBLEMS" % self.n_prob)
+        self.w_mf_dev = torch.tensor(self.w_mf, dtype=torch.float32, device=dev)
+        self.graph_exec = None
+        self.static = None
+
+    # -- raw kernel helpers -----------------------------------------------------------------------
+    def _spmm(self, a: ops.Csr, X, Y, accumulate=False):
+        pl = a.plan
+        partials = None
+        if pl.n_long:
+            key = (id(pl), X.shape[1])
+            partials = self._partials.get(key)
+            if partials is None:
+                partials = self._partials[key] = torch.empty(pl.n_seg * X.shape[1], dtype=torch.float32, device=X.device)
+        _call("llmrec_spmm_f32", a.n_rows, a.n_cols, _p(a.rowptr), _p(a.colidx), _p(a.val), _p(a.row_scale), _p(a.col_scale),
+              _p(X), _ld(X), _p(Y), _ld(Y), X.shape[1], pl.n_long, _p(pl.long_rows), _p(pl.long_seg_begin), pl.n_seg,
+              _p(pl.seg_long), _p(partials), 1 if accumulate else 0)
+
+    def _linear(self, X, lin, out):
+        _call("llmrec_linear_fwd_f32", X.shape[0], self.d, X.shape[1], _p(X), _ld(X), _p(lin.weight), _ld(lin.weight), _p(lin.bias),
+              _p(out), _ld(out))
+
+    def _wgrad(self, dY, X, lin, accumulate):
+        _call("llmrec_linear_wgrad_f32", X.shape[0], self.d, X.shape[1], _p(dY), _ld(dY), _p(X), _ld(X), _p(lin.weight.grad),
+              _ld(lin.weight.grad), _p(lin.bias.grad), 1 if accumulate else 0, _p(self.ws_wgrad), self.ws_wgrad.numel())
+
+    def _softmax(self, Z, Y):
+        _call("llmrec_softmax_rows_fwd_f32", Z.shape[0], self.d, _p(Z), _ld(Z), _p(Y), _ld(Y))
+
+    def _softmax_bwd(self, Y, dY, dZ):
+        _call("llmrec_softmax_rows_bwd_f32", Y.shape[0], self.d, _p(Y), _ld(Y), _p(dY), _ld(dY), _p(dZ), _ld(dZ))
+
+    def _axpy(self, alpha, X, Y, accumulate, rows=None, cols=None):
+        rows = X.shape[0] if rows is None else rows
+        cols = X.shape[1] if cols is None else cols
+        _call("llmrec_axpy_f32", rows, cols, float(alpha), None, _p(X), _ld(X), _p(Y), _ld(Y), 1 if accumulate else 0)
+
+    @staticmethod
+    def _tables(ts):
+        return (_c.c_void_p * len(ts))(*[t.data_ptr() for t in ts]), (_c.c_int64 * len(ts))(*[_ld(t) for t in ts])
+
+    def _side(self, cat, s):
+        return cat[:, s * self.d:(s + 1) * self.d]
+
+    def _norm_terms(self, cat, prof):
+        """[image, text, profile, attributes...] in the reference's order of addition (Models.py:188-197)."""
+        return [self._side(cat, 0), self._side(cat, 1), prof] + [self._side(cat, 2 + k) for k in range(len(self.keys))]
+
+    def _rates(self):
+        r = [self.c_m, self.c_m, self.c_u] + [self.c_a] * len(self.keys)
+        return (_c.c_float * len(r))(*r)
+
+    # -- forward ----------------------------------------------------------------------------------
+    def forward(self):
+        m, d = self.m, self.d
+        self._linear(m.image_feats, m.image_trans, self._side(self.P_cat, 0))
+        self._linear(m.text_feats, m.text_trans, self._side(self.P_cat, 1))
+        for k, key in enumerate(self.keys):
+            self._linear(m.item_feats[key], m.item_trans, self._side(self.P_cat, 2 + k))
+        self._linear(m.user_feats, m.user_trans, self.P_usr)
+        self._spmm(self.ui.fwd, self.P_cat, self.U_cat)                  # 7 streams, one adjacency pass
+        self._spmm(self.iu.fwd, self.U_cat, self.I_cat)
+        self._spmm(self.iu.fwd, self.P_usr, self.prof_i)                 # profile stream: items first
+        self._spmm(self.ui.fwd, self.prof_i, self.prof_u)
+        i_prev = m.item_id_embedding.weight
+        for l in range(self.L):
+            last = l == self.L - 1
+            if last:
+                self._spmm(self.ui.fwd, i_prev, self.tmpU); self._softmax(self.tmpU, self.Ul[l])
+                self._spmm(self.iu.fwd, self.Ul[l], self.tmpI); self._softmax(self.tmpI, self.Il[l])
+            else:
+                self._spmm(self.ui.fwd, i_prev, self.Ul[l])
+                self._spmm(self.iu.fwd, self.Ul[l], self.Il[l])
+            i_prev = self.Il[l]
+        for out, base, layers, cat, prof in ((self.E_u, m.user_id_embedding.weight, self.Ul, self.U_cat, self.prof_u),
+                                             (self.E_i, m.item_id_embedding.weight, self.Il, self.I_cat, self.prof_i)):
+            means = [base] + layers
+            norms = self._norm_terms(cat, prof)
+            mp, ml = self._tables(means)
+            npt, nl = self._tables(norms)
+            _call("llmrec_fuse_fwd_f32", out.shape[0], d, 1.0 / len(means), len(means), mp, ml, len(norms), npt, nl, self._rates(),
+                  _p(out), _ld(out))
+
+    def outputs(self):
+        """The reference's 14-tuple as views of the forward buffers (Models.py:199)."""
+        att_i = {k: self._side(self.I_cat, 2 + j) for j, k in enumerate(self.keys)}
+        att_u = {k: self._side(self.U_cat, 2 + j) for j, k in enumerate(self.keys)}
+        return (self.E_u, self.E_i, self._side(self.I_cat, 0), self._side(self.I_cat, 1), self._side(self.U_cat, 0),
+                self._side(self.U_cat, 1), self.P_usr, att_i, self.prof_u, self.prof_i, att_u, att_i, None, None)
+
+    # -- losses + backward ------------------------------------------------------------------------
+    def _problems(self):
+        arr = (ops.BprProblem * self.n_prob)()
+        tabs = [(self.E_u, self.E_i, self.dE_u, self.dE_i)]
+        for s in range(2):
+            tabs.append((self._side(self.U_cat, s), self._side(self.I_cat, s), self._side(self.dU_cat, s), self._side(self.dI_cat, s)))
+        for k in range(len(self.keys)):
+            tabs.append((self.prof_u, self._side(self.I_cat, 2 + k), self.dprof_u, self._side(self.dI_cat, 2 + k)))
+        for i, (eu, ei, deu, dei) in enumerate(tabs):
+            arr[i].Eu, arr[i].ldu, arr[i].Ei, arr[i].ldi = eu.data_ptr(), _ld(eu), ei.data_ptr(), _ld(ei)
+            arr[i].dEu, arr[i].lddu, arr[i].dEi, arr[i].lddi = deu.data_ptr(), _ld(deu), dei.data_ptr(), _ld(dei)
+            arr[i].g_mf, arr[i].g_emb = self.w_mf[i], self.w_emb[i]
+        return arr
+
+    def loss_backward(self, users, pos, neg, n_valid=None):
+        hp, d, L, S = self.hp, self.d, self.L, self.S
+        B = users.numel()
+        if B > self.b_max:
+            raise RuntimeError("FusedStep: batch of %d exceeds b_max %d" % (B, self.b_max))
+        probs = self._problems()
+        remember = 1 - hp.prune_loss_drop_rate
+        _call("llmrec_bpr_multi_fwd_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), float(remember),
+              float(hp.decay), float(hp.batch_size), _p(self.out), _p(self.saved))
+        # feature regulariser (main.py:151-156) over the image/text columns of both cat buffers
+        coef = hp.feat_reg_decay * 0.5 / self.I
+        for k, blk in enumerate((self.I_cat, self.U_cat)):
+            _call("llmrec_sumsq_f32", blk.shape[0], 2 * d, _p(blk), _ld(blk), float(coef), k, _p(self.scal), _p(self.ws_sumsq),
+                  self.ws_sumsq.numel())
+        # loss values for logging: loss = sum_p w_mf[p] * mf_p + emb_0 + feat_reg
+        self.scal[2:3] = self.out[0, 0:1]
+        self.scal[3:4] = self.out[0, 1:2]
+        self.scal[1:2] = (self.out[: self.n_prob, 0] * self.w_mf_dev).sum() + self.out[0, 1] + self.scal[0]
+
+        # ---- backward ----
+        for t in (self.dE_u, self.dE_i, self.dU_cat, self.dI_cat, self.dprof_u, self.dprof_i):
+            t.zero_()
+        _call("llmrec_bpr_multi_bwd_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), float(hp.decay),
+              float(hp.batch_size), _p(self.saved))
+        self._axpy(2.0 * coef, self.I_cat, self.dI_cat, True, cols=2 * d)
+        self._axpy(2.0 * coef, self.U_cat, self.dU_cat, True, cols=2 * d)
+        for dout, cat, prof, dcat, dprof in ((self.dE_u, self.U_cat, self.prof_u, self.dU_cat, self.dprof_u),
+                                             (self.dE_i, self.I_cat, self.prof_i, self.dI_cat, self.dprof_i)):
+            norms, dnorms = self._norm_terms(cat, prof), self._norm_terms(dcat, dprof)
+            npt, nl = self._tables(norms)
+            dp, dl = self._tables(dnorms)
+            _call("llmrec_fuse_bwd_f32", dout.shape[0], d, _p(dout), _ld(dout), len(norms), npt, nl, self._rates(), dp, dl, 1)
+        m = self.m
+        # profile chain: prof_u = ui(prof_i), prof_i = iu(P_usr)
+        self._spmm(self.ui.bwd, self.dprof_u, self.dprof_i, accumulate=True)
+        self._spmm(self.iu.bwd, self.dprof_i, self.dP_usr)
+        # side chain: I_cat = iu(U_cat), U_cat = ui(P_cat)
+        self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
+        self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
+        # ID chain (items of layer l+1 from the new users; softmax on the last layer)
+        inv = 1.0 / (L + 1)
+        self._axpy(inv, self.dE_i, self.bufI, False)                      # dI[L] = mean part
+        for l in range(L - 1, -1, -1):
+            last = l == L - 1
+            g = self.bufI
+            if last:
+                self._softmax_bwd(self.Il[l], self.bufI, self.tmpI); g = self.tmpI
+            self._axpy(inv, self.dE_u, self.bufU, False)
+            self._spmm(self.iu.bwd, g, self.bufU, accumulate=True)         # dU[l+1] complete
+            h = self.bufU
+            if last:
+                self._softmax_bwd(self.Ul[l], self.bufU, self.tmpU); h = self.tmpU
+            self._axpy(inv, self.dE_i, self.bufI, False)
+            self._spmm(self.ui.bwd, h, self.bufI, accumulate=True)         # dI[l] complete
+        self._axpy(1.0, self.bufI, m.item_id_embedding.weight.grad, False)
+        self._axpy(inv, self.dE_u, m.user_id_embedding.weight.grad, False)  # U^0 only enters the mean
+        # weight gradients (the features are constants: no dX)
+        self._wgrad(self._side(self.dP_cat, 0), m.image_feats, m.image_trans, False)
+        self._wgrad(self._side(self.dP_cat, 1), m.text_feats, m.text_trans, False)
+        for k, key in enumerate(self.keys):
+            self._wgrad(self._side(self.dP_cat, 2 + k), m.item_feats[key], m.item_trans, k > 0)
+        self._wgrad(self.dP_usr, m.user_feats, m.user_trans, False)
+
+    def step_eager(self, users, pos, neg, n_valid=None):
+        self.forward()
+        self.loss_backward(users, pos, neg, n_valid)
+        self.opt.step()
+        return self.scal[1], self.scal[2], self.scal[3]
+
+    # -- HIP graph --------------------------------------------------------------------------------
+    def capture(self, warm_users, warm_pos, warm_neg, warm_n_valid=None):
+        """Capture one step (fixed batch capacity b_max, actual size on the device in n_valid)."""
+        dev = self.E_u.device
+        st = {"users": torch.zeros(self.b_max, dtype=torch.int64, device=dev), "pos": torch.zeros(self.b_max, dtype=torch.int64, device=dev),
+              "neg": torch.zeros(self.b_max, dtype=torch.int64, device=dev), "n_valid": torch.zeros(1, dtype=torch.int32, device=dev)}
+        self.static = st
+        self._load(warm_users, warm_pos, warm_neg, warm_n_valid)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                             # warm-up on a side stream (allocations, plan caches)
+            self.step_eager(st["users"], st["pos"], st["neg"], st["n_valid"])
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.step_eager(st["users"], st["pos"], st["neg"], st["n_valid"])
+        self.graph_exec = g
+
+    def _load(self, users, pos, neg, n_valid):
+        st, B = self.static, users.numel()
+        if B > self.b_max:
+            raise RuntimeError("FusedStep: batch of %d exceeds b_max %d" % (B, self.b_max))
+        st["users"][:B].copy_(users); st["pos"][:B].copy_(pos); st["neg"][:B].copy_(neg)
+        if n_valid is None:
+            st["n_valid"].fill_(B)
+        else:
+            st["n_valid"].copy_(n_valid)
+
+    def step(self, users, pos, neg, n_valid=None):
+        """One training step; replays the captured graph when there is one."""
+        if self.graph_exec is None:
+            return self.step_eager(users, pos, neg, n_valid)
+        self._load(users, pos, neg, n_valid)
+        self.graph_exec.replay()
+        return self.scal[1], self.scal[2], self.scal[3]

@@ -199,7 +199,7 @@ class BipartiteGraph:
 # ---------------------------------------------------------------------------------------------
 # R2: SpMM
 # ---------------------------------------------------------------------------------------------
-def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     _need_gpu(X, a.rowptr)
     X = _rowmajor(X)
     if X.shape[0] != a.n_cols:
@@ -210,7 +210,7 @@ def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None) -> tor
     partials = torch.empty(pl.n_seg * d, dtype=torch.float32, device=X.device) if pl.n_long else None
     _lib.call("llmrec_spmm_f32", a.n_rows, a.n_cols, _p(a.rowptr), _p(a.colidx), _p(a.val), _p(a.row_scale),
               _p(a.col_scale), _p(X), _ld(X), _p(Y), _ld(Y), d, pl.n_long, _p(pl.long_rows), _p(pl.long_seg_begin),
-              pl.n_seg, _p(pl.seg_long), _p(partials), _stream())
+              pl.n_seg, _p(pl.seg_long), _p(partials), 1 if accumulate else 0, _stream())
     return Y
 
 
@@ -381,6 +381,18 @@ def fuse(mean_terms: List[torch.Tensor], norm_terms: List[torch.Tensor], rates: 
 # ---------------------------------------------------------------------------------------------
 # R7: BPR + prune
 # ---------------------------------------------------------------------------------------------
+def bpr_saved_floats(B: int) -> int:
+    """LLMREC_BPR_SAVED_FLOATS(B) of include/llmrec_hip.h."""
+    return 6 * B + 8
+
+
+class BprProblem(_c.Structure):
+    """llmrec_bpr_problem_t"""
+    _fields_ = [("Eu", _c.c_void_p), ("ldu", _c.c_int64), ("Ei", _c.c_void_p), ("ldi", _c.c_int64),
+                ("dEu", _c.c_void_p), ("lddu", _c.c_int64), ("dEi", _c.c_void_p), ("lddi", _c.c_int64),
+                ("g_mf", _c.c_float), ("g_emb", _c.c_float)]
+
+
 class _BprPrune(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Eu, Ei, users, pos, neg, remember_rate, decay, batch_size_flag, n_valid):
@@ -389,7 +401,7 @@ class _BprPrune(torch.autograd.Function):
         B = users.numel()
         d = Eu.shape[1]
         out = torch.empty(2, dtype=torch.float32, device=Eu.device)
-        saved = torch.empty(B + 4, dtype=torch.float32, device=Eu.device)
+        saved = torch.empty(bpr_saved_floats(B), dtype=torch.float32, device=Eu.device)
         _lib.call("llmrec_bpr_prune_fwd_f32", _p(Eu), _ld(Eu), _p(Ei), _ld(Ei), d, _p(users), _p(pos), _p(neg), B, _p(n_valid),
                   float(remember_rate), float(decay), float(batch_size_flag), _p(out), _p(saved), _stream())
         ctx.save_for_backward(Eu, Ei, users, pos, neg, saved)

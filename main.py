@@ -105,6 +105,7 @@ class Trainer(object):
         self.de_optimizer = torch.optim.AdamW([{'params': self.decoder.parameters()}], lr=args.de_lr)   # never stepped
         self.hyper = engine.Hyper.from_args(args)
         self._on_bpr = None                                   # test hook: called with (mf, emb) of each BPR call
+        self._fused = None
         self._device_sampler = os.environ.get("LLMREC_DEVICE_SAMPLER", "0") == "1"
         self._global_step = 0
 
@@ -182,9 +183,40 @@ class Trainer(object):
         packed = torch.tensor([users + users_aug, pos_items + pos_aug, neg_items + neg_aug], dtype=torch.int64).to(device)
         return packed[0], packed[1], packed[2]
 
+    def _fused_step(self):
+        """The fused step (llmrec_amd/fused.py) when the configuration allows it: no dropout, no
+        --mask. LLMREC_FUSED=0 forces the modular autograd path; LLMREC_GRAPH=1 additionally
+        replays the step from one captured HIP graph."""
+        if self._fused is None:
+            ok = (os.environ.get("LLMREC_FUSED", "1") == "1" and not args.mask and args.drop_rate == 0
+                  and device.type == "cuda")
+            if ok:
+                from llmrec_amd.fused import FusedStep
+                graph = type("G", (), {"ui": ops.operand_from_sparse_tensor(self.ui_graph),
+                                       "iu": ops.operand_from_sparse_tensor(self.iu_graph)})
+                b_max = self.batch_size + int(self.batch_size * args.aug_sample_rate)
+                self._fused = FusedStep(self.model_mm, graph, self.hyper,
+                                        (args.model_cat_rate, args.user_cat_rate, args.item_cat_rate), self.optimizer, b_max)
+            else:
+                self._fused = False
+        return self._fused
+
     def train_step(self, users, pos_items, neg_items, n_valid=None):
-        """Forward, the 8 BPR(+prune) losses, feature regulariser, backward, AdamW
-        (llmrec_amd/engine.py). Returns the device scalars (batch_loss, mf_loss, emb_loss)."""
+        """Forward, the 8 BPR(+prune) losses, feature regulariser, backward, AdamW.
+        Returns the device scalars (batch_loss, mf_loss, emb_loss)."""
+        fused = self._fused_step()
+        if fused:
+            self.model_mm.train()
+            if os.environ.get("LLMREC_GRAPH", "0") == "1" and fused.graph_exec is None:
+                fused.capture(users, pos_items, neg_items, n_valid)      # the capture run itself is a real step
+                out = (fused.scal[1].clone(), fused.scal[2].clone(), fused.scal[3].clone())
+            else:
+                out = tuple(x.clone() for x in fused.step(users, pos_items, neg_items, n_valid))
+            if self._on_bpr is not None:
+                for k in range(fused.n_prob):
+                    self._on_bpr(fused.out[k, 0].clone(), fused.out[k, 1].clone())
+            self._global_step += 1
+            return out
         out = engine.train_step(self.model_mm, self.optimizer, self.ui_graph, self.iu_graph, users, pos_items, neg_items,
                                 self.hyper, n_valid=n_valid, on_bpr=self._on_bpr,
                                 extra_loss=self._mask_loss if args.mask else None)

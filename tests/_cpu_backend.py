@@ -56,6 +56,9 @@ class CpuBackend:
         out = torch.stack([-(m[keep].sum() / k), torch.tensor(0.0)])
         return out, saved
 
+    def bpr_local_m(self, saved, B):
+        return saved[:B]
+
     def bpr_bwd(self, Eu, Ei, u, p, n, decay, bsz, saved, grads2):
         B = u.numel()
         ds = grads2[0] * saved[:B]

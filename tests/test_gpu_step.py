@@ -21,8 +21,13 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def test_training_steps_and_eval_match_reference(golden):
+@pytest.mark.parametrize("path", ["fused", "modular", "graph"])
+def test_training_steps_and_eval_match_reference(golden, path, monkeypatch):
+    """path: fused = hand-written backward over preallocated buffers (llmrec_amd/fused.py, the
+    default), modular = torch.autograd over the per-op Functions, graph = fused + HIP graph replay."""
     assert torch.cuda.is_available()
+    monkeypatch.setenv("LLMREC_FUSED", "0" if path == "modular" else "1")
+    monkeypatch.setenv("LLMREC_GRAPH", "1" if path == "graph" else "0")
     m = load_dropin(golden_argv(golden))
     m.set_seed(golden.args["seed"])
     tr = m.Trainer(data_config={})
