@@ -161,18 +161,23 @@ class NetflixShaped:
         out = []
         W = self.model.item_trans.weight.detach(); b = self.model.item_trans.bias.detach()
         X = self.feats["attr/" + self.keys[0]]
-        ms = event_time_ms(lambda: ops.linear_fwd_raw(X, W, b), 20)
+        feats = [self.feats["image"], self.feats["text"], self.feats["user"]] + [self.feats["attr/" + k] for k in self.keys]
+        flop_all = sum(2.0 * x.shape[0] * x.shape[1] * d for x in feats)
+        byts_all = sum(4.0 * (x.shape[0] * x.shape[1] + d * x.shape[1] + x.shape[0] * d) for x in feats)
+        ms = event_time_ms(self.fused._project_all, 20)
+        out.append({"kernel": "linear_fwd_grouped_kernel<4> (all 8 projections of one forward, one launch)", "calls_per_step": 1, "ms": ms,
+                    "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                    "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
+                    "algorithmic_flop_per_launch": flop_all, "algorithmic_bytes_per_launch": byts_all})
         flop = 2.0 * sh.n_items * sh.llm_dim * d
         byts = 4.0 * (sh.n_items * sh.llm_dim + d * sh.llm_dim + sh.n_items * d)
-        out.append({"kernel": "linear_fwd_kernel<4,1> (I x 1536 -> 64)", "calls_per_step": 5, "ms": ms,
-                    "tflops": flop / ms / 1e9, "frac_mfma_f32": flop / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
-                    "gbs": byts / ms / 1e6, "frac_hbm": byts / ms / 1e6 / HBM_PEAK_GBS})
         dY = torch.randn(sh.n_items, d, device=self.device)
         dW = torch.empty_like(W); db = torch.empty_like(b)
         ms = event_time_ms(lambda: ops.linear_wgrad_raw(dY, X, dW, db, False), 20)
-        out.append({"kernel": "linear_wgrad_kernel + reduce (I x 1536, N = 64)", "calls_per_step": 5, "ms": ms,
+        out.append({"kernel": "linear_wgrad_kernel + reduce_chunks_kernel (I x 1536, N = 64)", "calls_per_step": 6, "ms": ms,
                     "tflops": flop / ms / 1e9, "frac_mfma_f32": flop / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
-                    "gbs": byts / ms / 1e6, "frac_hbm": byts / ms / 1e6 / HBM_PEAK_GBS})
+                    "gbs": byts / ms / 1e6, "frac_hbm": byts / ms / 1e6 / HBM_PEAK_GBS,
+                    "algorithmic_flop_per_launch": flop, "algorithmic_bytes_per_launch": byts})
         Xi = torch.randn(sh.n_items, d, device=self.device)
         a = self.graph.ui.fwd
         ms = event_time_ms(lambda: ops.spmm_raw(a, Xi), 50)

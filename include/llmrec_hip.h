@@ -109,6 +109,16 @@ int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
 int llmrec_linear_fwd_f32(int64_t M, int32_t N, int32_t K, const float* X, int64_t ldx,
                           const float* W, int64_t ldw, const float* bias,
                           float* Y, int64_t ldy, llmrec_stream_t stream);
+/* Several projections in one launch (the reference runs 8 per forward, Models.py:145-150):
+ * Y_p = X_p W_p^T + b_p with a common N <= 64. Y_p may be a column slice of a wider buffer (ldy). */
+#define LLMREC_LINEAR_MAX_PROBLEMS 8
+typedef struct {
+    const float* X; int64_t ldx; int64_t M; int32_t K;
+    const float* W; int64_t ldw; const float* bias;
+    float* Y; int64_t ldy;
+} llmrec_linear_problem_t;
+int llmrec_linear_fwd_grouped_f32(int32_t n_problems, const llmrec_linear_problem_t* problems_host, int32_t N,
+                                  llmrec_stream_t stream);
 int64_t llmrec_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K);
 int llmrec_linear_wgrad_f32(int64_t M, int32_t N, int32_t K, const float* dY, int64_t lddy,
                             const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,

@@ -142,6 +142,137 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(int64_t M, int N, int K
 }
 
 // ---------------------------------------------------------------------------------------------
+// grouped forward: up to LLMREC_LINEAR_MAX_PROBLEMS projections (different X, K, W, Y; one N) in
+// ONE launch - the reference runs 8 per forward (Models.py:145-150). Work unit = 128 rows of one
+// problem; block = 4 waves x (32 rows x N). The W k-slice (N x 32) is shared by the block through a
+// double-buffered LDS tile (so W costs one L2 fetch per 128 rows, not per 16), X goes straight from
+// global memory to the MFMA A operand with a two-step register prefetch.
+// ---------------------------------------------------------------------------------------------
+struct LinearGroup {
+    const float* X[LLMREC_LINEAR_MAX_PROBLEMS];
+    const float* W[LLMREC_LINEAR_MAX_PROBLEMS];
+    const float* bias[LLMREC_LINEAR_MAX_PROBLEMS];
+    float* Y[LLMREC_LINEAR_MAX_PROBLEMS];
+    int64_t ldx[LLMREC_LINEAR_MAX_PROBLEMS];
+    int64_t ldw[LLMREC_LINEAR_MAX_PROBLEMS];
+    int64_t ldy[LLMREC_LINEAR_MAX_PROBLEMS];
+    int64_t M[LLMREC_LINEAR_MAX_PROBLEMS];
+    int32_t K[LLMREC_LINEAR_MAX_PROBLEMS];
+    int32_t vec_ok[LLMREC_LINEAR_MAX_PROBLEMS];
+    int32_t unit_begin[LLMREC_LINEAR_MAX_PROBLEMS + 1];
+    int32_t n_problems;
+};
+
+constexpr int GF_BK = 32;              // k per step
+constexpr int GF_WS = GF_BK + 4;       // LDS row stride in floats (144 B: spreads ds_read_b128 over the banks)
+
+template <int NT>
+__global__ __launch_bounds__(256) void linear_fwd_grouped_kernel(LinearGroup g, int N) {
+    __shared__ __attribute__((aligned(16))) float w_lds[2][NT * 16 * GF_WS];
+    int prob = 0;
+    while (prob + 1 < g.n_problems && (int)blockIdx.x >= g.unit_begin[prob + 1]) ++prob;
+    const int64_t M = g.M[prob];
+    const int K = g.K[prob];
+    const bool vec_ok = g.vec_ok[prob];
+    const float* __restrict__ X = g.X[prob];
+    const float* __restrict__ W = g.W[prob];
+    const int64_t ldx = g.ldx[prob], ldw = g.ldw[prob];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t row0 = (int64_t)(blockIdx.x - g.unit_begin[prob]) * 128 + wave * 32;
+
+    const float* xrow[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int64_t r = row0 + t * 16 + li;
+        if (r > M - 1) r = M - 1;
+        xrow[t] = X + r * ldx;
+    }
+    // W staging: thread -> (n = tid / 8 (+32), 4 k's = (tid % 8) * 4)
+    const int wn = threadIdx.x >> 3, wk = (threadIdx.x & 7) * 4;
+    constexpr int WLOADS = (NT * 16 + 31) / 32;                          // float4 per thread per step
+    auto load_w = [&](int kb, float4 (&wr)[WLOADS]) {
+#pragma unroll
+        for (int j = 0; j < WLOADS; ++j) {
+            int n = wn + 32 * j;
+            const bool in = n < NT * 16;
+            if (n > N - 1) n = N - 1;
+            wr[j] = in ? load4_guard(W + (int64_t)n * ldw, kb + wk, K, vec_ok) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_w = [&](int buf, const float4 (&wr)[WLOADS]) {
+#pragma unroll
+        for (int j = 0; j < WLOADS; ++j) {
+            const int n = wn + 32 * j;
+            if (n < NT * 16) *reinterpret_cast<float4*>(&w_lds[buf][n * GF_WS + wk]) = wr[j];
+        }
+    };
+    auto load_x = [&](int kb, float4 (&xr)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) xr[t][h] = load4_guard(xrow[t], kb + 16 * h + 4 * lq, K, vec_ok);
+    };
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 wreg[WLOADS];
+    float4 x0[2][2], x1[2][2], x2[2][2];
+    load_w(0, wreg);
+    load_x(0, x0);
+    load_x(GF_BK, x1);
+    store_w(0, wreg);
+    __syncthreads();
+    int cur = 0;
+    for (int kb = 0; kb < K; kb += GF_BK) {
+        const bool more = kb + GF_BK < K;
+        if (more) load_w(kb + GF_BK, wreg);
+        load_x(kb + 2 * GF_BK, x2);                                      // zeros beyond K (guarded)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 wf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                wf[n] = *reinterpret_cast<const float4*>(&w_lds[cur][(n * 16 + li) * GF_WS + 16 * h + 4 * lq]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(x0[t][h], s), comp(wf[n], s), acc[t][n], 0, 0, 0);
+        }
+        if (more) store_w(cur ^ 1, wreg);
+        __syncthreads();
+        cur ^= 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { x0[t][h] = x1[t][h]; x1[t][h] = x2[t][h]; }
+    }
+    float* __restrict__ Y = g.Y[prob];
+    const int64_t ldy = g.ldy[prob];
+    const float* bias = g.bias[prob];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int c = n * 16 + li;
+        if (c >= N) continue;
+        const float b = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + t * 16 + lq * 4 + r;
+                if (row < M) Y[row * ldy + c] = acc[t][n][r] + b;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient: wave tile = 64 n (interleaved tiles q) x 64 k (interleaved tiles p), over a
 // chunk of MC rows; partial[chunk][n][k] then reduced in chunk order (deterministic).
 // ---------------------------------------------------------------------------------------------
@@ -169,7 +300,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int64_t M, int N, int
         for (int p = 0; p < 4; ++p) acc[q][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    float4 a[4], b[4], an[4], bn[4];
+    float4 a[4], b[4], an[4], bn[4], a2[4], b2[4];
     auto load_tile = [&](int64_t m0, float4 (&aa)[4], float4 (&bb)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {                            // 4 MFMA k-steps of 4 rows each
@@ -184,8 +315,9 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int64_t M, int N, int
         }
     };
     load_tile(m_begin, a, b);
+    load_tile(m_begin + 16, an, bn);                             // rows past m_end load zeros
     for (int64_t m0 = m_begin; m0 < m_end; m0 += 16) {
-        if (m0 + 16 < m_end) load_tile(m0 + 16, an, bn);         // register double buffer
+        load_tile(m0 + 32, a2, b2);                              // two tiles in flight beyond the one being multiplied
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             dbs.x += a[s].x; dbs.y += a[s].y; dbs.z += a[s].z; dbs.w += a[s].w;
@@ -196,7 +328,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int64_t M, int N, int
                     acc[q][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(a[s], q), comp(b[s], p), acc[q][p], 0, 0, 0);
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { a[s] = an[s]; b[s] = bn[s]; }
+        for (int s = 0; s < 4; ++s) { a[s] = an[s]; b[s] = bn[s]; an[s] = a2[s]; bn[s] = b2[s]; }
     }
     // D[q][p]: lane holds rows i = lq*4 + r (n = nblk*64 + 4 i + q), col j = li (k = kslab*64 + 4 j + p)
     float* pw = partial + chunk * (int64_t)N * K;
@@ -293,6 +425,35 @@ int llmrec_linear_fwd_f32(int64_t M, int32_t N, int32_t K, const float* X, int64
     }
 #undef LAUNCH_ROWS
 #undef LAUNCH_SPLITK
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_linear_fwd_grouped_f32(int32_t n_problems, const llmrec_linear_problem_t* p, int32_t N, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_LINEAR_MAX_PROBLEMS && p && N > 0, "linear_fwd_grouped: bad argument");
+    if (N > 64) { set_error("linear_fwd_grouped: N = %d > 64", N); return LLMREC_EUNSUPPORTED; }
+    LinearGroup g = {};
+    g.n_problems = n_problems;
+    int units = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        LLMREC_CHECK_ARG(p[i].M >= 0 && p[i].K > 0, "linear_fwd_grouped: problem %d has bad sizes", i);
+        LLMREC_CHECK_ARG(p[i].M == 0 || (p[i].X && p[i].W && p[i].Y && p[i].ldx >= p[i].K && p[i].ldw >= p[i].K && p[i].ldy >= N),
+                         "linear_fwd_grouped: problem %d has a null pointer or a small ld", i);
+        g.X[i] = p[i].X; g.W[i] = p[i].W; g.bias[i] = p[i].bias; g.Y[i] = p[i].Y;
+        g.ldx[i] = p[i].ldx; g.ldw[i] = p[i].ldw; g.ldy[i] = p[i].ldy; g.M[i] = p[i].M; g.K[i] = p[i].K;
+        g.vec_ok[i] = (p[i].ldx % 4 == 0) && (p[i].ldw % 4 == 0) && (((uintptr_t)p[i].X | (uintptr_t)p[i].W) % 16 == 0);
+        g.unit_begin[i] = units;
+        units += (int)ceil_div(p[i].M, 128);
+    }
+    for (int i = n_problems; i <= LLMREC_LINEAR_MAX_PROBLEMS; ++i) g.unit_begin[i] = units;
+    if (units == 0) return LLMREC_OK;
+    switch ((N + 15) / 16) {
+        case 1: linear_fwd_grouped_kernel<1><<<units, 256, 0, stream>>>(g, N); break;
+        case 2: linear_fwd_grouped_kernel<2><<<units, 256, 0, stream>>>(g, N); break;
+        case 3: linear_fwd_grouped_kernel<3><<<units, 256, 0, stream>>>(g, N); break;
+        default: linear_fwd_grouped_kernel<4><<<units, 256, 0, stream>>>(g, N); break;
+    }
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

@@ -96,6 +96,23 @@ class FusedStep:
         _call("llmrec_linear_fwd_f32", X.shape[0], self.d, X.shape[1], _p(X), _ld(X), _p(lin.weight), _ld(lin.weight), _p(lin.bias),
               _p(out), _ld(out))
 
+    def _project_all(self):
+        """All 8 projections of Models.py:145-150 in one grouped launch (d <= 64), else one by one."""
+        m = self.m
+        jobs = [(m.image_feats, m.image_trans, self._side(self.P_cat, 0)), (m.text_feats, m.text_trans, self._side(self.P_cat, 1))]
+        jobs += [(m.item_feats[key], m.item_trans, self._side(self.P_cat, 2 + k)) for k, key in enumerate(self.keys)]
+        jobs.append((m.user_feats, m.user_trans, self.P_usr))
+        if self.d > 64 or len(jobs) > _lib.CONST["LLMREC_LINEAR_MAX_PROBLEMS"]:
+            for X, lin, out in jobs:
+                self._linear(X, lin, out)
+            return
+        arr = (ops.LinearProblem * len(jobs))()
+        for i, (X, lin, out) in enumerate(jobs):
+            arr[i].X, arr[i].ldx, arr[i].M, arr[i].K = X.data_ptr(), _ld(X), X.shape[0], X.shape[1]
+            arr[i].W, arr[i].ldw, arr[i].bias = lin.weight.data_ptr(), _ld(lin.weight), lin.bias.data_ptr()
+            arr[i].Y, arr[i].ldy = out.data_ptr(), _ld(out)
+        _call("llmrec_linear_fwd_grouped_f32", len(jobs), arr, self.d)
+
     def _wgrad(self, dY, X, lin, accumulate):
         _call("llmrec_linear_wgrad_f32", X.shape[0], self.d, X.shape[1], _p(dY), _ld(dY), _p(X), _ld(X), _p(lin.weight.grad),
               _ld(lin.weight.grad), _p(lin.bias.grad), 1 if accumulate else 0, _p(self.ws_wgrad), self.ws_wgrad.numel())
@@ -129,11 +146,7 @@ class FusedStep:
     # -- forward ----------------------------------------------------------------------------------
     def forward(self):
         m, d = self.m, self.d
-        self._linear(m.image_feats, m.image_trans, self._side(self.P_cat, 0))
-        self._linear(m.text_feats, m.text_trans, self._side(self.P_cat, 1))
-        for k, key in enumerate(self.keys):
-            self._linear(m.item_feats[key], m.item_trans, self._side(self.P_cat, 2 + k))
-        self._linear(m.user_feats, m.user_trans, self.P_usr)
+        self._project_all()
         self._spmm(self.ui.fwd, self.P_cat, self.U_cat)                  # 7 streams, one adjacency pass
         self._spmm(self.iu.fwd, self.U_cat, self.I_cat)
         self._spmm(self.iu.fwd, self.P_usr, self.prof_i)                 # profile stream: items first

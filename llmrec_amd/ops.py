@@ -393,6 +393,23 @@ class BprProblem(_c.Structure):
                 ("g_mf", _c.c_float), ("g_emb", _c.c_float)]
 
 
+class LinearProblem(_c.Structure):
+    """llmrec_linear_problem_t"""
+    _fields_ = [("X", _c.c_void_p), ("ldx", _c.c_int64), ("M", _c.c_int64), ("K", _c.c_int32),
+                ("W", _c.c_void_p), ("ldw", _c.c_int64), ("bias", _c.c_void_p), ("Y", _c.c_void_p), ("ldy", _c.c_int64)]
+
+
+def linear_fwd_grouped(jobs, N: int):
+    """jobs: list of (X, W, bias, out) - one launch (llmrec_linear_fwd_grouped_f32)."""
+    arr = (LinearProblem * len(jobs))()
+    for i, (X, W, b, out) in enumerate(jobs):
+        _need_gpu(X, W, b, out)
+        arr[i].X, arr[i].ldx, arr[i].M, arr[i].K = X.data_ptr(), _ld(X), X.shape[0], X.shape[1]
+        arr[i].W, arr[i].ldw, arr[i].bias = W.data_ptr(), _ld(W), (b.data_ptr() if b is not None else None)
+        arr[i].Y, arr[i].ldy = out.data_ptr(), _ld(out)
+    _lib.call("llmrec_linear_fwd_grouped_f32", len(jobs), arr, N, _stream())
+
+
 class _BprPrune(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Eu, Ei, users, pos, neg, remember_rate, decay, batch_size_flag, n_valid):

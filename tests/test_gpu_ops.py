@@ -167,6 +167,25 @@ def test_linear_forward_and_weight_grad(ops, M, K, N):
     assert rel_err(bg.grad.cpu(), b.grad) < 2e-5
 
 
+def test_linear_grouped_matches_single_launches(ops):
+    """llmrec_linear_fwd_grouped_f32: several projections (different M, K, strided outputs) in one launch."""
+    rng = np.random.default_rng(8)
+    for N in (64, 16, 48):
+        shapes = [(700, 512), (700, 768), (530, 1536), (129, 24), (1, 40), (300, 36)]
+        big = torch.zeros(700, 3 * N, device=DEV)
+        jobs, refs = [], []
+        for i, (M, K) in enumerate(shapes):
+            X = torch.tensor(rng.standard_normal((M, K)).astype(np.float32))
+            W = torch.tensor((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+            b = torch.tensor(rng.standard_normal(N).astype(np.float32))
+            out = big[:M, (i % 3) * N:(i % 3 + 1) * N] if i < 2 else torch.empty(M, N, device=DEV)
+            jobs.append((X.to(DEV), W.to(DEV), b.to(DEV), out))
+            refs.append(F.linear(X, W, b))
+        ops.linear_fwd_grouped(jobs, N)
+        for (X, W, b, out), ref in zip(jobs, refs):
+            assert rel_err(out.cpu(), ref) < 5e-6
+
+
 def test_linear_multi_shares_one_weight(ops):
     rng = np.random.default_rng(3)
     M, K, N = 300, 56, 64
