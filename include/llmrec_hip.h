@@ -119,6 +119,13 @@ typedef struct {
 } llmrec_linear_problem_t;
 int llmrec_linear_fwd_grouped_f32(int32_t n_problems, const llmrec_linear_problem_t* problems_host, int32_t N,
                                   llmrec_stream_t stream);
+/* Weight gradient of one Linear fed by several (dY_p, X_p) pairs - the reference's shared
+ * item_trans receives 5 per step (Models.py:150): dW (+)= sum_p dY_p^T X_p, db (+)= sum_p colsum(dY_p).
+ * Workspace: llmrec_linear_wgrad_workspace_bytes(sum_p M_p, N, K). */
+typedef struct { const float* dY; int64_t lddy; const float* X; int64_t ldx; int64_t M; } llmrec_wgrad_problem_t;
+int llmrec_linear_wgrad_grouped_f32(int32_t n_problems, const llmrec_wgrad_problem_t* problems_host, int32_t N, int32_t K,
+                                    float* dW, int64_t lddw, float* db, int32_t accumulate,
+                                    void* workspace, int64_t workspace_bytes, llmrec_stream_t stream);
 int64_t llmrec_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K);
 int llmrec_linear_wgrad_f32(int64_t M, int32_t N, int32_t K, const float* dY, int64_t lddy,
                             const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,

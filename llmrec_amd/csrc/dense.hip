@@ -167,7 +167,7 @@ constexpr int GF_BK = 32;              // k per step
 constexpr int GF_WS = GF_BK + 4;       // LDS row stride in floats (144 B: spreads ds_read_b128 over the banks)
 
 template <int NT>
-__global__ __launch_bounds__(256) void linear_fwd_grouped_kernel(LinearGroup g, int N) {
+__global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup g, int N) {
     __shared__ __attribute__((aligned(16))) float w_lds[2][NT * 16 * GF_WS];
     int prob = 0;
     while (prob + 1 < g.n_problems && (int)blockIdx.x >= g.unit_begin[prob + 1]) ++prob;
@@ -228,10 +228,12 @@ __global__ __launch_bounds__(256) void linear_fwd_grouped_kernel(LinearGroup g, 
     store_w(0, wreg);
     __syncthreads();
     int cur = 0;
-    for (int kb = 0; kb < K; kb += GF_BK) {
+    // one k-step: prefetch X two steps ahead into `xl` (static register names: the loop below is
+    // unrolled by 3, so no stage is ever copied - a copy would wait for the load it just issued)
+    auto kstep = [&](int kb, const float4 (&xc)[2][2], float4 (&xl)[2][2]) {
         const bool more = kb + GF_BK < K;
-        if (more) load_w(kb + GF_BK, wreg);
-        load_x(kb + 2 * GF_BK, x2);                                      // zeros beyond K (guarded)
+        load_w(kb + GF_BK, wreg);                                        // zeros beyond K (guarded)
+        load_x(kb + 2 * GF_BK, xl);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float4 wf[NT];
@@ -244,15 +246,17 @@ __global__ __launch_bounds__(256) void linear_fwd_grouped_kernel(LinearGroup g, 
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(x0[t][h], s), comp(wf[n], s), acc[t][n], 0, 0, 0);
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(xc[t][h], s), comp(wf[n], s), acc[t][n], 0, 0, 0);
         }
-        if (more) store_w(cur ^ 1, wreg);
+        store_w(cur ^ 1, wreg);
         __syncthreads();
         cur ^= 1;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) { x0[t][h] = x1[t][h]; x1[t][h] = x2[t][h]; }
+        (void)more;
+    };
+    for (int kb = 0; kb < K; kb += 3 * GF_BK) {                          // steps past K multiply zeros
+        kstep(kb, x0, x2);
+        kstep(kb + GF_BK, x1, x0);
+        kstep(kb + 2 * GF_BK, x2, x1);
     }
     float* __restrict__ Y = g.Y[prob];
     const int64_t ldy = g.ldy[prob];
@@ -276,19 +280,38 @@ __global__ __launch_bounds__(256) void linear_fwd_grouped_kernel(LinearGroup g, 
 // weight gradient: wave tile = 64 n (interleaved tiles q) x 64 k (interleaved tiles p), over a
 // chunk of MC rows; partial[chunk][n][k] then reduced in chunk order (deterministic).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(int64_t M, int N, int K, const float* __restrict__ dY, int64_t lddy,
-                                                           const float* __restrict__ X, int64_t ldx,
-                                                           float* __restrict__ partial, float* __restrict__ partial_db,
-                                                           int64_t MC, int n_kslab, int vec_ok) {
+struct WgradGroup {
+    const float* dY[LLMREC_LINEAR_MAX_PROBLEMS];
+    const float* X[LLMREC_LINEAR_MAX_PROBLEMS];
+    int64_t lddy[LLMREC_LINEAR_MAX_PROBLEMS];
+    int64_t ldx[LLMREC_LINEAR_MAX_PROBLEMS];
+    int64_t M[LLMREC_LINEAR_MAX_PROBLEMS];
+    int32_t vec_ok[LLMREC_LINEAR_MAX_PROBLEMS];
+    int32_t chunk_begin[LLMREC_LINEAR_MAX_PROBLEMS + 1];   // first partial slab of each problem
+    int32_t n_problems;
+};
+
+// One wave = (slab = chunk of MC rows of one problem, 64-wide k slab, 64-wide n block).
+// Three register stages rotate STATICALLY (the loop is unrolled by 3), so a tile's loads have two
+// full MFMA stages (2 x 2048 cycles) to land before they are consumed.
+template <bool FAST>
+__global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(WgradGroup g, int N, int K, float* __restrict__ partial,
+                                                           float* __restrict__ partial_db, int64_t MC, int n_kslab, int n_slabs) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;          // (chunk, kslab) flattened, kslab fastest
-    const int64_t chunk = wid / n_kslab;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;          // (slab, kslab) flattened, kslab fastest
+    const int slab = (int)(wid / n_kslab);
     const int kslab = (int)(wid % n_kslab);
+    if (slab >= n_slabs) return;
+    int prob = 0;
+    while (prob + 1 < g.n_problems && slab >= g.chunk_begin[prob + 1]) ++prob;
+    const float* __restrict__ dY = g.dY[prob];
+    const float* __restrict__ X = g.X[prob];
+    const int64_t lddy = g.lddy[prob], ldx = g.ldx[prob], M = g.M[prob];
+    const bool vec_ok = g.vec_ok[prob];
     const int nblk = blockIdx.y;                                 // 64-wide block of output rows n
-    const int64_t m_begin = chunk * MC;
-    if (m_begin >= M) return;
+    const int64_t m_begin = (int64_t)(slab - g.chunk_begin[prob]) * MC;
     const int64_t m_end = (m_begin + MC < M) ? m_begin + MC : M;
     const int n_base = nblk * 64 + 4 * li;                       // this lane's 4 n's: n_base + q
     const int k_base = kslab * 64 + 4 * li;                      // this lane's 4 k's: k_base + p
@@ -300,10 +323,25 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int64_t M, int N, int
         for (int p = 0; p < 4; ++p) acc[q][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    float4 a[4], b[4], an[4], bn[4], a2[4], b2[4];
+    // FAST (chosen on the host): N % 64 == 0, K % 64 == 0, 16-byte aligned rows -> straight-line
+    // float4 loads; rows past the slab end are clamped and their dY operand zeroed (a * b = 0).
+    const float* pa = dY + n_base;
+    const float* pb = X + k_base;
     auto load_tile = [&](int64_t m0, float4 (&aa)[4], float4 (&bb)[4]) {
+        if (FAST) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {                            // 4 MFMA k-steps of 4 rows each
+            for (int s = 0; s < 4; ++s) {                        // 4 MFMA k-steps of 4 rows each
+                const int64_t m = m0 + 4 * s + lq;
+                const int64_t mc = m < m_end ? m : m_end - 1;
+                float4 va = *reinterpret_cast<const float4*>(pa + mc * lddy);
+                bb[s] = *reinterpret_cast<const float4*>(pb + mc * ldx);
+                if (m >= m_end) va = make_float4(0.f, 0.f, 0.f, 0.f);
+                aa[s] = va;
+            }
+            return;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
             const int64_t m = m0 + 4 * s + lq;
             if (m < m_end) {
                 aa[s] = load4_guard(dY + m * lddy, n_base, N, vec_ok);
@@ -314,44 +352,55 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(int64_t M, int N, int
             }
         }
     };
-    load_tile(m_begin, a, b);
-    load_tile(m_begin + 16, an, bn);                             // rows past m_end load zeros
-    for (int64_t m0 = m_begin; m0 < m_end; m0 += 16) {
-        load_tile(m0 + 32, a2, b2);                              // two tiles in flight beyond the one being multiplied
+    auto mma_tile = [&](const float4 (&aa)[4], const float4 (&bb)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            dbs.x += a[s].x; dbs.y += a[s].y; dbs.z += a[s].z; dbs.w += a[s].w;
+            dbs.x += aa[s].x; dbs.y += aa[s].y; dbs.z += aa[s].z; dbs.w += aa[s].w;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
-                    acc[q][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(a[s], q), comp(b[s], p), acc[q][p], 0, 0, 0);
+                    acc[q][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(aa[s], q), comp(bb[s], p), acc[q][p], 0, 0, 0);
         }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { a[s] = an[s]; b[s] = bn[s]; an[s] = a2[s]; bn[s] = b2[s]; }
+    };
+    float4 a0[4], b0[4], a1[4], b1[4], a2[4], b2[4];
+    load_tile(m_begin, a0, b0);
+    load_tile(m_begin + 16, a1, b1);
+    // no early exits: slabs are multiples of 48 rows and tiles past m_end load zeros, so the loop
+    // body is one straight-line block (early exits made the compiler keep several accumulator sets)
+    for (int64_t m0 = m_begin; m0 < m_end; m0 += 48) {
+        load_tile(m0 + 32, a2, b2);
+        mma_tile(a0, b0);
+        load_tile(m0 + 48, a0, b0);
+        mma_tile(a1, b1);
+        load_tile(m0 + 64, a1, b1);
+        mma_tile(a2, b2);
     }
     // D[q][p]: lane holds rows i = lq*4 + r (n = nblk*64 + 4 i + q), col j = li (k = kslab*64 + 4 j + p)
-    float* pw = partial + chunk * (int64_t)N * K;
+    float* pw = partial + (int64_t)slab * N * K;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = nblk * 64 + 4 * (lq * 4 + r) + q;
             if (n >= N) continue;
+            float* dst = pw + (int64_t)n * K + kslab * 64 + 4 * li;
+            const float4 v = make_float4(acc[q][0][r], acc[q][1][r], acc[q][2][r], acc[q][3][r]);
+            if (kslab * 64 + 4 * li + 3 < K && (K & 3) == 0) *reinterpret_cast<float4*>(dst) = v;
+            else {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int k = kslab * 64 + 4 * li + p;
-                if (k < K) pw[(int64_t)n * K + k] = acc[q][p][r];
+                for (int p = 0; p < 4; ++p)
+                    if (kslab * 64 + 4 * li + p < K) dst[p] = acc[q][p][r];
             }
         }
     if (kslab == 0 && partial_db) {
-        // column sums of dY over this chunk: combine the 4 row groups (lq) in a fixed order
+        // column sums of dY over this slab: combine the 4 row groups (lq) in a fixed order
         dbs.x += __shfl_xor(dbs.x, 16, 64); dbs.y += __shfl_xor(dbs.y, 16, 64);
         dbs.z += __shfl_xor(dbs.z, 16, 64); dbs.w += __shfl_xor(dbs.w, 16, 64);
         dbs.x += __shfl_xor(dbs.x, 32, 64); dbs.y += __shfl_xor(dbs.y, 32, 64);
         dbs.z += __shfl_xor(dbs.z, 32, 64); dbs.w += __shfl_xor(dbs.w, 32, 64);
         if (lq == 0) {
-            float* pd = partial_db + chunk * (int64_t)N;
+            float* pd = partial_db + (int64_t)slab * N;
             if (n_base + 0 < N) pd[n_base + 0] = dbs.x;
             if (n_base + 1 < N) pd[n_base + 1] = dbs.y;
             if (n_base + 2 < N) pd[n_base + 2] = dbs.z;
@@ -379,15 +428,12 @@ __global__ void reduce_chunks_kernel(int64_t n_elem, int64_t n_chunks, const flo
     }
 }
 
-static void wgrad_geometry(int64_t M, int K, int64_t* MC, int64_t* n_chunks, int* n_kslab) {
-    *n_kslab = (int)ceil_div(K, 64);
-    // aim for ~2048 waves (2 per SIMD); chunks are multiples of 16 rows, at least 128 rows each so
-    // the partial slabs (n_chunks x N x K floats) stay small next to the X stream
-    int64_t want_chunks = ceil_div(2048, *n_kslab);
-    int64_t mc = align_up(ceil_div(M, want_chunks), 16);
-    if (mc < 128) mc = 128;
-    *MC = mc;
-    *n_chunks = ceil_div(M, mc);
+// rows per slab (multiple of 16, >= 128) so that the launch has ~2048 waves over all problems
+static int64_t wgrad_slab_rows(int64_t M_total, int K) {
+    const int64_t n_kslab = ceil_div(K, 64);
+    const int64_t want_slabs = ceil_div(2048, n_kslab);
+    int64_t mc = align_up(ceil_div(M_total > 0 ? M_total : 1, want_slabs), 48);
+    return mc < 144 ? 144 : mc;
 }
 
 }  // namespace llmrec
@@ -458,50 +504,78 @@ int llmrec_linear_fwd_grouped_f32(int32_t n_problems, const llmrec_linear_proble
     return LLMREC_OK;
 }
 
-int64_t llmrec_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K) {
-    if (M < 0 || N <= 0 || K <= 0) return -1;
-    int64_t MC, n_chunks; int n_kslab;
-    wgrad_geometry(M > 0 ? M : 1, K, &MC, &n_chunks, &n_kslab);
-    return align_up(4 * n_chunks * (int64_t)N * K, 256) + align_up(4 * n_chunks * (int64_t)N, 256);
+static int64_t wgrad_ws_bytes(int64_t n_slabs, int N, int K) {
+    return align_up(4 * n_slabs * (int64_t)N * K, 256) + align_up(4 * n_slabs * (int64_t)N, 256);
 }
 
-int llmrec_linear_wgrad_f32(int64_t M, int32_t N, int32_t K, const float* dY, int64_t lddy,
-                            const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,
-                            int32_t accumulate, void* workspace, int64_t workspace_bytes,
-                            llmrec_stream_t stream_) {
+int64_t llmrec_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+    if (M < 0 || N <= 0 || K <= 0) return -1;
+    // bound for any split of M rows into <= LLMREC_LINEAR_MAX_PROBLEMS problems
+    const int64_t mc = wgrad_slab_rows(M, K);
+    return wgrad_ws_bytes(ceil_div(M > 0 ? M : 1, mc) + LLMREC_LINEAR_MAX_PROBLEMS, N, K);
+}
+
+int llmrec_linear_wgrad_grouped_f32(int32_t n_problems, const llmrec_wgrad_problem_t* p, int32_t N, int32_t K,
+                                    float* dW, int64_t lddw, float* db, int32_t accumulate,
+                                    void* workspace, int64_t workspace_bytes, llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    LLMREC_CHECK_ARG(M >= 0 && N > 0 && K > 0, "linear_wgrad: bad sizes");
-    LLMREC_CHECK_ARG(dW && lddw >= K && (M == 0 || (dY && X && lddy >= N && ldx >= K)), "linear_wgrad: null pointer or ld too small");
-    if (M == 0) {
+    LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_LINEAR_MAX_PROBLEMS && p && N > 0 && K > 0, "linear_wgrad: bad argument");
+    LLMREC_CHECK_ARG(dW && lddw >= K, "linear_wgrad: null dW or ld < K");
+    int64_t M_total = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        LLMREC_CHECK_ARG(p[i].M >= 0 && (p[i].M == 0 || (p[i].dY && p[i].X && p[i].lddy >= N && p[i].ldx >= K)),
+                         "linear_wgrad: problem %d has a null pointer or a small ld", i);
+        M_total += p[i].M;
+    }
+    if (M_total == 0) {
         if (!accumulate) {
             LLMREC_HIP(hipMemset2DAsync(dW, 4 * lddw, 0, 4 * (size_t)K, N, stream));
             if (db) LLMREC_HIP(hipMemsetAsync(db, 0, 4 * (size_t)N, stream));
         }
         return LLMREC_OK;
     }
-    if (workspace_bytes < llmrec_linear_wgrad_workspace_bytes(M, N, K) || !workspace) {
-        set_error("linear_wgrad: workspace %lld < %lld", (long long)workspace_bytes,
-                  (long long)llmrec_linear_wgrad_workspace_bytes(M, N, K));
+    const int64_t MC = wgrad_slab_rows(M_total, K);
+    WgradGroup g = {};
+    g.n_problems = n_problems;
+    int n_slabs = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        g.dY[i] = p[i].dY; g.X[i] = p[i].X; g.lddy[i] = p[i].lddy; g.ldx[i] = p[i].ldx; g.M[i] = p[i].M;
+        g.vec_ok[i] = (p[i].lddy % 4 == 0) && (p[i].ldx % 4 == 0) && (((uintptr_t)p[i].dY | (uintptr_t)p[i].X) % 16 == 0);
+        g.chunk_begin[i] = n_slabs;
+        n_slabs += (int)ceil_div(p[i].M, MC);
+    }
+    for (int i = n_problems; i <= LLMREC_LINEAR_MAX_PROBLEMS; ++i) g.chunk_begin[i] = n_slabs;
+    if (!workspace || workspace_bytes < wgrad_ws_bytes(n_slabs, N, K)) {
+        set_error("linear_wgrad: workspace %lld < %lld", (long long)workspace_bytes, (long long)wgrad_ws_bytes(n_slabs, N, K));
         return LLMREC_EWORKSPACE;
     }
-    int64_t MC, n_chunks; int n_kslab;
-    wgrad_geometry(M, K, &MC, &n_chunks, &n_kslab);
+    const int n_kslab = (int)ceil_div(K, 64);
     float* partial = (float*)workspace;
-    float* partial_db = (float*)((char*)workspace + align_up(4 * n_chunks * (int64_t)N * K, 256));
-    const int vec_ok = (lddy % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)dY | (uintptr_t)X) % 16 == 0);
-    const int64_t n_waves = n_chunks * n_kslab;
+    float* partial_db = (float*)((char*)workspace + align_up(4 * (int64_t)n_slabs * N * K, 256));
+    const int64_t n_waves = (int64_t)n_slabs * n_kslab;
     dim3 grid((unsigned)ceil_div(n_waves, 4), (unsigned)ceil_div(N, 64));
-    // waves past n_waves in the last block compute chunk >= n_chunks and exit (m_begin >= M)
-    linear_wgrad_kernel<<<grid, 256, 0, stream>>>(M, N, K, dY, lddy, X, ldx, partial, db ? partial_db : nullptr, MC, n_kslab, vec_ok);
+    bool fast = (N % 64 == 0) && (K % 64 == 0);
+    for (int i = 0; i < n_problems; ++i) fast = fast && g.vec_ok[i];
+    if (fast) linear_wgrad_kernel<true><<<grid, 256, 0, stream>>>(g, N, K, partial, db ? partial_db : nullptr, MC, n_kslab, n_slabs);
+    else linear_wgrad_kernel<false><<<grid, 256, 0, stream>>>(g, N, K, partial, db ? partial_db : nullptr, MC, n_kslab, n_slabs);
     LLMREC_LAUNCH_CHECK();
     const int64_t ne = (int64_t)N * K;
-    reduce_chunks_kernel<<<grid_for(ne, 256), 256, 0, stream>>>(ne, n_chunks, partial, dW, lddw, K, accumulate);
+    reduce_chunks_kernel<<<grid_for(ne, 256), 256, 0, stream>>>(ne, n_slabs, partial, dW, lddw, K, accumulate);
     LLMREC_LAUNCH_CHECK();
     if (db) {
-        reduce_chunks_kernel<<<1, 128, 0, stream>>>(N, n_chunks, partial_db, db, N, N, accumulate);
+        reduce_chunks_kernel<<<1, 128, 0, stream>>>(N, n_slabs, partial_db, db, N, N, accumulate);
         LLMREC_LAUNCH_CHECK();
     }
     return LLMREC_OK;
+}
+
+int llmrec_linear_wgrad_f32(int64_t M, int32_t N, int32_t K, const float* dY, int64_t lddy,
+                            const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,
+                            int32_t accumulate, void* workspace, int64_t workspace_bytes,
+                            llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(M >= 0, "linear_wgrad: bad sizes");
+    llmrec_wgrad_problem_t one = {dY, lddy, X, ldx, M};
+    return llmrec_linear_wgrad_grouped_f32(1, &one, N, K, dW, lddw, db, accumulate, workspace, workspace_bytes, stream_);
 }
 
 }  // extern "C"

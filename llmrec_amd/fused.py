@@ -63,7 +63,8 @@ class FusedStep:
         self.scal = f(4)                                     # [feat_reg, loss, mf, emb]
         self.ws_sumsq = torch.empty(_lib.query("llmrec_sumsq_workspace_bytes", 0, 0), dtype=torch.uint8, device=dev)
         feats = [model.image_feats, model.text_feats, model.user_feats] + [model.item_feats[k] for k in self.keys]
-        ws = max(_lib.query("llmrec_linear_wgrad_workspace_bytes", x.shape[0], d, x.shape[1]) for x in feats)
+        ws = max(_lib.query("llmrec_linear_wgrad_workspace_bytes", x.shape[0] * (len(self.keys) if i >= 3 else 1), d, x.shape[1])
+                 for i, x in enumerate(feats))
         self.ws_wgrad = torch.empty(ws, dtype=torch.uint8, device=dev)
         self._partials = {}
         for p in model.parameters():
@@ -99,9 +100,11 @@ class FusedStep:
     def _project_all(self):
         """All 8 projections of Models.py:145-150 in one grouped launch (d <= 64), else one by one."""
         m = self.m
-        jobs = [(m.image_feats, m.image_trans, self._side(self.P_cat, 0)), (m.text_feats, m.text_trans, self._side(self.P_cat, 1))]
-        jobs += [(m.item_feats[key], m.item_trans, self._side(self.P_cat, 2 + k)) for k, key in enumerate(self.keys)]
+        # longest K first: the launch's tail then consists of the short (512/768-wide) work units
+        jobs = [(m.item_feats[key], m.item_trans, self._side(self.P_cat, 2 + k)) for k, key in enumerate(self.keys)]
         jobs.append((m.user_feats, m.user_trans, self.P_usr))
+        jobs += [(m.text_feats, m.text_trans, self._side(self.P_cat, 1)), (m.image_feats, m.image_trans, self._side(self.P_cat, 0))]
+        jobs.sort(key=lambda j: -j[0].shape[1])
         if self.d > 64 or len(jobs) > _lib.CONST["LLMREC_LINEAR_MAX_PROBLEMS"]:
             for X, lin, out in jobs:
                 self._linear(X, lin, out)
@@ -250,8 +253,9 @@ class FusedStep:
         # weight gradients (the features are constants: no dX)
         self._wgrad(self._side(self.dP_cat, 0), m.image_feats, m.image_trans, False)
         self._wgrad(self._side(self.dP_cat, 1), m.text_feats, m.text_trans, False)
-        for k, key in enumerate(self.keys):
-            self._wgrad(self._side(self.dP_cat, 2 + k), m.item_feats[key], m.item_trans, k > 0)
+        # the shared item_trans receives all attribute streams in one grouped launch
+        ops.linear_wgrad_grouped([(self._side(self.dP_cat, 2 + k), m.item_feats[key]) for k, key in enumerate(self.keys)],
+                                 m.item_trans.weight.grad, m.item_trans.bias.grad, False, self.ws_wgrad)
         self._wgrad(self.dP_usr, m.user_feats, m.user_trans, False)
 
     def step_eager(self, users, pos, neg, n_valid=None):

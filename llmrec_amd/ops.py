@@ -399,6 +399,26 @@ class LinearProblem(_c.Structure):
                 ("W", _c.c_void_p), ("ldw", _c.c_int64), ("bias", _c.c_void_p), ("Y", _c.c_void_p), ("ldy", _c.c_int64)]
 
 
+class WgradProblem(_c.Structure):
+    """llmrec_wgrad_problem_t"""
+    _fields_ = [("dY", _c.c_void_p), ("lddy", _c.c_int64), ("X", _c.c_void_p), ("ldx", _c.c_int64), ("M", _c.c_int64)]
+
+
+def linear_wgrad_grouped(pairs, dW, db, accumulate: bool, ws: Optional[torch.Tensor] = None):
+    """dW (+)= sum_p dY_p^T X_p for several (dY, X) pairs sharing one weight (one launch + reduce)."""
+    arr = (WgradProblem * len(pairs))()
+    M_total = 0
+    for i, (dY, X) in enumerate(pairs):
+        _need_gpu(dY, X)
+        arr[i].dY, arr[i].lddy, arr[i].X, arr[i].ldx, arr[i].M = dY.data_ptr(), _ld(dY), X.data_ptr(), _ld(X), X.shape[0]
+        M_total += X.shape[0]
+    N, K = dW.shape
+    need = _lib.query("llmrec_linear_wgrad_workspace_bytes", M_total, N, K)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dW.device)
+    _lib.call("llmrec_linear_wgrad_grouped_f32", len(pairs), arr, N, K, _p(dW), _ld(dW), _p(db), 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
+
+
 def linear_fwd_grouped(jobs, N: int):
     """jobs: list of (X, W, bias, out) - one launch (llmrec_linear_fwd_grouped_f32)."""
     arr = (LinearProblem * len(jobs))()

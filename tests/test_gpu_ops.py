@@ -186,6 +186,24 @@ def test_linear_grouped_matches_single_launches(ops):
             assert rel_err(out.cpu(), ref) < 5e-6
 
 
+def test_linear_wgrad_grouped(ops):
+    rng = np.random.default_rng(12)
+    for (N, K) in ((64, 1536), (64, 192), (16, 40), (64, 36)):
+        Ms = [700, 333, 48, 1]
+        Xs = [torch.tensor(rng.standard_normal((M, K)).astype(np.float32)) for M in Ms]
+        big = torch.tensor(rng.standard_normal((700, 3 * N)).astype(np.float32))
+        dYs = [big[:Ms[0], N:2 * N]] + [torch.tensor(rng.standard_normal((M, N)).astype(np.float32)) for M in Ms[1:]]
+        ref_w = sum(dy.t() @ x for dy, x in zip(dYs, Xs)); ref_b = sum(dy.sum(0) for dy in dYs)
+        bigg = big.to(DEV)
+        pairs = [(bigg[:Ms[0], N:2 * N], Xs[0].to(DEV))] + [(dy.to(DEV), x.to(DEV)) for dy, x in zip(dYs[1:], Xs[1:])]
+        dW = torch.full((N, K), 7.0, device=DEV); db = torch.full((N,), -3.0, device=DEV)
+        ops.linear_wgrad_grouped(pairs, dW, db, False)
+        assert rel_err(dW.cpu(), ref_w) < 2e-5 and rel_err(db.cpu(), ref_b) < 2e-5
+        ops.linear_wgrad_grouped(pairs[:2], dW, db, True)          # accumulate
+        ref_w2 = ref_w + sum(dy.t() @ x for dy, x in zip(dYs[:2], Xs[:2])); ref_b2 = ref_b + sum(dy.sum(0) for dy in dYs[:2])
+        assert rel_err(dW.cpu(), ref_w2) < 2e-5 and rel_err(db.cpu(), ref_b2) < 2e-5
+
+
 def test_linear_multi_shares_one_weight(ops):
     rng = np.random.default_rng(3)
     M, K, N = 300, 56, 64
