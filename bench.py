@@ -187,6 +187,25 @@ class NetflixShaped:
         return out
 
 
+def pmc_traffic_bytes(kernel_label: str):
+    """HBM-side bytes per launch of the named kernel from the committed PMC pass
+    (profiles/r01_pmc_counters.json: separate rocprofv3 --pmc runs with --kernel-trace only, as
+    MI355X_MICROARCH.md prescribes; FETCH_SIZE is doubled per its gfx950 note, WRITE_SIZE taken as
+    reported; both in KB). None when that kernel was not in the pass."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        data = json.load(open(path))
+    except Exception:
+        return None
+    key = kernel_label.split("<")[0].split(" ")[0]
+    for name, counters in data.items():
+        if key in name and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+            return (2.0 * counters["FETCH_SIZE"]["mean"] + counters["WRITE_SIZE"]["mean"]) * 1024.0
+    return None
+
+
 def spmm_roofline_large(device, seed, n_users=2_000_000, n_items=1_000_000, n_edges=40_000_000, d=64):
     """The HBM-bound regime of the SpMM (north_star's roofline target): cfg-4-shaped synthetic
     graph at single-GPU size. Algorithmic bytes per SURVEY.md 8(d):
@@ -263,12 +282,14 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    from llmrec_amd import build as _build
-    _build.build(force=False, verbose=False)
+    if local == 0:                                           # one builder per node; the .so normally travels prebuilt
+        from llmrec_amd import build as _build
+        _build.build(force=False, verbose=False)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
+        dist.barrier()                                       # the library exists before any rank loads it
     workload = a.workload
     if workload == "auto":
         workload = "nf" if world == 1 else "synth"
@@ -315,7 +336,9 @@ def main():
             line["kernels"] = ks
             dom = max(ks[:2], key=lambda k: k["ms"] * k["calls_per_step"])
             line["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_F32_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": dom["frac_mfma_f32"], "traffic": None,
+                                "unit": "TFLOP/s", "frac": dom["frac_mfma_f32"], "traffic": pmc_traffic_bytes(dom["kernel"]),
+                                "algorithmic_flop_per_launch": dom["algorithmic_flop_per_launch"],
+                                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                                 "ms_per_launch": dom["ms"], "hbm_gbs": dom["gbs"], "frac_hbm": dom["frac_hbm"]}
             line["spmm_roofline"] = spmm_roofline_large(device, a.seed)
         if not a.no_cpu_baseline and world == 1:

@@ -242,6 +242,12 @@ int llmrec_adamw_advance(float* state3, float lr, float beta1, float beta2, llmr
 int llmrec_adamw_f32(int64_t n, float* p, const float* g, float* m, float* v, const float* state3,
                      float lr, float beta1, float beta2, float eps, float weight_decay, llmrec_stream_t stream);
 
+/* the same update for up to LLMREC_ADAMW_MAX_TENSORS parameters in one launch */
+#define LLMREC_ADAMW_MAX_TENSORS 16
+typedef struct { float* p; const float* g; float* m; float* v; int64_t n; } llmrec_adamw_tensor_t;
+int llmrec_adamw_multi_f32(int32_t n_tensors, const llmrec_adamw_tensor_t* tensors_host, const float* state3,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, llmrec_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * R9/R10  full-rank scoring + masked top-K + hit vectors
  *                                        replaces torch.matmul(E_u[blk], E_i^T), the D2H copy of

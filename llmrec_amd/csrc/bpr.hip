@@ -8,7 +8,6 @@
 namespace llmrec {
 
 constexpr int BPR_THREADS = 1024;
-constexpr int BPR_GROUPS = BPR_THREADS / 16;
 
 __device__ __forceinline__ float logsigmoid_f(float x) {
     // min(x, 0) - log1p(exp(-|x|)), the form aten::log_sigmoid_forward uses
@@ -16,14 +15,15 @@ __device__ __forceinline__ float logsigmoid_f(float x) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Forward = two launches over up to LLMREC_BPR_MAX_PROBLEMS (user table, item table) pairs that
+// Forward = three launches over up to LLMREC_BPR_MAX_PROBLEMS (user table, item table) pairs that
 // share one (users, pos, neg) batch - the reference evaluates 8 such losses per step
 // (main.py:232-254):
 //   bpr_scores_kernel  one 16-lane group per (problem, sample): the three row gathers, both dot
 //                      products, log-sigmoid, its derivative and the three squared row norms;
-//   bpr_select_kernel  one 1024-thread block per problem: rank counting over the B log-sigmoids
-//                      held in LDS (keep the k smallest, ties by lower index), the kept mean and
-//                      the norm sums by fixed-order trees (deterministic).
+//   bpr_rank_kernel    one thread per (problem, sample): rank counting against the B log-sigmoids
+//                      staged in LDS (keep the k smallest, ties by lower index);
+//   bpr_reduce_kernel  one block per problem: the kept mean and the norm sums by fixed-order
+//                      trees (deterministic).
 // saved layout per problem (LLMREC_BPR_SAVED_FLOATS(B) floats):
 //   [0, B) d(mf)/d(s_b) | [B..B+2] Su, Sp, Sq | [B+3] k | [B+4 + {0..4} * B + b] m, sg, nu, np, nq
 // ---------------------------------------------------------------------------------------------
@@ -86,40 +86,58 @@ __device__ __forceinline__ float block_tree_sum(float v, float* red) {
     return r;
 }
 
-__global__ __launch_bounds__(BPR_THREADS) void bpr_select_kernel(int B_max, const int32_t* __restrict__ n_valid_dev,
+// selection, step 1: rank counting. grid = (ceil(B / 256), problems); each thread ranks one sample
+// against the Bg log-sigmoids staged in LDS and writes d(mf)/d(s_b) (0 when dropped) plus the kept
+// m_b into the scratch (slot 1 = sg is consumed here and overwritten with the kept value).
+__global__ __launch_bounds__(256) void bpr_rank_kernel(int B_max, const int32_t* __restrict__ n_valid_dev, double remember_rate,
+                                                       float* __restrict__ saved_all, int saved_stride,
+                                                       const float* __restrict__ global_m, int global_B, int my_offset) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* m_s = reinterpret_cast<float*>(smem);
+    const int B = bpr_batch(n_valid_dev, B_max);
+    const int prob = blockIdx.y;
+    float* saved = saved_all + (int64_t)prob * saved_stride;
+    float* sc = saved + B_max + 4;
+    const int Bg = global_m ? global_B : B;
+    for (int j = threadIdx.x; j < Bg; j += 256) m_s[j] = global_m ? global_m[j] : sc[j];
+    __syncthreads();
+    const int k = (int)(remember_rate * (double)Bg);                   // int((1 - drop) * len) of main.py:161-162
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B_max) return;
+    if (b >= B) { saved[b] = 0.f; sc[B_max + b] = 0.f; return; }
+    const float mb = sc[b];
+    bool keep = true;
+    if (k < Bg) {
+        int rank = 0;
+        const int me = my_offset + b;
+        for (int j = 0; j < Bg; ++j) {
+            const float mj = m_s[j];
+            rank += (mj < mb) || (mj == mb && j < me);
+        }
+        keep = rank < k;
+    }
+    saved[b] = keep ? (-1.0f / (float)k) * sc[B_max + b] : 0.f;
+    sc[B_max + b] = keep ? mb : 0.f;
+}
+
+// selection, step 2: one block per problem sums the kept log-sigmoids and the three squared norms
+// with fixed-order trees (deterministic) and writes the two loss values.
+__global__ __launch_bounds__(BPR_THREADS) void bpr_reduce_kernel(int B_max, const int32_t* __restrict__ n_valid_dev,
                                                                  double remember_rate, float decay, float bsz,
                                                                  float* __restrict__ out_all, float* __restrict__ saved_all,
-                                                                 int saved_stride, const float* __restrict__ global_m,
-                                                                 int global_B, int my_offset) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* m_s = reinterpret_cast<float*>(smem);                       // [Bg] log-sigmoids ranked against
-    float* red = m_s + (global_m ? global_B : B_max);                  // [BPR_THREADS]
+                                                                 int saved_stride, int global_B) {
+    __shared__ float red[BPR_THREADS];
     const int B = bpr_batch(n_valid_dev, B_max);
     const int prob = blockIdx.x;
     float* saved = saved_all + (int64_t)prob * saved_stride;
     const float* sc = saved + B_max + 4;
-    const int Bg = global_m ? global_B : B;
-    for (int j = threadIdx.x; j < Bg; j += BPR_THREADS) m_s[j] = global_m ? global_m[j] : sc[j];
-    __syncthreads();
-    const int k = (int)(remember_rate * (double)Bg);                   // int((1 - drop) * len) of main.py:161-162
+    const int Bg = global_B > 0 ? global_B : B;
+    const int k = (int)(remember_rate * (double)Bg);
     float part = 0.f, su = 0.f, sp = 0.f, sq = 0.f;
     for (int b = threadIdx.x; b < B; b += BPR_THREADS) {
-        const float mb = sc[b];
-        bool keep = true;
-        if (k < Bg) {
-            int rank = 0;
-            const int me = my_offset + b;
-            for (int j = 0; j < Bg; ++j) {
-                const float mj = m_s[j];
-                rank += (mj < mb) || (mj == mb && j < me);
-            }
-            keep = rank < k;
-        }
-        if (keep) part += mb;
-        saved[b] = keep ? (-1.0f / (float)k) * sc[B_max + b] : 0.f;
+        part += sc[B_max + b];
         su += sc[2 * B_max + b]; sp += sc[3 * B_max + b]; sq += sc[4 * B_max + b];
     }
-    for (int b = B + threadIdx.x; b < B_max; b += BPR_THREADS) saved[b] = 0.f;
     const float kept = block_tree_sum(part, red);
     const float Su = block_tree_sum(su, red), Sp = block_tree_sum(sp, red), Sq = block_tree_sum(sq, red);
     if (threadIdx.x == 0) {
@@ -290,9 +308,12 @@ static int launch_bpr_fwd(const BprTables& t, int n_prob, int d, const int64_t* 
         LLMREC_LAUNCH_CHECK();
     }
     if (do_select) {
-        const size_t shmem = sizeof(float) * ((size_t)(global_m ? global_B : B_max) + BPR_THREADS);
-        bpr_select_kernel<<<n_prob, BPR_THREADS, shmem, stream>>>(B_max, n_valid_dev, remember_rate, decay, bsz, out, saved, stride,
-                                                                  global_m, global_B, my_offset);
+        const size_t shmem = sizeof(float) * (size_t)(global_m ? global_B : (B_max > 0 ? B_max : 1));
+        dim3 grid((unsigned)ceil_div(B_max > 0 ? B_max : 1, 256), (unsigned)n_prob);
+        bpr_rank_kernel<<<grid, 256, shmem, stream>>>(B_max, n_valid_dev, remember_rate, saved, stride, global_m, global_B, my_offset);
+        LLMREC_LAUNCH_CHECK();
+        bpr_reduce_kernel<<<n_prob, BPR_THREADS, 0, stream>>>(B_max, n_valid_dev, remember_rate, decay, bsz, out, saved, stride,
+                                                              global_m ? global_B : 0);
         LLMREC_LAUNCH_CHECK();
     }
     return LLMREC_OK;

@@ -263,6 +263,42 @@ __global__ __launch_bounds__(256) void adamw_kernel(int64_t n, float* __restrict
     }
 }
 
+struct AdamwTensors {
+    float* p[LLMREC_ADAMW_MAX_TENSORS];
+    const float* g[LLMREC_ADAMW_MAX_TENSORS];
+    float* m[LLMREC_ADAMW_MAX_TENSORS];
+    float* v[LLMREC_ADAMW_MAX_TENSORS];
+    int64_t n[LLMREC_ADAMW_MAX_TENSORS];
+    int32_t block_begin[LLMREC_ADAMW_MAX_TENSORS + 1];
+    int32_t n_tensors;
+};
+constexpr int ADAMW_PER_BLOCK = 256 * 16;
+
+// all parameters of the model in one launch: block -> (tensor, 4096-element chunk)
+__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamwTensors t, const float* __restrict__ state, float decay_mul,
+                                                          float b1, float b2, float eps) {
+    int k = 0;
+    while (k + 1 < t.n_tensors && (int)blockIdx.x >= t.block_begin[k + 1]) ++k;
+    const int64_t base = (int64_t)(blockIdx.x - t.block_begin[k]) * ADAMW_PER_BLOCK;
+    float* __restrict__ p = t.p[k]; const float* __restrict__ g = t.g[k];
+    float* __restrict__ m = t.m[k]; float* __restrict__ v = t.v[k];
+    const int64_t n = t.n[k];
+    const float step_size = state[1], bc2s = state[2];
+    const float w1 = 1.0f - b1, w2 = 1.0f - b2;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i >= n) break;
+        const float gi = g[i];
+        float pi = p[i] * decay_mul;
+        const float mi = m[i] + w1 * (gi - m[i]);
+        const float vi = fmaf(w2 * gi, gi, v[i] * b2);
+        const float denom = sqrtf(vi) / bc2s + eps;
+        pi = pi - step_size * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
 template <typename F4, typename F1>
 static int dispatch_rows(int d, bool vec4, F4 f4, F1 f1) {
     if (vec4) {
@@ -421,6 +457,28 @@ int llmrec_adamw_f32(int64_t n, float* p, const float* g, float* m, float* v, co
     LLMREC_CHECK_ARG(p && g && m && v, "adamw: null pointer");
     const float decay_mul = (float)(1.0 - (double)lr * (double)weight_decay);
     adamw_kernel<<<grid_for(n, 256 * 4), 256, 0, (hipStream_t)stream_>>>(n, p, g, m, v, state3, decay_mul, beta1, beta2, eps);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_adamw_multi_f32(int32_t n_tensors, const llmrec_adamw_tensor_t* tensors_host, const float* state3,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_tensors >= 0 && n_tensors <= LLMREC_ADAMW_MAX_TENSORS && state3 && (n_tensors == 0 || tensors_host),
+                     "adamw_multi: bad argument (at most %d tensors)", LLMREC_ADAMW_MAX_TENSORS);
+    AdamwTensors t = {};
+    t.n_tensors = n_tensors;
+    int blocks = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        const llmrec_adamw_tensor_t& x = tensors_host[i];
+        LLMREC_CHECK_ARG(x.n >= 0 && (x.n == 0 || (x.p && x.g && x.m && x.v)), "adamw_multi: tensor %d has a null pointer", i);
+        t.p[i] = x.p; t.g[i] = x.g; t.m[i] = x.m; t.v[i] = x.v; t.n[i] = x.n;
+        t.block_begin[i] = blocks;
+        blocks += (int)ceil_div(x.n, ADAMW_PER_BLOCK);
+    }
+    for (int i = n_tensors; i <= LLMREC_ADAMW_MAX_TENSORS; ++i) t.block_begin[i] = blocks;
+    if (blocks == 0) return LLMREC_OK;
+    const float decay_mul = (float)(1.0 - (double)lr * (double)weight_decay);
+    adamw_multi_kernel<<<blocks, 256, 0, (hipStream_t)stream_>>>(t, state3, decay_mul, beta1, beta2, eps);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

@@ -503,6 +503,11 @@ def sumsq(coef: float, Xs: Sequence[torch.Tensor]):
 # ---------------------------------------------------------------------------------------------
 # R8: AdamW
 # ---------------------------------------------------------------------------------------------
+class AdamwTensor(_c.Structure):
+    """llmrec_adamw_tensor_t"""
+    _fields_ = [("p", _c.c_void_p), ("g", _c.c_void_p), ("m", _c.c_void_p), ("v", _c.c_void_p), ("n", _c.c_int64)]
+
+
 class FusedAdamW:
     """torch.optim.AdamW(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01) semantics as built
     at reference main.py:100-104, one HIP launch per parameter, bias corrections kept on device
@@ -530,15 +535,22 @@ class FusedAdamW:
         if self.dev_state is None:
             self.dev_state = torch.zeros(3, dtype=torch.float32, device=live[0].device)
         _lib.call("llmrec_adamw_advance", _p(self.dev_state), self.lr, self.betas[0], self.betas[1], _stream())
-        for p in live:
-            st = self.state.get(p)
-            if st is None:
-                st = self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
-            if not p.is_contiguous():
-                raise RuntimeError("FusedAdamW: contiguous parameters expected")
-            g = p.grad.contiguous()
-            _lib.call("llmrec_adamw_f32", p.numel(), _p(p), _p(g), _p(st[0]), _p(st[1]), _p(self.dev_state), self.lr,
-                      self.betas[0], self.betas[1], self.eps, self.wd, _stream())
+        cap = CONST["LLMREC_ADAMW_MAX_TENSORS"]
+        for lo in range(0, len(live), cap):
+            group = live[lo:lo + cap]
+            arr = (AdamwTensor * len(group))()
+            keep = []
+            for i, p in enumerate(group):
+                st = self.state.get(p)
+                if st is None:
+                    st = self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
+                if not p.is_contiguous():
+                    raise RuntimeError("FusedAdamW: contiguous parameters expected")
+                g = p.grad.contiguous()
+                keep.append(g)
+                arr[i].p, arr[i].g, arr[i].m, arr[i].v, arr[i].n = p.data_ptr(), g.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), p.numel()
+            _lib.call("llmrec_adamw_multi_f32", len(group), arr, _p(self.dev_state), self.lr, self.betas[0], self.betas[1],
+                      self.eps, self.wd, _stream())
 
 
 # ---------------------------------------------------------------------------------------------
@@ -556,6 +568,16 @@ def score_topk(Eu, Ei, query_users: torch.Tensor, train: Optional[Csr], K: int):
               _p(train.rowptr) if train is not None else None, _p(train.colidx) if train is not None else None,
               K, _p(idx), _p(sc), _stream())
     return idx, sc
+
+
+def export_candidates(Eu, Ei, k: int = 10, query_users: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Stage-1 candidate export: the top-k item ids per user WITHOUT masking, i.e. what the reference
+    README's `torch.topk(user_emb @ item_emb.T, k=10)` snippet (README.md:243-247) produces for
+    `candidate_indices`, as an int64 [n, k] tensor - computed by the scoring kernel, never
+    materialising U x I. Ties are broken by ascending item id."""
+    q = torch.arange(Eu.shape[0], device=Eu.device) if query_users is None else query_users
+    idx, _ = score_topk(Eu, Ei, q, None, k)
+    return idx.to(torch.int64)
 
 
 def scores(Eu, Ei, query_users: torch.Tensor):

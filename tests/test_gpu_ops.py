@@ -371,6 +371,16 @@ def test_score_topk_exact_ties_follow_reference_rule(ops):
         assert idx[u].tolist() == O.rank_topk(S_ref[u], train_items[u], K), u
 
 
+def test_export_candidates_matches_torch_topk(ops):
+    rng = np.random.default_rng(21)
+    U, I, d = 130, 900, 64
+    Eu = torch.tensor(rng.standard_normal((U, d)).astype(np.float32)); Ei = torch.tensor(rng.standard_normal((I, d)).astype(np.float32))
+    got = ops.export_candidates(Eu.to(DEV), Ei.to(DEV), 10).cpu()
+    S = ops.scores(Eu.to(DEV), Ei.to(DEV), torch.arange(U).to(DEV)).cpu()
+    want = torch.topk(S, k=10, dim=1).indices                      # no exact ties in random fp32 data
+    assert torch.equal(got, want)
+
+
 def test_topk_hits(ops):
     rng = np.random.default_rng(1)
     U, I, K = 40, 300, 50
