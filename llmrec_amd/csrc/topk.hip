@@ -6,16 +6,18 @@
 // The only MFMA user on the path: v_mfma_f32_16x16x4_f32 (exact fp32; a k-ordered fma chain, so
 // the scores are reproducible bit for bit by a scalar fmaf loop in the order documented below).
 //
-// Geometry: block = 4 wavefronts; each wavefront owns 16 query users (one MFMA row tile, A
-// operand resident in registers for the whole launch) and sweeps the items in tiles of 64
-// (4 MFMA column tiles). Operands are fed straight from global memory as float4 along k (see
+// Geometry: block = 4 wavefronts sharing 16 query users (one MFMA row tile, A operand resident in
+// registers for the whole launch); wavefront w sweeps the w-th quarter of the items in tiles of 64
+// (4 MFMA column tiles) with its own candidate lists, and a bitonic merge of the four lists per
+// user ends the block (825 blocks x 4 waves at the Netflix shape instead of 207 x 4). Operands are fed straight from global memory as float4 along k (see
 // dense.hip for the k-permutation argument): lane l holds E[row (l&15)][16 c + 4 (l>>4) + s].
 // Chain order of k for one score: for c in 0..d/16-1, for s in 0..3, for q in 0..3: k = 16c + 4q + s.
 //
 // Selection: each wavefront keeps, per user, a sorted 64-slot list (score desc, item id asc) in
 // LDS, one slot per lane (a lane only ever touches its own slot column, so no LDS hand-off
 // between lanes exists). A score enters the insert path only if it is >= the user's current K-th
-// score; the insert is a ballot/popcount position search plus a one-lane shift, all in-wave.
+// score; all candidates of one user in a tile are inserted with the list held in registers: a
+// ballot/popcount position search plus a one-lane DPP shift (v_mov_b32 wave_shr:1) per candidate.
 // Train items are removed with a per-user cursor into the user's (ascending) CSR row, turned
 // into a 64-bit tile mask.
 #include "common.h"
@@ -61,16 +63,40 @@ __device__ __forceinline__ void load_items(const TopkArgs& a, int64_t base, int 
     }
 }
 
+__device__ __forceinline__ float wave_shr1(float x) {     // lane i <- lane i-1 (lane 0 keeps its value)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int wave_shr1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ bool pair_better(float s, int i, float t, int j) { return (s > t) || (s == t && i < j); }
+
+// top-64 of the union of two descending 64-lists held one entry per lane: elementwise best of A and
+// reversed B is bitonic and holds the 64 best; six compare-exchange stages sort it (best first).
+__device__ __forceinline__ void merge64(float& s, int& i, float bs, int bi, int lane) {
+    const float rs = __shfl(bs, 63 - lane, 64);
+    const int ri = __shfl(bi, 63 - lane, 64);
+    if (pair_better(rs, ri, s, i)) { s = rs; i = ri; }
+#pragma unroll
+    for (int stride = 32; stride > 0; stride >>= 1) {
+        const float os = __shfl_xor(s, stride, 64);
+        const int oi = __shfl_xor(i, stride, 64);
+        const bool take_best = (lane & stride) == 0;
+        const bool other_better = pair_better(os, oi, s, i);
+        if (take_best == other_better) { s = os; i = oi; }
+    }
+}
+
+// block = 4 wavefronts sharing 16 query users; wave w sweeps the w-th quarter of the item tiles
+// and keeps its own lists; a bitonic merge of the four lists per user ends the block.
 template <int DK, bool SELECT>
 __global__ __launch_bounds__(256) void score_topk_kernel(TopkArgs a) {
     __shared__ float list_s[4][16][64];
     __shared__ int32_t list_i[4][16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int q0 = (blockIdx.x * 4 + w) * 16;
-    if (q0 >= a.n_query) return;
+    const int q0 = blockIdx.x * 16;
+    if (q0 >= a.n_query) return;                               // block-uniform
 
-    // A operand: this wave's 16 users
+    // A operand: the block's 16 users
     int qa = q0 + li;
     if (qa > a.n_query - 1) qa = a.n_query - 1;
     const int64_t user_a = a.query_users[qa];
@@ -78,7 +104,12 @@ __global__ __launch_bounds__(256) void score_topk_kernel(TopkArgs a) {
 #pragma unroll
     for (int c = 0; c < DK; ++c) ua[c] = ld4g(a.Eu + user_a * a.ldu, 16 * c + 4 * lq, a.d, a.vec_ok);
 
-    // lanes 0..15 own one user each: train-row cursor and current K-th score
+    const int64_t tiles_total = (a.n_items + 63) / 64;
+    const int64_t tiles_per_wave = (tiles_total + 3) / 4;
+    const int64_t t_begin = w * tiles_per_wave;
+    const int64_t t_end = t_begin + tiles_per_wave < tiles_total ? t_begin + tiles_per_wave : tiles_total;
+
+    // lanes 0..15 own one user each: train-row cursor and current K-th score of THIS wave's list
     int32_t cur = 0, end = 0;
     float thr = -INFINITY;
     if (SELECT) {
@@ -87,11 +118,10 @@ __global__ __launch_bounds__(256) void score_topk_kernel(TopkArgs a) {
         for (int r = 0; r < 16; ++r) { list_s[w][r][lane] = -INFINITY; list_i[w][r][lane] = INT_MAX; }
     }
 
-    constexpr bool PREFETCH = DK <= 4;
-    float4 b[4][DK], bn[4][DK];
-    load_items<DK>(a, 0, li, lq, b);
-    for (int64_t base = 0; base < a.n_items; base += 64) {
-        if (PREFETCH && base + 64 < a.n_items) load_items<DK>(a, base + 64, li, lq, bn);
+    for (int64_t t = t_begin; t < t_end; ++t) {
+        const int64_t base = t * 64;
+        float4 b[4][DK];
+        load_items<DK>(a, base, li, lq, b);
         f32x4 acc[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -112,76 +142,83 @@ __global__ __launch_bounds__(256) void score_topk_kernel(TopkArgs a) {
                     const int64_t item = base + 16 * n + li;
                     if (q < a.n_query && item < a.n_items) a.S[(int64_t)q * a.lds + item] = acc[n][r];
                 }
-        } else {
-            // 64-bit mask of this tile's train items, built by the row-owner lanes
-            uint32_t mlo = 0, mhi = 0;
-            if (lane < 16) {
-                while (cur < end) {
-                    const int64_t c = a.train_colidx[cur];
-                    if (c >= base + 64) break;
-                    const int bit = (int)(c - base);
-                    if (bit >= 0) { if (bit < 32) mlo |= 1u << bit; else mhi |= 1u << (bit - 32); }
-                    ++cur;
-                }
-            }
-            uint32_t rm_lo[4], rm_hi[4];
-            float rthr[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                rm_lo[r] = __shfl(mlo, lq * 4 + r, 64);
-                rm_hi[r] = __shfl(mhi, lq * 4 + r, 64);
-                rthr[r] = __shfl(thr, lq * 4 + r, 64);
-            }
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[n][r];
-                    const int col = 16 * n + li;
-                    const uint32_t mword = (n < 2) ? rm_lo[r] : rm_hi[r];
-                    const bool masked = (mword >> (col & 31)) & 1u;
-                    const bool valid = (base + col < a.n_items) && (q0 + lq * 4 + r < a.n_query) && !masked;
-                    unsigned long long bal = __ballot(valid && v >= rthr[r]);
-                    while (bal) {
-                        const int src = __ffsll((long long)bal) - 1;
-                        bal &= bal - 1;
-                        const float cv = __shfl(v, src, 64);
-                        const int crow = (src >> 4) * 4 + r;
-                        const int32_t citem = (int32_t)(base + 16 * n + (src & 15));
-                        const float ls = list_s[w][crow][lane];
-                        const int32_t lid = list_i[w][crow][lane];
-                        const bool better = (ls > cv) || (ls == cv && lid < citem);
-                        const int pos = __popcll(__ballot(better));
-                        if (pos < a.K) {
-                            const float ps = __shfl_up(ls, 1, 64);
-                            const int32_t pi = __shfl_up(lid, 1, 64);
-                            const float ns = lane < pos ? ls : (lane == pos ? cv : ps);
-                            const int32_t ni = lane < pos ? lid : (lane == pos ? citem : pi);
-                            list_s[w][crow][lane] = ns;
-                            list_i[w][crow][lane] = ni;
-                            const float nthr = __shfl(ns, a.K - 1, 64);
-                            if (lane == crow) thr = nthr;
-                        }
-                    }
-                }
+            continue;
+        }
+        // 64-bit mask of this tile's train items, built by the row-owner lanes
+        uint32_t mlo = 0, mhi = 0;
+        if (lane < 16) {
+            while (cur < end) {
+                const int64_t c = a.train_colidx[cur];
+                if (c >= base + 64) break;
+                const int bit = (int)(c - base);
+                if (bit >= 0) { if (bit < 32) mlo |= 1u << bit; else mhi |= 1u << (bit - 32); }
+                ++cur;                                             // entries before this wave's quarter are skipped
             }
         }
-        if (PREFETCH) {
+        uint32_t rm_lo[4], rm_hi[4];
+        float rthr[4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+        for (int r = 0; r < 4; ++r) {
+            rm_lo[r] = __shfl(mlo, lq * 4 + r, 64);
+            rm_hi[r] = __shfl(mhi, lq * 4 + r, 64);
+            rthr[r] = __shfl(thr, lq * 4 + r, 64);
+        }
 #pragma unroll
-                for (int c = 0; c < DK; ++c) b[n][c] = bn[n][c];
-        } else if (base + 64 < a.n_items) {
-            load_items<DK>(a, base + 64, li, lq, b);
+        for (int n = 0; n < 4; ++n) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[n][r];
+                const int col = 16 * n + li;
+                const uint32_t mword = (n < 2) ? rm_lo[r] : rm_hi[r];
+                const bool masked = (mword >> (col & 31)) & 1u;
+                const bool valid = (base + col < a.n_items) && (q0 + lq * 4 + r < a.n_query) && !masked;
+                const unsigned long long bal = __ballot(valid && v >= rthr[r]);
+                if (bal == 0) continue;
+                // candidates of lane group g all belong to user row g*4 + r: insert them with the
+                // row's list held in registers (one LDS round trip per row, not per candidate)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned sub = (unsigned)((bal >> (16 * g)) & 0xffffull);
+                    if (sub == 0) continue;
+                    const int crow = g * 4 + r;
+                    float ls = list_s[w][crow][lane];
+                    int32_t lid = list_i[w][crow][lane];
+                    do {
+                        const int bpos = __ffs((int)sub) - 1;
+                        sub &= sub - 1;
+                        const float cv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16 * g + bpos));
+                        const int32_t citem = (int32_t)(base + 16 * n + bpos);
+                        const int pos = __popcll(__ballot(pair_better(ls, lid, cv, citem)));
+                        if (pos < a.K) {
+                            const float ps = wave_shr1(ls);
+                            const int32_t pi = wave_shr1(lid);
+                            ls = lane < pos ? ls : (lane == pos ? cv : ps);
+                            lid = lane < pos ? lid : (lane == pos ? citem : pi);
+                        }
+                    } while (sub);
+                    list_s[w][crow][lane] = ls;
+                    list_i[w][crow][lane] = lid;
+                    const float nthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ls), a.K - 1));
+                    if (lane == crow) thr = nthr;
+                }
+            }
         }
     }
     if (SELECT) {
-        for (int r = 0; r < 16; ++r) {
+        __syncthreads();
+        // wave w merges the four quarter lists of users 4w .. 4w+3
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * w + rr;
             const int q = q0 + r;
-            if (q < a.n_query && lane < a.K) {
-                const int32_t id = list_i[w][r][lane];
-                a.out_idx[(int64_t)q * a.K + lane] = id == INT_MAX ? -1 : id;
-                a.out_score[(int64_t)q * a.K + lane] = list_s[w][r][lane];
+            if (q >= a.n_query) break;                             // wave-uniform
+            float s0 = list_s[0][r][lane]; int i0 = list_i[0][r][lane];
+            float s2 = list_s[2][r][lane]; int i2 = list_i[2][r][lane];
+            merge64(s0, i0, list_s[1][r][lane], list_i[1][r][lane], lane);
+            merge64(s2, i2, list_s[3][r][lane], list_i[3][r][lane], lane);
+            merge64(s0, i0, s2, i2, lane);
+            if (lane < a.K) {
+                a.out_idx[(int64_t)q * a.K + lane] = i0 == INT_MAX ? -1 : i0;
+                a.out_score[(int64_t)q * a.K + lane] = s0;
             }
         }
     }
@@ -207,7 +244,7 @@ __global__ void topk_hits_kernel(int n_query, const int64_t* __restrict__ query_
 template <bool SELECT>
 static int launch_topk(const TopkArgs& a, hipStream_t stream) {
     const int DK = (a.d + 15) / 16;
-    const int grid = (int)ceil_div(a.n_query, 64);
+    const int grid = (int)ceil_div(a.n_query, 16);
     switch (DK) {
         case 1: score_topk_kernel<1, SELECT><<<grid, 256, 0, stream>>>(a); break;
         case 2: score_topk_kernel<2, SELECT><<<grid, 256, 0, stream>>>(a); break;
