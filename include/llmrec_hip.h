@@ -126,6 +126,12 @@ typedef struct { const float* dY; int64_t lddy; const float* X; int64_t ldx; int
 int llmrec_linear_wgrad_grouped_f32(int32_t n_problems, const llmrec_wgrad_problem_t* problems_host, int32_t N, int32_t K,
                                     float* dW, int64_t lddw, float* db, int32_t accumulate,
                                     void* workspace, int64_t workspace_bytes, llmrec_stream_t stream);
+/* Same contract, split precision: each fp32 operand = exact sum of three bf16 numbers, product by the
+ * six bf16 MFMAs (v_mfma_f32_16x16x32_bf16, fp32 accumulate) whose terms are >= 2^-24 relative.
+ * fp32-roundoff-class error (not the bit-identical fma chain); 3/8 of the fp32 matrix time, so the
+ * kernel becomes HBM-bound on the X stream. */
+int llmrec_linear_fwd_grouped_bf16x3(int32_t n_problems, const llmrec_linear_problem_t* problems_host, int32_t N,
+                                     llmrec_stream_t stream);
 int64_t llmrec_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K);
 int llmrec_linear_wgrad_f32(int64_t M, int32_t N, int32_t K, const float* dY, int64_t lddy,
                             const float* X, int64_t ldx, float* dW, int64_t lddw, float* db,

@@ -277,6 +277,179 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup 
 }
 
 // ---------------------------------------------------------------------------------------------
+// split-precision variant of the grouped forward ("bf16x3"): every fp32 operand is written as the
+// EXACT sum of three bf16 numbers (hi + mid + lo: 3 x 8 significant bits = fp32's 24) and the product
+// is evaluated with the six bf16 MFMAs whose terms are >= 2^-24 relative:
+//     x w ~= xh wh + xh wm + xm wh + xh wl + xm wm + xl wh          (dropped: 2^-24 |x||w| and below)
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (bf16 x bf16 products are exact in fp32). Six MFMAs
+// at 16x the fp32-MFMA rate = 3/8 of the matrix time, so the projection becomes HBM-bound on the X
+// stream. Error is fp32-roundoff class (tests assert 2e-6 relative); it is NOT the bit-identical fma
+// chain of the fp32 kernel, which stays available (LLMREC_GEMM=f32).
+// X is split in registers on the fly (6 integer/float VALU ops per element), W when it is staged
+// into LDS. A/B operand = 8 consecutive k per lane (lane l: row l&15, k = 8 (l>>4) + j).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Split3 { uint32_t h, m, l; };                       // each: a bf16 value in the HIGH 16 bits
+__device__ __forceinline__ Split3 split3(float x) {
+    Split3 r;
+    r.h = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(r.h);             // exact
+    r.m = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(r.m);            // exact, <= 8 significant bits
+    r.l = __float_as_uint(r2) & 0xffff0000u;
+    return r;
+}
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t e0, uint32_t e1) { return (e0 >> 16) | e1; }   // element 0 in the low half
+
+// 8 floats (two float4) -> three packed bf16x8 fragments
+__device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& H, uint4& M, uint4& L) {
+    const Split3 s0 = split3(a.x), s1 = split3(a.y), s2 = split3(a.z), s3 = split3(a.w);
+    const Split3 s4 = split3(b.x), s5 = split3(b.y), s6 = split3(b.z), s7 = split3(b.w);
+    H = make_uint4(pack_hi16(s0.h, s1.h), pack_hi16(s2.h, s3.h), pack_hi16(s4.h, s5.h), pack_hi16(s6.h, s7.h));
+    M = make_uint4(pack_hi16(s0.m, s1.m), pack_hi16(s2.m, s3.m), pack_hi16(s4.m, s5.m), pack_hi16(s6.m, s7.m));
+    L = make_uint4(pack_hi16(s0.l, s1.l), pack_hi16(s2.l, s3.l), pack_hi16(s4.l, s5.l), pack_hi16(s6.l, s7.l));
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+constexpr int GB_WS = 40;              // LDS row stride of one bf16 W tile in 2-byte units (32 k + 8 pad = 80 B)
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(LinearGroup g, int N) {
+    // [buffer][term h/m/l][n][k] bf16
+    __shared__ __attribute__((aligned(16))) uint16_t w_lds[2][3][NT * 16 * GB_WS];
+    int prob = 0;
+    while (prob + 1 < g.n_problems && (int)blockIdx.x >= g.unit_begin[prob + 1]) ++prob;
+    const int64_t M = g.M[prob];
+    const int K = g.K[prob];
+    const bool vec_ok = g.vec_ok[prob];
+    const float* __restrict__ X = g.X[prob];
+    const float* __restrict__ W = g.W[prob];
+    const int64_t ldx = g.ldx[prob], ldw = g.ldw[prob];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t row0 = (int64_t)(blockIdx.x - g.unit_begin[prob]) * 128 + wave * 32;
+
+    const float* xrow[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int64_t r = row0 + t * 16 + li;
+        if (r > M - 1) r = M - 1;
+        xrow[t] = X + r * ldx;
+    }
+    const int wn = threadIdx.x >> 3, wk = (threadIdx.x & 7) * 4;
+    constexpr int WLOADS = (NT * 16 + 31) / 32;
+    auto load_w = [&](int kb, float4 (&wr)[WLOADS]) {
+#pragma unroll
+        for (int j = 0; j < WLOADS; ++j) {
+            int n = wn + 32 * j;
+            const bool in = n < NT * 16;
+            if (n > N - 1) n = N - 1;
+            wr[j] = in ? load4_guard(W + (int64_t)n * ldw, kb + wk, K, vec_ok) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_w = [&](int buf, const float4 (&wr)[WLOADS]) {               // split while staging
+#pragma unroll
+        for (int j = 0; j < WLOADS; ++j) {
+            const int n = wn + 32 * j;
+            if (n >= NT * 16) continue;
+            const Split3 s0 = split3(wr[j].x), s1 = split3(wr[j].y), s2 = split3(wr[j].z), s3 = split3(wr[j].w);
+            const int off = n * GB_WS + wk;
+            *reinterpret_cast<uint2*>(&w_lds[buf][0][off]) = make_uint2(pack_hi16(s0.h, s1.h), pack_hi16(s2.h, s3.h));
+            *reinterpret_cast<uint2*>(&w_lds[buf][1][off]) = make_uint2(pack_hi16(s0.m, s1.m), pack_hi16(s2.m, s3.m));
+            *reinterpret_cast<uint2*>(&w_lds[buf][2][off]) = make_uint2(pack_hi16(s0.l, s1.l), pack_hi16(s2.l, s3.l));
+        }
+    };
+    auto load_x = [&](int kb, float4 (&xr)[2][2]) {                         // lane: k = kb + 8 lq + {0..3 | 4..7}
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) xr[t][h] = load4_guard(xrow[t], kb + 8 * lq + 4 * h, K, vec_ok);
+    };
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 wreg[WLOADS];
+    float4 x0[2][2], x1[2][2], x2[2][2];
+    load_w(0, wreg);
+    load_x(0, x0);
+    load_x(GF_BK, x1);
+    store_w(0, wreg);
+    __syncthreads();
+    int cur = 0;
+    auto kstep = [&](int kb, const float4 (&xc)[2][2], float4 (&xl)[2][2]) {
+        load_w(kb + GF_BK, wreg);                                        // zeros beyond K (guarded)
+        load_x(kb + 2 * GF_BK, xl);
+        uint4 ah[2], am[2], al[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) split8(xc[t][0], xc[t][1], ah[t], am[t], al[t]);
+        uint4 bh[NT], bm[NT], bl[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int off = (n * 16 + li) * GB_WS + 8 * lq;
+            bh[n] = *reinterpret_cast<const uint4*>(&w_lds[cur][0][off]);
+            bm[n] = *reinterpret_cast<const uint4*>(&w_lds[cur][1][off]);
+            bl[n] = *reinterpret_cast<const uint4*>(&w_lds[cur][2][off]);
+        }
+        // smallest terms first; consecutive MFMAs hit different accumulators
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(al[t], bh[n], acc[t][n]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(ah[t], bl[n], acc[t][n]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(am[t], bm[n], acc[t][n]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(am[t], bh[n], acc[t][n]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(ah[t], bm[n], acc[t][n]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(ah[t], bh[n], acc[t][n]);
+        store_w(cur ^ 1, wreg);
+        __syncthreads();
+        cur ^= 1;
+    };
+    for (int kb = 0; kb < K; kb += 3 * GF_BK) {                          // steps past K multiply zeros
+        kstep(kb, x0, x2);
+        kstep(kb + GF_BK, x1, x0);
+        kstep(kb + 2 * GF_BK, x2, x1);
+    }
+    float* __restrict__ Y = g.Y[prob];
+    const int64_t ldy = g.ldy[prob];
+    const float* bias = g.bias[prob];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int c = n * 16 + li;
+        if (c >= N) continue;
+        const float b = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + t * 16 + lq * 4 + r;
+                if (row < M) Y[row * ldy + c] = acc[t][n][r] + b;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient: wave tile = 64 n (interleaved tiles q) x 64 k (interleaved tiles p), over a
 // chunk of MC rows; partial[chunk][n][k] then reduced in chunk order (deterministic).
 // ---------------------------------------------------------------------------------------------
@@ -475,7 +648,17 @@ int llmrec_linear_fwd_f32(int64_t M, int32_t N, int32_t K, const float* X, int64
     return LLMREC_OK;
 }
 
+static int linear_fwd_grouped_impl(int32_t n_problems, const llmrec_linear_problem_t* p, int32_t N, bool bf16x3, llmrec_stream_t stream_);
+
 int llmrec_linear_fwd_grouped_f32(int32_t n_problems, const llmrec_linear_problem_t* p, int32_t N, llmrec_stream_t stream_) {
+    return linear_fwd_grouped_impl(n_problems, p, N, false, stream_);
+}
+
+int llmrec_linear_fwd_grouped_bf16x3(int32_t n_problems, const llmrec_linear_problem_t* p, int32_t N, llmrec_stream_t stream_) {
+    return linear_fwd_grouped_impl(n_problems, p, N, true, stream_);
+}
+
+static int linear_fwd_grouped_impl(int32_t n_problems, const llmrec_linear_problem_t* p, int32_t N, bool bf16x3, llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_LINEAR_MAX_PROBLEMS && p && N > 0, "linear_fwd_grouped: bad argument");
     if (N > 64) { set_error("linear_fwd_grouped: N = %d > 64", N); return LLMREC_EUNSUPPORTED; }
@@ -494,7 +677,14 @@ int llmrec_linear_fwd_grouped_f32(int32_t n_problems, const llmrec_linear_proble
     }
     for (int i = n_problems; i <= LLMREC_LINEAR_MAX_PROBLEMS; ++i) g.unit_begin[i] = units;
     if (units == 0) return LLMREC_OK;
-    switch ((N + 15) / 16) {
+    if (bf16x3) {
+        switch ((N + 15) / 16) {
+            case 1: linear_fwd_grouped_bf16x3_kernel<1><<<units, 256, 0, stream>>>(g, N); break;
+            case 2: linear_fwd_grouped_bf16x3_kernel<2><<<units, 256, 0, stream>>>(g, N); break;
+            case 3: linear_fwd_grouped_bf16x3_kernel<3><<<units, 256, 0, stream>>>(g, N); break;
+            default: linear_fwd_grouped_bf16x3_kernel<4><<<units, 256, 0, stream>>>(g, N); break;
+        }
+    } else switch ((N + 15) / 16) {
         case 1: linear_fwd_grouped_kernel<1><<<units, 256, 0, stream>>>(g, N); break;
         case 2: linear_fwd_grouped_kernel<2><<<units, 256, 0, stream>>>(g, N); break;
         case 3: linear_fwd_grouped_kernel<3><<<units, 256, 0, stream>>>(g, N); break;

@@ -79,6 +79,9 @@ class FusedStep:
         self.w_mf_dev = torch.tensor(self.w_mf, dtype=torch.float32, device=dev)
         self.graph_exec = None
         self.static = None
+        # projection arithmetic: "f32" = exact fp32 MFMA chain; "bf16x3" = 3-term bf16 split (fp32-class error, HBM-bound)
+        import os
+        self.gemm = os.environ.get("LLMREC_GEMM", "f32")
 
     # -- raw kernel helpers -----------------------------------------------------------------------
     def _spmm(self, a: ops.Csr, X, Y, accumulate=False):
@@ -114,7 +117,7 @@ class FusedStep:
             arr[i].X, arr[i].ldx, arr[i].M, arr[i].K = X.data_ptr(), _ld(X), X.shape[0], X.shape[1]
             arr[i].W, arr[i].ldw, arr[i].bias = lin.weight.data_ptr(), _ld(lin.weight), lin.bias.data_ptr()
             arr[i].Y, arr[i].ldy = out.data_ptr(), _ld(out)
-        _call("llmrec_linear_fwd_grouped_f32", len(jobs), arr, self.d)
+        _call("llmrec_linear_fwd_grouped_bf16x3" if self.gemm == "bf16x3" else "llmrec_linear_fwd_grouped_f32", len(jobs), arr, self.d)
 
     def _wgrad(self, dY, X, lin, accumulate):
         _call("llmrec_linear_wgrad_f32", X.shape[0], self.d, X.shape[1], _p(dY), _ld(dY), _p(X), _ld(X), _p(lin.weight.grad),

@@ -419,15 +419,18 @@ def linear_wgrad_grouped(pairs, dW, db, accumulate: bool, ws: Optional[torch.Ten
     _lib.call("llmrec_linear_wgrad_grouped_f32", len(pairs), arr, N, K, _p(dW), _ld(dW), _p(db), 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
 
 
-def linear_fwd_grouped(jobs, N: int):
-    """jobs: list of (X, W, bias, out) - one launch (llmrec_linear_fwd_grouped_f32)."""
+def linear_fwd_grouped(jobs, N: int, precision: str = "f32"):
+    """jobs: list of (X, W, bias, out) - one launch. precision "f32": exact fp32 MFMA
+    (llmrec_linear_fwd_grouped_f32); "bf16x3": three-term bf16 split, six bf16 MFMAs, fp32-class
+    error (llmrec_linear_fwd_grouped_bf16x3)."""
     arr = (LinearProblem * len(jobs))()
     for i, (X, W, b, out) in enumerate(jobs):
         _need_gpu(X, W, b, out)
         arr[i].X, arr[i].ldx, arr[i].M, arr[i].K = X.data_ptr(), _ld(X), X.shape[0], X.shape[1]
         arr[i].W, arr[i].ldw, arr[i].bias = W.data_ptr(), _ld(W), (b.data_ptr() if b is not None else None)
         arr[i].Y, arr[i].ldy = out.data_ptr(), _ld(out)
-    _lib.call("llmrec_linear_fwd_grouped_f32", len(jobs), arr, N, _stream())
+    name = {"f32": "llmrec_linear_fwd_grouped_f32", "bf16x3": "llmrec_linear_fwd_grouped_bf16x3"}[precision]
+    _lib.call(name, len(jobs), arr, N, _stream())
 
 
 class _BprPrune(torch.autograd.Function):

@@ -184,6 +184,13 @@ def test_linear_grouped_matches_single_launches(ops):
         ops.linear_fwd_grouped(jobs, N)
         for (X, W, b, out), ref in zip(jobs, refs):
             assert rel_err(out.cpu(), ref) < 5e-6
+        # split-precision variant: fp32-roundoff-class error against an fp64 product
+        for _, _, _, out in jobs:
+            out.zero_()
+        ops.linear_fwd_grouped(jobs, N, precision="bf16x3")
+        for (X, W, b, out) in jobs:
+            ref64 = X.double().cpu() @ W.double().cpu().t() + b.double().cpu()
+            assert rel_err(out.cpu(), ref64) < 2e-6
 
 
 def test_linear_wgrad_grouped(ops):

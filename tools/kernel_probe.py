@@ -27,6 +27,13 @@ if which in ("fwd", "all"):
     ms = timeit(lambda: ops.linear_fwd_grouped(jobs, d))
     fl = sum(2.0 * x.shape[0] * x.shape[1] * d for x in feats)
     print("fwd_grouped ms %.4f TF %.1f" % (ms, fl / ms / 1e9))
+    ms3 = timeit(lambda: ops.linear_fwd_grouped(jobs, d, precision="bf16x3"))
+    byts = sum(4.0 * (x.shape[0] * x.shape[1] + d * x.shape[1] + x.shape[0] * d) for x in feats)
+    ref = [torch.empty_like(o) for o in outs]
+    ops.linear_fwd_grouped([(x, w, b, o) for x, w, o in zip(feats, Ws, ref)], d)
+    ops.linear_fwd_grouped(jobs, d, precision="bf16x3")
+    err = max(float((o - r).abs().max() / r.abs().max()) for o, r in zip(outs, ref))
+    print("fwd_grouped_bf16x3 ms %.4f equivalent-TF %.1f HBM GB/s %.0f max rel diff vs f32 kernel %.2e" % (ms3, fl / ms3 / 1e9, byts / ms3 / 1e6, err))
     ms = timeit(lambda: ops.linear_fwd_raw(feats[2], Ws[2], b, out=outs[2]))
     print("fwd_single(I x 1536) ms %.4f TF %.1f" % (ms, 2.0 * I * 1536 * d / ms / 1e9))
 if which in ("wgrad", "all"):
