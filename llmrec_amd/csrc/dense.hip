@@ -220,19 +220,21 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup 
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 wreg[WLOADS];
+    // Software pipeline, all register stages named statically (loop unrolled by 3):
+    //   step s: issue global loads of X(s+2) and W(s+2); multiply X(s) with the W(s) tile in LDS;
+    //           write W(s+1) (loaded during step s-1) into the other LDS buffer; barrier.
+    // Every load has two full steps to land; a stage is never copied (a copy would wait for it).
+    float4 w0[WLOADS], w1[WLOADS], w2[WLOADS];
     float4 x0[2][2], x1[2][2], x2[2][2];
-    load_w(0, wreg);
+    load_w(0, w0);
     load_x(0, x0);
+    load_w(GF_BK, w1);
     load_x(GF_BK, x1);
-    store_w(0, wreg);
+    store_w(0, w0);
     __syncthreads();
     int cur = 0;
-    // one k-step: prefetch X two steps ahead into `xl` (static register names: the loop below is
-    // unrolled by 3, so no stage is ever copied - a copy would wait for the load it just issued)
-    auto kstep = [&](int kb, const float4 (&xc)[2][2], float4 (&xl)[2][2]) {
-        const bool more = kb + GF_BK < K;
-        load_w(kb + GF_BK, wreg);                                        // zeros beyond K (guarded)
+    auto kstep = [&](int kb, const float4 (&xc)[2][2], float4 (&xl)[2][2], const float4 (&ws)[WLOADS], float4 (&wl)[WLOADS]) {
+        load_w(kb + 2 * GF_BK, wl);                                      // zeros beyond K (guarded)
         load_x(kb + 2 * GF_BK, xl);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -248,15 +250,14 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup 
                     for (int n = 0; n < NT; ++n)
                         acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(xc[t][h], s), comp(wf[n], s), acc[t][n], 0, 0, 0);
         }
-        store_w(cur ^ 1, wreg);
+        store_w(cur ^ 1, ws);
         __syncthreads();
         cur ^= 1;
-        (void)more;
     };
     for (int kb = 0; kb < K; kb += 3 * GF_BK) {                          // steps past K multiply zeros
-        kstep(kb, x0, x2);
-        kstep(kb + GF_BK, x1, x0);
-        kstep(kb + 2 * GF_BK, x2, x1);
+        kstep(kb, x0, x2, w1, w2);
+        kstep(kb + GF_BK, x1, x0, w2, w0);
+        kstep(kb + 2 * GF_BK, x2, x1, w0, w1);
     }
     float* __restrict__ Y = g.Y[prob];
     const int64_t ldy = g.ldy[prob];
@@ -375,16 +376,17 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 wreg[WLOADS];
+    float4 w0[WLOADS], w1[WLOADS], w2[WLOADS];
     float4 x0[2][2], x1[2][2], x2[2][2];
-    load_w(0, wreg);
+    load_w(0, w0);
     load_x(0, x0);
+    load_w(GF_BK, w1);
     load_x(GF_BK, x1);
-    store_w(0, wreg);
+    store_w(0, w0);
     __syncthreads();
     int cur = 0;
-    auto kstep = [&](int kb, const float4 (&xc)[2][2], float4 (&xl)[2][2]) {
-        load_w(kb + GF_BK, wreg);                                        // zeros beyond K (guarded)
+    auto kstep = [&](int kb, const float4 (&xc)[2][2], float4 (&xl)[2][2], const float4 (&ws)[WLOADS], float4 (&wl)[WLOADS]) {
+        load_w(kb + 2 * GF_BK, wl);                                        // zeros beyond K (guarded)
         load_x(kb + 2 * GF_BK, xl);
         uint4 ah[2], am[2], al[2];
 #pragma unroll
@@ -422,14 +424,14 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(ah[t], bh[n], acc[t][n]);
-        store_w(cur ^ 1, wreg);
+        store_w(cur ^ 1, ws);
         __syncthreads();
         cur ^= 1;
     };
     for (int kb = 0; kb < K; kb += 3 * GF_BK) {                          // steps past K multiply zeros
-        kstep(kb, x0, x2);
-        kstep(kb + GF_BK, x1, x0);
-        kstep(kb + 2 * GF_BK, x2, x1);
+        kstep(kb, x0, x2, w1, w2);
+        kstep(kb + GF_BK, x1, x0, w2, w0);
+        kstep(kb + 2 * GF_BK, x2, x1, w0, w1);
     }
     float* __restrict__ Y = g.Y[prob];
     const int64_t ldy = g.ldy[prob];
