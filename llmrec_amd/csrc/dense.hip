@@ -31,6 +31,16 @@ __device__ __forceinline__ float4 load4_guard(const float* row, int k, int K, bo
     return r;
 }
 
+// Branch-free variant for 16-byte aligned rows with K % 4 == 0: the address is clamped into the row
+// and the value zeroed by a select. (A branch around a load makes hipcc fall back to
+// s_waitcnt vmcnt(0) inside the k-loop, which serialises the whole software pipeline.)
+__device__ __forceinline__ float4 load4_fast(const float* row, int k, int K) {
+    const int kc = k < K ? k : K - 4;
+    float4 v = *reinterpret_cast<const float4*>(row + kc);
+    if (k >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
+}
+
 __device__ __forceinline__ float comp(const float4& v, int s) {
     return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w));
 }
@@ -166,7 +176,7 @@ struct LinearGroup {
 constexpr int GF_BK = 32;              // k per step
 constexpr int GF_WS = GF_BK + 4;       // LDS row stride in floats (144 B: spreads ds_read_b128 over the banks)
 
-template <int NT>
+template <int NT, bool FAST>
 __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup g, int N) {
     __shared__ __attribute__((aligned(16))) float w_lds[2][NT * 16 * GF_WS];
     int prob = 0;
@@ -197,7 +207,13 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup 
             int n = wn + 32 * j;
             const bool in = n < NT * 16;
             if (n > N - 1) n = N - 1;
-            wr[j] = in ? load4_guard(W + (int64_t)n * ldw, kb + wk, K, vec_ok) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FAST) {
+                float4 v = load4_fast(W + (int64_t)n * ldw, kb + wk, K);
+                if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                wr[j] = v;
+            } else {
+                wr[j] = in ? load4_guard(W + (int64_t)n * ldw, kb + wk, K, vec_ok) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     auto store_w = [&](int buf, const float4 (&wr)[WLOADS]) {
@@ -211,7 +227,8 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup 
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) xr[t][h] = load4_guard(xrow[t], kb + 16 * h + 4 * lq, K, vec_ok);
+            for (int h = 0; h < 2; ++h)
+                xr[t][h] = FAST ? load4_fast(xrow[t], kb + 16 * h + 4 * lq, K) : load4_guard(xrow[t], kb + 16 * h + 4 * lq, K, vec_ok);
     };
 
     f32x4 acc[2][NT];
@@ -317,7 +334,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4
 
 constexpr int GB_WS = 40;              // LDS row stride of one bf16 W tile in 2-byte units (32 k + 8 pad = 80 B)
 
-template <int NT>
+template <int NT, bool FAST>
 __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(LinearGroup g, int N) {
     // [buffer][term h/m/l][n][k] bf16
     __shared__ __attribute__((aligned(16))) uint16_t w_lds[2][3][NT * 16 * GB_WS];
@@ -348,7 +365,13 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
             int n = wn + 32 * j;
             const bool in = n < NT * 16;
             if (n > N - 1) n = N - 1;
-            wr[j] = in ? load4_guard(W + (int64_t)n * ldw, kb + wk, K, vec_ok) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FAST) {
+                float4 v = load4_fast(W + (int64_t)n * ldw, kb + wk, K);
+                if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                wr[j] = v;
+            } else {
+                wr[j] = in ? load4_guard(W + (int64_t)n * ldw, kb + wk, K, vec_ok) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     auto store_w = [&](int buf, const float4 (&wr)[WLOADS]) {               // split while staging
@@ -367,7 +390,8 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) xr[t][h] = load4_guard(xrow[t], kb + 8 * lq + 4 * h, K, vec_ok);
+            for (int h = 0; h < 2; ++h)
+                xr[t][h] = FAST ? load4_fast(xrow[t], kb + 8 * lq + 4 * h, K) : load4_guard(xrow[t], kb + 8 * lq + 4 * h, K, vec_ok);
     };
 
     f32x4 acc[2][NT];
@@ -679,19 +703,23 @@ static int linear_fwd_grouped_impl(int32_t n_problems, const llmrec_linear_probl
     }
     for (int i = n_problems; i <= LLMREC_LINEAR_MAX_PROBLEMS; ++i) g.unit_begin[i] = units;
     if (units == 0) return LLMREC_OK;
+    bool fast = true;                                  // every problem: 16-byte aligned rows, K % 4 == 0
+    for (int i = 0; i < n_problems; ++i) fast = fast && g.vec_ok[i] && (g.K[i] % 4 == 0) && g.K[i] >= 4;
+#define GROUPED_LAUNCH(KERNEL, NT_)                                                         \
+    do { if (fast) KERNEL<NT_, true><<<units, 256, 0, stream>>>(g, N); else KERNEL<NT_, false><<<units, 256, 0, stream>>>(g, N); } while (0)
+    const int nt = (N + 15) / 16;
     if (bf16x3) {
-        switch ((N + 15) / 16) {
-            case 1: linear_fwd_grouped_bf16x3_kernel<1><<<units, 256, 0, stream>>>(g, N); break;
-            case 2: linear_fwd_grouped_bf16x3_kernel<2><<<units, 256, 0, stream>>>(g, N); break;
-            case 3: linear_fwd_grouped_bf16x3_kernel<3><<<units, 256, 0, stream>>>(g, N); break;
-            default: linear_fwd_grouped_bf16x3_kernel<4><<<units, 256, 0, stream>>>(g, N); break;
-        }
-    } else switch ((N + 15) / 16) {
-        case 1: linear_fwd_grouped_kernel<1><<<units, 256, 0, stream>>>(g, N); break;
-        case 2: linear_fwd_grouped_kernel<2><<<units, 256, 0, stream>>>(g, N); break;
-        case 3: linear_fwd_grouped_kernel<3><<<units, 256, 0, stream>>>(g, N); break;
-        default: linear_fwd_grouped_kernel<4><<<units, 256, 0, stream>>>(g, N); break;
+        if (nt == 1) GROUPED_LAUNCH(linear_fwd_grouped_bf16x3_kernel, 1);
+        else if (nt == 2) GROUPED_LAUNCH(linear_fwd_grouped_bf16x3_kernel, 2);
+        else if (nt == 3) GROUPED_LAUNCH(linear_fwd_grouped_bf16x3_kernel, 3);
+        else GROUPED_LAUNCH(linear_fwd_grouped_bf16x3_kernel, 4);
+    } else {
+        if (nt == 1) GROUPED_LAUNCH(linear_fwd_grouped_kernel, 1);
+        else if (nt == 2) GROUPED_LAUNCH(linear_fwd_grouped_kernel, 2);
+        else if (nt == 3) GROUPED_LAUNCH(linear_fwd_grouped_kernel, 3);
+        else GROUPED_LAUNCH(linear_fwd_grouped_kernel, 4);
     }
+#undef GROUPED_LAUNCH
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }
