@@ -176,7 +176,7 @@ struct LinearGroup {
 constexpr int GF_BK = 32;              // k per step
 constexpr int GF_WS = GF_BK + 4;       // LDS row stride in floats (144 B: spreads ds_read_b128 over the banks)
 
-template <int NT, bool FAST>
+template <int NT, int RT, bool FAST>
 __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup g, int N) {
     __shared__ __attribute__((aligned(16))) float w_lds[2][NT * 16 * GF_WS];
     int prob = 0;
@@ -189,11 +189,11 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup 
     const int64_t ldx = g.ldx[prob], ldw = g.ldw[prob];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int64_t row0 = (int64_t)(blockIdx.x - g.unit_begin[prob]) * 128 + wave * 32;
+    const int64_t row0 = (int64_t)(blockIdx.x - g.unit_begin[prob]) * (64 * RT) + wave * (16 * RT);
 
-    const float* xrow[2];
+    const float* xrow[RT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < RT; ++t) {
         int64_t r = row0 + t * 16 + li;
         if (r > M - 1) r = M - 1;
         xrow[t] = X + r * ldx;
@@ -223,17 +223,17 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup 
             if (n < NT * 16) *reinterpret_cast<float4*>(&w_lds[buf][n * GF_WS + wk]) = wr[j];
         }
     };
-    auto load_x = [&](int kb, float4 (&xr)[2][2]) {
+    auto load_x = [&](int kb, float4 (&xr)[RT][2]) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
                 xr[t][h] = FAST ? load4_fast(xrow[t], kb + 16 * h + 4 * lq, K) : load4_guard(xrow[t], kb + 16 * h + 4 * lq, K, vec_ok);
     };
 
-    f32x4 acc[2][NT];
+    f32x4 acc[RT][NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup 
     //           write W(s+1) (loaded during step s-1) into the other LDS buffer; barrier.
     // Every load has two full steps to land; a stage is never copied (a copy would wait for it).
     float4 w0[WLOADS], w1[WLOADS], w2[WLOADS];
-    float4 x0[2][2], x1[2][2], x2[2][2];
+    float4 x0[RT][2], x1[RT][2], x2[RT][2];
     load_w(0, w0);
     load_x(0, x0);
     load_w(GF_BK, w1);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup 
     store_w(0, w0);
     __syncthreads();
     int cur = 0;
-    auto kstep = [&](int kb, const float4 (&xc)[2][2], float4 (&xl)[2][2], const float4 (&ws)[WLOADS], float4 (&wl)[WLOADS]) {
+    auto kstep = [&](int kb, const float4 (&xc)[RT][2], float4 (&xl)[RT][2], const float4 (&ws)[WLOADS], float4 (&wl)[WLOADS]) {
         load_w(kb + 2 * GF_BK, wl);                                      // zeros beyond K (guarded)
         load_x(kb + 2 * GF_BK, xl);
 #pragma unroll
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup 
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < RT; ++t)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(xc[t][h], s), comp(wf[n], s), acc[t][n], 0, 0, 0);
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup 
         if (c >= N) continue;
         const float b = bias ? bias[c] : 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = row0 + t * 16 + lq * 4 + r;
@@ -334,7 +334,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4
 
 constexpr int GB_WS = 40;              // LDS row stride of one bf16 W tile in 2-byte units (32 k + 8 pad = 80 B)
 
-template <int NT, bool FAST>
+template <int NT, int RT, bool FAST>
 __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(LinearGroup g, int N) {
     // [buffer][term h/m/l][n][k] bf16
     __shared__ __attribute__((aligned(16))) uint16_t w_lds[2][3][NT * 16 * GB_WS];
@@ -348,11 +348,11 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
     const int64_t ldx = g.ldx[prob], ldw = g.ldw[prob];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int64_t row0 = (int64_t)(blockIdx.x - g.unit_begin[prob]) * 128 + wave * 32;
+    const int64_t row0 = (int64_t)(blockIdx.x - g.unit_begin[prob]) * (64 * RT) + wave * (16 * RT);
 
-    const float* xrow[2];
+    const float* xrow[RT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < RT; ++t) {
         int64_t r = row0 + t * 16 + li;
         if (r > M - 1) r = M - 1;
         xrow[t] = X + r * ldx;
@@ -386,22 +386,22 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
             *reinterpret_cast<uint2*>(&w_lds[buf][2][off]) = make_uint2(pack_hi16(s0.l, s1.l), pack_hi16(s2.l, s3.l));
         }
     };
-    auto load_x = [&](int kb, float4 (&xr)[2][2]) {                         // lane: k = kb + 8 lq + {0..3 | 4..7}
+    auto load_x = [&](int kb, float4 (&xr)[RT][2]) {                         // lane: k = kb + 8 lq + {0..3 | 4..7}
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
                 xr[t][h] = FAST ? load4_fast(xrow[t], kb + 8 * lq + 4 * h, K) : load4_guard(xrow[t], kb + 8 * lq + 4 * h, K, vec_ok);
     };
 
-    f32x4 acc[2][NT];
+    f32x4 acc[RT][NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 w0[WLOADS], w1[WLOADS], w2[WLOADS];
-    float4 x0[2][2], x1[2][2], x2[2][2];
+    float4 x0[RT][2], x1[RT][2], x2[RT][2];
     load_w(0, w0);
     load_x(0, x0);
     load_w(GF_BK, w1);
@@ -409,12 +409,12 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
     store_w(0, w0);
     __syncthreads();
     int cur = 0;
-    auto kstep = [&](int kb, const float4 (&xc)[2][2], float4 (&xl)[2][2], const float4 (&ws)[WLOADS], float4 (&wl)[WLOADS]) {
+    auto kstep = [&](int kb, const float4 (&xc)[RT][2], float4 (&xl)[RT][2], const float4 (&ws)[WLOADS], float4 (&wl)[WLOADS]) {
         load_w(kb + 2 * GF_BK, wl);                                        // zeros beyond K (guarded)
         load_x(kb + 2 * GF_BK, xl);
-        uint4 ah[2], am[2], al[2];
+        uint4 ah[RT], am[RT], al[RT];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) split8(xc[t][0], xc[t][1], ah[t], am[t], al[t]);
+        for (int t = 0; t < RT; ++t) split8(xc[t][0], xc[t][1], ah[t], am[t], al[t]);
         uint4 bh[NT], bm[NT], bl[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -425,27 +425,27 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
         }
         // smallest terms first; consecutive MFMAs hit different accumulators
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(al[t], bh[n], acc[t][n]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(ah[t], bl[n], acc[t][n]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(am[t], bm[n], acc[t][n]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(am[t], bh[n], acc[t][n]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(ah[t], bm[n], acc[t][n]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(ah[t], bh[n], acc[t][n]);
         store_w(cur ^ 1, ws);
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
         if (c >= N) continue;
         const float b = bias ? bias[c] : 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = row0 + t * 16 + lq * 4 + r;
@@ -698,15 +698,25 @@ static int linear_fwd_grouped_impl(int32_t n_problems, const llmrec_linear_probl
         g.X[i] = p[i].X; g.W[i] = p[i].W; g.bias[i] = p[i].bias; g.Y[i] = p[i].Y;
         g.ldx[i] = p[i].ldx; g.ldw[i] = p[i].ldw; g.ldy[i] = p[i].ldy; g.M[i] = p[i].M; g.K[i] = p[i].K;
         g.vec_ok[i] = (p[i].ldx % 4 == 0) && (p[i].ldw % 4 == 0) && (((uintptr_t)p[i].X | (uintptr_t)p[i].W) % 16 == 0);
+    }
+    // 128-row work units when that still gives >= 4 rounds of 3 blocks per CU, else 64-row units
+    // (finer units shorten the ragged tail of the launch)
+    int64_t units128 = 0;
+    for (int i = 0; i < n_problems; ++i) units128 += ceil_div(p[i].M, 128);
+    const int rows_per_unit = units128 >= 4 * 768 ? 128 : 64;
+    for (int i = 0; i < n_problems; ++i) {
         g.unit_begin[i] = units;
-        units += (int)ceil_div(p[i].M, 128);
+        units += (int)ceil_div(p[i].M, rows_per_unit);
     }
     for (int i = n_problems; i <= LLMREC_LINEAR_MAX_PROBLEMS; ++i) g.unit_begin[i] = units;
     if (units == 0) return LLMREC_OK;
     bool fast = true;                                  // every problem: 16-byte aligned rows, K % 4 == 0
     for (int i = 0; i < n_problems; ++i) fast = fast && g.vec_ok[i] && (g.K[i] % 4 == 0) && g.K[i] >= 4;
 #define GROUPED_LAUNCH(KERNEL, NT_)                                                         \
-    do { if (fast) KERNEL<NT_, true><<<units, 256, 0, stream>>>(g, N); else KERNEL<NT_, false><<<units, 256, 0, stream>>>(g, N); } while (0)
+    do {                                                                                    \
+        if (rows_per_unit == 128) { if (fast) KERNEL<NT_, 2, true><<<units, 256, 0, stream>>>(g, N); else KERNEL<NT_, 2, false><<<units, 256, 0, stream>>>(g, N); } \
+        else { if (fast) KERNEL<NT_, 1, true><<<units, 256, 0, stream>>>(g, N); else KERNEL<NT_, 1, false><<<units, 256, 0, stream>>>(g, N); } \
+    } while (0)
     const int nt = (N + 15) / 16;
     if (bf16x3) {
         if (nt == 1) GROUPED_LAUNCH(linear_fwd_grouped_bf16x3_kernel, 1);
