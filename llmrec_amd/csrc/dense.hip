@@ -699,11 +699,11 @@ static int linear_fwd_grouped_impl(int32_t n_problems, const llmrec_linear_probl
         g.ldx[i] = p[i].ldx; g.ldw[i] = p[i].ldw; g.ldy[i] = p[i].ldy; g.M[i] = p[i].M; g.K[i] = p[i].K;
         g.vec_ok[i] = (p[i].ldx % 4 == 0) && (p[i].ldw % 4 == 0) && (((uintptr_t)p[i].X | (uintptr_t)p[i].W) % 16 == 0);
     }
-    // 128-row work units when that still gives >= 4 rounds of 3 blocks per CU, else 64-row units
-    // (finer units shorten the ragged tail of the launch)
+    // 128-row work units (W tile amortised over 128 rows); 64-row units only when the whole launch
+    // would not even give one block per CU (measured: at 1056 units, 64-row units are 3-12 % slower)
     int64_t units128 = 0;
     for (int i = 0; i < n_problems; ++i) units128 += ceil_div(p[i].M, 128);
-    const int rows_per_unit = units128 >= 4 * 768 ? 128 : 64;
+    const int rows_per_unit = units128 >= 256 ? 128 : 64;
     for (int i = 0; i < n_problems; ++i) {
         g.unit_begin[i] = units;
         units += (int)ceil_div(p[i].M, rows_per_unit);

@@ -21,15 +21,15 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-@pytest.mark.parametrize("path", ["fused", "modular", "graph", "fused_bf16x3"])
+@pytest.mark.parametrize("path", ["fused", "modular", "graph", "fused_f32"])
 def test_training_steps_and_eval_match_reference(golden, path, monkeypatch):
     """path: fused = hand-written backward over preallocated buffers (llmrec_amd/fused.py, the
     default), modular = torch.autograd over the per-op Functions, graph = fused + HIP graph replay,
-    fused_bf16x3 = fused with the split-precision (3-term bf16) projection kernel."""
+    fused_f32 = fused with the bit-exact fp32-MFMA projection instead of the default 3-term bf16 split."""
     assert torch.cuda.is_available()
     monkeypatch.setenv("LLMREC_FUSED", "0" if path == "modular" else "1")
     monkeypatch.setenv("LLMREC_GRAPH", "1" if path == "graph" else "0")
-    monkeypatch.setenv("LLMREC_GEMM", "bf16x3" if path == "fused_bf16x3" else "f32")
+    monkeypatch.setenv("LLMREC_GEMM", "f32" if path == "fused_f32" else "bf16x3")
     m = load_dropin(golden_argv(golden))
     m.set_seed(golden.args["seed"])
     tr = m.Trainer(data_config={})
