@@ -86,6 +86,21 @@ class HipBackend:
     def layer_mean(self, terms):
         return self.ops.fuse(list(terms), [], [])
 
+    def linear(self, X, W, b):
+        return self.ops.linear(X, W, b)
+
+    def fuse(self, mean_terms, norm_terms, rates):
+        return self.ops.fuse(list(mean_terms), list(norm_terms), list(rates))
+
+    def sumsq(self, coef, Xs):
+        return self.ops.sumsq(coef, list(Xs))[0]
+
+    def score_topk(self, Eu, Ei, q, train, K):
+        return self.ops.score_topk(Eu, Ei, q, train, K)
+
+    def topk_hits(self, idx, q, rowptr, colidx):
+        return self.ops.topk_hits(idx, q, rowptr, colidx)
+
     def bpr_fwd(self, Eu, Ei, u, p, n, remember, decay, bsz, global_m, global_B, offset, scores_only):
         o = self.ops
         Eu, Ei = o._rowmajor(Eu), o._rowmajor(Ei)
@@ -243,6 +258,130 @@ class ShardedIDModel(nn.Module):
         e_u = self.backend.layer_mean(us)
         e_i = self.replicated(self.backend.layer_mean(is_))
         return e_u, e_i
+
+
+class ShardedMMModel(nn.Module):
+    """The full multi-modal model (reference Models.py:127-199) over a sharded graph.
+
+    Layout: user-side tensors hold this rank's user rows only (user_id_embedding, the LLM user
+    profile features, every *_u stream); item-side tensors and the four Linear layers are
+    replicated. Collectives: one all-reduce per iu-direction SpMM forward and per ui-direction SpMM
+    backward (ShardedIU / ShardedUI), one all-reduce of the gradient of each replicated tensor that
+    feeds a rank-dependent loss (ReplicatedGrad), and of user_trans' weight gradient (its input rows
+    are sharded). Item-feature projections are computed on every rank (replicated compute)."""
+
+    def __init__(self, graph: ShardedGraph, comm: Comm, backend, d: int, n_layers: int, n_users_global: int,
+                 item_feats: dict, user_feats_local: torch.Tensor, keys, rates, seed: int):
+        super().__init__()
+        self.graph, self.comm, self.backend, self.n_layers, self.keys = graph, comm, backend, n_layers, list(keys)
+        self.c_m, self.c_u, self.c_a = rates
+        self.item_feats, self.user_feats = item_feats, user_feats_local
+        dev = graph.s_i.device
+        torch.manual_seed(seed)                                # identical replicated parameters on every rank
+        self.image_trans = nn.Linear(item_feats["image"].shape[1], d)
+        self.text_trans = nn.Linear(item_feats["text"].shape[1], d)
+        self.user_trans = nn.Linear(user_feats_local.shape[1], d)
+        self.item_trans = nn.Linear(item_feats["attr/" + self.keys[0]].shape[1], d)
+        for lin in (self.image_trans, self.text_trans, self.user_trans, self.item_trans):
+            nn.init.xavier_uniform_(lin.weight)
+        self.item_id_embedding = nn.Parameter(torch.empty(graph.n_items, d))
+        nn.init.xavier_uniform_(self.item_id_embedding)
+        gu = torch.Generator(); gu.manual_seed(seed * 7919 + 1 + comm.rank)
+        bu = math.sqrt(6.0 / (n_users_global + d))
+        self.user_id_embedding = nn.Parameter((torch.rand(graph.n_users_local, d, generator=gu) * 2 - 1) * bu)
+        self.to(dev)
+        self.ui = _fn_ui(graph, comm, backend)
+        self.iu = _fn_iu(graph, comm, backend)
+        self.replicated = _fn_replicated(comm)
+
+    def forward(self):
+        be, rep = self.backend, self.replicated
+        p_img = be.linear(self.item_feats["image"], self.image_trans.weight, self.image_trans.bias)
+        p_txt = be.linear(self.item_feats["text"], self.text_trans.weight, self.text_trans.bias)
+        p_att = {k: be.linear(self.item_feats["attr/" + k], self.item_trans.weight, self.item_trans.bias) for k in self.keys}
+        # user_trans is replicated but sees only this rank's rows: its gradient is the sum over ranks
+        p_usr = be.linear(self.user_feats, rep(self.user_trans.weight), rep(self.user_trans.bias))
+        img_u = self.ui(p_img); img_i = self.iu(img_u)
+        txt_u = self.ui(p_txt); txt_i = self.iu(txt_u)
+        att_u, att_i = {}, {}
+        for k in self.keys:
+            att_u[k] = self.ui(p_att[k]); att_i[k] = self.iu(att_u[k])
+        prof_i = self.iu(p_usr); prof_u = self.ui(prof_i)
+        u, i = self.user_id_embedding, self.item_id_embedding
+        us, is_ = [u], [i]
+        for layer in range(self.n_layers):
+            last = layer == self.n_layers - 1
+            u = self.ui(i)
+            if last:
+                u = be.softmax_rows(u)
+            i = self.iu(u)
+            if last:
+                i = be.softmax_rows(i)
+            us.append(u); is_.append(i)
+        rates = [self.c_m, self.c_m, self.c_u] + [self.c_a] * len(self.keys)
+        e_u = be.fuse(us, [img_u, txt_u, prof_u] + [att_u[k] for k in self.keys], rates)
+        e_i = be.fuse(is_, [img_i, txt_i, prof_i] + [att_i[k] for k in self.keys], rates)
+        # replicated tensors that feed rank-dependent losses: true gradient = sum over ranks
+        return {"E_u": e_u, "E_i": rep(e_i), "img_u": img_u, "txt_u": txt_u, "img_i": rep(img_i), "txt_i": rep(txt_i),
+                "prof_u": prof_u, "att_i": {k: rep(att_i[k]) for k in self.keys}}
+
+
+class ShardedMMTrainer:
+    """Step of the full model on a sharded batch (reference main.py:228-278): the 8 BPR + prune losses
+    over the GLOBAL batch, the feature regulariser (user rows local, item rows replicated and
+    weighted 1/world so their all-reduced gradient counts once), backward, AdamW."""
+
+    def __init__(self, model: ShardedMMModel, hp, batch_local: int, n_items: int):
+        self.model, self.comm, self.backend, self.hp = model, model.comm, model.backend, hp
+        self.n_items = n_items
+        self.opt = self.backend.optimizer(list(model.parameters()), hp_lr(hp))
+        bsz_flag = float(hp.batch_size)
+        self.bpr = _fn_bpr(self.comm, self.backend, 1 - hp.prune_loss_drop_rate, hp.decay, bsz_flag)
+
+    def step(self, users_local, pos, neg):
+        hp, be, m = self.hp, self.backend, self.model
+        fw = m()
+        main = self.bpr(fw["E_u"], fw["E_i"], users_local, pos, neg)
+        img = self.bpr(fw["img_u"], fw["img_i"], users_local, pos, neg)
+        txt = self.bpr(fw["txt_u"], fw["txt_i"], users_local, pos, neg)
+        aug = 0
+        for k in m.keys:
+            aug = aug + self.bpr(fw["prof_u"], fw["att_i"][k], users_local, pos, neg)[0]
+        coef = hp.feat_reg_decay * 0.5 / self.n_items
+        reg_local = be.sumsq(coef, [fw["img_u"], fw["txt_u"]]) + be.sumsq(coef / self.comm.world, [fw["img_i"], fw["txt_i"]])
+        loss = main[0] + main[1] + reg_local + hp.aug_mf_rate * aug + hp.mm_mf_rate * (img[0] + txt[0])
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        reg_global = self.comm.all_reduce_(reg_local.detach().clone().reshape(1))[0]
+        return (loss.detach() - reg_local.detach() + reg_global), main.detach()
+
+
+def hp_lr(hp):
+    return getattr(hp, "lr", 1e-4)
+
+
+@torch.no_grad()
+def sharded_evaluate(model, comm: Comm, backend, graph: ShardedGraph, test_rowptr, test_colidx, n_test_users_global: int, Ks):
+    """Full-rank evaluation, embarrassingly parallel by user (reference utility/batch_test.py:112-169):
+    each rank ranks its own users against the replicated item table and the 12 metric sums are
+    all-reduced. test_rowptr/test_colidx: CSR of the held-out items of this rank's users."""
+    import numpy as np
+    from utility.metrics import metrics_from_hit_matrix          # host-side formulae of the drop-in
+    fw = model()
+    deg = (test_rowptr[1:] - test_rowptr[:-1])
+    q = torch.nonzero(deg > 0).reshape(-1).to(torch.int64)
+    kmax = max(Ks)
+    sums = torch.zeros(4 * len(Ks), dtype=torch.float64, device=graph.s_i.device)
+    if q.numel():
+        idx, _ = backend.score_topk(fw["E_u"], fw["E_i"], q, graph.by_user, kmax)
+        hits = backend.topk_hits(idx, q, test_rowptr, test_colidx).cpu().numpy()
+        per = metrics_from_hit_matrix(hits, deg[q].cpu().numpy(), Ks, (idx >= 0).sum(1).cpu().numpy())
+        vec = np.concatenate([per[k].sum(0) for k in ("precision", "recall", "ndcg", "hit_ratio")])
+        sums += torch.from_numpy(vec).to(sums.device)
+    comm.all_reduce_(sums)
+    out = (sums / n_test_users_global).cpu().numpy().reshape(4, len(Ks))
+    return {"precision": out[0], "recall": out[1], "ndcg": out[2], "hit_ratio": out[3], "auc": 0.0}
 
 
 class ShardedTrainer:

@@ -33,6 +33,18 @@ class CpuBackend:
     def layer_mean(self, terms):
         return torch.mean(torch.stack(list(terms)), dim=0)
 
+    def linear(self, X, W, b):
+        return F.linear(X, W, b)
+
+    def fuse(self, mean_terms, norm_terms, rates):
+        out = torch.mean(torch.stack(list(mean_terms)), dim=0)
+        for r, t in zip(rates, norm_terms):
+            out = out + r * F.normalize(t, p=2, dim=1)
+        return out
+
+    def sumsq(self, coef, Xs):
+        return sum(coef * (x ** 2).sum() for x in Xs)
+
     def bpr_fwd(self, Eu, Ei, u, p, n, remember, decay, bsz, global_m, global_B, offset, scores_only):
         B = u.numel()
         eu, ep, en = Eu[u], Ei[p], Ei[n]

@@ -110,3 +110,103 @@ def test_user_block_partition_covers_all_users():
         blocks = [user_block(n, r, w) for r in range(w)]
         assert blocks[0][0] == 0 and blocks[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+
+
+# ---------------------------------------------------------------------------------------------
+# full multi-modal model, two ranks vs the single-process oracle
+# ---------------------------------------------------------------------------------------------
+MM_KEYS = ("year", "title", "director", "country", "language")
+
+
+def _mm_problem():
+    rng = np.random.default_rng(5)
+    rows, cols, u_tab, i_tab, batches = _problem()
+    feats = {"image": rng.standard_normal((I, 12)).astype(np.float32), "text": rng.standard_normal((I, 20)).astype(np.float32),
+             "user": rng.standard_normal((U, 28)).astype(np.float32)}
+    for k in MM_KEYS:
+        feats["attr/" + k] = rng.standard_normal((I, 28)).astype(np.float32)
+    lin = {}
+    for name, fin in (("image_trans", 12), ("text_trans", 20), ("user_trans", 28), ("item_trans", 28)):
+        lin[name + ".weight"] = (rng.standard_normal((D, fin)) * 0.2).astype(np.float32)
+        lin[name + ".bias"] = (rng.standard_normal(D) * 0.1).astype(np.float32)
+    return rows, cols, u_tab, i_tab, batches, feats, lin
+
+
+def _mm_cfg():
+    return O.Config(embed_size=D, n_layers=L, batch_size=2 * B_LOCAL, decay=DECAY, prune_loss_drop_rate=DROP, lr=LR, keys=MM_KEYS)
+
+
+def _mm_oracle_run():
+    import scipy.sparse as sp
+    rows, cols, u_tab, i_tab, batches, feats, lin = _mm_problem()
+    R = sp.csr_matrix((np.ones(rows.size, dtype=np.float32), (rows, cols)), shape=(U, I))
+    a_ui, a_iu = O.normalized_graphs(R)
+    cfg = _mm_cfg()
+    params = {k: torch.tensor(v, requires_grad=True) for k, v in lin.items()}
+    params["user_id_embedding.weight"] = torch.tensor(u_tab, requires_grad=True)
+    params["item_id_embedding.weight"] = torch.tensor(i_tab, requires_grad=True)
+    opt = torch.optim.AdamW([{"params": list(params.values())}], lr=LR)
+    ft = {k: torch.tensor(v) for k, v in feats.items()}
+    losses = []
+    for per_rank in batches:
+        us = np.concatenate([b[0] for b in per_rank]); ps = np.concatenate([b[1] for b in per_rank]); ns = np.concatenate([b[2] for b in per_rank])
+        fw = O.forward(params, ft, a_ui, a_iu, cfg)
+        loss, _ = O.step_loss(fw, us, ps, ns, I, cfg)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(float(loss))
+    with torch.no_grad():
+        fw = O.forward(params, ft, a_ui, a_iu, cfg)
+    return {k: v.detach().numpy() for k, v in params.items()}, losses, fw["E_u"].numpy(), fw["E_i"].numpy(), rows, cols
+
+
+def _mm_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from llmrec_amd import dist as ld
+    from llmrec_amd.engine import Hyper
+    from tests._cpu_backend import CpuBackend
+    rows, cols, u_tab, i_tab, batches, feats, lin = _mm_problem()
+    comm, be = ld.Comm(), CpuBackend()
+    u0, u1 = ld.user_block(U, rank, world)
+    sel = (rows >= u0) & (rows < u1)
+    g = ld.ShardedGraph.build(torch.tensor(rows[sel] - u0), torch.tensor(cols[sel]), u1 - u0, I, u0, comm, be)
+    item_feats = {k: torch.tensor(v) for k, v in feats.items() if k != "user"}
+    model = ld.ShardedMMModel(g, comm, be, D, L, U, item_feats, torch.tensor(feats["user"][u0:u1]), MM_KEYS, (0.02, 2.8, 0.005), seed=3)
+    with torch.no_grad():
+        for name, v in lin.items():
+            mod, attr = name.split(".")
+            getattr(getattr(model, mod), attr).copy_(torch.tensor(v))
+        model.user_id_embedding.copy_(torch.tensor(u_tab[u0:u1])); model.item_id_embedding.copy_(torch.tensor(i_tab))
+    hp = Hyper(batch_size=2 * B_LOCAL, decay=DECAY, prune_loss_drop_rate=DROP); hp.lr = LR
+    tr = ld.ShardedMMTrainer(model, hp, B_LOCAL, I)
+    losses = []
+    for per_rank in batches:
+        us, ps, ns = per_rank[rank]
+        loss, _ = tr.step(torch.tensor(us - u0), torch.tensor(ps), torch.tensor(ns))
+        losses.append(float(loss))
+    with torch.no_grad():
+        fw = model()
+    out = {"losses": np.array(losses), "E_u": fw["E_u"].numpy(), "E_i": fw["E_i"].numpy()}
+    for name, p_ in model.named_parameters():
+        out["p/" + name] = p_.detach().numpy()
+    np.savez(os.path.join(out_dir, "mm%d.npz" % rank), **out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_full_model_matches_single_process_oracle(tmp_path):
+    ref_params, ref_losses, ref_eu, ref_ei, rows, cols = _mm_oracle_run()
+    mp.spawn(_mm_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "mm0.npz"), np.load(tmp_path / "mm1.npz")
+    rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    assert np.allclose(r0["losses"], ref_losses, rtol=2e-5) and np.allclose(r1["losses"], ref_losses, rtol=2e-5)
+    for name in ("image_trans.weight", "image_trans.bias", "text_trans.weight", "user_trans.weight", "user_trans.bias",
+                 "item_trans.weight", "item_trans.bias"):
+        assert np.array_equal(r0["p/" + name], r1["p/" + name]), name           # replicas stay identical
+        assert rel(r0["p/" + name], ref_params[name]) < 1e-4, name
+    assert rel(r0["p/item_id_embedding"], ref_params["item_id_embedding.weight"]) < 1e-4
+    got_u = np.concatenate([r0["p/user_id_embedding"], r1["p/user_id_embedding"]])
+    assert rel(got_u, ref_params["user_id_embedding.weight"]) < 1e-4
+    assert rel(np.concatenate([r0["E_u"], r1["E_u"]]), ref_eu) < 1e-4
+    assert rel(r0["E_i"], ref_ei) < 1e-4

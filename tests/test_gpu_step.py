@@ -148,3 +148,45 @@ def test_sharded_trainer_single_rank_matches_oracle():
     # the device sampler path of the trainer
     loss, _ = tr.step()
     assert np.isfinite(float(loss))
+
+
+def test_sharded_full_model_single_rank_matches_oracle_and_eval():
+    """llmrec_amd/dist.ShardedMMModel + ShardedMMTrainer + sharded_evaluate on the HIP backend with
+    one rank, against the single-process oracle (same problem as the 2-rank gloo test)."""
+    from tests.test_dist_cpu import _mm_problem, _mm_oracle_run, MM_KEYS, U, I, D, L, B_LOCAL, DROP, DECAY, LR
+    from oracle import oracle as O
+    from llmrec_amd import dist as ld
+    from llmrec_amd.engine import Hyper
+    ref_params, ref_losses, ref_eu, ref_ei, rows, cols = _mm_oracle_run()
+    _, _, u_tab, i_tab, batches, feats, lin = _mm_problem()
+    comm, be = ld.Comm(), ld.HipBackend()
+    g = ld.ShardedGraph.build(torch.tensor(rows).cuda(), torch.tensor(cols).cuda(), U, I, 0, comm, be)
+    item_feats = {k: torch.tensor(v).cuda() for k, v in feats.items() if k != "user"}
+    model = ld.ShardedMMModel(g, comm, be, D, L, U, item_feats, torch.tensor(feats["user"]).cuda(), MM_KEYS, (0.02, 2.8, 0.005), seed=3)
+    with torch.no_grad():
+        for name, v in lin.items():
+            mod, attr = name.split(".")
+            getattr(getattr(model, mod), attr).copy_(torch.tensor(v))
+        model.user_id_embedding.copy_(torch.tensor(u_tab)); model.item_id_embedding.copy_(torch.tensor(i_tab))
+    hp = Hyper(batch_size=2 * B_LOCAL, decay=DECAY, prune_loss_drop_rate=DROP); hp.lr = LR
+    tr = ld.ShardedMMTrainer(model, hp, 2 * B_LOCAL, I)
+    for per_rank, want in zip(batches, ref_losses):
+        us = np.concatenate([b[0] for b in per_rank]); ps = np.concatenate([b[1] for b in per_rank]); ns = np.concatenate([b[2] for b in per_rank])
+        loss, _ = tr.step(torch.tensor(us).cuda(), torch.tensor(ps).cuda(), torch.tensor(ns).cuda())
+        assert abs(float(loss) - want) <= 2e-5 * abs(want)
+    params = dict(model.named_parameters())
+    assert rel(params["item_id_embedding"].detach().cpu().numpy(), ref_params["item_id_embedding.weight"]) < RTOL
+    assert rel(params["user_id_embedding"].detach().cpu().numpy(), ref_params["user_id_embedding.weight"]) < RTOL
+    assert rel(params["item_trans.weight"].detach().cpu().numpy(), ref_params["item_trans.weight"]) < RTOL
+    # sharded evaluation == the oracle's evaluation of the same embeddings
+    rng = np.random.default_rng(0)
+    test_set = {u: sorted(rng.choice(I, size=2, replace=False).tolist()) for u in range(0, U, 2)}
+    train_items = {u: cols[rows == u].tolist() for u in range(U)}
+    trows = np.concatenate([np.full(len(v), u) for u, v in test_set.items()]); tcols = np.concatenate([v for v in test_set.values()])
+    trp, tci, _ = be.ops.csr_from_coo(torch.tensor(trows).cuda(), torch.tensor(tcols).cuda(), None, U, I)
+    got = ld.sharded_evaluate(model, comm, be, g, trp, tci, len(test_set), (10, 20, 50))
+    with torch.no_grad():
+        fw = model()
+    want, _ = O.evaluate(fw["E_u"].cpu().numpy(), fw["E_i"].cpu().numpy(), sorted(test_set), train_items, test_set, (10, 20, 50), batch_size=64)
+    for k in ("precision", "recall", "ndcg", "hit_ratio"):
+        assert np.allclose(got[k], want[k], rtol=0, atol=1e-12), k
