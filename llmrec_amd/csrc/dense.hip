@@ -532,10 +532,8 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(WgradGroup g, int 
             for (int s = 0; s < 4; ++s) {                        // 4 MFMA k-steps of 4 rows each
                 const int64_t m = m0 + 4 * s + lq;
                 const int64_t mc = m < m_end ? m : m_end - 1;
-                float4 va = *reinterpret_cast<const float4*>(pa + mc * lddy);
+                aa[s] = *reinterpret_cast<const float4*>(pa + mc * lddy);   // zeroed at use (mma_tile) if m >= m_end
                 bb[s] = *reinterpret_cast<const float4*>(pb + mc * ldx);
-                if (m >= m_end) va = make_float4(0.f, 0.f, 0.f, 0.f);
-                aa[s] = va;
             }
             return;
         }
@@ -551,9 +549,10 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(WgradGroup g, int 
             }
         }
     };
-    auto mma_tile = [&](const float4 (&aa)[4], const float4 (&bb)[4]) {
+    auto mma_tile = [&](int64_t m0, float4 (&aa)[4], const float4 (&bb)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            if (FAST && m0 + 4 * s + lq >= m_end) aa[s] = make_float4(0.f, 0.f, 0.f, 0.f);   // select, at consumption time
             dbs.x += aa[s].x; dbs.y += aa[s].y; dbs.z += aa[s].z; dbs.w += aa[s].w;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -567,13 +566,21 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(WgradGroup g, int 
     load_tile(m_begin + 16, a1, b1);
     // no early exits: slabs are multiples of 48 rows and tiles past m_end load zeros, so the loop
     // body is one straight-line block (early exits made the compiler keep several accumulator sets)
+    // sched_barrier pins each stage's loads BEFORE the MFMA block that follows: left alone, the
+    // scheduler sinks the loads between the MFMAs (register pressure) and then waits vmcnt(0) on them
     for (int64_t m0 = m_begin; m0 < m_end; m0 += 48) {
         load_tile(m0 + 32, a2, b2);
-        mma_tile(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(m0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
         load_tile(m0 + 48, a0, b0);
-        mma_tile(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(m0 + 16, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
         load_tile(m0 + 64, a1, b1);
-        mma_tile(a2, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(m0 + 32, a2, b2);
+        __builtin_amdgcn_sched_barrier(0);
     }
     // D[q][p]: lane holds rows i = lq*4 + r (n = nblk*64 + 4 i + q), col j = li (k = kslab*64 + 4 j + p)
     float* pw = partial + (int64_t)slab * N * K;
