@@ -66,7 +66,15 @@ class FusedStep:
         ws = max(_lib.query("llmrec_linear_wgrad_workspace_bytes", x.shape[0] * (len(self.keys) if i >= 3 else 1), d, x.shape[1])
                  for i, x in enumerate(feats))
         self.ws_wgrad = torch.empty(ws, dtype=torch.uint8, device=dev)
+        self.ws_wgrad_b = torch.empty(_lib.query("llmrec_linear_wgrad_workspace_bytes", model.user_feats.shape[0], d, model.user_feats.shape[1]),
+                                      dtype=torch.uint8, device=dev)
         self._partials = {}
+        # Three independent chains (7-stream side features / LLM profile / ID embeddings) run on three
+        # HIP streams in forward and in backward; under capture the fork/join becomes graph edges, so
+        # the latency-bound Netflix-scale SpMMs and the four weight-gradient GEMMs overlap.
+        import os as _os
+        self.multi_stream = _os.environ.get("LLMREC_STREAMS", "1") == "1"
+        self.s1, self.s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         for p in model.parameters():
             if p.requires_grad and p.grad is None and p is not model.batch_norm.weight and p is not model.batch_norm.bias:
                 p.grad = torch.zeros_like(p)
@@ -85,11 +93,27 @@ class FusedStep:
         self.gemm = os.environ.get("LLMREC_GEMM", "bf16x3")
 
     # -- raw kernel helpers -----------------------------------------------------------------------
-    def _spmm(self, a: ops.Csr, X, Y, accumulate=False):
+    def _fork(self, *streams):
+        if self.multi_stream:
+            cur = torch.cuda.current_stream()
+            for st in streams:
+                st.wait_stream(cur)
+
+    def _join(self, *streams):
+        if self.multi_stream:
+            cur = torch.cuda.current_stream()
+            for st in streams:
+                cur.wait_stream(st)
+
+    def _on(self, st):
+        """Context: launch on side stream `st` (or stay on the current stream when disabled)."""
+        return torch.cuda.stream(st) if self.multi_stream else torch.cuda.stream(torch.cuda.current_stream())
+
+    def _spmm(self, a: ops.Csr, X, Y, accumulate=False, tag=0):
         pl = a.plan
         partials = None
         if pl.n_long:
-            key = (id(pl), X.shape[1])
+            key = (id(pl), X.shape[1], tag)                   # one scratch per concurrent chain
             partials = self._partials.get(key)
             if partials is None:
                 partials = self._partials[key] = torch.empty(pl.n_seg * X.shape[1], dtype=torch.float32, device=X.device)
@@ -120,9 +144,10 @@ class FusedStep:
             arr[i].Y, arr[i].ldy = out.data_ptr(), _ld(out)
         _call("llmrec_linear_fwd_grouped_bf16x3" if self.gemm == "bf16x3" else "llmrec_linear_fwd_grouped_f32", len(jobs), arr, self.d)
 
-    def _wgrad(self, dY, X, lin, accumulate):
+    def _wgrad(self, dY, X, lin, accumulate, ws=None):
+        ws = self.ws_wgrad if ws is None else ws
         _call("llmrec_linear_wgrad_f32", X.shape[0], self.d, X.shape[1], _p(dY), _ld(dY), _p(X), _ld(X), _p(lin.weight.grad),
-              _ld(lin.weight.grad), _p(lin.bias.grad), 1 if accumulate else 0, _p(self.ws_wgrad), self.ws_wgrad.numel())
+              _ld(lin.weight.grad), _p(lin.bias.grad), 1 if accumulate else 0, _p(ws), ws.numel())
 
     def _softmax(self, Z, Y):
         _call("llmrec_softmax_rows_fwd_f32", Z.shape[0], self.d, _p(Z), _ld(Z), _p(Y), _ld(Y))
@@ -153,21 +178,26 @@ class FusedStep:
     # -- forward ----------------------------------------------------------------------------------
     def forward(self):
         m, d = self.m, self.d
+        self._fork(self.s2)
+        with self._on(self.s2):                                          # ID chain: needs no projection
+            i_prev = m.item_id_embedding.weight
+            for l in range(self.L):
+                last = l == self.L - 1
+                if last:
+                    self._spmm(self.ui.fwd, i_prev, self.tmpU, tag=2); self._softmax(self.tmpU, self.Ul[l])
+                    self._spmm(self.iu.fwd, self.Ul[l], self.tmpI, tag=2); self._softmax(self.tmpI, self.Il[l])
+                else:
+                    self._spmm(self.ui.fwd, i_prev, self.Ul[l], tag=2)
+                    self._spmm(self.iu.fwd, self.Ul[l], self.Il[l], tag=2)
+                i_prev = self.Il[l]
         self._project_all()
+        self._fork(self.s1)
+        with self._on(self.s1):                                          # profile stream: items first
+            self._spmm(self.iu.fwd, self.P_usr, self.prof_i, tag=1)
+            self._spmm(self.ui.fwd, self.prof_i, self.prof_u, tag=1)
         self._spmm(self.ui.fwd, self.P_cat, self.U_cat)                  # 7 streams, one adjacency pass
         self._spmm(self.iu.fwd, self.U_cat, self.I_cat)
-        self._spmm(self.iu.fwd, self.P_usr, self.prof_i)                 # profile stream: items first
-        self._spmm(self.ui.fwd, self.prof_i, self.prof_u)
-        i_prev = m.item_id_embedding.weight
-        for l in range(self.L):
-            last = l == self.L - 1
-            if last:
-                self._spmm(self.ui.fwd, i_prev, self.tmpU); self._softmax(self.tmpU, self.Ul[l])
-                self._spmm(self.iu.fwd, self.Ul[l], self.tmpI); self._softmax(self.tmpI, self.Il[l])
-            else:
-                self._spmm(self.ui.fwd, i_prev, self.Ul[l])
-                self._spmm(self.iu.fwd, self.Ul[l], self.Il[l])
-            i_prev = self.Il[l]
+        self._join(self.s1, self.s2)
         for out, base, layers, cat, prof in ((self.E_u, m.user_id_embedding.weight, self.Ul, self.U_cat, self.prof_u),
                                              (self.E_i, m.item_id_embedding.weight, self.Il, self.I_cat, self.prof_i)):
             means = [base] + layers
@@ -231,36 +261,39 @@ class FusedStep:
             dp, dl = self._tables(dnorms)
             _call("llmrec_fuse_bwd_f32", dout.shape[0], d, _p(dout), _ld(dout), len(norms), npt, nl, self._rates(), dp, dl, 1)
         m = self.m
-        # profile chain: prof_u = ui(prof_i), prof_i = iu(P_usr)
-        self._spmm(self.ui.bwd, self.dprof_u, self.dprof_i, accumulate=True)
-        self._spmm(self.iu.bwd, self.dprof_i, self.dP_usr)
-        # side chain: I_cat = iu(U_cat), U_cat = ui(P_cat)
+        inv = 1.0 / (L + 1)
+        self._fork(self.s1, self.s2)
+        with self._on(self.s1):
+            # profile chain: prof_u = ui(prof_i), prof_i = iu(P_usr); then user_trans' weight gradient
+            self._spmm(self.ui.bwd, self.dprof_u, self.dprof_i, accumulate=True, tag=1)
+            self._spmm(self.iu.bwd, self.dprof_i, self.dP_usr, tag=1)
+            self._wgrad(self.dP_usr, m.user_feats, m.user_trans, False, ws=self.ws_wgrad_b)
+        with self._on(self.s2):
+            # ID chain (items of layer l+1 from the new users; softmax on the last layer)
+            self._axpy(inv, self.dE_i, self.bufI, False)                  # dI[L] = mean part
+            for l in range(L - 1, -1, -1):
+                last = l == L - 1
+                g = self.bufI
+                if last:
+                    self._softmax_bwd(self.Il[l], self.bufI, self.tmpI); g = self.tmpI
+                self._axpy(inv, self.dE_u, self.bufU, False)
+                self._spmm(self.iu.bwd, g, self.bufU, accumulate=True, tag=2)     # dU[l+1] complete
+                h = self.bufU
+                if last:
+                    self._softmax_bwd(self.Ul[l], self.bufU, self.tmpU); h = self.tmpU
+                self._axpy(inv, self.dE_i, self.bufI, False)
+                self._spmm(self.ui.bwd, h, self.bufI, accumulate=True, tag=2)     # dI[l] complete
+            self._axpy(1.0, self.bufI, m.item_id_embedding.weight.grad, False)
+            self._axpy(inv, self.dE_u, m.user_id_embedding.weight.grad, False)    # U^0 only enters the mean
+        # side chain: I_cat = iu(U_cat), U_cat = ui(P_cat); then the item-side weight gradients
         self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
         self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
-        # ID chain (items of layer l+1 from the new users; softmax on the last layer)
-        inv = 1.0 / (L + 1)
-        self._axpy(inv, self.dE_i, self.bufI, False)                      # dI[L] = mean part
-        for l in range(L - 1, -1, -1):
-            last = l == L - 1
-            g = self.bufI
-            if last:
-                self._softmax_bwd(self.Il[l], self.bufI, self.tmpI); g = self.tmpI
-            self._axpy(inv, self.dE_u, self.bufU, False)
-            self._spmm(self.iu.bwd, g, self.bufU, accumulate=True)         # dU[l+1] complete
-            h = self.bufU
-            if last:
-                self._softmax_bwd(self.Ul[l], self.bufU, self.tmpU); h = self.tmpU
-            self._axpy(inv, self.dE_i, self.bufI, False)
-            self._spmm(self.ui.bwd, h, self.bufI, accumulate=True)         # dI[l] complete
-        self._axpy(1.0, self.bufI, m.item_id_embedding.weight.grad, False)
-        self._axpy(inv, self.dE_u, m.user_id_embedding.weight.grad, False)  # U^0 only enters the mean
-        # weight gradients (the features are constants: no dX)
-        self._wgrad(self._side(self.dP_cat, 0), m.image_feats, m.image_trans, False)
-        self._wgrad(self._side(self.dP_cat, 1), m.text_feats, m.text_trans, False)
-        # the shared item_trans receives all attribute streams in one grouped launch
+        # the shared item_trans receives all attribute streams in one grouped launch (features are constants: no dX)
         ops.linear_wgrad_grouped([(self._side(self.dP_cat, 2 + k), m.item_feats[key]) for k, key in enumerate(self.keys)],
                                  m.item_trans.weight.grad, m.item_trans.bias.grad, False, self.ws_wgrad)
-        self._wgrad(self.dP_usr, m.user_feats, m.user_trans, False)
+        self._wgrad(self._side(self.dP_cat, 1), m.text_feats, m.text_trans, False)
+        self._wgrad(self._side(self.dP_cat, 0), m.image_feats, m.image_trans, False)
+        self._join(self.s1, self.s2)
 
     def step_eager(self, users, pos, neg, n_valid=None):
         self.forward()
