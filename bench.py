@@ -143,7 +143,9 @@ class NetflixShaped:
     def eval_once(self):
         import torch
         q = torch.arange(self.sh.n_users, dtype=torch.int64, device=self.device)
-        return self.engine.evaluate_topk(self.model, self.graph.ui, self.graph.iu, q, self.graph.by_user, 50)
+        with torch.no_grad():
+            self.fused.forward()                               # the eval-mode forward (no dropout in this config)
+            return self.ops.score_topk(self.fused.E_u, self.fused.E_i, q, self.graph.by_user, 50)
 
     def config(self):
         return {"workload": "netflix_shaped_cfg2" if self.shape_name == "nf" else "movielens_shaped_cfg3",

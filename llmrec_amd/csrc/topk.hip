@@ -91,10 +91,16 @@ template <int DK, bool SELECT>
 __global__ __launch_bounds__(256) void score_topk_kernel(TopkArgs a) {
     __shared__ float list_s[4][16][64];
     __shared__ int32_t list_i[4][16][64];
+    // each wave publishes its current K-th score per user; the global K-th score is >= every wave's
+    // local one, so max over the four is a valid (and much tighter) filter for all of them. Reads may
+    // be stale - that only lets a few more candidates through.
+    __shared__ float thr_pub[4][16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int q0 = blockIdx.x * 16;
     if (q0 >= a.n_query) return;                               // block-uniform
+    if (threadIdx.x < 64) thr_pub[threadIdx.x >> 4][threadIdx.x & 15] = -INFINITY;
+    __syncthreads();
 
     // A operand: the block's 16 users
     int qa = q0 + li;
@@ -157,11 +163,17 @@ __global__ __launch_bounds__(256) void score_topk_kernel(TopkArgs a) {
         }
         uint32_t rm_lo[4], rm_hi[4];
         float rthr[4];
+        float tshared = thr;
+        if (lane < 16) {
+            const volatile float* tp = &thr_pub[0][0];
+            tshared = fmaxf(fmaxf(tp[lane], tp[16 + lane]), fmaxf(tp[32 + lane], tp[48 + lane]));
+            tshared = fmaxf(tshared, thr);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             rm_lo[r] = __shfl(mlo, lq * 4 + r, 64);
             rm_hi[r] = __shfl(mhi, lq * 4 + r, 64);
-            rthr[r] = __shfl(thr, lq * 4 + r, 64);
+            rthr[r] = __shfl(tshared, lq * 4 + r, 64);
         }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(256) void score_topk_kernel(TopkArgs a) {
                     list_s[w][crow][lane] = ls;
                     list_i[w][crow][lane] = lid;
                     const float nthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ls), a.K - 1));
-                    if (lane == crow) thr = nthr;
+                    if (lane == crow) { thr = nthr; *(volatile float*)&thr_pub[w][crow] = nthr; }
                 }
             }
         }

@@ -158,9 +158,14 @@ class Trainer(object):
     # -- evaluation -------------------------------------------------------------------------------
     def test(self, users_to_test, is_val):
         self.model_mm.eval()
+        fused = self._fused_step()
         with torch.no_grad():
-            ua_embeddings, ia_embeddings, *rest = self.model_mm(self.ui_graph, self.iu_graph, self.image_ui_graph,
-                                                                self.image_iu_graph, self.text_ui_graph, self.text_iu_graph)
+            if fused:                                          # same forward, ~30 launches over preallocated buffers
+                fused.forward()
+                ua_embeddings, ia_embeddings = fused.E_u, fused.E_i
+            else:
+                ua_embeddings, ia_embeddings, *rest = self.model_mm(self.ui_graph, self.iu_graph, self.image_ui_graph,
+                                                                    self.image_iu_graph, self.text_ui_graph, self.text_iu_graph)
         return test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val)
 
     # -- one step ---------------------------------------------------------------------------------
