@@ -1,4 +1,5 @@
 #!/bin/bash
-python tools/kernel_probe.py fwd 20
-python tools/kernel_probe.py wgrad 20
+# extra runs for the record: kernel probes, cfg 3 (MovieLens-shaped) bench, exact-fp32 projection bench
+python tools/kernel_probe.py all 10
+python bench.py --workload ml --steps 50 --warmup 10 --no-cpu-baseline --no-kernel-roofline
 LLMREC_GEMM=f32 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kernel-roofline
