@@ -14,7 +14,12 @@ metric value = BPR train edges/s = steps * batch_size / time (the reference's ow
 definition, main.py:200,297); the full-rank eval rate (users/s, main.py:297-303) is reported in
 "eval". Inputs are resident in HBM before the timed region.
 
-N > 1: the path shards by user; see llmrec_amd/dist.py and --workload.
+N > 1 (one process per GPU, RCCL): the SAME workload with the global batch N x 1024 sharded over
+batch-sharded replicas (llmrec_amd/dp.py): graph and tables replicated (they are < 1 GB), prune
+threshold and regulariser norms over the GLOBAL batch (one 36 KB all-gather), one all-reduce of
+the flat gradient bucket (9.4 MB) per step - weak scaling in the batch. Evaluation shards the
+users. The user-ROW-sharded path for graphs that need it (cfg 4/5, SURVEY.md 8(e): per-layer
+all-reduce of the item messages, llmrec_amd/dist.py) is --workload synth.
 One JSON line on rank 0.
 """
 from __future__ import annotations
@@ -80,8 +85,9 @@ def event_time_ms(fn, iters: int, warmup: int = 3):
 class NetflixShaped:
     """cfg 2 (and cfg 3 with shape='ml'): the full multi-modal step on one GPU."""
 
-    def __init__(self, shape: str, seed: int, device):
+    def __init__(self, shape: str, seed: int, device, rank: int = 0, world: int = 1, comm=None):
         import numpy as np
+        self.rank, self.world = rank, world
         import torch
         from llmrec_amd import ops, engine, synth
         self.shape_name = shape
@@ -115,15 +121,19 @@ class NetflixShaped:
         self.aug_neg = torch.from_numpy(rng.integers(0, hi, size=sh.n_users)).to(device)
         exist = torch.unique(torch.from_numpy(rows)).to(device)
         self.batcher = engine.DeviceBatcher(self.graph.by_user, exist, sh.n_items, self.hp.batch_size,
-                                            self.aug_pos, self.aug_neg, self.hp.aug_sample_rate, seed)
+                                            self.aug_pos, self.aug_neg, self.hp.aug_sample_rate, seed, rank=rank, world=world)
         self.engine, self.ops, self.device = engine, ops, device
         self.step_id = 0
         self.units_per_step = self.hp.batch_size
         # the fused step (hand-written backward, 7-stream SpMM operands, multi-BPR) replayed from a HIP graph
         from llmrec_amd.fused import FusedStep
         a = self.args
-        self.fused = FusedStep(self.model, self.graph, self.hp, (a.model_cat_rate, a.user_cat_rate, a.item_cat_rate), self.opt,
-                               self.hp.batch_size + self.batcher.n_aug)
+        rates, cap = (a.model_cat_rate, a.user_cat_rate, a.item_cat_rate), self.hp.batch_size + self.batcher.n_aug
+        if world > 1 or os.environ.get("LLMREC_FORCE_DP", "0") == "1":   # batch-sharded replicas: global prune + gradient all-reduce
+            from llmrec_amd.dp import DataParallelStep
+            self.fused = DataParallelStep(self.model, self.graph, self.hp, rates, self.opt, cap, comm=comm)
+        else:
+            self.fused = FusedStep(self.model, self.graph, self.hp, rates, self.opt, cap)
         self.use_graph = os.environ.get("LLMREC_GRAPH", "1") == "1"
 
     def step(self):
@@ -141,8 +151,11 @@ class NetflixShaped:
         return self.engine.train_step(self.model, self.opt, self.graph.ui, self.graph.iu, u, p, n, self.hp, n_valid=nv)
 
     def eval_once(self):
+        """Full-rank evaluation of this rank's user block (users shard, items are replicated: SURVEY.md 8(e))."""
         import torch
-        q = torch.arange(self.sh.n_users, dtype=torch.int64, device=self.device)
+        per = (self.sh.n_users + self.world - 1) // self.world
+        q = torch.arange(min(self.rank * per, self.sh.n_users), min((self.rank + 1) * per, self.sh.n_users), dtype=torch.int64,
+                         device=self.device)
         with torch.no_grad():
             self.fused.forward()                               # the eval-mode forward (no dropout in this config)
             return self.ops.score_topk(self.fused.E_u, self.fused.E_i, q, self.graph.by_user, 50)
@@ -153,8 +166,13 @@ class NetflixShaped:
                 "embed_size": self.args.embed_size, "prop_layers": len(eval(self.args.weight_size)),
                 "batch_size": self.hp.batch_size, "aug_sample_rate": self.hp.aug_sample_rate,
                 "prune_loss_drop_rate": self.hp.prune_loss_drop_rate, "side_features": "image512+text768+llm1536x(1+5)",
-                "sampler": "device (llmrec_sample_bpr)", "parallelism": "single GPU",
-                "step": "fused (llmrec_amd/fused.py)" + (" + HIP graph replay" if self.use_graph else "")}
+                "sampler": "device (llmrec_sample_bpr)", "global_batch": self.hp.batch_size * self.world,
+                "parallelism": "single GPU" if not hasattr(self.fused, "gsz") else
+                ("dp%d: batch-sharded replicas (llmrec_amd/dp.py), graph + tables replicated, prune over the global batch "
+                 "(1 all-gather of %d B) + 1 all-reduce of the %d B gradient bucket per step; eval shards the users"
+                 % (self.world, 4 * self.fused.gsz, 4 * self.fused.bucket.numel())),
+                "step": ("fused (llmrec_amd/fused.py)" if not hasattr(self.fused, "gsz") else "fused, 3 segments between the 2 exchanges (llmrec_amd/dp.py)")
+                        + (" + HIP graph replay" if self.use_graph else "")}
 
     # ---- per-kernel roofline (dominant kernels of this workload, timed in isolation) -------------
     def kernel_rooflines(self):
@@ -300,18 +318,20 @@ def main():
     if local == 0:                                           # one builder per node; the .so normally travels prebuilt
         from llmrec_amd import build as _build
         _build.build(force=False, verbose=False)
-    if world > 1:
+    use_pg = world > 1 or ("RANK" in os.environ and os.environ.get("LLMREC_DP_FORCE_COLLECTIVES", "0") == "1")
+    if use_pg:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
         dist.barrier()                                       # the library exists before any rank loads it
     workload = a.workload
     if workload == "auto":
-        workload = "nf" if world == 1 else "synth"
+        workload = "nf"
 
     if workload in ("nf", "ml"):
-        w = NetflixShaped(workload, a.seed, device)
-        step, units = w.step, w.units_per_step * world      # N > 1 on this workload = independent replicas
+        from llmrec_amd import dist as ldist
+        w = NetflixShaped(workload, a.seed, device, rank, world, ldist.Comm() if use_pg else None)
+        step, units = w.step, w.units_per_step * world      # global batch = world x batch_size
     else:
         from llmrec_amd import dist as ldist
         w = ldist.ShardedBench(a.synth_users, a.synth_items, a.synth_edges, a.seed, device, rank, world)
@@ -340,12 +360,14 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": w.config()}
 
+    if workload in ("nf", "ml"):
+        w.eval_once(); torch.cuda.synchronize(); barrier()
+        t1 = time.perf_counter(); w.eval_once(); torch.cuda.synchronize(); barrier()
+        te = time.perf_counter() - t1                        # every rank ranks its user block; the barrier makes it the slowest rank's time
     if rank == 0 and workload in ("nf", "ml"):
-        w.eval_once(); torch.cuda.synchronize()
-        t1 = time.perf_counter(); w.eval_once(); torch.cuda.synchronize()
-        te = time.perf_counter() - t1
         line["eval"] = {"metric": "full_rank_eval_users_per_sec", "value": w.sh.n_users / te, "ms": te * 1e3,
-                        "n_users": w.sh.n_users, "includes": "no-grad full-graph forward + fp32 MFMA scoring + masked top-50"}
+                        "n_users": w.sh.n_users, "users_per_rank": (w.sh.n_users + world - 1) // world,
+                        "includes": "no-grad full-graph forward + fp32 MFMA scoring + masked top-50"}
         if not a.no_kernel_roofline:
             ks = w.kernel_rooflines()
             line["kernels"] = ks
@@ -364,9 +386,10 @@ def main():
     elif rank == 0:
         line.update(w.extras())
     if rank == 0:
-        print(json.dumps(line))
-    if world > 1:
+        print(json.dumps(line), flush=True)
+    if use_pg:
         import torch.distributed as dist
+        dist.barrier()                                       # rank 0's per-kernel measurements are done
         dist.destroy_process_group()
 
 

@@ -215,6 +215,24 @@ int llmrec_bpr_multi_fwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* pro
                              const int64_t* users, const int64_t* pos, const int64_t* neg,
                              int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
                              float batch_size_flag, float* out, float* saved, llmrec_stream_t stream);
+/* Batch-sharded form of llmrec_bpr_multi_fwd_f32 (data-parallel replicas or user-sharded ranks;
+ * SURVEY.md 8(e) "all-gather the B log-sigmoids, select the threshold redundantly"). The global
+ * batch is the concatenation of the ranks' valid samples in rank order; prune keeps the
+ * k = (int)(remember_rate * B_global) smallest m_b of the GLOBAL batch (ties: lower global index).
+ *   phase 1: scores + this rank's gather block -> gather_block[LLMREC_BPR_GATHER_FLOATS(P, B_max)]:
+ *            [P][B_max] m_b (+inf beyond n_valid) | [P][4] Su, Sp, Sq, - (local sums) | n_valid as float
+ *   (host: all-gather the blocks, RCCL; every rank's B_max must be equal)
+ *   phase 2: selection against `gathered` ([n_ranks] blocks, rank_stride floats apart): out[p][0] is
+ *            this rank's SHARE of mf_p (sum over ranks = mf_p), out[p][1] = emb_p from the global
+ *            norms (identical on every rank); `saved` is then ready for llmrec_bpr_multi_bwd_f32.
+ * n_ranks * B_max <= 4 * LLMREC_BPR_MAX_B. */
+#define LLMREC_BPR_GATHER_FLOATS(P, B) ((P) * (B) + 4 * (P) + 1)
+int llmrec_bpr_multi_fwd_sharded_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
+                                     const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                     int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
+                                     float batch_size_flag, int32_t phase, float* gather_block,
+                                     const float* gathered, int32_t n_ranks, int64_t rank_stride, int32_t my_rank,
+                                     float* out, float* saved, llmrec_stream_t stream);
 int llmrec_bpr_multi_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
                              const int64_t* users, const int64_t* pos, const int64_t* neg,
                              int32_t B_max, const int32_t* n_valid_dev, float decay, float batch_size_flag,

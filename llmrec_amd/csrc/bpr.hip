@@ -86,20 +86,56 @@ __device__ __forceinline__ float block_tree_sum(float v, float* red) {
     return r;
 }
 
+// Batch-sharded selection (data-parallel or user-sharded ranks): every rank all-gathers one block of
+// LLMREC_BPR_GATHER_FLOATS(P, cap) floats, laid out  [P][cap] m_b | [P][4] Su, Sp, Sq, k | n_valid (as float);
+// the global batch is the concatenation of the ranks' valid samples in rank order.
+struct BprGather {
+    const float* g;        // null: the batch is local
+    int n_ranks;           // blocks in g
+    int64_t stride;        // floats between two ranks' blocks
+    int cap;               // sample capacity per rank (= that rank's B_max)
+    int n_prob;            // problems per block (P)
+    int my_offset;         // global padded index of this rank's sample 0 (= my_rank * cap)
+    int has_tail;          // 0: g is a plain [n_ranks * cap] array of m_b, all valid (single-problem API)
+};
+
+__device__ __forceinline__ int gather_valid(const BprGather& ga, int r) {
+    if (!ga.has_tail) return ga.cap;
+    const int nv = (int)ga.g[r * ga.stride + (int64_t)ga.n_prob * ga.cap + 4 * ga.n_prob];
+    return nv > ga.cap ? ga.cap : (nv < 0 ? 0 : nv);
+}
+
+__device__ __forceinline__ int gather_batch(const BprGather& ga) {
+    int n = 0;
+    for (int r = 0; r < ga.n_ranks; ++r) n += gather_valid(ga, r);
+    return n;
+}
+
 // selection, step 1: rank counting. grid = (ceil(B / 256), problems); each thread ranks one sample
 // against the Bg log-sigmoids staged in LDS and writes d(mf)/d(s_b) (0 when dropped) plus the kept
 // m_b into the scratch (slot 1 = sg is consumed here and overwritten with the kept value).
+// Padding slots of the gathered layout are staged as +inf: they never precede a real sample.
 __global__ __launch_bounds__(256) void bpr_rank_kernel(int B_max, const int32_t* __restrict__ n_valid_dev, double remember_rate,
-                                                       float* __restrict__ saved_all, int saved_stride,
-                                                       const float* __restrict__ global_m, int global_B, int my_offset) {
+                                                       float* __restrict__ saved_all, int saved_stride, BprGather ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* m_s = reinterpret_cast<float*>(smem);
     const int B = bpr_batch(n_valid_dev, B_max);
     const int prob = blockIdx.y;
     float* saved = saved_all + (int64_t)prob * saved_stride;
     float* sc = saved + B_max + 4;
-    const int Bg = global_m ? global_B : B;
-    for (int j = threadIdx.x; j < Bg; j += 256) m_s[j] = global_m ? global_m[j] : sc[j];
+    int Bg, slots;
+    if (ga.g) {
+        slots = ga.n_ranks * ga.cap;
+        Bg = gather_batch(ga);
+        for (int r = 0; r < ga.n_ranks; ++r) {
+            const int nv = gather_valid(ga, r);
+            const float* src = ga.g + r * ga.stride + (int64_t)prob * ga.cap;
+            for (int j = threadIdx.x; j < ga.cap; j += 256) m_s[r * ga.cap + j] = j < nv ? src[j] : __builtin_inff();
+        }
+    } else {
+        slots = Bg = B;
+        for (int j = threadIdx.x; j < B; j += 256) m_s[j] = sc[j];
+    }
     __syncthreads();
     const int k = (int)(remember_rate * (double)Bg);                   // int((1 - drop) * len) of main.py:161-162
     const int b = blockIdx.x * 256 + threadIdx.x;
@@ -109,8 +145,8 @@ __global__ __launch_bounds__(256) void bpr_rank_kernel(int B_max, const int32_t*
     bool keep = true;
     if (k < Bg) {
         int rank = 0;
-        const int me = my_offset + b;
-        for (int j = 0; j < Bg; ++j) {
+        const int me = ga.my_offset + b;
+        for (int j = 0; j < slots; ++j) {
             const float mj = m_s[j];
             rank += (mj < mb) || (mj == mb && j < me);
         }
@@ -121,17 +157,19 @@ __global__ __launch_bounds__(256) void bpr_rank_kernel(int B_max, const int32_t*
 }
 
 // selection, step 2: one block per problem sums the kept log-sigmoids and the three squared norms
-// with fixed-order trees (deterministic) and writes the two loss values.
+// with fixed-order trees (deterministic) and writes the two loss values. With a gathered layout the
+// norms (and the batch size) are the sums over the ranks' blocks in rank order - identical on every
+// rank - while out[0] stays this rank's share of mf.
 __global__ __launch_bounds__(BPR_THREADS) void bpr_reduce_kernel(int B_max, const int32_t* __restrict__ n_valid_dev,
                                                                  double remember_rate, float decay, float bsz,
                                                                  float* __restrict__ out_all, float* __restrict__ saved_all,
-                                                                 int saved_stride, int global_B) {
+                                                                 int saved_stride, BprGather ga) {
     __shared__ float red[BPR_THREADS];
     const int B = bpr_batch(n_valid_dev, B_max);
     const int prob = blockIdx.x;
     float* saved = saved_all + (int64_t)prob * saved_stride;
     const float* sc = saved + B_max + 4;
-    const int Bg = global_B > 0 ? global_B : B;
+    const int Bg = ga.g ? gather_batch(ga) : B;
     const int k = (int)(remember_rate * (double)Bg);
     float part = 0.f, su = 0.f, sp = 0.f, sq = 0.f;
     for (int b = threadIdx.x; b < B; b += BPR_THREADS) {
@@ -139,12 +177,39 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_reduce_kernel(int B_max, cons
         su += sc[2 * B_max + b]; sp += sc[3 * B_max + b]; sq += sc[4 * B_max + b];
     }
     const float kept = block_tree_sum(part, red);
-    const float Su = block_tree_sum(su, red), Sp = block_tree_sum(sp, red), Sq = block_tree_sum(sq, red);
+    float Su = block_tree_sum(su, red), Sp = block_tree_sum(sp, red), Sq = block_tree_sum(sq, red);
     if (threadIdx.x == 0) {
+        if (ga.g && ga.has_tail) {
+            Su = Sp = Sq = 0.f;
+            for (int r = 0; r < ga.n_ranks; ++r) {
+                const float* nb = ga.g + r * ga.stride + (int64_t)ga.n_prob * ga.cap + 4 * prob;
+                Su += nb[0]; Sp += nb[1]; Sq += nb[2];
+            }
+        }
         out_all[prob * 2 + 0] = -(kept / (float)k);                    // k == 0 -> nan, as torch's empty mean
         const float reg = 1.0f / (2.0f * Su + 1e-8f) + 1.0f / (2.0f * Sp + 1e-8f) + 1.0f / (2.0f * Sq + 1e-8f);
         out_all[prob * 2 + 1] = decay * (reg / bsz);
         saved[B_max + 0] = Su; saved[B_max + 1] = Sp; saved[B_max + 2] = Sq; saved[B_max + 3] = (float)k;
+    }
+}
+
+// pass 1 of the batch-sharded forward: this rank's block of the gathered layout
+__global__ __launch_bounds__(256) void bpr_pack_kernel(int n_prob, int B_max, const int32_t* __restrict__ n_valid_dev,
+                                                       const float* __restrict__ saved_all, int saved_stride, float* __restrict__ block) {
+    const int B = bpr_batch(n_valid_dev, B_max);
+    const int total = n_prob * B_max + 4 * n_prob + 1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        float v;
+        if (i < n_prob * B_max) {
+            const int p = i / B_max, b = i - p * B_max;
+            v = b < B ? saved_all[(int64_t)p * saved_stride + B_max + 4 + b] : __builtin_inff();
+        } else if (i < n_prob * B_max + 4 * n_prob) {
+            const int j = i - n_prob * B_max;
+            v = saved_all[(int64_t)(j >> 2) * saved_stride + B_max + (j & 3)];
+        } else {
+            v = (float)B;
+        }
+        block[i] = v;
     }
 }
 
@@ -299,21 +364,27 @@ extern "C" {
 
 static int launch_bpr_fwd(const BprTables& t, int n_prob, int d, const int64_t* users, const int64_t* pos, const int64_t* neg,
                           int B_max, const int32_t* n_valid_dev, double remember_rate, float decay, float bsz,
-                          float* out, float* saved, const float* global_m, int global_B, int my_offset,
-                          bool do_scores, bool do_select, hipStream_t stream) {
+                          float* out, float* saved, const BprGather& ga, bool do_scores, bool do_select, float* pack_out,
+                          hipStream_t stream) {
     const int stride = LLMREC_BPR_SAVED_FLOATS(B_max);
+    const BprGather none = {};
     if (do_scores && B_max > 0) {
         dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_prob);
         bpr_scores_kernel<<<grid, 256, 0, stream>>>(t, d, users, pos, neg, B_max, n_valid_dev, saved, stride);
         LLMREC_LAUNCH_CHECK();
     }
-    if (do_select) {
-        const size_t shmem = sizeof(float) * (size_t)(global_m ? global_B : (B_max > 0 ? B_max : 1));
-        dim3 grid((unsigned)ceil_div(B_max > 0 ? B_max : 1, 256), (unsigned)n_prob);
-        bpr_rank_kernel<<<grid, 256, shmem, stream>>>(B_max, n_valid_dev, remember_rate, saved, stride, global_m, global_B, my_offset);
+    if (pack_out) {                                                     // local norm sums, then this rank's gather block
+        bpr_reduce_kernel<<<n_prob, BPR_THREADS, 0, stream>>>(B_max, n_valid_dev, remember_rate, decay, bsz, out, saved, stride, none);
         LLMREC_LAUNCH_CHECK();
-        bpr_reduce_kernel<<<n_prob, BPR_THREADS, 0, stream>>>(B_max, n_valid_dev, remember_rate, decay, bsz, out, saved, stride,
-                                                              global_m ? global_B : 0);
+        bpr_pack_kernel<<<ceil_div(n_prob * B_max + 4 * n_prob + 1, 256), 256, 0, stream>>>(n_prob, B_max, n_valid_dev, saved, stride, pack_out);
+        LLMREC_LAUNCH_CHECK();
+    }
+    if (do_select) {
+        const size_t shmem = sizeof(float) * (size_t)(ga.g ? ga.n_ranks * ga.cap : (B_max > 0 ? B_max : 1));
+        dim3 grid((unsigned)ceil_div(B_max > 0 ? B_max : 1, 256), (unsigned)n_prob);
+        bpr_rank_kernel<<<grid, 256, shmem, stream>>>(B_max, n_valid_dev, remember_rate, saved, stride, ga);
+        LLMREC_LAUNCH_CHECK();
+        bpr_reduce_kernel<<<n_prob, BPR_THREADS, 0, stream>>>(B_max, n_valid_dev, remember_rate, decay, bsz, out, saved, stride, ga);
         LLMREC_LAUNCH_CHECK();
     }
     return LLMREC_OK;
@@ -330,7 +401,7 @@ int llmrec_bpr_prune_fwd_f32(const float* Eu, int64_t ldu, const float* Ei, int6
     BprTables t = {};
     t.Eu[0] = Eu; t.Ei[0] = Ei; t.ldu[0] = ldu; t.ldi[0] = ldi;
     return launch_bpr_fwd(t, 1, d, users, pos, neg, B_max, n_valid_dev, remember_rate, decay, batch_size_flag, out2, saved,
-                          nullptr, 0, 0, true, true, (hipStream_t)stream_);
+                          BprGather{}, true, true, nullptr, (hipStream_t)stream_);
 }
 
 int llmrec_bpr_prune_fwd_sharded_f32(const float* Eu, int64_t ldu, const float* Ei, int64_t ldi, int32_t d,
@@ -346,8 +417,10 @@ int llmrec_bpr_prune_fwd_sharded_f32(const float* Eu, int64_t ldu, const float* 
     BprTables t = {};
     t.Eu[0] = Eu; t.Ei[0] = Ei; t.ldu[0] = ldu; t.ldi[0] = ldi;
     // pass 1 writes the per-sample scratch (m at saved[B_local + 4 ...)); pass 2 only selects
+    BprGather ga = {};
+    if (!scores_only) { ga.g = global_m; ga.n_ranks = 1; ga.stride = 0; ga.cap = global_B; ga.n_prob = 1; ga.my_offset = my_offset; ga.has_tail = 0; }
     return launch_bpr_fwd(t, 1, d, users, pos, neg, B_local, nullptr, remember_rate, decay, batch_size_flag, out2, saved,
-                          global_m, global_B, my_offset, scores_only != 0, scores_only == 0, (hipStream_t)stream_);
+                          ga, scores_only != 0, scores_only == 0, nullptr, (hipStream_t)stream_);
 }
 
 static int fill_tables(BprTables& t, int n, const llmrec_bpr_problem_t* p, int d, bool need_grads) {
@@ -372,7 +445,38 @@ int llmrec_bpr_multi_fwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* pro
     BprTables t = {};
     LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, false), "bpr_multi_fwd: bad problem table");
     return launch_bpr_fwd(t, n_problems, d, users, pos, neg, B_max, n_valid_dev, remember_rate, decay, batch_size_flag, out, saved,
-                          nullptr, 0, 0, true, true, (hipStream_t)stream_);
+                          BprGather{}, true, true, nullptr, (hipStream_t)stream_);
+}
+
+int llmrec_bpr_multi_fwd_sharded_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
+                                     const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                     int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
+                                     float batch_size_flag, int32_t phase, float* gather_block,
+                                     const float* gathered, int32_t n_ranks, int64_t rank_stride, int32_t my_rank,
+                                     float* out, float* saved, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && problems_host && d > 0 && out && saved,
+                     "bpr_multi_fwd_sharded: bad argument");
+    LLMREC_CHECK_ARG(phase == 1 || phase == 2, "bpr_multi_fwd_sharded: phase is 1 (scores + gather block) or 2 (selection)");
+    if (B_max > LLMREC_BPR_MAX_B) { set_error("bpr_multi_fwd_sharded: B_max %d > %d", B_max, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
+    LLMREC_CHECK_ARG(B_max == 0 || (users && pos && neg), "bpr_multi_fwd_sharded: null index pointer");
+    BprTables t = {};
+    LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, false), "bpr_multi_fwd_sharded: bad problem table");
+    if (phase == 1) {
+        LLMREC_CHECK_ARG(gather_block, "bpr_multi_fwd_sharded: phase 1 needs the gather block");
+        return launch_bpr_fwd(t, n_problems, d, users, pos, neg, B_max, n_valid_dev, remember_rate, decay, batch_size_flag, out, saved,
+                              BprGather{}, true, false, gather_block, (hipStream_t)stream_);
+    }
+    LLMREC_CHECK_ARG(gathered && n_ranks >= 1 && my_rank >= 0 && my_rank < n_ranks &&
+                     rank_stride >= LLMREC_BPR_GATHER_FLOATS(n_problems, B_max), "bpr_multi_fwd_sharded: bad gathered layout");
+    if ((int64_t)n_ranks * B_max > 4 * LLMREC_BPR_MAX_B) {
+        set_error("bpr_multi_fwd_sharded: global batch capacity %lld > %d", (long long)n_ranks * B_max, 4 * LLMREC_BPR_MAX_B);
+        return LLMREC_EUNSUPPORTED;
+    }
+    BprGather ga = {};
+    ga.g = gathered; ga.n_ranks = n_ranks; ga.stride = rank_stride; ga.cap = B_max; ga.n_prob = n_problems;
+    ga.my_offset = my_rank * B_max; ga.has_tail = 1;
+    return launch_bpr_fwd(t, n_problems, d, users, pos, neg, B_max, n_valid_dev, remember_rate, decay, batch_size_flag, out, saved,
+                          ga, false, true, nullptr, (hipStream_t)stream_);
 }
 
 int llmrec_bpr_multi_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,

@@ -40,6 +40,14 @@ class Comm:
             self.dist.all_reduce(t)
         return t
 
+    def all_gather_into(self, out: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        """out[world * n] <- the ranks' t[n] in rank order (preallocated, graph-step friendly)."""
+        if self.dist and self.world > 1:
+            self.dist.all_gather_into_tensor(out, t)
+        else:
+            out.copy_(t)
+        return out
+
     def all_gather_cat(self, t: torch.Tensor) -> torch.Tensor:
         if not (self.dist and self.world > 1):
             return t

@@ -1,0 +1,162 @@
+"""Batch-sharded replicas of the fused step: the multi-GPU form of cfg 2 / cfg 3.
+
+At Netflix / MovieLens scale the whole problem (100 k edges, 30 k x 64 embeddings, < 0.5 GB of side
+features) is a rounding error of one MI355X's 288 GB, and a step is 1.2 ms. Row-sharding the users
+(llmrec_amd.dist, the layout for cfg 4 / 5) would all-reduce every per-layer item message - two
+I x 7d operands and ~7 I x d ones per step, ~93 MB - to save SpMM time that is not the bottleneck.
+Here every rank keeps the full graph and all tables, takes 1/world of the GLOBAL batch, and the
+step exchanges exactly two things:
+
+  1. one all-gather of LLMREC_BPR_GATHER_FLOATS(8, B) floats per rank (36 KB): the log-sigmoids of
+     the 8 BPR problems, the local squared-norm sums and the valid-sample count - so that the prune
+     threshold of reference main.py:158-165 is taken over the GLOBAL batch and the reciprocal
+     regulariser sees the global norms (identical values on every rank);
+  2. one all-reduce (sum) of the flat gradient bucket (every .grad is a view of it; 9.4 MB at
+     Netflix shape) whose tail carries the loss scalars for logging.
+
+The result equals the single-GPU step of the reference on the concatenated batch (batch size
+world x B, same --batch_size flag in the regulariser): tests/test_gpu_step.py runs two replicas
+through a loop-back exchange on one GPU against FusedStep on the concatenated batch.
+Replicas stay bit-identical: both collectives deliver identical values to every rank, and every
+rank applies the same AdamW update.
+
+Between the exchanges the step is three HIP graphs (forward + scores | selection + backward |
+AdamW); the collectives run between them on the same stream (RCCL, or nothing when world == 1).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, ops
+from .fused import FusedStep, _call, _p
+
+
+def gather_floats(n_prob: int, b_max: int) -> int:
+    """LLMREC_BPR_GATHER_FLOATS(P, B) of include/llmrec_hip.h."""
+    return n_prob * b_max + 4 * n_prob + 1
+
+
+def bucket_gradients(model, extra: int = 16):
+    """Make every trainable parameter's .grad a view of one flat fp32 buffer (+ `extra` floats of
+    tail for the loss scalars). Returns (bucket, n_grad_floats)."""
+    params = [p for p in model.parameters() if p.requires_grad and p is not model.batch_norm.weight and p is not model.batch_norm.bias]
+    pad = lambda k: (k + 63) // 64 * 64                        # 256-byte aligned views (vector loads in AdamW / weight-grad)
+    n = sum(pad(p.numel()) for p in params)
+    bucket = torch.zeros(n + extra, dtype=torch.float32, device=params[0].device)
+    off = 0
+    for p in params:
+        p.grad = bucket[off:off + p.numel()].view_as(p)
+        off += pad(p.numel())
+    return bucket, n
+
+
+class DataParallelStep(FusedStep):
+    """FusedStep over a batch that is sharded across `world` replicas (this rank holds `b_max`
+    slots of it). comm: llmrec_amd.dist.Comm (.rank, .world, .dist = torch.distributed); None = single
+    replica or a loop-back harness that moves the two exchange buffers itself (rank=, world=)."""
+
+    def __init__(self, model, graph, hp, rates, optimizer, b_max: int, comm=None, rank: int = None, world: int = None):
+        self.bucket, self.n_grad = bucket_gradients(model)
+        super().__init__(model, graph, hp, rates, optimizer, b_max)
+        self.comm = comm
+        self.rank = comm.rank if comm is not None else (rank or 0)
+        self.world = comm.world if comm is not None else (world or 1)
+        if self.world * b_max > 4 * _lib.CONST["LLMREC_BPR_MAX_B"]:
+            raise RuntimeError("DataParallelStep: global batch capacity %d exceeds %d" % (self.world * b_max, 4 * _lib.CONST["LLMREC_BPR_MAX_B"]))
+        dev = self.E_u.device
+        self.gsz = gather_floats(self.n_prob, b_max)
+        self.g_local = torch.zeros(self.gsz, dtype=torch.float32, device=dev)
+        self.g_all = torch.zeros(self.world * self.gsz, dtype=torch.float32, device=dev)
+        self.tail = self.bucket[self.n_grad:]
+        self.graphs = None
+        import os
+        # LLMREC_DP_FORCE_COLLECTIVES=1: issue the RCCL calls even in a world of one rank (plumbing check on a 1-GPU box)
+        self.force = os.environ.get("LLMREC_DP_FORCE_COLLECTIVES", "0") == "1" and comm is not None and comm.dist is not None
+
+    # -- the three compute phases -----------------------------------------------------------------
+    def _bpr_phase(self, phase, users, pos, neg, n_valid):
+        hp = self.hp
+        _call("llmrec_bpr_multi_fwd_sharded_f32", self.n_prob, self._problems(), self.d, _p(users), _p(pos), _p(neg), users.numel(),
+              _p(n_valid), float(1 - hp.prune_loss_drop_rate), float(hp.decay), float(hp.batch_size), phase, _p(self.g_local),
+              _p(self.g_all), self.world, self.gsz, self.rank, _p(self.out), _p(self.saved))
+
+    def phase_a(self, users, pos, neg, n_valid=None):
+        """forward + BPR scores + this rank's gather block."""
+        if users.numel() != self.b_max:
+            raise RuntimeError("DataParallelStep: every rank passes exactly b_max = %d slots (n_valid marks the used ones)" % self.b_max)
+        self.forward()
+        self._bpr_phase(1, users, pos, neg, n_valid)
+
+    def phase_b(self, users, pos, neg, n_valid=None):
+        """selection against the gathered global batch + backward into the gradient bucket."""
+        self._bpr_phase(2, users, pos, neg, n_valid)
+        self._feat_reg()
+        P = self.n_prob
+        self.tail[:P] = self.out[:P, 0]                                  # this rank's shares of the mf values
+        self.tail[P:P + 1] = (self.out[0, 1:2] + self.scal[0:1]) * (1.0 / self.world)   # emb + feat_reg: identical on all ranks
+        self._backward(self._problems(), users, pos, neg, n_valid, replicated_scale=1.0 / self.world)
+
+    def phase_c(self):
+        """loss scalars from the reduced tail + AdamW."""
+        P = self.n_prob
+        self.scal[2:3] = self.tail[0:1]
+        self.scal[3:4] = self.out[0, 1:2]
+        self.scal[1:2] = (self.tail[:P] * self.w_mf_dev).sum() + self.tail[P]
+        self.opt.step()
+
+    # -- the two exchanges ------------------------------------------------------------------------
+    def exchange_scores(self):
+        if self.comm is not None and (self.world > 1 or self.force):
+            self.comm.dist.all_gather_into_tensor(self.g_all, self.g_local)
+        else:                                                  # single replica, or a loop-back harness that fills the other blocks
+            self.g_all[self.rank * self.gsz:(self.rank + 1) * self.gsz].copy_(self.g_local)
+
+    def exchange_grads(self):
+        if self.comm is not None and (self.world > 1 or self.force):
+            self.comm.dist.all_reduce(self.bucket)
+
+    def loss_backward(self, users, pos, neg, n_valid=None):
+        raise RuntimeError("DataParallelStep: use step_eager()/step() (the loss needs the score exchange)")
+
+    def step_eager(self, users, pos, neg, n_valid=None):
+        self.phase_a(users, pos, neg, n_valid)
+        self.exchange_scores()
+        self.phase_b(users, pos, neg, n_valid)
+        self.exchange_grads()
+        self.phase_c()
+        return self.scal[1], self.scal[2], self.scal[3]
+
+    # -- HIP graphs -------------------------------------------------------------------------------
+    def capture(self, warm_users, warm_pos, warm_neg, warm_n_valid=None):
+        dev = self.E_u.device
+        st = {"users": torch.zeros(self.b_max, dtype=torch.int64, device=dev), "pos": torch.zeros(self.b_max, dtype=torch.int64, device=dev),
+              "neg": torch.zeros(self.b_max, dtype=torch.int64, device=dev), "n_valid": torch.zeros(1, dtype=torch.int32, device=dev)}
+        self.static = st
+        self._load(warm_users, warm_pos, warm_neg, warm_n_valid)
+        args = (st["users"], st["pos"], st["neg"], st["n_valid"])
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                             # warm-up: one full eager step (also warms the collectives)
+            self.step_eager(*args)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graphs = []
+        for fn in (lambda: self.phase_a(*args), lambda: self.phase_b(*args), self.phase_c):
+            g = torch.cuda.CUDAGraph()                         # capturing records, it does not execute: one step ran (the warm-up)
+            with torch.cuda.graph(g):
+                fn()
+            graphs.append(g)
+        self.graphs = graphs
+        self.graph_exec = graphs[0]
+
+    def step(self, users, pos, neg, n_valid=None):
+        if self.graphs is None:
+            return self.step_eager(users, pos, neg, n_valid)
+        self._load(users, pos, neg, n_valid)
+        ga, gb, gc = self.graphs
+        ga.replay()
+        self.exchange_scores()
+        gb.replay()
+        self.exchange_grads()
+        gc.replay()
+        return self.scal[1], self.scal[2], self.scal[3]

@@ -81,16 +81,24 @@ class DeviceBatcher:
     is used only if both ids are < n_items, as in the reference."""
 
     def __init__(self, train: ops.Csr, exist_users: torch.Tensor, n_items: int, batch_size: int,
-                 aug_pos: Optional[torch.Tensor], aug_neg: Optional[torch.Tensor], aug_rate: float, seed: int):
+                 aug_pos: Optional[torch.Tensor], aug_neg: Optional[torch.Tensor], aug_rate: float, seed: int,
+                 rank: int = 0, world: int = 1):
+        """rank/world: batch-sharded replicas (llmrec_amd.dp) - the sampler draws the GLOBAL batch of
+        world * batch_size users (one keyed permutation, so still without replacement) and this rank
+        keeps its slice; augmented triples are drawn from the slice."""
         self.train, self.exist_users, self.n_items, self.B = train, exist_users, n_items, batch_size
+        self.rank, self.world = rank, world
         self.aug_pos, self.aug_neg = aug_pos, aug_neg
         self.n_aug = int(batch_size * aug_rate) if aug_pos is not None else 0
         self.seed = seed
         self.gen = torch.Generator(device=exist_users.device)
-        self.gen.manual_seed(seed)
+        self.gen.manual_seed(seed + rank)
 
     def next(self, step: int):
-        u, p, n = ops.sample_bpr(self.seed, step, self.exist_users, self.n_items, self.train, self.B)
+        u, p, n = ops.sample_bpr(self.seed, step, self.exist_users, self.n_items, self.train, self.B * self.world)
+        if self.world > 1:
+            lo, hi = self.rank * self.B, (self.rank + 1) * self.B
+            u, p, n = u[lo:hi], p[lo:hi], n[lo:hi]
         if self.n_aug == 0:
             return u, p, n, None
         pick = u[torch.randperm(self.B, generator=self.gen, device=u.device)[: self.n_aug]]    # random.sample(users, k)

@@ -229,25 +229,34 @@ class FusedStep:
         return arr
 
     def loss_backward(self, users, pos, neg, n_valid=None):
-        hp, d, L, S = self.hp, self.d, self.L, self.S
         B = users.numel()
         if B > self.b_max:
             raise RuntimeError("FusedStep: batch of %d exceeds b_max %d" % (B, self.b_max))
         probs = self._problems()
-        remember = 1 - hp.prune_loss_drop_rate
-        _call("llmrec_bpr_multi_fwd_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), float(remember),
-              float(hp.decay), float(hp.batch_size), _p(self.out), _p(self.saved))
-        # feature regulariser (main.py:151-156) over the image/text columns of both cat buffers
-        coef = hp.feat_reg_decay * 0.5 / self.I
-        for k, blk in enumerate((self.I_cat, self.U_cat)):
-            _call("llmrec_sumsq_f32", blk.shape[0], 2 * d, _p(blk), _ld(blk), float(coef), k, _p(self.scal), _p(self.ws_sumsq),
-                  self.ws_sumsq.numel())
+        hp = self.hp
+        _call("llmrec_bpr_multi_fwd_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid),
+              float(1 - hp.prune_loss_drop_rate), float(hp.decay), float(hp.batch_size), _p(self.out), _p(self.saved))
+        self._feat_reg()
         # loss values for logging: loss = sum_p w_mf[p] * mf_p + emb_0 + feat_reg
         self.scal[2:3] = self.out[0, 0:1]
         self.scal[3:4] = self.out[0, 1:2]
         self.scal[1:2] = (self.out[: self.n_prob, 0] * self.w_mf_dev).sum() + self.out[0, 1] + self.scal[0]
+        self._backward(probs, users, pos, neg, n_valid)
 
-        # ---- backward ----
+    def _feat_reg(self):
+        """Feature regulariser (main.py:151-156) over the image/text columns of both cat buffers -> scal[0]."""
+        coef = self.hp.feat_reg_decay * 0.5 / self.I
+        for k, blk in enumerate((self.I_cat, self.U_cat)):
+            _call("llmrec_sumsq_f32", blk.shape[0], 2 * self.d, _p(blk), _ld(blk), float(coef), k, _p(self.scal), _p(self.ws_sumsq),
+                  self.ws_sumsq.numel())
+
+    def _backward(self, probs, users, pos, neg, n_valid, replicated_scale: float = 1.0):
+        """Hand-written backward from the saved BPR state to the parameter gradients. replicated_scale
+        weights the batch-independent loss terms (1 / world on batch-sharded replicas, whose
+        gradients are summed over ranks afterwards)."""
+        hp, d, L, S = self.hp, self.d, self.L, self.S
+        B = users.numel()
+        coef = hp.feat_reg_decay * 0.5 / self.I * replicated_scale
         for t in (self.dE_u, self.dE_i, self.dU_cat, self.dI_cat, self.dprof_u, self.dprof_i):
             t.zero_()
         _call("llmrec_bpr_multi_bwd_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), float(hp.decay),

@@ -326,6 +326,62 @@ def test_bpr_device_batch_count(ops):
     assert abs(float(out[1]) - float(emb)) < 2e-6 * abs(float(emb))
 
 
+def test_bpr_multi_sharded_matches_oracle_on_concatenated_batch(ops):
+    """llmrec_bpr_multi_fwd_sharded_f32 (phase 1 -> gather blocks -> phase 2) + llmrec_bpr_multi_bwd_f32
+    on three ranks with ragged valid counts (one rank empty), two problems over one batch: the sum of
+    the ranks' mf shares, the emb value and the summed gradients equal the oracle's BPR + prune on
+    the concatenation of the valid samples."""
+    import ctypes
+    from llmrec_amd import _lib
+    rng = np.random.default_rng(11)
+    U, I, d, cap, P, W = 200, 260, 64, 96, 2, 3
+    valid = [70, 0, 96]
+    tabs = [(torch.tensor((rng.standard_normal((U, d)) * 0.3).astype(np.float32)), torch.tensor((rng.standard_normal((I, d)) * 0.3).astype(np.float32)))
+            for _ in range(P)]
+    idx = [[torch.tensor(rng.integers(0, n, size=cap)) for n in (U, I, I)] for _ in range(W)]
+    cat = [torch.cat([idx[r][k][:valid[r]] for r in range(W)]) for k in range(3)]
+    cfg = O.Config(batch_size=64, decay=1e-5, prune_loss_drop_rate=0.71)
+    want = []
+    for Eu, Ei in tabs:
+        a = Eu.clone().requires_grad_(True); b = Ei.clone().requires_grad_(True)
+        mf, emb = O.bpr_loss(a[cat[0]], b[cat[1]], b[cat[2]], cfg)
+        (0.7 * mf + 1.3 * emb).backward()
+        want.append((float(mf.detach()), float(emb.detach()), a.grad, b.grad))
+    gsz = P * cap + 4 * P + 1
+    dev_t = [(Eu.to(DEV), Ei.to(DEV)) for Eu, Ei in tabs]
+    grads = [(torch.zeros(U, d, device=DEV), torch.zeros(I, d, device=DEV)) for _ in range(P)]
+    arr = (ops.BprProblem * P)()
+    for i in range(P):
+        arr[i].Eu, arr[i].ldu, arr[i].Ei, arr[i].ldi = dev_t[i][0].data_ptr(), d, dev_t[i][1].data_ptr(), d
+        arr[i].dEu, arr[i].lddu, arr[i].dEi, arr[i].lddi = grads[i][0].data_ptr(), d, grads[i][1].data_ptr(), d
+        arr[i].g_mf, arr[i].g_emb = 0.7, 1.3
+    st = torch.cuda.current_stream().cuda_stream
+    dev_idx = [[x.to(DEV) for x in idx[r]] for r in range(W)]
+    nv = [torch.tensor([valid[r]], dtype=torch.int32, device=DEV) for r in range(W)]
+    saved = [torch.zeros(P * ops.bpr_saved_floats(cap), device=DEV) for _ in range(W)]
+    outs = [torch.zeros(P, 2, device=DEV) for _ in range(W)]
+    blocks = torch.zeros(W, gsz, device=DEV)
+    p_ = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def call(phase, r):
+        _lib.call("llmrec_bpr_multi_fwd_sharded_f32", P, arr, d, p_(dev_idx[r][0]), p_(dev_idx[r][1]), p_(dev_idx[r][2]), cap, p_(nv[r]),
+                  1 - 0.71, 1e-5, 64.0, phase, p_(blocks[r]), p_(blocks), W, gsz, r, p_(outs[r]), p_(saved[r]), st)
+    for r in range(W):
+        call(1, r)
+    assert [int(blocks[r, -1]) for r in range(W)] == valid
+    for r in range(W):
+        call(2, r)
+        _lib.call("llmrec_bpr_multi_bwd_f32", P, arr, d, p_(dev_idx[r][0]), p_(dev_idx[r][1]), p_(dev_idx[r][2]), cap, p_(nv[r]),
+                  1e-5, 64.0, p_(saved[r]), st)
+    for i in range(P):
+        mf = sum(float(outs[r][i, 0]) for r in range(W))
+        assert abs(mf - want[i][0]) < 3e-6 * abs(want[i][0])
+        for r in range(W):
+            assert abs(float(outs[r][i, 1]) - want[i][1]) < 3e-6 * abs(want[i][1])
+        assert rel_err(grads[i][0].cpu(), want[i][2]) < 2e-5
+        assert rel_err(grads[i][1].cpu(), want[i][3]) < 2e-5
+
+
 # ------------------------------------------------------------------------------------------
 # R9/R10 scoring + top-K
 # ------------------------------------------------------------------------------------------
