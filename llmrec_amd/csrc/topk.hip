@@ -7,19 +7,24 @@
 // the scores are reproducible bit for bit by a scalar fmaf loop in the order documented below).
 //
 // Geometry: block = 4 wavefronts sharing 16 query users (one MFMA row tile, A operand resident in
-// registers for the whole launch); wavefront w sweeps the w-th quarter of the items in tiles of 64
-// (4 MFMA column tiles) with its own candidate lists, and a bitonic merge of the four lists per
-// user ends the block (825 blocks x 4 waves at the Netflix shape instead of 207 x 4). Operands are fed straight from global memory as float4 along k (see
-// dense.hip for the k-permutation argument): lane l holds E[row (l&15)][16 c + 4 (l>>4) + s].
+// registers for the whole launch); wavefront w sweeps the w-th quarter of the items, 32 items (two
+// MFMA column tiles) per round (825 blocks x 4 waves at the Netflix shape; <= 128 registers, so all
+// of them are resident at once). Operands are fed straight from global memory as float4 along k
+// (see dense.hip for the k-permutation argument): lane l holds E[row (l&15)][16 c + 4 (l>>4) + s].
 // Chain order of k for one score: for c in 0..d/16-1, for s in 0..3, for q in 0..3: k = 16c + 4q + s.
 //
-// Selection: each wavefront keeps, per user, a sorted 64-slot list (score desc, item id asc) in
-// LDS, one slot per lane (a lane only ever touches its own slot column, so no LDS hand-off
-// between lanes exists). A score enters the insert path only if it is >= the user's current K-th
-// score; all candidates of one user in a tile are inserted with the list held in registers: a
-// ballot/popcount position search plus a one-lane DPP shift (v_mov_b32 wave_shr:1) per candidate.
+// Selection (order: score desc, item id asc - heapq.nlargest over (score, item) with the
+// reference's tie behaviour): a score that reaches the user's current K-th score is APPENDED to
+// an unsorted LDS buffer of its (wave, user) - all candidates of a round in parallel, slots from
+// ballot/popcount prefix sums, no serial insert. The block keeps ONE sorted list per user (64
+// slots, one per lane, in the registers of the wave that owns the user: wave w owns users
+// 4w..4w+3). When some buffer may not hold another round (block-uniform flag after the round's
+// barrier) the owners drain all buffers: 64 entries at a time, bitonic sort across the lanes, then
+// a bitonic merge into the list; the new K-th score is the filter for all four waves - the GLOBAL
+// K-th score of everything the block has seen, not a per-quarter one. A sweep needs ~5 drains
+// (the filter tightens geometrically) and ~12 sorted vectors per user.
 // Train items are removed with a per-user cursor into the user's (ascending) CSR row, turned
-// into a 64-bit tile mask.
+// into a 32-bit tile mask.
 #include "common.h"
 #include <limits.h>
 
@@ -69,62 +74,105 @@ __device__ __forceinline__ float wave_shr1(float x) {     // lane i <- lane i-1 
 __device__ __forceinline__ int wave_shr1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ bool pair_better(float s, int i, float t, int j) { return (s > t) || (s == t && i < j); }
 
-// top-64 of the union of two descending 64-lists held one entry per lane: elementwise best of A and
-// reversed B is bitonic and holds the 64 best; six compare-exchange stages sort it (best first).
-__device__ __forceinline__ void merge64(float& s, int& i, float bs, int bi, int lane) {
-    const float rs = __shfl(bs, 63 - lane, 64);
-    const int ri = __shfl(bi, 63 - lane, 64);
-    if (pair_better(rs, ri, s, i)) { s = rs; i = ri; }
+// value of lane (lane ^ J): DPP inside a 16-lane row (no LDS round trip), ds_swizzle for 16, ds_bpermute for 32
+template <int J>
+__device__ __forceinline__ int xor_lane_i(int x, int lane) {
+    if (J == 1) return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);          // quad_perm [1,0,3,2]
+    if (J == 2) return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);          // quad_perm [2,3,0,1]
+    if (J == 4) {
+        const int up = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0xf, false);         // row_shl:4  lane i <- i + 4
+        const int dn = __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xf, false);         // row_shr:4  lane i <- i - 4
+        return (lane & 4) ? dn : up;
+    }
+    if (J == 8) return __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false);          // row_ror:8
+    if (J == 16) return __builtin_amdgcn_ds_swizzle(x, 0x401F);                            // bit mode: and 0x1f, xor 0x10
+    return __shfl_xor(x, J, 64);
+}
+template <int J> __device__ __forceinline__ float xor_lane_f(float x, int lane) { return __int_as_float(xor_lane_i<J>(__float_as_int(x), lane)); }
+
+// compare-exchange with lane ^ J for NV independent vectors at once: the chains of one vector are
+// latency-bound (DPP / LDS crossbar -> compare -> select), NV of them interleave in the instruction stream
+template <int J, int NV>
+__device__ __forceinline__ void cmpx(float (&s)[NV], int (&i)[NV], int lane, bool keep_better) {
+    float os[NV]; int oi[NV];
 #pragma unroll
-    for (int stride = 32; stride > 0; stride >>= 1) {
-        const float os = __shfl_xor(s, stride, 64);
-        const int oi = __shfl_xor(i, stride, 64);
-        const bool take_best = (lane & stride) == 0;
-        const bool other_better = pair_better(os, oi, s, i);
-        if (take_best == other_better) { s = os; i = oi; }
+    for (int v = 0; v < NV; ++v) { os[v] = xor_lane_f<J>(s[v], lane); oi[v] = xor_lane_i<J>(i[v], lane); }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const bool other_better = pair_better(os[v], oi[v], s[v], i[v]);
+        if (keep_better == other_better) { s[v] = os[v]; i[v] = oi[v]; }
     }
 }
 
-// block = 4 wavefronts sharing 16 query users; wave w sweeps the w-th quarter of the item tiles
-// and keeps its own lists; a bitonic merge of the four lists per user ends the block.
-template <int DK, bool SELECT>
-__global__ __launch_bounds__(256) void score_topk_kernel(TopkArgs a) {
-    __shared__ float list_s[4][16][64];
-    __shared__ int32_t list_i[4][16][64];
-    // each wave publishes its current K-th score per user; the global K-th score is >= every wave's
-    // local one, so max over the four is a valid (and much tighter) filter for all of them. Reads may
-    // be stale - that only lets a few more candidates through.
-    __shared__ float thr_pub[4][16];
+// one bitonic merge network over 64 lanes: strides FROM ... 1; blocks of size 2*FROM alternate
+// direction with bit `dirbit` of the lane (0 = best first everywhere)
+template <int FROM, int NV>
+__device__ __forceinline__ void bitonic_net(float (&s)[NV], int (&i)[NV], int lane, int dirbit) {
+    const bool up = (lane & dirbit) == 0;
+    if (FROM >= 32) cmpx<32, NV>(s, i, lane, ((lane & 32) == 0) == up);
+    if (FROM >= 16) cmpx<16, NV>(s, i, lane, ((lane & 16) == 0) == up);
+    if (FROM >= 8) cmpx<8, NV>(s, i, lane, ((lane & 8) == 0) == up);
+    if (FROM >= 4) cmpx<4, NV>(s, i, lane, ((lane & 4) == 0) == up);
+    if (FROM >= 2) cmpx<2, NV>(s, i, lane, ((lane & 2) == 0) == up);
+    cmpx<1, NV>(s, i, lane, ((lane & 1) == 0) == up);
+}
+
+// top-64 of the union of two descending 64-lists held one entry per lane: elementwise best of A and
+// reversed B is bitonic and holds the 64 best; six compare-exchange stages sort it (best first).
+template <int NV>
+__device__ __forceinline__ void merge64(float (&s)[NV], int (&i)[NV], const float (&bs)[NV], const int (&bi)[NV], int lane) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const float rs = __shfl(bs[v], 63 - lane, 64);
+        const int ri = __shfl(bi[v], 63 - lane, 64);
+        if (pair_better(rs, ri, s[v], i[v])) { s[v] = rs; i[v] = ri; }
+    }
+    bitonic_net<32, NV>(s, i, lane, 0);
+}
+
+// bitonic sort of 64 (score, item) pairs, one per lane, best first
+template <int NV>
+__device__ __forceinline__ void sort64(float (&s)[NV], int (&i)[NV], int lane) {
+    bitonic_net<1, NV>(s, i, lane, 2);
+    bitonic_net<2, NV>(s, i, lane, 4);
+    bitonic_net<4, NV>(s, i, lane, 8);
+    bitonic_net<8, NV>(s, i, lane, 16);
+    bitonic_net<16, NV>(s, i, lane, 32);
+    bitonic_net<32, NV>(s, i, lane, 0);
+}
+
+// cycle accounting for tools/topk_prof.hip (compiled out of the library)
+#ifdef LLMREC_TOPK_PROFILE
+__device__ unsigned long long g_topk_prof[8];
+#define TK_NOW() clock64()
+#define TK_ADD(slot, since) do { tk_acc[slot] += clock64() - (since); } while (0)
+#define TK_DECL() long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TK_FLUSH() do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_topk_prof[i_], (unsigned long long)tk_acc[i_]); } while (0)
+#else
+#define TK_DECL() do {} while (0)
+#define TK_FLUSH() do {} while (0)
+#define TK_NOW() 0ll
+#define TK_ADD(slot, since) do { (void)(since); } while (0)
+#endif
+
+constexpr int TK_TILE = 32;   // items per wave per round
+constexpr int TK_CAP = 64;    // buffer slots per (wave, user): drained before a round could overflow it
+
+// scores only (llmrec_scores_f32): S[q][item], same MFMA chain as the selection kernel
+template <int DK>
+__global__ __launch_bounds__(256) void scores_kernel(TopkArgs a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int q0 = blockIdx.x * 16;
-    if (q0 >= a.n_query) return;                               // block-uniform
-    if (threadIdx.x < 64) thr_pub[threadIdx.x >> 4][threadIdx.x & 15] = -INFINITY;
-    __syncthreads();
-
-    // A operand: the block's 16 users
+    if (q0 >= a.n_query) return;
     int qa = q0 + li;
     if (qa > a.n_query - 1) qa = a.n_query - 1;
     const int64_t user_a = a.query_users[qa];
     float4 ua[DK];
 #pragma unroll
     for (int c = 0; c < DK; ++c) ua[c] = ld4g(a.Eu + user_a * a.ldu, 16 * c + 4 * lq, a.d, a.vec_ok);
-
     const int64_t tiles_total = (a.n_items + 63) / 64;
-    const int64_t tiles_per_wave = (tiles_total + 3) / 4;
-    const int64_t t_begin = w * tiles_per_wave;
-    const int64_t t_end = t_begin + tiles_per_wave < tiles_total ? t_begin + tiles_per_wave : tiles_total;
-
-    // lanes 0..15 own one user each: train-row cursor and current K-th score of THIS wave's list
-    int32_t cur = 0, end = 0;
-    float thr = -INFINITY;
-    if (SELECT) {
-        if (lane < 16 && a.train_rowptr) { cur = a.train_rowptr[user_a]; end = a.train_rowptr[user_a + 1]; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { list_s[w][r][lane] = -INFINITY; list_i[w][r][lane] = INT_MAX; }
-    }
-
-    for (int64_t t = t_begin; t < t_end; ++t) {
+    for (int64_t t = w; t < tiles_total; t += 4) {
         const int64_t base = t * 64;
         float4 b[4][DK];
         load_items<DK>(a, base, li, lq, b);
@@ -138,100 +186,223 @@ __global__ __launch_bounds__(256) void score_topk_kernel(TopkArgs a) {
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(cmp4(ua[c], s), cmp4(b[n][c], s), acc[n], 0, 0, 0);
-
-        if (!SELECT) {
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = q0 + lq * 4 + r;
-                    const int64_t item = base + 16 * n + li;
-                    if (q < a.n_query && item < a.n_items) a.S[(int64_t)q * a.lds + item] = acc[n][r];
-                }
-            continue;
-        }
-        // 64-bit mask of this tile's train items, built by the row-owner lanes
-        uint32_t mlo = 0, mhi = 0;
-        if (lane < 16) {
-            while (cur < end) {
-                const int64_t c = a.train_colidx[cur];
-                if (c >= base + 64) break;
-                const int bit = (int)(c - base);
-                if (bit >= 0) { if (bit < 32) mlo |= 1u << bit; else mhi |= 1u << (bit - 32); }
-                ++cur;                                             // entries before this wave's quarter are skipped
-            }
-        }
-        uint32_t rm_lo[4], rm_hi[4];
-        float rthr[4];
-        float tshared = thr;
-        if (lane < 16) {
-            const volatile float* tp = &thr_pub[0][0];
-            tshared = fmaxf(fmaxf(tp[lane], tp[16 + lane]), fmaxf(tp[32 + lane], tp[48 + lane]));
-            tshared = fmaxf(tshared, thr);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            rm_lo[r] = __shfl(mlo, lq * 4 + r, 64);
-            rm_hi[r] = __shfl(mhi, lq * 4 + r, 64);
-            rthr[r] = __shfl(tshared, lq * 4 + r, 64);
-        }
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = acc[n][r];
-                const int col = 16 * n + li;
-                const uint32_t mword = (n < 2) ? rm_lo[r] : rm_hi[r];
-                const bool masked = (mword >> (col & 31)) & 1u;
-                const bool valid = (base + col < a.n_items) && (q0 + lq * 4 + r < a.n_query) && !masked;
-                const unsigned long long bal = __ballot(valid && v >= rthr[r]);
-                if (bal == 0) continue;
-                // candidates of lane group g all belong to user row g*4 + r: insert them with the
-                // row's list held in registers (one LDS round trip per row, not per candidate)
+                const int q = q0 + lq * 4 + r;
+                const int64_t item = base + 16 * n + li;
+                if (q < a.n_query && item < a.n_items) a.S[(int64_t)q * a.lds + item] = acc[n][r];
+            }
+    }
+}
+
+// FAST: d == 16 DK and 16-byte aligned rows - plain float4 loads. (A branch around a global load makes
+// hipcc wait for each load before issuing the next: the guarded loader costs ~8 exposed L2 latencies per round.)
+template <int DK, bool FAST>
+__global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(TopkArgs a) {
+    __shared__ float buf_s[4][16][TK_CAP];
+    __shared__ int32_t buf_i[4][16][TK_CAP];
+    __shared__ int32_t cnt_s[4][16];
+    __shared__ float thr_s[16];
+    __shared__ int32_t flag_s[2];
+    // readfirstlane: tells the compiler the wave index is uniform, so the per-wave round counters and
+    // branches live in SGPRs / scalar branches instead of 64-bit VGPR arithmetic under exec masks
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int q0 = blockIdx.x * 16;
+    if (q0 >= a.n_query) return;                               // block-uniform
+    if (threadIdx.x < 16) thr_s[threadIdx.x] = -INFINITY;
+    if (threadIdx.x < 2) flag_s[threadIdx.x] = 0;             // [0] drain requested, [1] waves that finished their quarter
+    __syncthreads();
+
+    // A operand: the block's 16 users
+    int qa = q0 + li;
+    if (qa > a.n_query - 1) qa = a.n_query - 1;
+    const int64_t user_a = a.query_users[qa];
+    float4 ua[DK];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    unsigned sub = (unsigned)((bal >> (16 * g)) & 0xffffull);
-                    if (sub == 0) continue;
-                    const int crow = g * 4 + r;
-                    float ls = list_s[w][crow][lane];
-                    int32_t lid = list_i[w][crow][lane];
-                    do {
-                        const int bpos = __ffs((int)sub) - 1;
-                        sub &= sub - 1;
-                        const float cv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16 * g + bpos));
-                        const int32_t citem = (int32_t)(base + 16 * n + bpos);
-                        const int pos = __popcll(__ballot(pair_better(ls, lid, cv, citem)));
-                        if (pos < a.K) {
-                            const float ps = wave_shr1(ls);
-                            const int32_t pi = wave_shr1(lid);
-                            ls = lane < pos ? ls : (lane == pos ? cv : ps);
-                            lid = lane < pos ? lid : (lane == pos ? citem : pi);
-                        }
-                    } while (sub);
-                    list_s[w][crow][lane] = ls;
-                    list_i[w][crow][lane] = lid;
-                    const float nthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ls), a.K - 1));
-                    if (lane == crow) { thr = nthr; *(volatile float*)&thr_pub[w][crow] = nthr; }
+    for (int c = 0; c < DK; ++c)
+        ua[c] = FAST ? *reinterpret_cast<const float4*>(a.Eu + user_a * a.ldu + 16 * c + 4 * lq)
+                     : ld4g(a.Eu + user_a * a.ldu, 16 * c + 4 * lq, a.d, a.vec_ok);
+
+    const int64_t tiles_total = (a.n_items + TK_TILE - 1) / TK_TILE;
+    const int64_t tiles_per_wave = (tiles_total + 3) / 4;
+    const int64_t t_begin = w * tiles_per_wave;
+    const int64_t t_end = t_begin + tiles_per_wave < tiles_total ? t_begin + tiles_per_wave : tiles_total;
+
+    // lanes 0..15 own one user each for the train-row cursor: position of the first train item inside this
+    // wave's quarter (binary search) and that item's id in a register - a round touches memory only when
+    // it consumes a train item (a per-round peek would put a dependent global load, and a vmcnt(0) that
+    // also waits for the prefetched tile, on every round's critical path).
+    int32_t cur = 0, end = 0, nxt = INT_MAX;
+    if (lane < 16 && a.train_rowptr) {
+        cur = a.train_rowptr[user_a]; end = a.train_rowptr[user_a + 1];
+        const int64_t first = t_begin * TK_TILE;
+        int32_t lo = cur, hi = end;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (a.train_colidx[mid] < first) lo = mid + 1; else hi = mid;
+        }
+        cur = lo;
+        if (cur < end) nxt = a.train_colidx[cur];
+    }
+    int cntr[4] = {0, 0, 0, 0};                                // fill of this wave's buffers of users 4 lq + r (replicated in the lane group)
+    float ls[4]; int32_t lid[4];                               // the block's lists of users 4 w + rr, slot = lane
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) { ls[rr] = -INFINITY; lid[rr] = INT_MAX; }
+
+    // The waves of a block run decoupled: a wave that needs a drain (or has finished its quarter) raises
+    // the flag / waits at the rendezvous, the others join at their next round boundary.
+    const int64_t my_rounds = t_end > t_begin ? t_end - t_begin : 0;
+    float4 b[2][DK];
+    // this lane's two item rows of the current tile; full tiles advance the pointers by one tile stride,
+    // only the sweep's single partial tile (the end of the item table) takes the clamped path
+    const float* row0 = a.Ei + (t_begin * TK_TILE + li) * a.ldi;
+    const float* row1 = row0 + 16 * a.ldi;
+    const int64_t tile_stride = (int64_t)TK_TILE * a.ldi;
+    auto load_tile = [&](int64_t t) {
+        const float* r0 = row0; const float* r1 = row1;
+        if ((t + 1) * TK_TILE > a.n_items) {                   // wave-uniform
+            int64_t i0 = t * TK_TILE + li, i1 = i0 + 16;
+            if (i0 > a.n_items - 1) i0 = a.n_items - 1;
+            if (i1 > a.n_items - 1) i1 = a.n_items - 1;
+            r0 = a.Ei + i0 * a.ldi; r1 = a.Ei + i1 * a.ldi;
+        }
+#pragma unroll
+        for (int c = 0; c < DK; ++c) {
+            b[0][c] = FAST ? *reinterpret_cast<const float4*>(r0 + 16 * c + 4 * lq) : ld4g(r0, 16 * c + 4 * lq, a.d, a.vec_ok);
+            b[1][c] = FAST ? *reinterpret_cast<const float4*>(r1 + 16 * c + 4 * lq) : ld4g(r1, 16 * c + 4 * lq, a.d, a.vec_ok);
+        }
+        row0 += tile_stride; row1 += tile_stride;
+    };
+    if (my_rounds > 0) load_tile(t_begin);
+    TK_DECL();
+    const long long tk_start = TK_NOW();
+    int64_t round = 0;
+    bool counted = false;
+    for (;;) {
+        const bool fin = round >= my_rounds;
+        const int fill = max(max(cntr[0], cntr[1]), max(cntr[2], cntr[3]));
+        // a buffer must keep room for the next round's TK_TILE candidates
+        bool drain = fin || __ballot(fill > TK_CAP - TK_TILE) != 0ull;
+        // (an atomic load, not a volatile one: volatile accesses to LDS are compiled as FLAT loads with a vmcnt(0)
+        //  wait, which would also wait for the prefetched tile)
+        if (!drain) drain = __hip_atomic_load(&flag_s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+        if (drain) {                                           // wave-uniform; every wave of the block gets here
+            const long long tk_d0 = TK_NOW();
+            if (fin && !counted) { counted = true; if (lane == 0) atomicAdd(&flag_s[1], 1); }
+            if (!fin && lane == 0) __hip_atomic_store(&flag_s[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __syncthreads();
+            TK_ADD(3, tk_d0);                                  // waiting for the other waves at the rendezvous
+            if (li == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cnt_s[w][lq * 4 + r] = cntr[r];
+            }
+            __syncthreads();
+            const long long tk_d1 = TK_NOW();
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int u = 4 * w + rr;
+                const int p1 = cnt_s[0][u], p2 = p1 + cnt_s[1][u], p3 = p2 + cnt_s[2][u], total = p3 + cnt_s[3][u];
+                float l1[1] = {ls[rr]}; int32_t i1[1] = {lid[rr]};
+                for (int j0 = 0; j0 < total; j0 += 64) {       // wave-uniform
+                    const int j = j0 + lane;
+                    const int ww = (j >= p1) + (j >= p2) + (j >= p3);
+                    const int start = ww == 0 ? 0 : (ww == 1 ? p1 : (ww == 2 ? p2 : p3));
+                    float bs[1] = {-INFINITY}; int32_t bi[1] = {INT_MAX};
+                    if (j < total) { bs[0] = buf_s[ww][u][j - start]; bi[0] = buf_i[ww][u][j - start]; }
+                    sort64<1>(bs, bi, lane);
+                    merge64<1>(l1, i1, bs, bi, lane);
+                }
+                ls[rr] = l1[0]; lid[rr] = i1[0];
+                if (total > 0) {
+                    const float nthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ls[rr]), a.K - 1));
+                    if (lane == 0) thr_s[u] = nthr;
                 }
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cntr[r] = 0;
+            if (threadIdx.x == 0) flag_s[0] = 0;
+            TK_ADD(4, tk_d1);                                  // sort + merge
+            __syncthreads();
+            TK_ADD(2, tk_d0);                                  // whole drain
+            if (flag_s[1] == 4) break;    // all four quarters swept and drained
+            continue;
         }
-    }
-    if (SELECT) {
-        __syncthreads();
-        // wave w merges the four quarter lists of users 4w .. 4w+3
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = 4 * w + rr;
-            const int q = q0 + r;
-            if (q >= a.n_query) break;                             // wave-uniform
-            float s0 = list_s[0][r][lane]; int i0 = list_i[0][r][lane];
-            float s2 = list_s[2][r][lane]; int i2 = list_i[2][r][lane];
-            merge64(s0, i0, list_s[1][r][lane], list_i[1][r][lane], lane);
-            merge64(s2, i2, list_s[3][r][lane], list_i[3][r][lane], lane);
-            merge64(s0, i0, s2, i2, lane);
-            if (lane < a.K) {
-                a.out_idx[(int64_t)q * a.K + lane] = i0 == INT_MAX ? -1 : i0;
-                a.out_score[(int64_t)q * a.K + lane] = s0;
+        const int64_t base = (t_begin + round) * TK_TILE;
+        const long long tk_r0 = TK_NOW();
+#ifdef LLMREC_TOPK_PROFILE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TK_ADD(5, tk_r0);                                      // waiting for the prefetched tile
+        const long long tk_r1 = TK_NOW();
+#endif
+        f32x4 acc[2];
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+#pragma unroll
+        for (int c = 0; c < DK; ++c)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(cmp4(ua[c], s), cmp4(b[n][c], s), acc[n], 0, 0, 0);
+        // the next tile's operands go into the registers the MFMAs have just read: the loads fly during the selection
+        __builtin_amdgcn_sched_barrier(0);
+        if (round + 1 < my_rounds) load_tile(t_begin + round + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef LLMREC_TOPK_PROFILE
+        { const float touch = acc[0][0] + acc[1][0]; asm volatile("" :: "v"(touch)); }   // MFMA results have landed
+        TK_ADD(6, tk_r1);
+        const long long tk_r2 = TK_NOW();
+#endif
+
+        // 32-bit mask of this tile's train items and the current filter, by the row-owner lanes
+        uint32_t m = 0;
+        while ((int64_t)nxt < base + TK_TILE) {                     // lanes >= 16 hold INT_MAX
+            m |= 1u << (int)(nxt - base);
+            ++cur;
+            nxt = cur < end ? a.train_colidx[cur] : INT_MAX;
+        }
+        // first level: one compare per score against the user's filter (the compare's lane mask IS the ballot);
+        // range / train-mask checks only for the few (row, column-tile) pairs that have a candidate at all.
+        // Rows past n_query carry a +inf filter.
+        const unsigned long long any_train = __ballot(m != 0u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float rthr = (q0 + lq * 4 + r < a.n_query) ? thr_s[lq * 4 + r] : INFINITY;
+            uint32_t rm = 0;
+            if (any_train) rm = __shfl(m, lq * 4 + r, 64);       // wave-uniform branch
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const float v = acc[n][r];
+                if (__ballot(v >= rthr) == 0ull) continue;
+                const int col = 16 * n + li;
+                const bool pass = (v >= rthr) && (base + col < a.n_items) && !((rm >> col) & 1u);
+                const unsigned long long bal = __ballot(pass);
+                if (bal == 0) continue;
+                const unsigned sub = (unsigned)(bal >> (16 * lq)) & 0xffffu;   // my lane group = my user
+                if (pass) {
+                    const int off = cntr[r] + __popc(sub & ((1u << li) - 1u));
+                    buf_s[w][lq * 4 + r][off] = v;
+                    buf_i[w][lq * 4 + r][off] = (int32_t)(base + col);
+                }
+                cntr[r] += __popc(sub);
             }
+        }
+#ifdef LLMREC_TOPK_PROFILE
+        TK_ADD(7, tk_r2);                                      // train mask + selection
+#endif
+        TK_ADD(1, tk_r0);                                      // whole round
+        ++round;
+    }
+    TK_ADD(0, tk_start);
+    TK_FLUSH();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int q = q0 + 4 * w + rr;
+        if (q < a.n_query && lane < a.K) {
+            a.out_idx[(int64_t)q * a.K + lane] = lid[rr] == INT_MAX ? -1 : lid[rr];
+            a.out_score[(int64_t)q * a.K + lane] = ls[rr];
         }
     }
 }
@@ -257,17 +428,18 @@ template <bool SELECT>
 static int launch_topk(const TopkArgs& a, hipStream_t stream) {
     const int DK = (a.d + 15) / 16;
     const int grid = (int)ceil_div(a.n_query, 16);
+    const bool fast = a.vec_ok && a.d == 16 * DK;
+#define LLMREC_TOPK_CASE(D) case D: \
+        if (!SELECT) scores_kernel<D><<<grid, 256, 0, stream>>>(a); \
+        else if (fast) score_topk_kernel<D, true><<<grid, 256, 0, stream>>>(a); \
+        else score_topk_kernel<D, false><<<grid, 256, 0, stream>>>(a); \
+        break;
     switch (DK) {
-        case 1: score_topk_kernel<1, SELECT><<<grid, 256, 0, stream>>>(a); break;
-        case 2: score_topk_kernel<2, SELECT><<<grid, 256, 0, stream>>>(a); break;
-        case 3: score_topk_kernel<3, SELECT><<<grid, 256, 0, stream>>>(a); break;
-        case 4: score_topk_kernel<4, SELECT><<<grid, 256, 0, stream>>>(a); break;
-        case 5: score_topk_kernel<5, SELECT><<<grid, 256, 0, stream>>>(a); break;
-        case 6: score_topk_kernel<6, SELECT><<<grid, 256, 0, stream>>>(a); break;
-        case 7: score_topk_kernel<7, SELECT><<<grid, 256, 0, stream>>>(a); break;
-        case 8: score_topk_kernel<8, SELECT><<<grid, 256, 0, stream>>>(a); break;
+        LLMREC_TOPK_CASE(1) LLMREC_TOPK_CASE(2) LLMREC_TOPK_CASE(3) LLMREC_TOPK_CASE(4)
+        LLMREC_TOPK_CASE(5) LLMREC_TOPK_CASE(6) LLMREC_TOPK_CASE(7) LLMREC_TOPK_CASE(8)
         default: set_error("score_topk: d = %d > 128", a.d); return LLMREC_EUNSUPPORTED;
     }
+#undef LLMREC_TOPK_CASE
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }
