@@ -112,10 +112,10 @@ __device__ __forceinline__ void accumulate_range(const SpmmArgs& a, int32_t s, i
 
 // one lane group per row
 template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
-__global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
+__device__ __forceinline__ void rows_body(const SpmmArgs& a, int64_t block) {
     constexpr int GPB = 256 / LPR;
     const int gl = threadIdx.x & (LPR - 1);
-    const int64_t row = (int64_t)blockIdx.x * GPB + (threadIdx.x / LPR);
+    const int64_t row = block * GPB + (threadIdx.x / LPR);
     if (row >= a.n_rows) return;
     const int32_t s = a.rowptr[row], e = a.rowptr[row + 1];
     if (a.skip_long && (e - s) > LLMREC_SPMM_LONG_ROW) return;
@@ -136,14 +136,19 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
     }
 }
 
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
+__global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
+    rows_body<LPR, NCHUNK, VEC, WEIGHTED>(a, blockIdx.x);
+}
+
 // one wavefront per segment of a long row; the 64/LPR lane groups take contiguous quarters
 template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
-__global__ __launch_bounds__(256) void spmm_segments_kernel(SpmmArgs a, int32_t n_seg) {
+__device__ __forceinline__ void segments_body(const SpmmArgs& a, int32_t n_seg, int32_t block) {
     constexpr int G = 64 / LPR;                       // lane groups per wavefront
     const int lane = threadIdx.x & 63;
     const int gl = lane & (LPR - 1);
     const int g = lane / LPR;
-    const int32_t seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int32_t seg = block * 4 + (threadIdx.x >> 6);
     if (seg >= n_seg) return;
     const int32_t slot = a.seg_long[seg];
     const int32_t row = a.long_rows[slot];
@@ -170,6 +175,15 @@ __global__ __launch_bounds__(256) void spmm_segments_kernel(SpmmArgs a, int32_t 
             if (col < a.d) acc[k].store(pr + col);
         }
     }
+}
+
+// rows and segments are independent: one launch, blocks [0, seg_blocks) take four segments each (the heavy
+// blocks first), the rest the short rows (the 20 SpMMs of a Netflix-scale step are latency-bound; a
+// dependent launch costs ~7 us)
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
+__global__ __launch_bounds__(256) void spmm_rows_segments_kernel(SpmmArgs a, int32_t seg_blocks, int32_t n_seg) {
+    if ((int32_t)blockIdx.x < seg_blocks) segments_body<LPR, NCHUNK, VEC, WEIGHTED>(a, n_seg, blockIdx.x);
+    else rows_body<LPR, NCHUNK, VEC, WEIGHTED>(a, (int64_t)blockIdx.x - seg_blocks);
 }
 
 // one block per long row: the 256/LPR lane groups each add every (256/LPR)-th segment partial
@@ -231,17 +245,19 @@ static int launch_spmm(const SpmmArgs& a, int32_t n_long, int32_t n_seg, hipStre
     constexpr int GPB = 256 / LPR;
     const int64_t blocks = ceil_div(a.n_rows, GPB);
     if (blocks > 0x7fffffffll) { set_error("spmm: too many rows for one launch"); return LLMREC_EUNSUPPORTED; }
+    const int sb = (int)ceil_div(n_seg, 4);
+    if (n_long > 0 && blocks + sb <= 0x7fffffffll) {
+        const int grid = (int)(blocks + sb);
+        if (weighted) spmm_rows_segments_kernel<LPR, NCHUNK, VEC, true><<<grid, 256, 0, stream>>>(a, sb, n_seg);
+        else spmm_rows_segments_kernel<LPR, NCHUNK, VEC, false><<<grid, 256, 0, stream>>>(a, sb, n_seg);
+        LLMREC_LAUNCH_CHECK();
+        spmm_finalize_kernel<LPR, NCHUNK, VEC><<<n_long, 256, sizeof(float) * (256 / LPR) * NCHUNK * LPR * VEC, stream>>>(a);
+        LLMREC_LAUNCH_CHECK();
+        return LLMREC_OK;
+    }
     if (blocks > 0) {
         if (weighted) spmm_rows_kernel<LPR, NCHUNK, VEC, true><<<(int)blocks, 256, 0, stream>>>(a);
         else spmm_rows_kernel<LPR, NCHUNK, VEC, false><<<(int)blocks, 256, 0, stream>>>(a);
-        LLMREC_LAUNCH_CHECK();
-    }
-    if (n_long > 0) {
-        const int sb = (int)ceil_div(n_seg, 4);
-        if (weighted) spmm_segments_kernel<LPR, NCHUNK, VEC, true><<<sb, 256, 0, stream>>>(a, n_seg);
-        else spmm_segments_kernel<LPR, NCHUNK, VEC, false><<<sb, 256, 0, stream>>>(a, n_seg);
-        LLMREC_LAUNCH_CHECK();
-        spmm_finalize_kernel<LPR, NCHUNK, VEC><<<n_long, 256, sizeof(float) * (256 / LPR) * NCHUNK * LPR * VEC, stream>>>(a);
         LLMREC_LAUNCH_CHECK();
     }
     return LLMREC_OK;
