@@ -84,7 +84,7 @@ class DataParallelStep(FusedStep):
         """forward + BPR scores + this rank's gather block."""
         if users.numel() != self.b_max:
             raise RuntimeError("DataParallelStep: every rank passes exactly b_max = %d slots (n_valid marks the used ones)" % self.b_max)
-        self.forward()
+        self._train_forward()
         self._bpr_phase(1, users, pos, neg, n_valid)
 
     def phase_b(self, users, pos, neg, n_valid=None):

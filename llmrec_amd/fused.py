@@ -66,15 +66,16 @@ class FusedStep:
         ws = max(_lib.query("llmrec_linear_wgrad_workspace_bytes", x.shape[0] * (len(self.keys) if i >= 3 else 1), d, x.shape[1])
                  for i, x in enumerate(feats))
         self.ws_wgrad = torch.empty(ws, dtype=torch.uint8, device=dev)
-        self.ws_wgrad_b = torch.empty(_lib.query("llmrec_linear_wgrad_workspace_bytes", model.user_feats.shape[0], d, model.user_feats.shape[1]),
-                                      dtype=torch.uint8, device=dev)
+        wsq = lambda x: torch.empty(_lib.query("llmrec_linear_wgrad_workspace_bytes", x.shape[0], d, x.shape[1]), dtype=torch.uint8, device=dev)
+        # one workspace per weight gradient that may be in flight at the same time (user / text / image run beside item_trans')
+        self.ws_wgrad_b, self.ws_wgrad_c, self.ws_wgrad_d = wsq(model.user_feats), wsq(model.text_feats), wsq(model.image_feats)
         self._partials = {}
         # Three independent chains (7-stream side features / LLM profile / ID embeddings) run on three
         # HIP streams in forward and in backward; under capture the fork/join becomes graph edges, so
         # the latency-bound Netflix-scale SpMMs and the four weight-gradient GEMMs overlap.
         import os as _os
         self.multi_stream = _os.environ.get("LLMREC_STREAMS", "1") == "1"
-        self.s1, self.s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.s1, self.s2, self.s3, self.s4 = (torch.cuda.Stream(device=dev) for _ in range(4))
         for p in model.parameters():
             if p.requires_grad and p.grad is None and p is not model.batch_norm.weight and p is not model.batch_norm.bias:
                 p.grad = torch.zeros_like(p)
@@ -87,6 +88,9 @@ class FusedStep:
         self.w_mf_dev = torch.tensor(self.w_mf, dtype=torch.float32, device=dev)
         self.graph_exec = None
         self.static = None
+        self._bwd_accumulators = (self.dE_u, self.dE_i, self.dU_cat, self.dI_cat, self.dprof_u, self.dprof_i)
+        self._zeroed = False
+        self._zero_in_forward = False                         # set by step_eager: forward() alone (evaluation) must not pay for it
         # forward-projection arithmetic: "bf16x3" (default) = exact 3-term bf16 split of both operands, six bf16 MFMAs,
         # fp32-roundoff-class error (2e-6 measured), 1.4x faster; "f32" = the bit-exact fp32 MFMA fma chain
         import os
@@ -180,6 +184,9 @@ class FusedStep:
         m, d = self.m, self.d
         self._fork(self.s2)
         with self._on(self.s2):                                          # ID chain: needs no projection
+            if self._zero_in_forward:                                    # the backward's scatter targets, off the critical path
+                for t in self._bwd_accumulators:
+                    t.zero_()
             i_prev = m.item_id_embedding.weight
             for l in range(self.L):
                 last = l == self.L - 1
@@ -237,11 +244,14 @@ class FusedStep:
         _call("llmrec_bpr_multi_fwd_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid),
               float(1 - hp.prune_loss_drop_rate), float(hp.decay), float(hp.batch_size), _p(self.out), _p(self.saved))
         self._feat_reg()
-        # loss values for logging: loss = sum_p w_mf[p] * mf_p + emb_0 + feat_reg
-        self.scal[2:3] = self.out[0, 0:1]
-        self.scal[3:4] = self.out[0, 1:2]
-        self.scal[1:2] = (self.out[: self.n_prob, 0] * self.w_mf_dev).sum() + self.out[0, 1] + self.scal[0]
+        # loss values for logging (off the critical path): loss = sum_p w_mf[p] * mf_p + emb_0 + feat_reg
+        self._fork(self.s3)
+        with self._on(self.s3):
+            self.scal[2:3] = self.out[0, 0:1]
+            self.scal[3:4] = self.out[0, 1:2]
+            self.scal[1:2] = (self.out[: self.n_prob, 0] * self.w_mf_dev).sum() + self.out[0, 1] + self.scal[0]
         self._backward(probs, users, pos, neg, n_valid)
+        self._join(self.s3)
 
     def _feat_reg(self):
         """Feature regulariser (main.py:151-156) over the image/text columns of both cat buffers -> scal[0]."""
@@ -257,8 +267,10 @@ class FusedStep:
         hp, d, L, S = self.hp, self.d, self.L, self.S
         B = users.numel()
         coef = hp.feat_reg_decay * 0.5 / self.I * replicated_scale
-        for t in (self.dE_u, self.dE_i, self.dU_cat, self.dI_cat, self.dprof_u, self.dprof_i):
-            t.zero_()
+        if not self._zeroed:
+            for t in self._bwd_accumulators:
+                t.zero_()
+        self._zeroed = False
         _call("llmrec_bpr_multi_bwd_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), float(hp.decay),
               float(hp.batch_size), _p(self.saved))
         self._axpy(2.0 * coef, self.I_cat, self.dI_cat, True, cols=2 * d)
@@ -297,15 +309,28 @@ class FusedStep:
         # side chain: I_cat = iu(U_cat), U_cat = ui(P_cat); then the item-side weight gradients
         self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
         self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
+        # text / image weight gradients (and their partial-slab reductions) run beside item_trans' on their own streams
+        self._fork(self.s3, self.s4)
+        with self._on(self.s3):
+            self._wgrad(self._side(self.dP_cat, 1), m.text_feats, m.text_trans, False, ws=self.ws_wgrad_c)
+        with self._on(self.s4):
+            self._wgrad(self._side(self.dP_cat, 0), m.image_feats, m.image_trans, False, ws=self.ws_wgrad_d)
         # the shared item_trans receives all attribute streams in one grouped launch (features are constants: no dX)
         ops.linear_wgrad_grouped([(self._side(self.dP_cat, 2 + k), m.item_feats[key]) for k, key in enumerate(self.keys)],
                                  m.item_trans.weight.grad, m.item_trans.bias.grad, False, self.ws_wgrad)
-        self._wgrad(self._side(self.dP_cat, 1), m.text_feats, m.text_trans, False)
-        self._wgrad(self._side(self.dP_cat, 0), m.image_feats, m.image_trans, False)
-        self._join(self.s1, self.s2)
+        self._join(self.s1, self.s2, self.s3, self.s4)
+
+    def _train_forward(self):
+        """forward() of a training step: also clears the backward's scatter targets on a side stream."""
+        self._zero_in_forward = True
+        try:
+            self.forward()
+        finally:
+            self._zero_in_forward = False
+        self._zeroed = True
 
     def step_eager(self, users, pos, neg, n_valid=None):
-        self.forward()
+        self._train_forward()
         self.loss_backward(users, pos, neg, n_valid)
         self.opt.step()
         return self.scal[1], self.scal[2], self.scal[3]
