@@ -137,16 +137,20 @@ class NetflixShaped:
         self.use_graph = os.environ.get("LLMREC_GRAPH", "1") == "1"
 
     def step(self):
-        u, p, n, nv = self.batcher.next(self.step_id)
+        """One training step. With the HIP graph: sampler + forward + losses + backward + AdamW are ONE graph
+        replay (three between the two exchanges on batch-sharded replicas); nothing else is enqueued."""
         self.step_id += 1
-        if self.use_graph and self.fused.graph_exec is None:
-            self.fused.capture(u, p, n, nv)
-            return self.fused.scal[1:4]
-        return self.fused.step(u, p, n, nv)
+        if self.use_graph:
+            if self.fused.graph_exec is None:
+                self.fused.capture(batcher=self.batcher)       # the capture's warm-up is a real step
+                return self.fused.scal[1:4]
+            return self.fused.step()
+        u, p, n, nv = self.batcher.next()
+        return self.fused.step_eager(u, p, n, nv)
 
     def step_modular(self):
         """The same step through torch.autograd over the per-op Functions (reference-shaped path)."""
-        u, p, n, nv = self.batcher.next(self.step_id)
+        u, p, n, nv = self.batcher.next()
         self.step_id += 1
         return self.engine.train_step(self.model, self.opt, self.graph.ui, self.graph.iu, u, p, n, self.hp, n_valid=nv)
 

@@ -311,6 +311,17 @@ int llmrec_topk_hits(int32_t n_query, const int64_t* query_users, int32_t K, con
 int llmrec_sample_bpr(uint64_t seed, uint64_t step, int64_t n_exist_users, const int64_t* exist_users,
                       int64_t n_items, const int32_t* train_rowptr, const int32_t* train_colidx,
                       int32_t B, int64_t* users, int64_t* pos, int64_t* neg, llmrec_stream_t stream);
+/* The whole mini-batch of one step in one single-block launch a HIP graph can replay (the step counter is
+ * device memory, advanced by the launch): slots [0, B) = this rank's slice [slice_begin, slice_begin + B) of
+ * a global batch of B_global triples drawn exactly as llmrec_sample_bpr(seed, *step_dev, ..., B_global)
+ * would; slots [B, B + n_aug) = the LLM-augmented triples of reference main.py:216-224 (n_aug distinct
+ * users of the slice, their (aug_pos[u], aug_neg[u]) kept only if both are valid item ids; kept pairs first,
+ * in draw order); n_valid_dev[0] = B + kept. users/pos/neg hold B + n_aug entries. */
+int llmrec_sample_batch(uint64_t seed, uint64_t* step_dev, int64_t n_exist_users, const int64_t* exist_users,
+                        int64_t n_items, const int32_t* train_rowptr, const int32_t* train_colidx,
+                        int32_t B_global, int32_t slice_begin, int32_t B, int32_t n_aug,
+                        const int64_t* aug_pos, const int64_t* aug_neg,
+                        int64_t* users, int64_t* pos, int64_t* neg, int32_t* n_valid_dev, llmrec_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -111,7 +111,7 @@ __device__ __forceinline__ int gather_batch(const BprGather& ga) {
     return n;
 }
 
-// selection, step 1: rank counting. grid = (ceil(B / 256), problems); each thread ranks one sample
+// selection, step 1: rank counting. grid = (ceil(B / 16), problems); each 16-lane group ranks one sample
 // against the Bg log-sigmoids staged in LDS and writes d(mf)/d(s_b) (0 when dropped) plus the kept
 // m_b into the scratch (slot 1 = sg is consumed here and overwritten with the kept value).
 // Padding slots of the gathered layout are staged as +inf: they never precede a real sample.
@@ -138,22 +138,27 @@ __global__ __launch_bounds__(256) void bpr_rank_kernel(int B_max, const int32_t*
     }
     __syncthreads();
     const int k = (int)(remember_rate * (double)Bg);                   // int((1 - drop) * len) of main.py:161-162
-    const int b = blockIdx.x * 256 + threadIdx.x;
+    // one 16-lane group per sample: the lanes split the comparison loop (integer counts: order-independent)
+    const int gl = threadIdx.x & 15;
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (b >= B_max) return;
-    if (b >= B) { saved[b] = 0.f; sc[B_max + b] = 0.f; return; }
+    if (b >= B) { if (gl == 0) { saved[b] = 0.f; sc[B_max + b] = 0.f; } return; }
     const float mb = sc[b];
     bool keep = true;
     if (k < Bg) {
         int rank = 0;
         const int me = ga.my_offset + b;
-        for (int j = 0; j < slots; ++j) {
+        for (int j = gl; j < slots; j += 16) {
             const float mj = m_s[j];
             rank += (mj < mb) || (mj == mb && j < me);
         }
+        rank = (int)group_sum<16>((float)rank);                           // < 2^24: exact
         keep = rank < k;
     }
-    saved[b] = keep ? (-1.0f / (float)k) * sc[B_max + b] : 0.f;
-    sc[B_max + b] = keep ? mb : 0.f;
+    if (gl == 0) {
+        saved[b] = keep ? (-1.0f / (float)k) * sc[B_max + b] : 0.f;
+        sc[B_max + b] = keep ? mb : 0.f;
+    }
 }
 
 // selection, step 2: one block per problem sums the kept log-sigmoids and the three squared norms
@@ -317,14 +322,12 @@ __device__ uint64_t keyed_perm(uint64_t x, uint64_t n, int half_bits, const Phil
     return x;
 }
 
-__global__ void sample_bpr_kernel(uint64_t seed, uint64_t step, int64_t n_exist, const int64_t* __restrict__ exist_users,
-                                  int64_t n_items, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                  int B, int half_bits, int64_t* __restrict__ users, int64_t* __restrict__ pos,
-                                  int64_t* __restrict__ neg) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const Philox ph(seed);
-    const uint32_t slo = (uint32_t)step, shi = (uint32_t)(step >> 32);
+// one BPR triple of the global batch: user slot b of B (without replacement while B <= n_exist), a uniform
+// train item of that user, a uniform non-train item by rejection (binary search in the sorted row)
+__device__ __forceinline__ void sample_one(const Philox& ph, uint32_t slo, uint32_t shi, int b, int B, int half_bits,
+                                           int64_t n_exist, const int64_t* __restrict__ exist_users, int64_t n_items,
+                                           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                           int64_t& u_out, int64_t& p_out, int64_t& q_out) {
     // users: without replacement while B <= n_exist (rd.sample), with replacement otherwise (rd.choice)
     uint64_t slot;
     if ((int64_t)B <= n_exist) {
@@ -353,7 +356,72 @@ __global__ void sample_bpr_kernel(uint64_t seed, uint64_t step, int64_t n_exist,
         }
         if (!(lo < e && colidx[lo] == q)) break;                        // not a train item: accept
     }
-    users[b] = u; pos[b] = p; neg[b] = q;
+    u_out = u; p_out = p; q_out = q;
+}
+
+__global__ void sample_bpr_kernel(uint64_t seed, uint64_t step, int64_t n_exist, const int64_t* __restrict__ exist_users,
+                                  int64_t n_items, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                  int B, int half_bits, int64_t* __restrict__ users, int64_t* __restrict__ pos,
+                                  int64_t* __restrict__ neg) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const Philox ph(seed);
+    sample_one(ph, (uint32_t)step, (uint32_t)(step >> 32), b, B, half_bits, n_exist, exist_users, n_items, rowptr, colidx,
+               users[b], pos[b], neg[b]);
+}
+
+// The whole mini-batch of one step in ONE single-block launch that a HIP graph can replay: the step counter
+// lives on the device and is advanced here. Slots [0, B): this rank's slice [slice_begin, slice_begin + B) of
+// the global batch of B_global triples. Slots [B, B + n_aug): the LLM-augmented triples of reference
+// main.py:216-224 - n_aug distinct users of the slice (random.sample), their (aug_pos, aug_neg) pair kept
+// only if both ids are < n_items; kept pairs first, in draw order, then padding; n_valid = B + kept.
+constexpr int SAMPLE_THREADS = 1024;
+__global__ __launch_bounds__(SAMPLE_THREADS) void sample_batch_kernel(
+    uint64_t seed, unsigned long long* __restrict__ step_dev, int64_t n_exist, const int64_t* __restrict__ exist_users,
+    int64_t n_items, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+    int B_global, int half_bits_users, int slice_begin, int B, int n_aug, int half_bits_batch,
+    const int64_t* __restrict__ aug_pos, const int64_t* __restrict__ aug_neg,
+    int64_t* __restrict__ users, int64_t* __restrict__ pos, int64_t* __restrict__ neg, int32_t* __restrict__ n_valid_dev) {
+    __shared__ int wave_tot[SAMPLE_THREADS / 64];
+    __shared__ int base_s;
+    const unsigned long long step = *step_dev;
+    const uint32_t slo = (uint32_t)step, shi = (uint32_t)(step >> 32);
+    const Philox ph(seed);
+    for (int b = threadIdx.x; b < B; b += SAMPLE_THREADS)
+        sample_one(ph, slo, shi, slice_begin + b, B_global, half_bits_users, n_exist, exist_users, n_items, rowptr, colidx,
+                   users[b], pos[b], neg[b]);
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();                                                    // the slice is written (block-visible); everyone has read the step
+    const Philox pa(seed ^ 0x9E3779B97F4A7C15ull);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int a0 = 0; a0 < n_aug; a0 += SAMPLE_THREADS) {               // block-uniform
+        const int a = a0 + threadIdx.x;
+        int64_t u = 0, ap = 0, an = 0;
+        bool ok = false;
+        if (a < n_aug) {
+            const uint64_t slot = keyed_perm((uint64_t)a, (uint64_t)B, half_bits_batch, pa, slo, shi);   // distinct slots of the slice
+            u = users[slot];
+            ap = aug_pos[u]; an = aug_neg[u];
+            ok = ap >= 0 && an >= 0 && ap < n_items && an < n_items;
+        }
+        const unsigned long long bal = __ballot(ok);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wv] = __popcll(bal);
+        __syncthreads();
+        int wave_base = 0, chunk_tot = 0;
+        for (int k = 0; k < SAMPLE_THREADS / 64; ++k) { const int t = wave_tot[k]; if (k < wv) wave_base += t; chunk_tot += t; }
+        const int base = base_s;
+        if (a < n_aug && ok) {
+            const int o = B + base + wave_base + before;
+            users[o] = u; pos[o] = ap; neg[o] = an;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base_s = base + chunk_tot;
+        __syncthreads();
+    }
+    const int kept = base_s;
+    for (int o = B + kept + threadIdx.x; o < B + n_aug; o += SAMPLE_THREADS) { users[o] = 0; pos[o] = 0; neg[o] = 0; }   // padding (never read: beyond n_valid)
+    if (threadIdx.x == 0) { n_valid_dev[0] = B + kept; *step_dev = step + 1ull; }
 }
 
 }  // namespace llmrec
@@ -381,7 +449,7 @@ static int launch_bpr_fwd(const BprTables& t, int n_prob, int d, const int64_t* 
     }
     if (do_select) {
         const size_t shmem = sizeof(float) * (size_t)(ga.g ? ga.n_ranks * ga.cap : (B_max > 0 ? B_max : 1));
-        dim3 grid((unsigned)ceil_div(B_max > 0 ? B_max : 1, 256), (unsigned)n_prob);
+        dim3 grid((unsigned)ceil_div(B_max > 0 ? B_max : 1, 16), (unsigned)n_prob);
         bpr_rank_kernel<<<grid, 256, shmem, stream>>>(B_max, n_valid_dev, remember_rate, saved, stride, ga);
         LLMREC_LAUNCH_CHECK();
         bpr_reduce_kernel<<<n_prob, BPR_THREADS, 0, stream>>>(B_max, n_valid_dev, remember_rate, decay, bsz, out, saved, stride, ga);
@@ -522,6 +590,27 @@ int llmrec_sample_bpr(uint64_t seed, uint64_t step, int64_t n_exist_users, const
     while ((1ull << (2 * half_bits)) < (uint64_t)n_exist_users) ++half_bits;
     sample_bpr_kernel<<<(B + 255) / 256, 256, 0, (hipStream_t)stream_>>>(seed, step, n_exist_users, exist_users, n_items,
                                                                           train_rowptr, train_colidx, B, half_bits, users, pos, neg);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_sample_batch(uint64_t seed, uint64_t* step_dev, int64_t n_exist_users, const int64_t* exist_users,
+                        int64_t n_items, const int32_t* train_rowptr, const int32_t* train_colidx,
+                        int32_t B_global, int32_t slice_begin, int32_t B, int32_t n_aug,
+                        const int64_t* aug_pos, const int64_t* aug_neg,
+                        int64_t* users, int64_t* pos, int64_t* neg, int32_t* n_valid_dev, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(B >= 1 && B_global >= B && slice_begin >= 0 && slice_begin + B <= B_global && n_aug >= 0 && n_aug <= B &&
+                     n_exist_users > 0 && n_items > 0, "sample_batch: bad sizes");
+    LLMREC_CHECK_ARG(step_dev && exist_users && train_rowptr && train_colidx && users && pos && neg && n_valid_dev,
+                     "sample_batch: null pointer");
+    LLMREC_CHECK_ARG(n_aug == 0 || (aug_pos && aug_neg), "sample_batch: augmented pairs missing");
+    int hb_users = 1, hb_batch = 1;
+    while ((1ull << (2 * hb_users)) < (uint64_t)n_exist_users) ++hb_users;
+    while ((1ull << (2 * hb_batch)) < (uint64_t)B) ++hb_batch;
+    sample_batch_kernel<<<1, SAMPLE_THREADS, 0, (hipStream_t)stream_>>>(seed, (unsigned long long*)step_dev, n_exist_users, exist_users,
+                                                                       n_items, train_rowptr, train_colidx, B_global, hb_users,
+                                                                       slice_begin, B, n_aug, hb_batch, aug_pos, aug_neg,
+                                                                       users, pos, neg, n_valid_dev);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

@@ -90,11 +90,14 @@ class DataParallelStep(FusedStep):
     def phase_b(self, users, pos, neg, n_valid=None):
         """selection against the gathered global batch + backward into the gradient bucket."""
         self._bpr_phase(2, users, pos, neg, n_valid)
-        self._feat_reg()
         P = self.n_prob
-        self.tail[:P] = self.out[:P, 0]                                  # this rank's shares of the mf values
-        self.tail[P:P + 1] = (self.out[0, 1:2] + self.scal[0:1]) * (1.0 / self.world)   # emb + feat_reg: identical on all ranks
+        self._fork(self.s3)
+        with self._on(self.s3):                                          # loss scalars for the bucket's tail, off the critical path
+            self._feat_reg()
+            self.tail[:P] = self.out[:P, 0]                              # this rank's shares of the mf values
+            self.tail[P:P + 1] = (self.out[0, 1:2] + self.scal[0:1]) * (1.0 / self.world)   # emb + feat_reg: identical on all ranks
         self._backward(self._problems(), users, pos, neg, n_valid, replicated_scale=1.0 / self.world)
+        self._join(self.s3)
 
     def phase_c(self):
         """loss scalars from the reduced tail + AdamW."""
@@ -127,21 +130,29 @@ class DataParallelStep(FusedStep):
         return self.scal[1], self.scal[2], self.scal[3]
 
     # -- HIP graphs -------------------------------------------------------------------------------
-    def capture(self, warm_users, warm_pos, warm_neg, warm_n_valid=None):
-        dev = self.E_u.device
-        st = {"users": torch.zeros(self.b_max, dtype=torch.int64, device=dev), "pos": torch.zeros(self.b_max, dtype=torch.int64, device=dev),
-              "neg": torch.zeros(self.b_max, dtype=torch.int64, device=dev), "n_valid": torch.zeros(1, dtype=torch.int32, device=dev)}
-        self.static = st
-        self._load(warm_users, warm_pos, warm_neg, warm_n_valid)
+    def capture(self, warm_users=None, warm_pos=None, warm_neg=None, warm_n_valid=None, batcher=None):
+        """Three graphs between the two exchanges; with `batcher` the sampler opens the first one."""
+        st = self._make_static()
+        self.batcher = batcher
+        if batcher is not None:
+            if batcher.capacity != self.b_max:
+                raise RuntimeError("DataParallelStep.capture: batcher capacity %d != b_max %d" % (batcher.capacity, self.b_max))
+        else:
+            self._load(warm_users, warm_pos, warm_neg, warm_n_valid)
         args = (st["users"], st["pos"], st["neg"], st["n_valid"])
+
+        def first():
+            if batcher is not None:
+                batcher.fill(*args)
+            self.phase_a(*args)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):                             # warm-up: one full eager step (also warms the collectives)
-            self.step_eager(*args)
+            first(); self.exchange_scores(); self.phase_b(*args); self.exchange_grads(); self.phase_c()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         graphs = []
-        for fn in (lambda: self.phase_a(*args), lambda: self.phase_b(*args), self.phase_c):
+        for fn in (first, lambda: self.phase_b(*args), self.phase_c):
             g = torch.cuda.CUDAGraph()                         # capturing records, it does not execute: one step ran (the warm-up)
             with torch.cuda.graph(g):
                 fn()
@@ -149,10 +160,15 @@ class DataParallelStep(FusedStep):
         self.graphs = graphs
         self.graph_exec = graphs[0]
 
-    def step(self, users, pos, neg, n_valid=None):
+    def step(self, users=None, pos=None, neg=None, n_valid=None):
         if self.graphs is None:
             return self.step_eager(users, pos, neg, n_valid)
-        self._load(users, pos, neg, n_valid)
+        if users is not None:
+            if getattr(self, "batcher", None) is not None:
+                raise RuntimeError("DataParallelStep.step: this graph samples its own batch; call step() without arguments")
+            self._load(users, pos, neg, n_valid)
+        elif getattr(self, "batcher", None) is None:
+            raise RuntimeError("DataParallelStep.step: a batch is needed (the graphs were captured without a sampler)")
         ga, gb, gc = self.graphs
         ga.replay()
         self.exchange_scores()

@@ -73,42 +73,42 @@ def train_step(model, optimizer, ui, iu, users, pos, neg, hp: Hyper, n_valid=Non
 
 
 class DeviceBatcher:
-    """On-device mini-batch construction: BPR triples from the HIP sampler plus the LLM-augmented
-    triples of reference main.py:216-224, with no host synchronisation. The number of valid
-    triples stays on the device (``n_valid``), so a captured graph can replay the step.
+    """On-device mini-batch construction in ONE launch (llmrec_sample_batch): BPR triples from the HIP
+    sampler plus the LLM-augmented triples of reference main.py:216-224, no host synchronisation. The
+    number of valid triples and the step counter stay on the device, so a captured graph can contain
+    the sampler and a training step is a single graph replay.
 
     aug_pos / aug_neg: int64 [n_users] device arrays (the augmented_sample_dict columns); a pair
-    is used only if both ids are < n_items, as in the reference."""
+    is used only if both ids are < n_items, as in the reference.
+    rank/world: batch-sharded replicas (llmrec_amd.dp) - the sampler draws the GLOBAL batch of
+    world * batch_size users (one keyed permutation, so still without replacement) and this rank
+    keeps its slice; augmented triples are drawn from the slice."""
 
     def __init__(self, train: ops.Csr, exist_users: torch.Tensor, n_items: int, batch_size: int,
                  aug_pos: Optional[torch.Tensor], aug_neg: Optional[torch.Tensor], aug_rate: float, seed: int,
                  rank: int = 0, world: int = 1):
-        """rank/world: batch-sharded replicas (llmrec_amd.dp) - the sampler draws the GLOBAL batch of
-        world * batch_size users (one keyed permutation, so still without replacement) and this rank
-        keeps its slice; augmented triples are drawn from the slice."""
         self.train, self.exist_users, self.n_items, self.B = train, exist_users, n_items, batch_size
         self.rank, self.world = rank, world
         self.aug_pos, self.aug_neg = aug_pos, aug_neg
         self.n_aug = int(batch_size * aug_rate) if aug_pos is not None else 0
         self.seed = seed
-        self.gen = torch.Generator(device=exist_users.device)
-        self.gen.manual_seed(seed + rank)
+        self.capacity = self.B + self.n_aug
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=exist_users.device)
 
-    def next(self, step: int):
-        u, p, n = ops.sample_bpr(self.seed, step, self.exist_users, self.n_items, self.train, self.B * self.world)
-        if self.world > 1:
-            lo, hi = self.rank * self.B, (self.rank + 1) * self.B
-            u, p, n = u[lo:hi], p[lo:hi], n[lo:hi]
-        if self.n_aug == 0:
-            return u, p, n, None
-        pick = u[torch.randperm(self.B, generator=self.gen, device=u.device)[: self.n_aug]]    # random.sample(users, k)
-        ap, an = self.aug_pos[pick], self.aug_neg[pick]
-        ok = (ap < self.n_items) & (an < self.n_items)
-        order = torch.argsort((~ok).to(torch.int8), stable=True)                                # valid pairs first
-        ap = torch.where(ok, ap, torch.zeros_like(ap))[order]
-        an = torch.where(ok, an, torch.zeros_like(an))[order]
-        n_valid = (self.B + ok.sum()).to(torch.int32).reshape(1)
-        return torch.cat([u, pick[order]]), torch.cat([p, ap]), torch.cat([n, an]), n_valid
+    def fill(self, users, pos, neg, n_valid):
+        """Sample the next step's batch into the given buffers (capacity entries each); advances the device counter."""
+        ops.sample_batch(self.seed, self.step_dev, self.exist_users, self.n_items, self.train, self.B * self.world,
+                         self.rank * self.B, self.B, self.n_aug, self.aug_pos, self.aug_neg, users, pos, neg, n_valid)
+
+    def next(self, step: Optional[int] = None):
+        """(users, pos, neg, n_valid) in fresh buffers; step = None continues the device counter."""
+        dev = self.exist_users.device
+        if step is not None:
+            self.step_dev.fill_(int(step))
+        u, p, n = (torch.empty(self.capacity, dtype=torch.int64, device=dev) for _ in range(3))
+        nv = torch.empty(1, dtype=torch.int32, device=dev)
+        self.fill(u, p, n, nv)
+        return u, p, n, nv
 
 
 @torch.no_grad()

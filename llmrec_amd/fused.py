@@ -205,14 +205,19 @@ class FusedStep:
         self._spmm(self.ui.fwd, self.P_cat, self.U_cat)                  # 7 streams, one adjacency pass
         self._spmm(self.iu.fwd, self.U_cat, self.I_cat)
         self._join(self.s1, self.s2)
-        for out, base, layers, cat, prof in ((self.E_u, m.user_id_embedding.weight, self.Ul, self.U_cat, self.prof_u),
-                                             (self.E_i, m.item_id_embedding.weight, self.Il, self.I_cat, self.prof_i)):
+
+        def fuse(out, base, layers, cat, prof):
             means = [base] + layers
             norms = self._norm_terms(cat, prof)
             mp, ml = self._tables(means)
             npt, nl = self._tables(norms)
             _call("llmrec_fuse_fwd_f32", out.shape[0], d, 1.0 / len(means), len(means), mp, ml, len(norms), npt, nl, self._rates(),
                   _p(out), _ld(out))
+        self._fork(self.s3)
+        with self._on(self.s3):                                          # the item table beside the user table
+            fuse(self.E_i, m.item_id_embedding.weight, self.Il, self.I_cat, self.prof_i)
+        fuse(self.E_u, m.user_id_embedding.weight, self.Ul, self.U_cat, self.prof_u)
+        self._join(self.s3)
 
     def outputs(self):
         """The reference's 14-tuple as views of the forward buffers (Models.py:199)."""
@@ -243,10 +248,10 @@ class FusedStep:
         hp = self.hp
         _call("llmrec_bpr_multi_fwd_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid),
               float(1 - hp.prune_loss_drop_rate), float(hp.decay), float(hp.batch_size), _p(self.out), _p(self.saved))
-        self._feat_reg()
-        # loss values for logging (off the critical path): loss = sum_p w_mf[p] * mf_p + emb_0 + feat_reg
+        # feature regulariser value + loss values for logging, off the critical path: loss = sum_p w_mf[p] * mf_p + emb_0 + feat_reg
         self._fork(self.s3)
         with self._on(self.s3):
+            self._feat_reg()
             self.scal[2:3] = self.out[0, 0:1]
             self.scal[3:4] = self.out[0, 1:2]
             self.scal[1:2] = (self.out[: self.n_prob, 0] * self.w_mf_dev).sum() + self.out[0, 1] + self.scal[0]
@@ -273,14 +278,17 @@ class FusedStep:
         self._zeroed = False
         _call("llmrec_bpr_multi_bwd_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), float(hp.decay),
               float(hp.batch_size), _p(self.saved))
-        self._axpy(2.0 * coef, self.I_cat, self.dI_cat, True, cols=2 * d)
-        self._axpy(2.0 * coef, self.U_cat, self.dU_cat, True, cols=2 * d)
-        for dout, cat, prof, dcat, dprof in ((self.dE_u, self.U_cat, self.prof_u, self.dU_cat, self.dprof_u),
-                                             (self.dE_i, self.I_cat, self.prof_i, self.dI_cat, self.dprof_i)):
+        def fuse_bwd(dout, cat, prof, dcat, dprof):
+            self._axpy(2.0 * coef, cat, dcat, True, cols=2 * d)          # feature regulariser: image / text columns
             norms, dnorms = self._norm_terms(cat, prof), self._norm_terms(dcat, dprof)
             npt, nl = self._tables(norms)
             dp, dl = self._tables(dnorms)
             _call("llmrec_fuse_bwd_f32", dout.shape[0], d, _p(dout), _ld(dout), len(norms), npt, nl, self._rates(), dp, dl, 1)
+        self._fork(self.s4)
+        with self._on(self.s4):                                          # item side beside the user side
+            fuse_bwd(self.dE_i, self.I_cat, self.prof_i, self.dI_cat, self.dprof_i)
+        fuse_bwd(self.dE_u, self.U_cat, self.prof_u, self.dU_cat, self.dprof_u)
+        self._join(self.s4)
         m = self.m
         inv = 1.0 / (L + 1)
         self._fork(self.s1, self.s2)
@@ -336,22 +344,37 @@ class FusedStep:
         return self.scal[1], self.scal[2], self.scal[3]
 
     # -- HIP graph --------------------------------------------------------------------------------
-    def capture(self, warm_users, warm_pos, warm_neg, warm_n_valid=None):
-        """Capture one step (fixed batch capacity b_max, actual size on the device in n_valid)."""
+    def _make_static(self):
         dev = self.E_u.device
-        st = {"users": torch.zeros(self.b_max, dtype=torch.int64, device=dev), "pos": torch.zeros(self.b_max, dtype=torch.int64, device=dev),
-              "neg": torch.zeros(self.b_max, dtype=torch.int64, device=dev), "n_valid": torch.zeros(1, dtype=torch.int32, device=dev)}
-        self.static = st
-        self._load(warm_users, warm_pos, warm_neg, warm_n_valid)
+        self.static = {"users": torch.zeros(self.b_max, dtype=torch.int64, device=dev), "pos": torch.zeros(self.b_max, dtype=torch.int64, device=dev),
+                       "neg": torch.zeros(self.b_max, dtype=torch.int64, device=dev), "n_valid": torch.zeros(1, dtype=torch.int32, device=dev)}
+        return self.static
+
+    def capture(self, warm_users=None, warm_pos=None, warm_neg=None, warm_n_valid=None, batcher=None):
+        """Capture one step (fixed batch capacity b_max, actual size on the device in n_valid).
+        With `batcher` (engine.DeviceBatcher, capacity == b_max) the sampler is part of the graph: a
+        training step is then ``step()`` with no arguments = one graph replay, nothing else on the stream."""
+        st = self._make_static()
+        self.batcher = batcher
+        if batcher is not None:
+            if batcher.capacity != self.b_max:
+                raise RuntimeError("FusedStep.capture: batcher capacity %d != b_max %d" % (batcher.capacity, self.b_max))
+        else:
+            self._load(warm_users, warm_pos, warm_neg, warm_n_valid)
+
+        def one_step():
+            if batcher is not None:
+                batcher.fill(st["users"], st["pos"], st["neg"], st["n_valid"])
+            self.step_eager(st["users"], st["pos"], st["neg"], st["n_valid"])
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):                             # warm-up on a side stream (allocations, plan caches)
-            self.step_eager(st["users"], st["pos"], st["neg"], st["n_valid"])
+            one_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.step_eager(st["users"], st["pos"], st["neg"], st["n_valid"])
+            one_step()
         self.graph_exec = g
 
     def _load(self, users, pos, neg, n_valid):
@@ -364,10 +387,16 @@ class FusedStep:
         else:
             st["n_valid"].copy_(n_valid)
 
-    def step(self, users, pos, neg, n_valid=None):
-        """One training step; replays the captured graph when there is one."""
+    def step(self, users=None, pos=None, neg=None, n_valid=None):
+        """One training step; replays the captured graph when there is one (no arguments when the
+        sampler was captured with it)."""
         if self.graph_exec is None:
             return self.step_eager(users, pos, neg, n_valid)
-        self._load(users, pos, neg, n_valid)
+        if users is not None:
+            if getattr(self, "batcher", None) is not None:
+                raise RuntimeError("FusedStep.step: this graph samples its own batch; call step() without arguments")
+            self._load(users, pos, neg, n_valid)
+        elif getattr(self, "batcher", None) is None:
+            raise RuntimeError("FusedStep.step: a batch is needed (the graph was captured without a sampler)")
         self.graph_exec.replay()
         return self.scal[1], self.scal[2], self.scal[3]

@@ -607,3 +607,15 @@ def sample_bpr(seed: int, step: int, exist_users: torch.Tensor, n_items: int, tr
     _lib.call("llmrec_sample_bpr", seed, step, exist_users.numel(), _p(exist_users), n_items, _p(train.rowptr), _p(train.colidx),
               B, _p(u), _p(p), _p(n), _stream())
     return u, p, n
+
+
+def sample_batch(seed: int, step_dev: torch.Tensor, exist_users: torch.Tensor, n_items: int, train: Csr, B_global: int,
+                 slice_begin: int, B: int, n_aug: int, aug_pos: Optional[torch.Tensor], aug_neg: Optional[torch.Tensor],
+                 users: torch.Tensor, pos: torch.Tensor, neg: torch.Tensor, n_valid: torch.Tensor):
+    """llmrec_sample_batch: this rank's slice of the step's BPR triples + the LLM-augmented triples, written
+    into the given (static) buffers; step_dev (int64[1], device) is the step counter the launch advances."""
+    _need_gpu(step_dev, exist_users, users, pos, neg, n_valid)
+    if users.numel() < B + n_aug or step_dev.dtype != torch.int64 or n_valid.dtype != torch.int32:
+        raise RuntimeError("sample_batch: buffers of B + n_aug int64 entries, int64 step counter, int32 n_valid expected")
+    _lib.call("llmrec_sample_batch", seed, _p(step_dev), exist_users.numel(), _p(exist_users), n_items, _p(train.rowptr), _p(train.colidx),
+              B_global, slice_begin, B, n_aug, _p(aug_pos), _p(aug_neg), _p(users), _p(pos), _p(neg), _p(n_valid), _stream())

@@ -478,3 +478,43 @@ def test_device_sampler_properties(ops):
     # B > n_exist -> with replacement
     u, _, _ = ops.sample_bpr(1, 0, exist[:50], I, csr, 128)
     assert u.numel() == 128 and set(u.cpu().tolist()) <= set(exist[:50].cpu().tolist())
+
+
+def test_sample_batch_one_launch_with_augmented_triples(ops):
+    """llmrec_sample_batch: slice of the global batch == llmrec_sample_bpr's triples; augmented triples are
+    distinct users of the slice with both ids valid, kept pairs first; device step counter advances; two ranks'
+    slices tile the global batch."""
+    rng = np.random.default_rng(8)
+    U, I, B, W = 700, 300, 96, 2
+    train_items = {u: sorted(rng.choice(I, size=int(rng.integers(1, 40)), replace=False).tolist()) for u in range(U)}
+    csr = _train_csr(ops, train_items, U, I)
+    exist = torch.arange(U, dtype=torch.int64, device=DEV)
+    aug_pos = torch.tensor(rng.integers(0, int(I * 1.3), size=U), device=DEV)      # ~23 % of the ids are out of range
+    aug_neg = torch.tensor(rng.integers(0, int(I * 1.3), size=U), device=DEV)
+    n_aug = 31
+    for step in (0, 5):
+        want = [t.cpu() for t in ops.sample_bpr(77, step, exist, I, csr, B * W)]
+        for r in range(W):
+            step_dev = torch.tensor([step], dtype=torch.int64, device=DEV)
+            u, p, n = (torch.full((B + n_aug,), -7, dtype=torch.int64, device=DEV) for _ in range(3))
+            nv = torch.zeros(1, dtype=torch.int32, device=DEV)
+            ops.sample_batch(77, step_dev, exist, I, csr, B * W, r * B, B, n_aug, aug_pos, aug_neg, u, p, n, nv)
+            assert int(step_dev) == step + 1
+            u, p, n = u.cpu(), p.cpu(), n.cpu()
+            for got, ref in zip((u, p, n), want):
+                assert torch.equal(got[:B], ref[r * B:(r + 1) * B])
+            kept = int(nv) - B
+            assert 0 < kept < n_aug
+            au, ap, an = u[B:B + kept].tolist(), p[B:B + kept].tolist(), n[B:B + kept].tolist()
+            assert len(set(au)) == kept and set(au) <= set(u[:B].tolist())
+            ap_all, an_all = aug_pos.cpu(), aug_neg.cpu()
+            for uu, pp, nn_ in zip(au, ap, an):
+                assert pp == int(ap_all[uu]) and nn_ == int(an_all[uu]) and pp < I and nn_ < I
+            # every drawn user whose pair is valid was kept: the dropped ones are exactly the invalid pairs
+            assert torch.equal(u[B + kept:], torch.zeros(n_aug - kept, dtype=torch.int64))
+    # run-to-run determinism
+    a = ops.sample_bpr(77, 5, exist, I, csr, B)
+    sd = torch.tensor([5], dtype=torch.int64, device=DEV)
+    u2 = torch.empty(B, dtype=torch.int64, device=DEV); p2 = torch.empty_like(u2); n2 = torch.empty_like(u2)
+    ops.sample_batch(77, sd, exist, I, csr, B, 0, B, 0, None, None, u2, p2, n2, torch.zeros(1, dtype=torch.int32, device=DEV))
+    assert torch.equal(a[0], u2) and torch.equal(a[1], p2) and torch.equal(a[2], n2)
