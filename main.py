@@ -206,6 +206,34 @@ class Trainer(object):
                 self._fused = False
         return self._fused
 
+    def _device_batcher(self):
+        """engine.DeviceBatcher over the training CSR and the augmented_sample_dict (LLMREC_DEVICE_SAMPLER=1)."""
+        if getattr(self, "_batcher", None) is None:
+            st = data_generator.device_state(device)
+            aug = self.augmented_sample_dict
+            big = np.iinfo(np.int64).max
+            ap = np.full(self.n_users, big, dtype=np.int64); an = np.full(self.n_users, big, dtype=np.int64)
+            for u_, pair in aug.items():
+                if 0 <= int(u_) < self.n_users:
+                    ap[int(u_)], an[int(u_)] = int(pair[0]), int(pair[1])
+            self._batcher = engine.DeviceBatcher(st["train"], st["exist_users"], self.n_items, self.batch_size,
+                                                 torch.from_numpy(ap).to(device), torch.from_numpy(an).to(device),
+                                                 args.aug_sample_rate, args.seed)
+        return self._batcher
+
+    def train_step_sampled(self):
+        """LLMREC_DEVICE_SAMPLER=1 + LLMREC_GRAPH=1: sampler, forward, the 8 losses, backward and AdamW are ONE
+        HIP-graph replay (the sampler's step counter lives on the device); nothing else is enqueued per step."""
+        fused = self._fused_step()
+        self.model_mm.train()
+        if fused.graph_exec is None:
+            fused.capture(batcher=self._device_batcher())        # the capture's warm-up is a real step
+            out = (fused.scal[1].clone(), fused.scal[2].clone(), fused.scal[3].clone())
+        else:
+            out = tuple(x.clone() for x in fused.step())
+        self._global_step += 1
+        return out
+
     def train_step(self, users, pos_items, neg_items, n_valid=None):
         """Forward, the 8 BPR(+prune) losses, feature regulariser, backward, AdamW.
         Returns the device scalars (batch_loss, mf_loss, emb_loss)."""
@@ -249,16 +277,20 @@ class Trainer(object):
         stopping_step = 0
         best_recall = 0
         test_ret = None
+        in_graph_sampler = bool(self._device_sampler and os.environ.get("LLMREC_GRAPH", "0") == "1" and self._fused_step())
         for epoch in range(args.epoch):
             t1 = time()
             n_batch = data_generator.n_train // args.batch_size + 1
             sums = torch.zeros(3, dtype=torch.float64, device=device)
             sample_time = 0.
             for idx in _progress(range(n_batch)):
-                sample_t1 = time()
-                users, pos_items, neg_items = self.sample_batch()
-                sample_time += time() - sample_t1
-                parts = self.train_step(users, pos_items, neg_items)
+                if in_graph_sampler:
+                    parts = self.train_step_sampled()
+                else:
+                    sample_t1 = time()
+                    users, pos_items, neg_items = self.sample_batch()
+                    sample_time += time() - sample_t1
+                    parts = self.train_step(users, pos_items, neg_items)
                 sums += torch.stack(parts).double()
             loss, mf_loss, emb_loss = (float(x) for x in sums.cpu())     # one sync per epoch
             reg_loss, contrastive_loss = 0., 0.

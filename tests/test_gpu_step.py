@@ -99,6 +99,28 @@ def test_device_sampler_epoch_runs(golden):
         os.environ.pop("LLMREC_DEVICE_SAMPLER", None)
 
 
+def test_in_graph_sampler_steps_run_and_learn(golden, monkeypatch):
+    """LLMREC_DEVICE_SAMPLER=1 + LLMREC_GRAPH=1: a step is one graph replay that samples its own batch
+    (llmrec_sample_batch with the device step counter). Batches differ step to step, the loss is finite
+    and the parameters move."""
+    monkeypatch.setenv("LLMREC_DEVICE_SAMPLER", "1"); monkeypatch.setenv("LLMREC_GRAPH", "1"); monkeypatch.setenv("LLMREC_FUSED", "1")
+    m = load_dropin(golden_argv(golden))
+    m.set_seed(1)
+    tr = m.Trainer(data_config={})
+    before = tr.model_mm.item_id_embedding.weight.detach().clone()
+    seen = []
+    for _ in range(4):
+        loss, mf, emb = tr.train_step_sampled()
+        assert np.isfinite(float(loss)) and float(mf) > 0
+        st = tr._fused_step().static
+        nv = int(st["n_valid"])
+        assert golden.args["batch_size"] <= nv <= tr._fused_step().b_max
+        seen.append(st["users"][:nv].cpu().clone())
+    assert int(tr._device_batcher().step_dev) == 4              # the capture call runs one real (warm-up) step, recording does not execute
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+    assert not torch.equal(before, tr.model_mm.item_id_embedding.weight.detach())
+
+
 def test_sharded_trainer_single_rank_matches_oracle():
     """llmrec_amd/dist.py on the HIP backend with a world of one rank (collectives are identities):
     the two-pass sharded BPR and the sharded SpMM operands must reproduce the oracle's steps."""
