@@ -126,6 +126,12 @@ typedef struct { const float* dY; int64_t lddy; const float* X; int64_t ldx; int
 int llmrec_linear_wgrad_grouped_f32(int32_t n_problems, const llmrec_wgrad_problem_t* problems_host, int32_t N, int32_t K,
                                     float* dW, int64_t lddw, float* db, int32_t accumulate,
                                     void* workspace, int64_t workspace_bytes, llmrec_stream_t stream);
+/* Same contract, split-precision arithmetic (three-term bf16 split of both operands, six bf16 MFMAs per tile pair,
+ * fp32 accumulate: fp32-roundoff-class error, bound by the X stream from HBM instead of the fp32 matrix pipe).
+ * Shapes outside the fast path (N % 64, K % 64, 16-byte aligned rows) run the exact fp32 kernel. */
+int llmrec_linear_wgrad_grouped_bf16x3(int32_t n_problems, const llmrec_wgrad_problem_t* problems_host, int32_t N, int32_t K,
+                                       float* dW, int64_t lddw, float* db, int32_t accumulate,
+                                       void* workspace, int64_t workspace_bytes, llmrec_stream_t stream);
 /* Same contract, split precision: each fp32 operand = exact sum of three bf16 numbers, product by the
  * six bf16 MFMAs (v_mfma_f32_16x16x32_bf16, fp32 accumulate) whose terms are >= 2^-24 relative.
  * fp32-roundoff-class error (not the bit-identical fma chain); 3/8 of the fp32 matrix time, so the

@@ -615,6 +615,150 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(WgradGroup g, int 
     }
 }
 
+// Split-precision weight gradient ("bf16x3", see the forward above): same wave tile (64 n x 64 k, interleaved
+// 16-wide tiles, coalesced float4 rows of dY and X), 32 rows per step = one v_mfma_f32_16x16x32_bf16 per
+// (tile pair, term): lane (li, lq) supplies the rows m0 + 4 j + lq (j = 0..7) of its n / k column to the 8
+// contraction slots of its lane group - any row -> slot map works as long as A and B agree. Each fp32 operand is
+// split in registers into hi + mid + lo bf16 (exact), six MFMAs per tile pair keep every term >= 2^-24: 96 MFMAs
+// x 16 cycles per 32 rows instead of 128 x 32 cycles per 32 rows in the fp32 chain, so the kernel is bound by
+// the X stream from HBM instead of the matrix pipe. One wave per SIMD (stages + split need > 256 registers).
+template <bool UNUSED = true>
+__global__ __launch_bounds__(256, 1) void linear_wgrad_bf16x3_kernel(WgradGroup g, int N, int K, float* __restrict__ partial,
+                                                                   float* __restrict__ partial_db, int64_t MC, int n_kslab, int n_slabs) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    // the four waves of a block take four consecutive slabs of ONE k slab and are summed through LDS in wave
+    // order before anything is written: a quarter of the partial-slab traffic (all problems feed the same dW)
+    __shared__ __attribute__((aligned(16))) float red[3][64 * 64 + 64];
+    const int kslab = (int)(blockIdx.x % n_kslab);
+    const int group = (int)(blockIdx.x / n_kslab);
+    const int slab_raw = group * 4 + wave;
+    const bool active = slab_raw < n_slabs;
+    const int slab = active ? slab_raw : n_slabs - 1;             // idle waves of the last group recompute a slab and drop it
+    int prob = 0;
+    while (prob + 1 < g.n_problems && slab >= g.chunk_begin[prob + 1]) ++prob;
+    const float* __restrict__ dY = g.dY[prob];
+    const float* __restrict__ X = g.X[prob];
+    const int64_t lddy = g.lddy[prob], ldx = g.ldx[prob], M = g.M[prob];
+    const int nblk = blockIdx.y;
+    const int64_t m_begin = (int64_t)(slab - g.chunk_begin[prob]) * MC;
+    const int64_t m_end = (m_begin + MC < M) ? m_begin + MC : M;
+    const int n_base = nblk * 64 + 4 * li;
+    const int k_base = kslab * 64 + 4 * li;
+
+    f32x4 acc[4][4];                                             // [q][p]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[q][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* pa = dY + n_base;
+    const float* pb = X + k_base;
+    auto load_tile = [&](int64_t m0, float4 (&aa)[8], float4 (&bb)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t m = m0 + 4 * j + lq;
+            const int64_t mc = m < m_end ? m : m_end - 1;        // clamped; the dY operand is zeroed at use
+            aa[j] = *reinterpret_cast<const float4*>(pa + mc * lddy);
+            bb[j] = *reinterpret_cast<const float4*>(pb + mc * ldx);
+        }
+    };
+    auto mma_tile = [&](int64_t m0, float4 (&aa)[8], const float4 (&bb)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (m0 + 4 * j + lq >= m_end) aa[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            dbs.x += aa[j].x; dbs.y += aa[j].y; dbs.z += aa[j].z; dbs.w += aa[j].w;
+        }
+        uint4 bh[4], bm[4], bl[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            split8(make_float4(comp(bb[0], p), comp(bb[1], p), comp(bb[2], p), comp(bb[3], p)),
+                   make_float4(comp(bb[4], p), comp(bb[5], p), comp(bb[6], p), comp(bb[7], p)), bh[p], bm[p], bl[p]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 ah, am, al;
+            split8(make_float4(comp(aa[0], q), comp(aa[1], q), comp(aa[2], q), comp(aa[3], q)),
+                   make_float4(comp(aa[4], q), comp(aa[5], q), comp(aa[6], q), comp(aa[7], q)), ah, am, al);
+            // smallest terms first (as in the forward)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[q][p] = mfma_bf16(al, bh[p], acc[q][p]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[q][p] = mfma_bf16(ah, bl[p], acc[q][p]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[q][p] = mfma_bf16(am, bm[p], acc[q][p]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[q][p] = mfma_bf16(am, bh[p], acc[q][p]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[q][p] = mfma_bf16(ah, bm[p], acc[q][p]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[q][p] = mfma_bf16(ah, bh[p], acc[q][p]);
+        }
+    };
+    float4 a0[8], b0[8], a1[8], b1[8], a2[8], b2[8];
+    load_tile(m_begin, a0, b0);
+    load_tile(m_begin + 32, a1, b1);
+    // three stages rotate statically (loads two 32-row steps ahead: 48 KB in flight per wave); slabs are multiples
+    // of 96 rows; tiles past m_end load clamped rows and multiply zeros (no early exit)
+    for (int64_t m0 = m_begin; m0 < m_end; m0 += 96) {
+        load_tile(m0 + 64, a2, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(m0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(m0 + 96, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(m0 + 32, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(m0 + 128, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(m0 + 64, a2, b2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    dbs.x += __shfl_xor(dbs.x, 16, 64); dbs.y += __shfl_xor(dbs.y, 16, 64);
+    dbs.z += __shfl_xor(dbs.z, 16, 64); dbs.w += __shfl_xor(dbs.w, 16, 64);
+    dbs.x += __shfl_xor(dbs.x, 32, 64); dbs.y += __shfl_xor(dbs.y, 32, 64);
+    dbs.z += __shfl_xor(dbs.z, 32, 64); dbs.w += __shfl_xor(dbs.w, 32, 64);
+    if (wave > 0) {                                               // tile element (q, p, r) of lane l at [(q * 4 + p) * 4 + r][l]: conflict-free
+        float* rw = red[wave - 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rw[((q * 4 + p) * 4 + r) * 64 + lane] = active ? acc[q][p][r] : 0.f;
+        if (lq == 0) {
+            rw[4096 + 4 * li + 0] = active ? dbs.x : 0.f; rw[4096 + 4 * li + 1] = active ? dbs.y : 0.f;
+            rw[4096 + 4 * li + 2] = active ? dbs.z : 0.f; rw[4096 + 4 * li + 3] = active ? dbs.w : 0.f;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {                                 // fixed order: slab 4g, +1, +2, +3
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[q][p][r] += red[w][((q * 4 + p) * 4 + r) * 64 + lane];
+        dbs.x += red[w][4096 + 4 * li + 0]; dbs.y += red[w][4096 + 4 * li + 1];
+        dbs.z += red[w][4096 + 4 * li + 2]; dbs.w += red[w][4096 + 4 * li + 3];
+    }
+    float* pw = partial + (int64_t)group * N * K;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nblk * 64 + 4 * (lq * 4 + r) + q;
+            float* dst = pw + (int64_t)n * K + kslab * 64 + 4 * li;
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[q][0][r], acc[q][1][r], acc[q][2][r], acc[q][3][r]);
+        }
+    if (kslab == 0 && partial_db && lq == 0) {
+        float* pd = partial_db + (int64_t)group * N;
+        pd[n_base + 0] = dbs.x; pd[n_base + 1] = dbs.y; pd[n_base + 2] = dbs.z; pd[n_base + 3] = dbs.w;
+    }
+}
+
 __global__ void reduce_chunks_kernel(int64_t n_elem, int64_t n_chunks, const float* __restrict__ partial,
                                      float* __restrict__ out, int64_t ld_out, int row_len, int accumulate) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elem; e += (int64_t)gridDim.x * blockDim.x) {
@@ -634,12 +778,13 @@ __global__ void reduce_chunks_kernel(int64_t n_elem, int64_t n_chunks, const flo
     }
 }
 
-// rows per slab (multiple of 16, >= 128) so that the launch has ~2048 waves over all problems
-static int64_t wgrad_slab_rows(int64_t M_total, int K) {
+// rows per slab so that the launch has ~2048 waves over all problems (two full rounds of one wave per SIMD for
+// the bf16x3 kernel); a multiple of the kernel's rotation length: 48 rows (fp32, 3 x 16) or 96 (bf16x3, 3 x 32)
+static int64_t wgrad_slab_rows(int64_t M_total, int K, bool bf16x3) {
     const int64_t n_kslab = ceil_div(K, 64);
     const int64_t want_slabs = ceil_div(2048, n_kslab);
-    int64_t mc = align_up(ceil_div(M_total > 0 ? M_total : 1, want_slabs), 48);
-    return mc < 144 ? 144 : mc;
+    const int64_t mc = align_up(ceil_div(M_total > 0 ? M_total : 1, want_slabs), bf16x3 ? 96 : 48);
+    return (!bf16x3 && mc < 144) ? 144 : mc;
 }
 
 }  // namespace llmrec
@@ -748,13 +893,29 @@ static int64_t wgrad_ws_bytes(int64_t n_slabs, int N, int K) {
 int64_t llmrec_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K) {
     if (M < 0 || N <= 0 || K <= 0) return -1;
     // bound for any split of M rows into <= LLMREC_LINEAR_MAX_PROBLEMS problems
-    const int64_t mc = wgrad_slab_rows(M, K);
+    const int64_t mc = std::min(wgrad_slab_rows(M, K, false), wgrad_slab_rows(M, K, true));   // either kernel
     return wgrad_ws_bytes(ceil_div(M > 0 ? M : 1, mc) + LLMREC_LINEAR_MAX_PROBLEMS, N, K);
 }
+
+static int linear_wgrad_grouped_impl(int32_t n_problems, const llmrec_wgrad_problem_t* p, int32_t N, int32_t K,
+                                     float* dW, int64_t lddw, float* db, int32_t accumulate,
+                                     void* workspace, int64_t workspace_bytes, bool bf16x3, llmrec_stream_t stream_);
 
 int llmrec_linear_wgrad_grouped_f32(int32_t n_problems, const llmrec_wgrad_problem_t* p, int32_t N, int32_t K,
                                     float* dW, int64_t lddw, float* db, int32_t accumulate,
                                     void* workspace, int64_t workspace_bytes, llmrec_stream_t stream_) {
+    return linear_wgrad_grouped_impl(n_problems, p, N, K, dW, lddw, db, accumulate, workspace, workspace_bytes, false, stream_);
+}
+
+int llmrec_linear_wgrad_grouped_bf16x3(int32_t n_problems, const llmrec_wgrad_problem_t* p, int32_t N, int32_t K,
+                                       float* dW, int64_t lddw, float* db, int32_t accumulate,
+                                       void* workspace, int64_t workspace_bytes, llmrec_stream_t stream_) {
+    return linear_wgrad_grouped_impl(n_problems, p, N, K, dW, lddw, db, accumulate, workspace, workspace_bytes, true, stream_);
+}
+
+static int linear_wgrad_grouped_impl(int32_t n_problems, const llmrec_wgrad_problem_t* p, int32_t N, int32_t K,
+                                     float* dW, int64_t lddw, float* db, int32_t accumulate,
+                                     void* workspace, int64_t workspace_bytes, bool bf16x3, llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_LINEAR_MAX_PROBLEMS && p && N > 0 && K > 0, "linear_wgrad: bad argument");
     LLMREC_CHECK_ARG(dW && lddw >= K, "linear_wgrad: null dW or ld < K");
@@ -771,7 +932,11 @@ int llmrec_linear_wgrad_grouped_f32(int32_t n_problems, const llmrec_wgrad_probl
         }
         return LLMREC_OK;
     }
-    const int64_t MC = wgrad_slab_rows(M_total, K);
+    bool fast_shape = (N % 64 == 0) && (K % 64 == 0);
+    for (int i = 0; i < n_problems; ++i)
+        fast_shape = fast_shape && (p[i].lddy % 4 == 0) && (p[i].ldx % 4 == 0) && (((uintptr_t)p[i].dY | (uintptr_t)p[i].X) % 16 == 0);
+    const bool use_bf16 = bf16x3 && fast_shape;
+    const int64_t MC = wgrad_slab_rows(M_total, K, use_bf16);
     WgradGroup g = {};
     g.n_problems = n_problems;
     int n_slabs = 0;
@@ -793,14 +958,20 @@ int llmrec_linear_wgrad_grouped_f32(int32_t n_problems, const llmrec_wgrad_probl
     dim3 grid((unsigned)ceil_div(n_waves, 4), (unsigned)ceil_div(N, 64));
     bool fast = (N % 64 == 0) && (K % 64 == 0);
     for (int i = 0; i < n_problems; ++i) fast = fast && g.vec_ok[i];
-    if (fast) linear_wgrad_kernel<true><<<grid, 256, 0, stream>>>(g, N, K, partial, db ? partial_db : nullptr, MC, n_kslab, n_slabs);
+    int64_t n_chunks = n_slabs;
+    if (fast && use_bf16) {
+        n_chunks = ceil_div(n_slabs, 4);                                 // the block sums its four slabs before writing
+        dim3 grid4((unsigned)(n_chunks * n_kslab), (unsigned)(N / 64));
+        linear_wgrad_bf16x3_kernel<true><<<grid4, 256, 0, stream>>>(g, N, K, partial, db ? partial_db : nullptr, MC, n_kslab, n_slabs);
+    }
+    else if (fast) linear_wgrad_kernel<true><<<grid, 256, 0, stream>>>(g, N, K, partial, db ? partial_db : nullptr, MC, n_kslab, n_slabs);
     else linear_wgrad_kernel<false><<<grid, 256, 0, stream>>>(g, N, K, partial, db ? partial_db : nullptr, MC, n_kslab, n_slabs);
     LLMREC_LAUNCH_CHECK();
     const int64_t ne = (int64_t)N * K;
-    reduce_chunks_kernel<<<grid_for(ne, 256), 256, 0, stream>>>(ne, n_slabs, partial, dW, lddw, K, accumulate);
+    reduce_chunks_kernel<<<grid_for(ne, 256), 256, 0, stream>>>(ne, n_chunks, partial, dW, lddw, K, accumulate);
     LLMREC_LAUNCH_CHECK();
     if (db) {
-        reduce_chunks_kernel<<<1, 128, 0, stream>>>(N, n_slabs, partial_db, db, N, N, accumulate);
+        reduce_chunks_kernel<<<1, 128, 0, stream>>>(N, n_chunks, partial_db, db, N, N, accumulate);
         LLMREC_LAUNCH_CHECK();
     }
     return LLMREC_OK;

@@ -91,8 +91,8 @@ class FusedStep:
         self._bwd_accumulators = (self.dE_u, self.dE_i, self.dU_cat, self.dI_cat, self.dprof_u, self.dprof_i)
         self._zeroed = False
         self._zero_in_forward = False                         # set by step_eager: forward() alone (evaluation) must not pay for it
-        # forward-projection arithmetic: "bf16x3" (default) = exact 3-term bf16 split of both operands, six bf16 MFMAs,
-        # fp32-roundoff-class error (2e-6 measured), 1.4x faster; "f32" = the bit-exact fp32 MFMA fma chain
+        # projection / weight-gradient arithmetic: "bf16x3" (default) = exact 3-term bf16 split of both operands, six bf16
+        # MFMAs, fp32-roundoff-class error (2e-6 measured), HBM-bound; "f32" = the exact fp32 MFMA fma chain
         import os
         self.gemm = os.environ.get("LLMREC_GEMM", "bf16x3")
 
@@ -149,9 +149,8 @@ class FusedStep:
         _call("llmrec_linear_fwd_grouped_bf16x3" if self.gemm == "bf16x3" else "llmrec_linear_fwd_grouped_f32", len(jobs), arr, self.d)
 
     def _wgrad(self, dY, X, lin, accumulate, ws=None):
-        ws = self.ws_wgrad if ws is None else ws
-        _call("llmrec_linear_wgrad_f32", X.shape[0], self.d, X.shape[1], _p(dY), _ld(dY), _p(X), _ld(X), _p(lin.weight.grad),
-              _ld(lin.weight.grad), _p(lin.bias.grad), 1 if accumulate else 0, _p(ws), ws.numel())
+        ops.linear_wgrad_grouped([(dY, X)], lin.weight.grad, lin.bias.grad, accumulate, self.ws_wgrad if ws is None else ws,
+                                 precision=self.gemm)
 
     def _softmax(self, Z, Y):
         _call("llmrec_softmax_rows_fwd_f32", Z.shape[0], self.d, _p(Z), _ld(Z), _p(Y), _ld(Y))
@@ -325,7 +324,7 @@ class FusedStep:
             self._wgrad(self._side(self.dP_cat, 0), m.image_feats, m.image_trans, False, ws=self.ws_wgrad_d)
         # the shared item_trans receives all attribute streams in one grouped launch (features are constants: no dX)
         ops.linear_wgrad_grouped([(self._side(self.dP_cat, 2 + k), m.item_feats[key]) for k, key in enumerate(self.keys)],
-                                 m.item_trans.weight.grad, m.item_trans.bias.grad, False, self.ws_wgrad)
+                                 m.item_trans.weight.grad, m.item_trans.bias.grad, False, self.ws_wgrad, precision=self.gemm)
         self._join(self.s1, self.s2, self.s3, self.s4)
 
     def _train_forward(self):

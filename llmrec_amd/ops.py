@@ -404,8 +404,9 @@ class WgradProblem(_c.Structure):
     _fields_ = [("dY", _c.c_void_p), ("lddy", _c.c_int64), ("X", _c.c_void_p), ("ldx", _c.c_int64), ("M", _c.c_int64)]
 
 
-def linear_wgrad_grouped(pairs, dW, db, accumulate: bool, ws: Optional[torch.Tensor] = None):
-    """dW (+)= sum_p dY_p^T X_p for several (dY, X) pairs sharing one weight (one launch + reduce)."""
+def linear_wgrad_grouped(pairs, dW, db, accumulate: bool, ws: Optional[torch.Tensor] = None, precision: str = "f32"):
+    """dW (+)= sum_p dY_p^T X_p for several (dY, X) pairs sharing one weight (one launch + reduce).
+    precision "bf16x3": llmrec_linear_wgrad_grouped_bf16x3 (three-term bf16 split, fp32-class error)."""
     arr = (WgradProblem * len(pairs))()
     M_total = 0
     for i, (dY, X) in enumerate(pairs):
@@ -416,7 +417,8 @@ def linear_wgrad_grouped(pairs, dW, db, accumulate: bool, ws: Optional[torch.Ten
     need = _lib.query("llmrec_linear_wgrad_workspace_bytes", M_total, N, K)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dW.device)
-    _lib.call("llmrec_linear_wgrad_grouped_f32", len(pairs), arr, N, K, _p(dW), _ld(dW), _p(db), 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
+    _lib.call("llmrec_linear_wgrad_grouped_bf16x3" if precision == "bf16x3" else "llmrec_linear_wgrad_grouped_f32",
+              len(pairs), arr, N, K, _p(dW), _ld(dW), _p(db), 1 if accumulate else 0, _p(ws), ws.numel(), _stream())
 
 
 def linear_fwd_grouped(jobs, N: int, precision: str = "f32"):

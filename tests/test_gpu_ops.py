@@ -211,6 +211,30 @@ def test_linear_wgrad_grouped(ops):
         assert rel_err(dW.cpu(), ref_w2) < 2e-5 and rel_err(db.cpu(), ref_b2) < 2e-5
 
 
+def test_linear_wgrad_bf16x3_matches_fp64(ops):
+    """llmrec_linear_wgrad_grouped_bf16x3: grouped (dY, X) pairs with ragged row counts (slab tails, a one-row
+    problem) against the fp64 product; error must be of fp32-roundoff class, like the fp32 MFMA kernel's."""
+    rng = np.random.default_rng(21)
+    N, K = 64, 320
+    Ms = [1000, 1, 333, 64]
+    pairs_cpu = [(torch.tensor(rng.standard_normal((m, N)).astype(np.float32)), torch.tensor(rng.standard_normal((m, K)).astype(np.float32) * 3)) for m in Ms]
+    want = sum(dy.double().t() @ x.double() for dy, x in pairs_cpu)
+    want_b = sum(dy.double().sum(0) for dy, _ in pairs_cpu)
+    big = torch.zeros(max(Ms), 3 * N, device=DEV)
+    pairs = []
+    for dy, x in pairs_cpu:                                    # dY as a strided view (ld = 3 N), as the fused step passes it
+        holder = torch.zeros(dy.shape[0], 3 * N, device=DEV); holder[:, N:2 * N] = dy.to(DEV)
+        pairs.append((holder[:, N:2 * N], x.to(DEV)))
+    for precision in ("bf16x3", "f32"):
+        dW = torch.full((N, K), 7.0, device=DEV); db = torch.full((N,), 7.0, device=DEV)
+        ops.linear_wgrad_grouped(pairs, dW, db, False, precision=precision)
+        e = float((dW.double().cpu() - want).abs().max() / want.abs().max())
+        eb = float((db.double().cpu() - want_b).abs().max() / want_b.abs().max())
+        assert e < 3e-6 and eb < 3e-6, (precision, e, eb)
+        ops.linear_wgrad_grouped(pairs, dW, db, True, precision=precision)       # accumulate
+        assert float((dW.double().cpu() - 2 * want).abs().max() / want.abs().max()) < 6e-6
+
+
 def test_linear_multi_shares_one_weight(ops):
     rng = np.random.default_rng(3)
     M, K, N = 300, 56, 64

@@ -44,6 +44,10 @@ if which in ("wgrad", "all"):
     X5 = torch.randn(5 * I, 1536, device=dev); dY5 = torch.randn(5 * I, d, device=dev)
     ms = timeit(lambda: ops.linear_wgrad_raw(dY5, X5, dW, db, False))
     print("wgrad(5I x 1536) ms %.4f TF %.1f" % (ms, 2.0 * 5 * I * 1536 * d / ms / 1e9))
+    ref = dW.clone()
+    ms = timeit(lambda: ops.linear_wgrad_grouped([(dY5, X5)], dW, db, False, precision="bf16x3"))
+    print("wgrad_bf16x3(5I x 1536) ms %.4f equivalent-TF %.1f HBM GB/s %.0f max rel diff vs f32 kernel %.2e" % (
+        ms, 2.0 * 5 * I * 1536 * d / ms / 1e9, 4.0 * 5 * I * (1536 + d) / ms / 1e6, float((dW - ref).abs().max() / ref.abs().max())))
 if which in ("spmm", "all"):
     nu, ni, ne = 2_000_000, 1_000_000, 40_000_000
     rows, cols = synth.bipartite_edges_device(nu, ni, ne, 0, dev)
