@@ -160,9 +160,10 @@ class NetflixShaped:
         per = (self.sh.n_users + self.world - 1) // self.world
         q = torch.arange(min(self.rank * per, self.sh.n_users), min((self.rank + 1) * per, self.sh.n_users), dtype=torch.int64,
                          device=self.device)
-        with torch.no_grad():
-            self.fused.forward()                               # the eval-mode forward (no dropout in this config)
-            return self.ops.score_topk(self.fused.E_u, self.fused.E_i, q, self.graph.by_user, 50)
+        if not hasattr(self, "_eval_q") or self._eval_q.numel() != q.numel():
+            self._eval_q = q                                    # fixed query set: the evaluation graph is captured once
+        with torch.no_grad():                                   # eval-mode forward (no dropout in this config) + scoring + top-50
+            return self.fused.eval_topk(self._eval_q, self.graph.by_user, 50, use_graph=self.use_graph)
 
     def config(self):
         return {"workload": "netflix_shaped_cfg2" if self.shape_name == "nf" else "movielens_shaped_cfg3",

@@ -88,6 +88,7 @@ class FusedStep:
         self.w_mf_dev = torch.tensor(self.w_mf, dtype=torch.float32, device=dev)
         self.graph_exec = None
         self.static = None
+        self._eval_graphs = {}
         self._bwd_accumulators = (self.dE_u, self.dE_i, self.dU_cat, self.dI_cat, self.dprof_u, self.dprof_i)
         self._zeroed = False
         self._zero_in_forward = False                         # set by step_eager: forward() alone (evaluation) must not pay for it
@@ -341,6 +342,40 @@ class FusedStep:
         self.loss_backward(users, pos, neg, n_valid)
         self.opt.step()
         return self.scal[1], self.scal[2], self.scal[3]
+
+    # -- evaluation -------------------------------------------------------------------------------
+    def eval_topk(self, query_users: torch.Tensor, train: Optional[ops.Csr], K: int, use_graph: bool = False):
+        """Reference Trainer.test up to the ranked lists (main.py:297-303, batch_test.py:83-109): no-grad forward +
+        scoring + masked top-K for the listed users -> (idx int32 [n, K], scores). With use_graph the whole
+        evaluation (~40 launches) is one HIP graph per (query set, K), replayed at every epoch end."""
+        if not use_graph:
+            self.forward()
+            return ops.score_topk(self.E_u, self.E_i, query_users, train, K)
+        key = (query_users.data_ptr(), query_users.numel(), K, id(train))
+        ev = self._eval_graphs.get(key)
+        if ev is None:
+            q = query_users.to(torch.int64).contiguous()
+            n = q.numel()
+            idx = torch.empty(n, K, dtype=torch.int32, device=q.device)
+            sc = torch.empty(n, K, dtype=torch.float32, device=q.device)
+
+            def run():
+                self.forward()
+                _call("llmrec_score_topk_f32", n, _p(q), _p(self.E_u), _ld(self.E_u), _p(self.E_i), _ld(self.E_i), self.I, self.d,
+                      _p(train.rowptr) if train is not None else None, _p(train.colidx) if train is not None else None,
+                      K, _p(idx), _p(sc))
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                run()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run()
+            ev = self._eval_graphs[key] = (g, idx, sc, q, train)         # keeps the captured operands alive
+        ev[0].replay()
+        return ev[1], ev[2]
 
     # -- HIP graph --------------------------------------------------------------------------------
     def _make_static(self):

@@ -160,7 +160,17 @@ class Trainer(object):
         self.model_mm.eval()
         fused = self._fused_step()
         with torch.no_grad():
-            if fused:                                          # same forward, ~30 launches over preallocated buffers
+            if fused and os.environ.get("LLMREC_GRAPH", "0") == "1" and args.test_flag == 'part':
+                # forward + scoring + masked top-K as ONE graph replay per evaluation
+                key = (len(users_to_test), is_val)
+                cache = getattr(self, "_eval_queries", None) or {}
+                if key not in cache:
+                    cache[key] = torch.as_tensor(list(users_to_test), dtype=torch.int64, device=device)
+                    self._eval_queries = cache
+                st = data_generator.device_state(device)
+                idx, _ = fused.eval_topk(cache[key], st["train"], max(eval(args.Ks)), use_graph=True)
+                return test_torch(fused.E_u, fused.E_i, users_to_test, is_val, topk=(cache[key], idx))
+            if fused:                                          # same forward, ~40 launches over preallocated buffers
                 fused.forward()
                 ua_embeddings, ia_embeddings = fused.E_u, fused.E_i
             else:

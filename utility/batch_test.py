@@ -65,7 +65,9 @@ def topk_lists(ua_embeddings, ia_embeddings, users_to_test):
     return q, idx
 
 
-def test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val, drop_flag=False, batch_test_flag=False):
+def test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val, drop_flag=False, batch_test_flag=False, topk=None):
+    """topk: optional (query tensor, ranked lists) already computed on the device for exactly users_to_test
+    (the graph-captured evaluation of llmrec_amd.fused.FusedStep.eval_topk)."""
     result = {'precision': np.zeros(len(Ks)), 'recall': np.zeros(len(Ks)), 'ndcg': np.zeros(len(Ks)),
               'hit_ratio': np.zeros(len(Ks)), 'auc': 0.}
     test_users = list(users_to_test)
@@ -76,7 +78,7 @@ def test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val, drop_flag=Fa
     held = data_generator.val_set if is_val else data_generator.test_set
     if args.test_flag == 'part':
         st = data_generator.device_state(ua_embeddings.device)
-        q, idx = topk_lists(ua_embeddings, ia_embeddings, test_users)
+        q, idx = topk if topk is not None else topk_lists(ua_embeddings, ia_embeddings, test_users)
         rp, ci = st["val"] if is_val else st["test"]
         hits = ops.topk_hits(idx, q, rp, ci).cpu().numpy()
         n_pos = np.array([len(held[u]) for u in test_users], dtype=np.float64)
