@@ -194,6 +194,7 @@ class NetflixShaped:
         out.append({"kernel": ("linear_fwd_grouped_bf16x3_kernel<4,2,true> (all 8 projections, one launch; 3-term bf16 split, 6 bf16 MFMAs: "
                                "HBM-bound on the X stream - tflops/frac_mfma_f32 are fp32-EQUIVALENT figures)") if bf else
                               "linear_fwd_grouped_kernel<4,2,true> (all 8 projections of one forward, one launch, exact fp32 MFMA)",
+                    "pmc": [("linear_fwd_grouped_bf16x3_kernel" if bf else "linear_fwd_grouped_kernel", 1)],
                     "bound": "hbm" if bf else "mfma", "calls_per_step": 1, "ms": ms,
                     "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                     "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
@@ -206,42 +207,49 @@ class NetflixShaped:
         ws = self.fused.ws_wgrad
 
         def wgrad_all():
+            pr = self.fused.gemm
             ops.linear_wgrad_grouped([(dYi[:, (2 + k) * d:(3 + k) * d], m_.item_feats[key]) for k, key in enumerate(self.keys)],
-                                     m_.item_trans.weight.grad, m_.item_trans.bias.grad, False, ws)
-            ops.linear_wgrad_grouped([(dYu, m_.user_feats)], m_.user_trans.weight.grad, m_.user_trans.bias.grad, False, ws)
-            ops.linear_wgrad_grouped([(dYi[:, d:2 * d], m_.text_feats)], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False, ws)
-            ops.linear_wgrad_grouped([(dYi[:, 0:d], m_.image_feats)], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False, ws)
+                                     m_.item_trans.weight.grad, m_.item_trans.bias.grad, False, ws, precision=pr)
+            ops.linear_wgrad_grouped([(dYu, m_.user_feats)], m_.user_trans.weight.grad, m_.user_trans.bias.grad, False, ws, precision=pr)
+            ops.linear_wgrad_grouped([(dYi[:, d:2 * d], m_.text_feats)], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False, ws, precision=pr)
+            ops.linear_wgrad_grouped([(dYi[:, 0:d], m_.image_feats)], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False, ws, precision=pr)
         ms = event_time_ms(wgrad_all, 20)
-        out.append({"kernel": "linear_wgrad_kernel<true> + reduce_chunks_kernel (the step's 4 launches: item_trans x5 grouped, user, text, image)",
-                    "bound": "mfma", "calls_per_step": 1, "ms": ms, "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
+        out.append({"kernel": ("linear_wgrad_bf16x3_kernel" if bf else "linear_wgrad_kernel<true>") +
+                              " + reduce_chunks_kernel (the step's 4 launches: item_trans x5 grouped, user, text, image" +
+                              ("; 3-term bf16 split: HBM-bound on the X stream, tflops are fp32-EQUIVALENT)" if bf else ")"),
+                    "pmc": [("linear_wgrad_bf16x3_kernel" if bf else "linear_wgrad_kernel", 4), ("reduce_chunks_kernel", 8)],
+                    "bound": "hbm" if bf else "mfma", "calls_per_step": 1, "ms": ms, "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                     "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
                     "algorithmic_flop_per_launch": flop_all, "algorithmic_bytes_per_launch": byts_all})
         Xi = torch.randn(sh.n_items, d, device=self.device)
         a = self.graph.ui.fwd
         ms = event_time_ms(lambda: ops.spmm_raw(a, Xi), 50)
         byts = 4.0 * a.nnz + 4.0 * (a.n_rows + 1) + 4.0 * a.n_rows + 4.0 * d * a.n_cols + 4.0 * d * a.n_rows
-        out.append({"kernel": "spmm_rows_kernel<16,1,4> (ui, d = 64, NF scale: L2-resident, launch-bound)", "calls_per_step": 20,
+        out.append({"kernel": "spmm_rows_segments_kernel<16,1,4> + spmm_finalize_kernel (ui, d = 64, NF scale: L2-resident, launch-bound)", "calls_per_step": 20,
                     "ms": ms, "gbs": byts / ms / 1e6, "frac_hbm": byts / ms / 1e6 / HBM_PEAK_GBS, "edges_per_s": a.nnz / ms * 1e3})
         return out
 
 
-def pmc_traffic_bytes(kernel_label: str):
-    """HBM-side bytes per launch of the named kernel from the committed PMC pass
-    (profiles/r01_pmc_counters.json: separate rocprofv3 --pmc runs with --kernel-trace only, as
-    MI355X_MICROARCH.md prescribes; FETCH_SIZE is doubled per its gfx950 note, WRITE_SIZE taken as
-    reported; both in KB). None when that kernel was not in the pass."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")
+def pmc_traffic_bytes(parts):
+    """HBM-side bytes of one "launch" as the roofline defines it, from the committed PMC pass
+    (profiles/r01_pmc_bench_step.json: separate rocprofv3 --pmc runs of this bench with --kernel-trace only, as
+    MI355X_MICROARCH.md prescribes; FETCH_SIZE is doubled per its gfx950 note, WRITE_SIZE taken as reported;
+    both in KB). parts: [(kernel-name substring, launches of it per roofline launch)]. None when a kernel
+    is missing from the pass."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_bench_step.json")
     if not os.path.exists(path):
         return None
     try:
         data = json.load(open(path))
     except Exception:
         return None
-    key = kernel_label.split("<")[0].split(" ")[0]
-    for name, counters in data.items():
-        if key in name and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
-            return (2.0 * counters["FETCH_SIZE"]["mean"] + counters["WRITE_SIZE"]["mean"]) * 1024.0
-    return None
+    total = 0.0
+    for key, launches in parts:
+        hit = [c for name, c in data.items() if key in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c]
+        if not hit:
+            return None
+        total += launches * (2.0 * hit[0]["FETCH_SIZE"]["mean"] + hit[0]["WRITE_SIZE"]["mean"]) * 1024.0
+    return total
 
 
 def spmm_roofline_large(device, seed, n_users=2_000_000, n_items=1_000_000, n_edges=40_000_000, d=64):
@@ -381,7 +389,7 @@ def main():
             line["roofline"] = {"kernel": dom["kernel"], "bound": dom.get("bound", "mfma"),
                                 "achieved": dom["gbs"] if hbm else dom["tflops"], "peak": HBM_PEAK_GBS if hbm else MFMA_F32_PEAK_TFLOPS,
                                 "unit": "GB/s" if hbm else "TFLOP/s", "frac": dom["frac_hbm"] if hbm else dom["frac_mfma_f32"],
-                                "traffic": pmc_traffic_bytes(dom["kernel"]),
+                                "traffic": pmc_traffic_bytes(dom["pmc"]),
                                 "algorithmic_flop_per_launch": dom["algorithmic_flop_per_launch"],
                                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                                 "ms_per_launch": dom["ms"], "hbm_gbs": dom["gbs"], "frac_hbm": dom["frac_hbm"]}

@@ -479,6 +479,17 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
 // weight gradient: wave tile = 64 n (interleaved tiles q) x 64 k (interleaved tiles p), over a
 // chunk of MC rows; partial[chunk][n][k] then reduced in chunk order (deterministic).
 // ---------------------------------------------------------------------------------------------
+// Consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2). Blocks that share operand
+// rows (all k slabs of one row slab re-read the same dY rows) should share an L2: logical id = the id's position
+// within its XCD's stream, so consecutive LOGICAL blocks run on one XCD. (PMC: 1.04 GB fetched per step's weight
+// gradients against 0.74 GB algorithmic before - every XCD fetched its own copy of each dY slab.)
+__device__ __forceinline__ int xcd_logical_block(int bid, int nblocks) {
+    constexpr int XCDS = 8;
+    const int per = nblocks / XCDS, rem = nblocks % XCDS;       // XCD x runs per + (x < rem) blocks
+    const int x = bid % XCDS, local = bid / XCDS;
+    return x * per + (x < rem ? x : rem) + local;
+}
+
 struct WgradGroup {
     const float* dY[LLMREC_LINEAR_MAX_PROBLEMS];
     const float* X[LLMREC_LINEAR_MAX_PROBLEMS];
@@ -499,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(WgradGroup g, int 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;          // (slab, kslab) flattened, kslab fastest
+    const int64_t wid = (int64_t)xcd_logical_block(blockIdx.x, gridDim.x) * 4 + wave;   // (slab, kslab) flattened, kslab fastest
     const int slab = (int)(wid / n_kslab);
     const int kslab = (int)(wid % n_kslab);
     if (slab >= n_slabs) return;
@@ -631,8 +642,9 @@ __global__ __launch_bounds__(256, 1) void linear_wgrad_bf16x3_kernel(WgradGroup 
     // the four waves of a block take four consecutive slabs of ONE k slab and are summed through LDS in wave
     // order before anything is written: a quarter of the partial-slab traffic (all problems feed the same dW)
     __shared__ __attribute__((aligned(16))) float red[3][64 * 64 + 64];
-    const int kslab = (int)(blockIdx.x % n_kslab);
-    const int group = (int)(blockIdx.x / n_kslab);
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int kslab = lb % n_kslab;
+    const int group = lb / n_kslab;
     const int slab_raw = group * 4 + wave;
     const bool active = slab_raw < n_slabs;
     const int slab = active ? slab_raw : n_slabs - 1;             // idle waves of the last group recompute a slab and drop it

@@ -154,7 +154,7 @@ class DataParallelStep(FusedStep):
         graphs = []
         for fn in (first, lambda: self.phase_b(*args), self.phase_c):
             g = torch.cuda.CUDAGraph()                         # capturing records, it does not execute: one step ran (the warm-up)
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (the RCCL watchdog) may touch the runtime
                 fn()
             graphs.append(g)
         self.graphs = graphs

@@ -371,7 +371,7 @@ class FusedStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (the RCCL watchdog) may touch the runtime
                 run()
             ev = self._eval_graphs[key] = (g, idx, sc, q, train)         # keeps the captured operands alive
         ev[0].replay()
@@ -407,7 +407,7 @@ class FusedStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (the RCCL watchdog) may touch the runtime
             one_step()
         self.graph_exec = g
 
