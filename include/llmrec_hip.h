@@ -305,6 +305,13 @@ int llmrec_scores_f32(int32_t n_query, const int64_t* query_users,
 int llmrec_topk_hits(int32_t n_query, const int64_t* query_users, int32_t K, const int32_t* topk_idx,
                      const int32_t* test_rowptr, const int32_t* test_colidx, uint8_t* hits,
                      llmrec_stream_t stream);
+/* R10 (reference utility/metrics.py:8-18,43-87 through batch_test.py:70-80): per-user precision, recall, ndcg and
+ * hit-ratio at each of the n_ks <= 8 cut-offs (host array ks), in double, from the hit matrix of llmrec_topk_hits and
+ * the ranked lists: out[q][4][n_ks]. ndcg uses the reference's IDCG (the retrieved hit vector sorted descending);
+ * precision averages over the ranked items that exist. The caller sums over users (12 doubles leave the device
+ * instead of n x K hits). */
+int llmrec_topk_metrics(int32_t n_query, const int64_t* query_users, int32_t K, const uint8_t* hits, const int32_t* topk_idx,
+                        const int32_t* test_rowptr, int32_t n_ks, const int32_t* ks_host, double* out, llmrec_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * R11  on-device BPR sampler             replaces Data.sample (reference

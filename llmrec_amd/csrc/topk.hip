@@ -424,6 +424,40 @@ __global__ void topk_hits_kernel(int n_query, const int64_t* __restrict__ query_
     hits[t] = (item >= 0 && lo < e && colidx[lo] == item) ? 1 : 0;
 }
 
+// R10: per-user precision / recall / ndcg / hit-ratio at every K of Ks from the hit matrix of the ranked lists
+// (reference utility/metrics.py:8-18,43-87 via batch_test.py:70-80), in double like numpy. One thread per user.
+// ndcg: IDCG from the retrieved hit vector itself, sorted descending (the reference's definition): the ideal
+// list is min(#hits in the top-Kmax list, K) ones. precision: mean over the ranked items that exist (a user with
+// fewer than K candidates has a shorter list). out: [n_query][4][n_ks] = precision, recall, ndcg, hit_ratio.
+struct MetricKs { int32_t k[8]; int32_t n; };
+__global__ void topk_metrics_kernel(int n_query, const int64_t* __restrict__ query_users, int K,
+                                    const uint8_t* __restrict__ hits, const int32_t* __restrict__ topk_idx,
+                                    const int32_t* __restrict__ test_rowptr, MetricKs ks, double* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_query) return;
+    const int64_t u = query_users[q];
+    const double n_pos = (double)(test_rowptr[u + 1] - test_rowptr[u]);
+    const uint8_t* h = hits + (int64_t)q * K;
+    const int32_t* id = topk_idx + (int64_t)q * K;
+    int total_hits = 0, list_len = 0;
+    for (int j = 0; j < K; ++j) { total_hits += h[j]; list_len += id[j] >= 0; }
+    double* o = out + (int64_t)q * 4 * ks.n;
+    for (int t = 0; t < ks.n; ++t) {
+        const int kk = ks.k[t] < K ? ks.k[t] : K;
+        double s = 0.0, dcg = 0.0, idcg = 0.0;
+        for (int j = 0; j < kk; ++j) {
+            const double disc = 1.0 / log2((double)(j + 2));
+            if (h[j]) { s += 1.0; dcg += disc; }
+            if (j < total_hits) idcg += disc;
+        }
+        const int denom = list_len < kk ? list_len : kk;
+        o[0 * ks.n + t] = s / (double)(denom > 0 ? denom : 1);
+        o[1 * ks.n + t] = n_pos > 0.0 ? s / n_pos : 0.0;
+        o[2 * ks.n + t] = idcg > 0.0 ? dcg / idcg : 0.0;
+        o[3 * ks.n + t] = s > 0.0 ? 1.0 : 0.0;
+    }
+}
+
 template <bool SELECT>
 static int launch_topk(const TopkArgs& a, hipStream_t stream) {
     const int DK = (a.d + 15) / 16;
@@ -489,6 +523,19 @@ int llmrec_topk_hits(int32_t n_query, const int64_t* query_users, int32_t K, con
     LLMREC_CHECK_ARG(query_users && topk_idx && test_rowptr && test_colidx && hits, "topk_hits: null pointer");
     const int64_t n = (int64_t)n_query * K;
     topk_hits_kernel<<<(int)ceil_div(n, 256), 256, 0, (hipStream_t)stream_>>>(n_query, query_users, K, topk_idx, test_rowptr, test_colidx, hits);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_topk_metrics(int32_t n_query, const int64_t* query_users, int32_t K, const uint8_t* hits, const int32_t* topk_idx,
+                        const int32_t* test_rowptr, int32_t n_ks, const int32_t* ks_host, double* out, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_query >= 0 && K > 0 && n_ks >= 1 && n_ks <= 8 && ks_host, "topk_metrics: bad sizes (at most 8 cut-offs)");
+    if (n_query == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(query_users && hits && topk_idx && test_rowptr && out, "topk_metrics: null pointer");
+    MetricKs ks = {};
+    ks.n = n_ks;
+    for (int i = 0; i < n_ks; ++i) { LLMREC_CHECK_ARG(ks_host[i] > 0, "topk_metrics: cut-offs must be positive"); ks.k[i] = ks_host[i]; }
+    topk_metrics_kernel<<<(int)ceil_div(n_query, 128), 128, 0, (hipStream_t)stream_>>>(n_query, query_users, K, hits, topk_idx, test_rowptr, ks, out);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

@@ -109,6 +109,10 @@ class HipBackend:
     def topk_hits(self, idx, q, rowptr, colidx):
         return self.ops.topk_hits(idx, q, rowptr, colidx)
 
+    def topk_metric_sums(self, idx, hits, q, rowptr, Ks):
+        """[4 * len(Ks)] float64 device sums over the listed users (precision, recall, ndcg, hit_ratio blocks)."""
+        return self.ops.topk_metrics(idx, hits, q, rowptr, Ks).sum(0).reshape(-1)
+
     def bpr_fwd(self, Eu, Ei, u, p, n, remember, decay, bsz, global_m, global_B, offset, scores_only):
         o = self.ops
         Eu, Ei = o._rowmajor(Eu), o._rowmajor(Ei)
@@ -374,8 +378,6 @@ def sharded_evaluate(model, comm: Comm, backend, graph: ShardedGraph, test_rowpt
     """Full-rank evaluation, embarrassingly parallel by user (reference utility/batch_test.py:112-169):
     each rank ranks its own users against the replicated item table and the 12 metric sums are
     all-reduced. test_rowptr/test_colidx: CSR of the held-out items of this rank's users."""
-    import numpy as np
-    from utility.metrics import metrics_from_hit_matrix          # host-side formulae of the drop-in
     fw = model()
     deg = (test_rowptr[1:] - test_rowptr[:-1])
     q = torch.nonzero(deg > 0).reshape(-1).to(torch.int64)
@@ -383,10 +385,8 @@ def sharded_evaluate(model, comm: Comm, backend, graph: ShardedGraph, test_rowpt
     sums = torch.zeros(4 * len(Ks), dtype=torch.float64, device=graph.s_i.device)
     if q.numel():
         idx, _ = backend.score_topk(fw["E_u"], fw["E_i"], q, graph.by_user, kmax)
-        hits = backend.topk_hits(idx, q, test_rowptr, test_colidx).cpu().numpy()
-        per = metrics_from_hit_matrix(hits, deg[q].cpu().numpy(), Ks, (idx >= 0).sum(1).cpu().numpy())
-        vec = np.concatenate([per[k].sum(0) for k in ("precision", "recall", "ndcg", "hit_ratio")])
-        sums += torch.from_numpy(vec).to(sums.device)
+        hits = backend.topk_hits(idx, q, test_rowptr, test_colidx)
+        sums += backend.topk_metric_sums(idx, hits, q, test_rowptr, Ks)      # metrics on the device: 12 doubles leave it, not n x K hits
     comm.all_reduce_(sums)
     out = (sums / n_test_users_global).cpu().numpy().reshape(4, len(Ks))
     return {"precision": out[0], "recall": out[1], "ndcg": out[2], "hit_ratio": out[3], "auc": 0.0}

@@ -621,3 +621,15 @@ def sample_batch(seed: int, step_dev: torch.Tensor, exist_users: torch.Tensor, n
         raise RuntimeError("sample_batch: buffers of B + n_aug int64 entries, int64 step counter, int32 n_valid expected")
     _lib.call("llmrec_sample_batch", seed, _p(step_dev), exist_users.numel(), _p(exist_users), n_items, _p(train.rowptr), _p(train.colidx),
               B_global, slice_begin, B, n_aug, _p(aug_pos), _p(aug_neg), _p(users), _p(pos), _p(neg), _p(n_valid), _stream())
+
+
+def topk_metrics(idx: torch.Tensor, hits: torch.Tensor, query_users: torch.Tensor, test_rowptr: torch.Tensor, Ks) -> torch.Tensor:
+    """Per-user [n, 4, len(Ks)] float64 (precision, recall, ndcg, hit_ratio) on the device (llmrec_topk_metrics)."""
+    _need_gpu(idx, hits, query_users, test_rowptr)
+    n, K = idx.shape
+    Ks = [int(k) for k in Ks]
+    out = torch.empty(n, 4, len(Ks), dtype=torch.float64, device=idx.device)
+    arr = (_c.c_int32 * len(Ks))(*Ks)
+    _lib.call("llmrec_topk_metrics", n, _p(query_users.to(torch.int64).contiguous()), K, _p(hits.contiguous()), _p(idx.contiguous()),
+              _p(test_rowptr), len(Ks), arr, _p(out), _stream())
+    return out

@@ -542,3 +542,45 @@ def test_sample_batch_one_launch_with_augmented_triples(ops):
     u2 = torch.empty(B, dtype=torch.int64, device=DEV); p2 = torch.empty_like(u2); n2 = torch.empty_like(u2)
     ops.sample_batch(77, sd, exist, I, csr, B, 0, B, 0, None, None, u2, p2, n2, torch.zeros(1, dtype=torch.int32, device=DEV))
     assert torch.equal(a[0], u2) and torch.equal(a[1], p2) and torch.equal(a[2], n2)
+
+
+def test_score_topk_exact_ties_are_ordered_by_item_id(ops):
+    """Duplicate item rows give bit-equal scores in different item quarters (different waves' buffers, different
+    drains): the lists must hold them in ascending item id, as the reference's (score, id) ordering does."""
+    rng = np.random.default_rng(123)
+    U, I, d, K = 48, 900, 64, 50
+    Eu = rng.standard_normal((U, d)).astype(np.float32)
+    base = rng.standard_normal((60, d)).astype(np.float32)
+    Ei = base[rng.integers(0, 60, size=I)]                       # only 60 distinct rows: every score value repeats ~15 times
+    Eug, Eig = torch.tensor(Eu).to(DEV), torch.tensor(Ei).to(DEV)
+    q = torch.arange(U).to(DEV)
+    train_items = {u: sorted(rng.choice(I, size=20, replace=False).tolist()) for u in range(U)}
+    S = ops.scores(Eug, Eig, q).cpu().numpy()
+    idx, sc = ops.score_topk(Eug, Eig, q, _train_csr(ops, train_items, U, I), K)
+    idx, sc = idx.cpu().numpy(), sc.cpu().numpy()
+    for u in range(U):
+        want = O.rank_topk_np(S[u], train_items[u], K)
+        assert np.array_equal(idx[u], want), u
+        assert np.array_equal(sc[u], S[u][want])
+
+
+def test_topk_metrics_match_host_formulae(ops):
+    """llmrec_topk_metrics == utility.metrics.metrics_from_hit_matrix (the drop-in's vectorised host formulae,
+    themselves checked against the reference's scalar functions in tests/test_host_cpu.py)."""
+    from utility.metrics import metrics_from_hit_matrix
+    rng = np.random.default_rng(31)
+    U, I, K, Ks = 300, 400, 50, (10, 20, 50)
+    test = {u: sorted(rng.choice(I, size=int(rng.integers(1, 9)), replace=False).tolist()) for u in range(U)}
+    topk = np.stack([rng.permutation(I)[:K] for _ in range(U)]).astype(np.int32)
+    for u in range(0, U, 3):                                   # make hits frequent
+        topk[u, rng.integers(0, K, size=3)] = rng.choice(test[u], size=3)
+    topk[5, 30:] = -1; topk[6, 3:] = -1; topk[7, :] = -1       # short lists
+    csr = _train_csr(ops, test, U, I)
+    q = torch.arange(U).to(DEV)
+    idx = torch.tensor(topk).to(DEV)
+    hits = ops.topk_hits(idx, q, csr.rowptr, csr.colidx)
+    got = ops.topk_metrics(idx, hits, q, csr.rowptr, Ks).cpu().numpy()
+    n_pos = np.array([len(test[u]) for u in range(U)], dtype=np.float64)
+    want = metrics_from_hit_matrix(hits.cpu().numpy(), n_pos, Ks, (topk >= 0).sum(1))
+    for j, k in enumerate(("precision", "recall", "ndcg", "hit_ratio")):
+        assert np.allclose(got[:, j, :], want[k], rtol=0, atol=1e-13), k

@@ -80,12 +80,12 @@ def test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val, drop_flag=Fa
         st = data_generator.device_state(ua_embeddings.device)
         q, idx = topk if topk is not None else topk_lists(ua_embeddings, ia_embeddings, test_users)
         rp, ci = st["val"] if is_val else st["test"]
-        hits = ops.topk_hits(idx, q, rp, ci).cpu().numpy()
-        n_pos = np.array([len(held[u]) for u in test_users], dtype=np.float64)
-        list_len = (idx >= 0).sum(1).cpu().numpy()
-        per_user = metrics.metrics_from_hit_matrix(hits, n_pos, Ks, list_len)
-        for k in ('precision', 'recall', 'ndcg', 'hit_ratio'):
-            result[k] = (per_user[k] / n_test_users).sum(0)
+        hits = ops.topk_hits(idx, q, rp, ci)
+        # precision / recall / ndcg / hit-ratio per user on the device (llmrec_topk_metrics, the formulae of
+        # utility/metrics.py); only the 4 x len(Ks) sums come back
+        sums = ops.topk_metrics(idx, hits, q, rp, Ks).sum(0).cpu().numpy() / n_test_users
+        for j, k in enumerate(('precision', 'recall', 'ndcg', 'hit_ratio')):
+            result[k] = sums[j]
         return result
     # test_flag == 'full': AUC needs every item's score -> score blocks on the device, rank on the host
     u_batch_size = BATCH_SIZE * 2
