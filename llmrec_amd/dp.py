@@ -80,10 +80,12 @@ class DataParallelStep(FusedStep):
               _p(n_valid), float(1 - hp.prune_loss_drop_rate), float(hp.decay), float(hp.batch_size), phase, _p(self.g_local),
               _p(self.g_all), self.world, self.gsz, self.rank, _p(self.out), _p(self.saved))
 
-    def phase_a(self, users, pos, neg, n_valid=None):
-        """forward + BPR scores + this rank's gather block."""
+    def phase_a(self, users, pos, neg, n_valid=None, sampler=None):
+        """[sampler +] forward + BPR scores + this rank's gather block."""
         if users.numel() != self.b_max:
             raise RuntimeError("DataParallelStep: every rank passes exactly b_max = %d slots (n_valid marks the used ones)" % self.b_max)
+        if sampler is not None:
+            sampler()
         self._train_forward()
         self._bpr_phase(1, users, pos, neg, n_valid)
 
@@ -105,7 +107,7 @@ class DataParallelStep(FusedStep):
         self.scal[2:3] = self.tail[0:1]
         self.scal[3:4] = self.out[0, 1:2]
         self.scal[1:2] = (self.tail[:P] * self.w_mf_dev).sum() + self.tail[P]
-        self.opt.step()
+        self.opt.step(advanced=True)                             # the counter was advanced during the forward
 
     # -- the two exchanges ------------------------------------------------------------------------
     def exchange_scores(self):
@@ -142,9 +144,7 @@ class DataParallelStep(FusedStep):
         args = (st["users"], st["pos"], st["neg"], st["n_valid"])
 
         def first():
-            if batcher is not None:
-                batcher.fill(*args)
-            self.phase_a(*args)
+            self.phase_a(*args, sampler=(lambda: batcher.fill(*args)) if batcher is not None else None)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):                             # warm-up: one full eager step (also warms the collectives)

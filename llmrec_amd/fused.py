@@ -187,6 +187,7 @@ class FusedStep:
             if self._zero_in_forward:                                    # the backward's scatter targets, off the critical path
                 for t in self._bwd_accumulators:
                     t.zero_()
+                self.opt.advance()                                       # AdamW's step counter / bias corrections, likewise
             i_prev = m.item_id_embedding.weight
             for l in range(self.L):
                 last = l == self.L - 1
@@ -337,10 +338,14 @@ class FusedStep:
             self._zero_in_forward = False
         self._zeroed = True
 
-    def step_eager(self, users, pos, neg, n_valid=None):
+    def step_eager(self, users, pos, neg, n_valid=None, sampler=None):
+        """sampler: optional callable that fills (users, pos, neg, n_valid) on the current stream first (inside the same
+        graph when captured; running it on a side stream beside the forward measured no faster)."""
+        if sampler is not None:
+            sampler()
         self._train_forward()
         self.loss_backward(users, pos, neg, n_valid)
-        self.opt.step()
+        self.opt.step(advanced=True)
         return self.scal[1], self.scal[2], self.scal[3]
 
     # -- evaluation -------------------------------------------------------------------------------
@@ -397,9 +402,8 @@ class FusedStep:
             self._load(warm_users, warm_pos, warm_neg, warm_n_valid)
 
         def one_step():
-            if batcher is not None:
-                batcher.fill(st["users"], st["pos"], st["neg"], st["n_valid"])
-            self.step_eager(st["users"], st["pos"], st["neg"], st["n_valid"])
+            fill = (lambda: batcher.fill(st["users"], st["pos"], st["neg"], st["n_valid"])) if batcher is not None else None
+            self.step_eager(st["users"], st["pos"], st["neg"], st["n_valid"], sampler=fill)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):                             # warm-up on a side stream (allocations, plan caches)

@@ -532,14 +532,22 @@ class FusedAdamW:
                 p.grad.zero_()
 
     @torch.no_grad()
-    def step(self):
+    def advance(self):
+        """Advance the device step counter / bias corrections (the first half of step()). A fused step calls it
+        early on a side stream so that only the multi-tensor update itself remains on the critical path."""
+        if self.dev_state is None:
+            dev = next(p for p in self.params if p.grad is not None).device
+            self.dev_state = torch.zeros(3, dtype=torch.float32, device=dev)
+        _lib.call("llmrec_adamw_advance", _p(self.dev_state), self.lr, self.betas[0], self.betas[1], _stream())
+
+    @torch.no_grad()
+    def step(self, advanced: bool = False):
         live = [p for p in self.params if p.grad is not None]
         if not live:
             return
         _need_gpu(*live)
-        if self.dev_state is None:
-            self.dev_state = torch.zeros(3, dtype=torch.float32, device=live[0].device)
-        _lib.call("llmrec_adamw_advance", _p(self.dev_state), self.lr, self.betas[0], self.betas[1], _stream())
+        if not advanced:
+            self.advance()
         cap = CONST["LLMREC_ADAMW_MAX_TENSORS"]
         for lo in range(0, len(live), cap):
             group = live[lo:lo + cap]
