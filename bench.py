@@ -326,8 +326,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    if os.environ.get("LLMREC_BENCH_SINGLE_DEVICE", "0") == "1":   # test hook: all ranks on cuda:0 (1-GPU box, with LLMREC_DIST_BACKEND=gloo)
+        local_dev = 0
+    else:
+        local_dev = local
+    torch.cuda.set_device(local_dev)
+    device = torch.device("cuda", local_dev)
     if local == 0:                                           # one builder per node; the .so normally travels prebuilt
         from llmrec_amd import build as _build
         _build.build(force=False, verbose=False)
@@ -335,7 +339,11 @@ def main():
     if use_pg:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("LLMREC_DIST_BACKEND", "nccl")             # "nccl" IS RCCL on ROCm; gloo only for the 1-GPU smoke of the N > 1 path
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         dist.barrier()                                       # the library exists before any rank loads it
     workload = a.workload
     if workload == "auto":

@@ -35,15 +35,29 @@ class Comm:
         self.rank = self.dist.get_rank() if self.dist else 0
         self.world = self.dist.get_world_size() if self.dist else 1
 
-    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
-        if self.dist and self.world > 1:
-            self.dist.all_reduce(t)
+    def _host_staged(self) -> bool:
+        """gloo (the CPU-test backend) moves device tensors through host copies and lacks some fused collectives."""
+        return self.dist is not None and self.dist.get_backend() == "gloo"
+
+    def all_reduce_(self, t: torch.Tensor, force: bool = False) -> torch.Tensor:
+        if self.dist and (self.world > 1 or force):
+            if self._host_staged() and t.is_cuda:
+                h = t.cpu()
+                self.dist.all_reduce(h)
+                t.copy_(h)
+            else:
+                self.dist.all_reduce(t)
         return t
 
-    def all_gather_into(self, out: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    def all_gather_into(self, out: torch.Tensor, t: torch.Tensor, force: bool = False) -> torch.Tensor:
         """out[world * n] <- the ranks' t[n] in rank order (preallocated, graph-step friendly)."""
-        if self.dist and self.world > 1:
-            self.dist.all_gather_into_tensor(out, t)
+        if self.dist and (self.world > 1 or force):
+            if self._host_staged() and t.is_cuda:
+                parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(self.world)]
+                self.dist.all_gather(parts, t.cpu())
+                out.copy_(torch.cat(parts).reshape(out.shape))
+            else:
+                self.dist.all_gather_into_tensor(out, t)
         else:
             out.copy_(t)
         return out

@@ -112,13 +112,13 @@ class DataParallelStep(FusedStep):
     # -- the two exchanges ------------------------------------------------------------------------
     def exchange_scores(self):
         if self.comm is not None and (self.world > 1 or self.force):
-            self.comm.dist.all_gather_into_tensor(self.g_all, self.g_local)
+            self.comm.all_gather_into(self.g_all, self.g_local, force=self.force)
         else:                                                  # single replica, or a loop-back harness that fills the other blocks
             self.g_all[self.rank * self.gsz:(self.rank + 1) * self.gsz].copy_(self.g_local)
 
     def exchange_grads(self):
         if self.comm is not None and (self.world > 1 or self.force):
-            self.comm.dist.all_reduce(self.bucket)
+            self.comm.all_reduce_(self.bucket, force=self.force)
 
     def loss_backward(self, users, pos, neg, n_valid=None):
         raise RuntimeError("DataParallelStep: use step_eager()/step() (the loss needs the score exchange)")
