@@ -2,6 +2,40 @@
 // instruction) as a function of the row stride, vs a plain coalesced stream.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+// The grouped projection's X stream exactly: 128-row blocks, 32 k per step, lane (li, lq) loads the 16-B pieces
+// k = kb + 8 lq + 4 h (h = 0, 1) of rows t * 16 + li (t = 0, 1); three register stages, optional barrier per
+// step. CONTIG = 1: pieces k = kb + 16 h + 4 lq instead (64 contiguous bytes of a row per instruction).
+template <int CONTIG, int BARRIER>
+__global__ __launch_bounds__(256, 2) void gemmx_kernel(const float* __restrict__ X, int64_t ldx, int K, float* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+    const float* row[2];
+    for (int t = 0; t < 2; ++t) row[t] = X + ((int64_t)blockIdx.x * 128 + wave * 32 + t * 16 + li) * ldx;
+    float4 acc = make_float4(0, 0, 0, 0);
+    auto load = [&](int kb, float4 (&x)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int k = CONTIG ? kb + 16 * h + 4 * lq : kb + 8 * lq + 4 * h;
+                if (k > K - 4) k = K - 4;
+                x[t][h] = *reinterpret_cast<const float4*>(row[t] + k);
+            }
+    };
+    auto use = [&](const float4 (&x)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { acc.x += x[t][h].x; acc.y += x[t][h].y; acc.z += x[t][h].z; acc.w += x[t][h].w; }
+    };
+    float4 x0[2][2], x1[2][2], x2[2][2];
+    load(0, x0); load(32, x1);
+    for (int kb = 0; kb < K; kb += 96) {
+        load(kb + 64, x2); use(x0); if (BARRIER) __syncthreads();
+        load(kb + 96, x0); use(x1); if (BARRIER) __syncthreads();
+        load(kb + 128, x1); use(x2); if (BARRIER) __syncthreads();
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
+}
 extern "C" {
 // each block: 128 rows (4 waves x 32 rows), sweeps `kbytes` bytes per row in 64-B pieces per instruction
 __global__ void frag_kernel(const float* __restrict__ X, int64_t row_stride_f, int64_t tile_stride_f, int kfloats, float* out) {
@@ -25,6 +59,13 @@ __global__ void stream_kernel(const float4* __restrict__ X, int64_t n4, float* o
         float4 v = X[i]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
+}
+int run_gemmx(const float* X, int64_t ldx, int K, int blocks, int contig, int barrier, float* out, void* stream) {
+    if (contig && barrier) gemmx_kernel<1, 1><<<blocks, 256, 0, (hipStream_t)stream>>>(X, ldx, K, out);
+    else if (contig) gemmx_kernel<1, 0><<<blocks, 256, 0, (hipStream_t)stream>>>(X, ldx, K, out);
+    else if (barrier) gemmx_kernel<0, 1><<<blocks, 256, 0, (hipStream_t)stream>>>(X, ldx, K, out);
+    else gemmx_kernel<0, 0><<<blocks, 256, 0, (hipStream_t)stream>>>(X, ldx, K, out);
+    return (int)hipGetLastError();
 }
 int run_frag(const float* X, int64_t row_stride_f, int64_t tile_stride_f, int kfloats, int blocks, float* out, void* stream) {
     frag_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(X, row_stride_f, tile_stride_f, kfloats, out);

@@ -27,3 +27,8 @@ for kt in (64,):
     # emulate: row stride = kt floats, consecutive k-tiles of a row block are 128*kt floats apart -> use kfloats=kt per launch "tile", blocks = all tiles
     ms = timeit(lambda: lib.run_frag(p(X), ctypes.c_int64(kt), ctypes.c_int64(128 * kt), kt, blocks * tiles_per_block, p(out), st))
     print("fragment, blocked tiles [128][%d] (one block per tile): %.3f ms  %.0f GB/s" % (kt, ms, byts / ms / 1e6))
+
+for contig in (0, 1):
+    for barrier in (0, 1):
+        ms = timeit(lambda: lib.run_gemmx(p(X), ctypes.c_int64(K), K, blocks, contig, barrier, p(out), st))
+        print("projection X pattern (32 k per step, 3 stages) contiguous-64B=%d barrier=%d: %.3f ms  %.0f GB/s" % (contig, barrier, ms, byts / ms / 1e6))
