@@ -665,15 +665,20 @@ __global__ __launch_bounds__(256, 1) void linear_wgrad_bf16x3_kernel(WgradGroup 
 #pragma unroll
         for (int p = 0; p < 4; ++p) acc[q][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* pa = dY + n_base;
-    const float* pb = X + k_base;
+    // Addressing without per-lane 64-bit arithmetic and without branches (a branch around a load costs the pipelining):
+    // 32-bit element offsets from the problem base (the host falls back to the fp32 kernel when M * ld >= 2^31),
+    // one add per load, and the clamp to the slab's last row is a v_min against one precomputed offset.
+    const uint32_t la = (uint32_t)lddy, lbx = (uint32_t)ldx;
+    const uint32_t a_last = (uint32_t)(m_end - 1) * la + (uint32_t)n_base;
+    const uint32_t b_last = (uint32_t)(m_end - 1) * lbx + (uint32_t)k_base;
     auto load_tile = [&](int64_t m0, float4 (&aa)[8], float4 (&bb)[8]) {
+        uint32_t oa = (uint32_t)(m0 + lq) * la + (uint32_t)n_base;
+        uint32_t ob = (uint32_t)(m0 + lq) * lbx + (uint32_t)k_base;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int64_t m = m0 + 4 * j + lq;
-            const int64_t mc = m < m_end ? m : m_end - 1;        // clamped; the dY operand is zeroed at use
-            aa[j] = *reinterpret_cast<const float4*>(pa + mc * lddy);
-            bb[j] = *reinterpret_cast<const float4*>(pb + mc * ldx);
+            aa[j] = *reinterpret_cast<const float4*>(dY + (oa < a_last ? oa : a_last));   // rows past the slab: clamped, zeroed at use
+            bb[j] = *reinterpret_cast<const float4*>(X + (ob < b_last ? ob : b_last));
+            oa += 4 * la; ob += 4 * lbx;
         }
     };
     auto mma_tile = [&](int64_t m0, float4 (&aa)[8], const float4 (&bb)[8]) {
@@ -947,7 +952,10 @@ static int linear_wgrad_grouped_impl(int32_t n_problems, const llmrec_wgrad_prob
     bool fast_shape = (N % 64 == 0) && (K % 64 == 0);
     for (int i = 0; i < n_problems; ++i)
         fast_shape = fast_shape && (p[i].lddy % 4 == 0) && (p[i].ldx % 4 == 0) && (((uintptr_t)p[i].dY | (uintptr_t)p[i].X) % 16 == 0);
-    const bool use_bf16 = bf16x3 && fast_shape;
+    bool small_offsets = true;                                              // the bf16x3 kernel addresses rows with 32-bit element offsets
+    for (int i = 0; i < n_problems; ++i)
+        small_offsets = small_offsets && (p[i].M + 256) * std::max(p[i].lddy, p[i].ldx) < (1ll << 31);
+    const bool use_bf16 = bf16x3 && fast_shape && small_offsets;
     const int64_t MC = wgrad_slab_rows(M_total, K, use_bf16);
     WgradGroup g = {};
     g.n_problems = n_problems;
