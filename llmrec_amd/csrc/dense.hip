@@ -308,17 +308,18 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup 
 // ---------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-struct Split3 { uint32_t h, m, l; };                       // each: a bf16 value in the HIGH 16 bits
+struct Split3 { uint32_t h, m, l; };                       // each: a bf16 value in the HIGH 16 bits (l: low half not cleared)
 __device__ __forceinline__ Split3 split3(float x) {
     Split3 r;
     r.h = __float_as_uint(x) & 0xffff0000u;
     const float r1 = x - __uint_as_float(r.h);             // exact
     r.m = __float_as_uint(r1) & 0xffff0000u;
     const float r2 = r1 - __uint_as_float(r.m);            // exact, <= 8 significant bits
-    r.l = __float_as_uint(r2) & 0xffff0000u;
+    r.l = __float_as_uint(r2);                             // the pack below keeps only its high half
     return r;
 }
-__device__ __forceinline__ uint32_t pack_hi16(uint32_t e0, uint32_t e1) { return (e0 >> 16) | e1; }   // element 0 in the low half
+// high halves of e0 (-> low half of the result) and e1 (-> high half) in one v_perm_b32: no masking needed
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t e0, uint32_t e1) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
 
 // 8 floats (two float4) -> three packed bf16x8 fragments
 __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& H, uint4& M, uint4& L) {
