@@ -163,7 +163,7 @@ int llmrec_softmax_rows_bwd_f32(int64_t rows, int32_t d, const float* Y, int64_t
  * normalize(x) = x / max(||x||_2, 1e-12) row-wise. Term pointer/ld/rate tables live on the HOST
  * (<= LLMREC_MAX_TERMS each) and are passed by value to the kernel.
  * bwd: d_mean (shared by all mean terms) = scale * dOut is NOT written (the caller scales);
- *      d_terms[t] (+)= rates[t] * (dOut - n <n, dOut>) / max(||x||, 1e-12)
+ *      d_terms[t] (+)= rates[t] * (dOut - n <n, dOut>) / max(||x||, 1e-12)   [+ reg_two_coef * x for t < n_reg_terms]
  * ------------------------------------------------------------------------------------------ */
 #define LLMREC_MAX_TERMS 12
 int llmrec_fuse_fwd_f32(int64_t rows, int32_t d, float mean_scale,
@@ -173,7 +173,10 @@ int llmrec_fuse_fwd_f32(int64_t rows, int32_t d, float mean_scale,
 int llmrec_fuse_bwd_f32(int64_t rows, int32_t d, const float* dOut, int64_t lddo,
                         int32_t n_norm, const float* const* norm_terms_host, const int64_t* norm_ld_host,
                         const float* rates_host, float* const* d_terms_host, const int64_t* d_ld_host,
-                        int32_t accumulate, llmrec_stream_t stream);
+                        int32_t accumulate, int32_t n_reg_terms, float reg_two_coef, llmrec_stream_t stream);
+/* n_reg_terms / reg_two_coef: the first n_reg_terms terms additionally receive reg_two_coef * x - the gradient of a
+ * sum-of-squares regulariser coef * sum x^2 on them (reference main.py:151-156 on the image / text streams), folded in
+ * because the kernel has x in registers anyway; pass 0, 0 for the plain backward. */
 
 /* ------------------------------------------------------------------------------------------
  * R7  fused BPR + prune loss             replaces the 3 gathers, mul/sum, logsigmoid, the

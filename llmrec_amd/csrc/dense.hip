@@ -777,21 +777,28 @@ __global__ __launch_bounds__(256, 1) void linear_wgrad_bf16x3_kernel(WgradGroup 
     }
 }
 
+// out[e] (+)= sum over chunks of partial[chunk][e], chunks in ascending order (deterministic); a second, short
+// segment (the bias gradient) rides in the same launch: elements [n_elem, n_elem + n_b) come from partial_b.
 __global__ void reduce_chunks_kernel(int64_t n_elem, int64_t n_chunks, const float* __restrict__ partial,
-                                     float* __restrict__ out, int64_t ld_out, int row_len, int accumulate) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elem; e += (int64_t)gridDim.x * blockDim.x) {
+                                     float* __restrict__ out, int64_t ld_out, int row_len, int accumulate,
+                                     int n_b, const float* __restrict__ partial_b, float* __restrict__ out_b) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_elem + n_b; e += (int64_t)gridDim.x * blockDim.x) {
+        const bool second = e >= n_elem;
+        const float* src = second ? partial_b + (e - n_elem) : partial + e;
+        const int64_t stride = second ? n_b : n_elem;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int64_t c = 0;
         for (; c + 4 <= n_chunks; c += 4) {                      // 4 independent loads in flight
-            s0 += partial[c * n_elem + e];
-            s1 += partial[(c + 1) * n_elem + e];
-            s2 += partial[(c + 2) * n_elem + e];
-            s3 += partial[(c + 3) * n_elem + e];
+            s0 += src[c * stride];
+            s1 += src[(c + 1) * stride];
+            s2 += src[(c + 2) * stride];
+            s3 += src[(c + 3) * stride];
         }
-        for (; c < n_chunks; ++c) s0 += partial[c * n_elem + e];
+        for (; c < n_chunks; ++c) s0 += src[c * stride];
         const float s = (s0 + s1) + (s2 + s3);
-        const int64_t r = e / row_len, col = e % row_len;
-        float* o = out + r * ld_out + col;
+        float* o;
+        if (second) o = out_b + (e - n_elem);
+        else { const int64_t r = e / row_len, col = e % row_len; o = out + r * ld_out + col; }
         *o = accumulate ? (*o + s) : s;
     }
 }
@@ -989,12 +996,9 @@ static int linear_wgrad_grouped_impl(int32_t n_problems, const llmrec_wgrad_prob
     else linear_wgrad_kernel<false><<<grid, 256, 0, stream>>>(g, N, K, partial, db ? partial_db : nullptr, MC, n_kslab, n_slabs);
     LLMREC_LAUNCH_CHECK();
     const int64_t ne = (int64_t)N * K;
-    reduce_chunks_kernel<<<grid_for(ne, 256), 256, 0, stream>>>(ne, n_chunks, partial, dW, lddw, K, accumulate);
+    reduce_chunks_kernel<<<grid_for(ne + (db ? N : 0), 256), 256, 0, stream>>>(ne, n_chunks, partial, dW, lddw, K, accumulate,
+                                                                              db ? N : 0, partial_db, db);
     LLMREC_LAUNCH_CHECK();
-    if (db) {
-        reduce_chunks_kernel<<<1, 128, 0, stream>>>(N, n_chunks, partial_db, db, N, N, accumulate);
-        LLMREC_LAUNCH_CHECK();
-    }
     return LLMREC_OK;
 }
 

@@ -123,6 +123,8 @@ struct FuseArgs {
     float rates[LLMREC_MAX_TERMS];
     int n_mean, n_norm;
     float mean_scale;
+    int n_reg;          // backward: the first n_reg norm terms also receive reg2 * x (a sum-of-squares regulariser on them)
+    float reg2;
 };
 
 template <int VEC, int NCHUNK>
@@ -179,6 +181,12 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(int64_t rows, int d, Fuse
                 for (int k = 0; k < NCHUNK; ++k)
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) o.x[k][q] += w * g.x[k][q];
+            }
+            if (i < a.n_reg) {                                           // d/dx of coef * sum x^2, folded in (x is already loaded)
+#pragma unroll
+                for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) o.x[k][q] = fmaf(a.reg2, t.x[k][q], o.x[k][q]);
             }
             o.store(dst, gl, d);
         }
@@ -390,14 +398,15 @@ int llmrec_fuse_fwd_f32(int64_t rows, int32_t d, float mean_scale,
 int llmrec_fuse_bwd_f32(int64_t rows, int32_t d, const float* dOut, int64_t lddo,
                         int32_t n_norm, const float* const* norm_terms, const int64_t* norm_ld,
                         const float* rates, float* const* d_terms, const int64_t* d_ld,
-                        int32_t accumulate, llmrec_stream_t stream_) {
+                        int32_t accumulate, int32_t n_reg_terms, float reg_two_coef, llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    LLMREC_CHECK_ARG(rows >= 0 && d > 0 && n_norm >= 0 && n_norm <= LLMREC_MAX_TERMS, "fuse_bwd: bad sizes");
+    LLMREC_CHECK_ARG(rows >= 0 && d > 0 && n_norm >= 0 && n_norm <= LLMREC_MAX_TERMS && n_reg_terms >= 0 && n_reg_terms <= n_norm,
+                     "fuse_bwd: bad sizes");
     if (rows == 0 || n_norm == 0) return LLMREC_OK;
     LLMREC_CHECK_ARG(dOut && lddo >= d, "fuse_bwd: null dOut or ld < d");
     FuseArgs a = {};
     bool vec4 = d % 4 == 0 && lddo % 4 == 0 && aligned16(dOut);
-    a.n_norm = n_norm;
+    a.n_norm = n_norm; a.n_reg = n_reg_terms; a.reg2 = reg_two_coef;
     for (int i = 0; i < n_norm; ++i) {
         LLMREC_CHECK_ARG(norm_terms[i] && d_terms[i] && norm_ld[i] >= d && d_ld[i] >= d, "fuse_bwd: bad term %d", i);
         a.norm_terms[i] = norm_terms[i]; a.norm_ld[i] = norm_ld[i]; a.rates[i] = rates[i];

@@ -280,11 +280,12 @@ class FusedStep:
         _call("llmrec_bpr_multi_bwd_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), float(hp.decay),
               float(hp.batch_size), _p(self.saved))
         def fuse_bwd(dout, cat, prof, dcat, dprof):
-            self._axpy(2.0 * coef, cat, dcat, True, cols=2 * d)          # feature regulariser: image / text columns
             norms, dnorms = self._norm_terms(cat, prof), self._norm_terms(dcat, dprof)
             npt, nl = self._tables(norms)
             dp, dl = self._tables(dnorms)
-            _call("llmrec_fuse_bwd_f32", dout.shape[0], d, _p(dout), _ld(dout), len(norms), npt, nl, self._rates(), dp, dl, 1)
+            # the feature regulariser's gradient on the image / text streams (terms 0, 1) rides along: 2 coef x
+            _call("llmrec_fuse_bwd_f32", dout.shape[0], d, _p(dout), _ld(dout), len(norms), npt, nl, self._rates(), dp, dl, 1,
+                  2, float(2.0 * coef))
         self._fork(self.s4)
         with self._on(self.s4):                                          # item side beside the user side
             fuse_bwd(self.dE_i, self.I_cat, self.prof_i, self.dI_cat, self.dprof_i)

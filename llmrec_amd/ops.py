@@ -367,7 +367,7 @@ class _Fuse(torch.autograd.Function):
             npt, nl = _ptr_table(norm_terms)
             dp, dl = _ptr_table(d_terms)
             r = (_c.c_float * len(ctx.rates))(*ctx.rates)
-            _lib.call("llmrec_fuse_bwd_f32", rows, d, _p(dOut), _ld(dOut), len(norm_terms), npt, nl, r, dp, dl, 0, _stream())
+            _lib.call("llmrec_fuse_bwd_f32", rows, d, _p(dOut), _ld(dOut), len(norm_terms), npt, nl, r, dp, dl, 0, 0, 0.0, _stream())
         return (None, None, None) + (d_mean,) * ctx.n_mean + tuple(d_terms)
 
 
