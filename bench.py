@@ -17,7 +17,7 @@ definition, main.py:200,297); the full-rank eval rate (users/s, main.py:297-303)
 N > 1 (one process per GPU, RCCL): the SAME workload with the global batch N x 1024 sharded over
 batch-sharded replicas (llmrec_amd/dp.py): graph and tables replicated (they are < 1 GB), prune
 threshold and regulariser norms over the GLOBAL batch (one 36 KB all-gather), one all-reduce of
-the flat gradient bucket (9.4 MB) per step - weak scaling in the batch. Evaluation shards the
+the flat gradient bucket (8.9 MB) per step - weak scaling in the batch. Evaluation shards the
 users. The user-ROW-sharded path for graphs that need it (cfg 4/5, SURVEY.md 8(e): per-layer
 all-reduce of the item messages, llmrec_amd/dist.py) is --workload synth.
 One JSON line on rank 0.
