@@ -491,6 +491,22 @@ __device__ __forceinline__ int xcd_logical_block(int bid, int nblocks) {
     return x * per + (x < rem ? x : rem) + local;
 }
 
+// a GLOBAL-memory pointer known to be the same in every lane, moved into scalar registers (so that loads can use the
+// scalar-base + 32-bit-lane-offset form); the address space is kept explicit - a pointer rebuilt from integers would
+// otherwise be generic and load through FLAT instructions
+typedef const char __attribute__((address_space(1))) * global_cptr;
+__device__ __forceinline__ global_cptr uniform_ptr(const void* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (global_cptr)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float4 load4_global(global_cptr base, uint32_t byte_off) {
+    typedef float raw4 __attribute__((ext_vector_type(4)));
+    typedef const raw4 __attribute__((address_space(1))) * graw4;
+    const raw4 v = *(graw4)(base + byte_off);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 struct WgradGroup {
     const float* dY[LLMREC_LINEAR_MAX_PROBLEMS];
     const float* X[LLMREC_LINEAR_MAX_PROBLEMS];
@@ -666,28 +682,29 @@ __global__ __launch_bounds__(256, 1) void linear_wgrad_bf16x3_kernel(WgradGroup 
 #pragma unroll
         for (int p = 0; p < 4; ++p) acc[q][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
-    // Addressing without per-lane 64-bit arithmetic and without branches (a branch around a load costs the pipelining):
-    // 32-bit element offsets from the problem base (the host falls back to the fp32 kernel when M * ld >= 2^31),
-    // one add per load, and the clamp to the slab's last row is a v_min against one precomputed offset.
-    const uint32_t la = (uint32_t)lddy, lbx = (uint32_t)ldx;
-    const uint32_t a_last = (uint32_t)(m_end - 1) * la + (uint32_t)n_base;
-    const uint32_t b_last = (uint32_t)(m_end - 1) * lbx + (uint32_t)k_base;
+    // Addressing without per-lane 64-bit arithmetic and without branches around the loads (a branch there costs the
+    // pipelining): the problem's base pointers are forced into scalar registers, a lane adds one 32-bit BYTE offset
+    // (the host falls back to the fp32 kernel when M * ld * 4 >= 2^32), one add per load, and rows past the slab end
+    // are clamped with a v_min against one precomputed offset. Full 32-row tiles run in the main loop with no
+    // zeroing at all; the ragged tail of a problem's last slab is one separate tile after the loop.
+    const global_cptr dYs = uniform_ptr(dY);
+    const global_cptr Xs = uniform_ptr(X);
+    const uint32_t la = 4u * (uint32_t)lddy, lbx = 4u * (uint32_t)ldx;             // row strides in bytes
+    const uint32_t a_last = (uint32_t)(m_end - 1) * la + 4u * (uint32_t)n_base;
+    const uint32_t b_last = (uint32_t)(m_end - 1) * lbx + 4u * (uint32_t)k_base;
     auto load_tile = [&](int64_t m0, float4 (&aa)[8], float4 (&bb)[8]) {
-        uint32_t oa = (uint32_t)(m0 + lq) * la + (uint32_t)n_base;
-        uint32_t ob = (uint32_t)(m0 + lq) * lbx + (uint32_t)k_base;
+        uint32_t oa = (uint32_t)(m0 + lq) * la + 4u * (uint32_t)n_base;
+        uint32_t ob = (uint32_t)(m0 + lq) * lbx + 4u * (uint32_t)k_base;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            aa[j] = *reinterpret_cast<const float4*>(dY + (oa < a_last ? oa : a_last));   // rows past the slab: clamped, zeroed at use
-            bb[j] = *reinterpret_cast<const float4*>(X + (ob < b_last ? ob : b_last));
+            aa[j] = load4_global(dYs, oa < a_last ? oa : a_last);
+            bb[j] = load4_global(Xs, ob < b_last ? ob : b_last);
             oa += 4 * la; ob += 4 * lbx;
         }
     };
-    auto mma_tile = [&](int64_t m0, float4 (&aa)[8], const float4 (&bb)[8]) {
+    auto mma_tile = [&](float4 (&aa)[8], const float4 (&bb)[8]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (m0 + 4 * j + lq >= m_end) aa[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            dbs.x += aa[j].x; dbs.y += aa[j].y; dbs.z += aa[j].z; dbs.w += aa[j].w;
-        }
+        for (int j = 0; j < 8; ++j) { dbs.x += aa[j].x; dbs.y += aa[j].y; dbs.z += aa[j].z; dbs.w += aa[j].w; }
         uint4 bh[4], bm[4], bl[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p)
@@ -713,24 +730,26 @@ __global__ __launch_bounds__(256, 1) void linear_wgrad_bf16x3_kernel(WgradGroup 
             for (int p = 0; p < 4; ++p) acc[q][p] = mfma_bf16(ah, bh[p], acc[q][p]);
         }
     };
-    float4 a0[8], b0[8], a1[8], b1[8], a2[8], b2[8];
+    // two 32-row stages rotate statically over the FULL tiles: the next tile's loads fly during this tile's 96 MFMAs
+    const int64_t m_full = m_begin + ((m_end - m_begin) / 32) * 32;
+    float4 a0[8], b0[8], a1[8], b1[8];
     load_tile(m_begin, a0, b0);
-    load_tile(m_begin + 32, a1, b1);
-    // three stages rotate statically (loads two 32-row steps ahead: 48 KB in flight per wave); slabs are multiples
-    // of 96 rows; tiles past m_end load clamped rows and multiply zeros (no early exit)
-    for (int64_t m0 = m_begin; m0 < m_end; m0 += 96) {
-        load_tile(m0 + 64, a2, b2);
+    for (int64_t m0 = m_begin; m0 < m_full; m0 += 64) {
+        load_tile(m0 + 32, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        mma_tile(m0, a0, b0);
+        mma_tile(a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        load_tile(m0 + 96, a0, b0);
+        load_tile(m0 + 64, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        mma_tile(m0 + 32, a1, b1);
+        if (m0 + 32 < m_full) mma_tile(a1, b1);                 // wave-uniform; no loads inside
         __builtin_amdgcn_sched_barrier(0);
-        load_tile(m0 + 128, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_tile(m0 + 64, a2, b2);
-        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (m_full < m_end) {                                        // the ragged tail (at most once per problem): clamped rows zeroed
+        load_tile(m_full, a0, b0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (m_full + 4 * j + lq >= m_end) a0[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        mma_tile(a0, b0);
     }
     dbs.x += __shfl_xor(dbs.x, 16, 64); dbs.y += __shfl_xor(dbs.y, 16, 64);
     dbs.z += __shfl_xor(dbs.z, 16, 64); dbs.w += __shfl_xor(dbs.w, 16, 64);
@@ -960,9 +979,9 @@ static int linear_wgrad_grouped_impl(int32_t n_problems, const llmrec_wgrad_prob
     bool fast_shape = (N % 64 == 0) && (K % 64 == 0);
     for (int i = 0; i < n_problems; ++i)
         fast_shape = fast_shape && (p[i].lddy % 4 == 0) && (p[i].ldx % 4 == 0) && (((uintptr_t)p[i].dY | (uintptr_t)p[i].X) % 16 == 0);
-    bool small_offsets = true;                                              // the bf16x3 kernel addresses rows with 32-bit element offsets
+    bool small_offsets = true;                                              // the bf16x3 kernel addresses rows with 32-bit byte offsets
     for (int i = 0; i < n_problems; ++i)
-        small_offsets = small_offsets && (p[i].M + 256) * std::max(p[i].lddy, p[i].ldx) < (1ll << 31);
+        small_offsets = small_offsets && (p[i].M + 256) * std::max(p[i].lddy, p[i].ldx) < (1ll << 30);   // byte offsets < 2^32
     const bool use_bf16 = bf16x3 && fast_shape && small_offsets;
     const int64_t MC = wgrad_slab_rows(M_total, K, use_bf16);
     WgradGroup g = {};
