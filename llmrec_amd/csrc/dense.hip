@@ -321,6 +321,8 @@ __device__ __forceinline__ Split3 split3(float x) {
 // high halves of e0 (-> low half of the result) and e1 (-> high half) in one v_perm_b32: no masking needed
 __device__ __forceinline__ uint32_t pack_hi16(uint32_t e0, uint32_t e1) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // 8 floats (two float4) -> three packed bf16x8 fragments
 __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& H, uint4& M, uint4& L) {
     const Split3 s0 = split3(a.x), s1 = split3(a.y), s2 = split3(a.z), s3 = split3(a.w);
@@ -329,6 +331,33 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
     M = make_uint4(pack_hi16(s0.m, s1.m), pack_hi16(s2.m, s3.m), pack_hi16(s4.m, s5.m), pack_hi16(s6.m, s7.m));
     L = make_uint4(pack_hi16(s0.l, s1.l), pack_hi16(s2.l, s3.l), pack_hi16(s4.l, s5.l), pack_hi16(s6.l, s7.l));
 }
+// 8 float4 (rows j = 0..7 of one lane; component c belongs to tile c) -> the three bf16x8 fragments of all four
+// tiles. The residual arithmetic runs on the register pairs (x, y) and (z, w) exactly as they were loaded (packed
+// subtractions, no moves); only the final v_perm_b32 packing crosses loads. 144 VALU instructions per 32 values.
+__device__ __forceinline__ void split32(const float4 (&v)[8], uint4 (&H)[4], uint4 (&M)[4], uint4 (&L)[4]) {
+    uint32_t h[8][4], m[8][4], l[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const f32x2 xy = {v[j].x, v[j].y}, zw = {v[j].z, v[j].w};
+        h[j][0] = __float_as_uint(xy.x) & 0xffff0000u; h[j][1] = __float_as_uint(xy.y) & 0xffff0000u;
+        h[j][2] = __float_as_uint(zw.x) & 0xffff0000u; h[j][3] = __float_as_uint(zw.y) & 0xffff0000u;
+        const f32x2 hxy = {__uint_as_float(h[j][0]), __uint_as_float(h[j][1])}, hzw = {__uint_as_float(h[j][2]), __uint_as_float(h[j][3])};
+        const f32x2 r1xy = xy - hxy, r1zw = zw - hzw;                       // exact
+        m[j][0] = __float_as_uint(r1xy.x) & 0xffff0000u; m[j][1] = __float_as_uint(r1xy.y) & 0xffff0000u;
+        m[j][2] = __float_as_uint(r1zw.x) & 0xffff0000u; m[j][3] = __float_as_uint(r1zw.y) & 0xffff0000u;
+        const f32x2 mxy = {__uint_as_float(m[j][0]), __uint_as_float(m[j][1])}, mzw = {__uint_as_float(m[j][2]), __uint_as_float(m[j][3])};
+        const f32x2 r2xy = r1xy - mxy, r2zw = r1zw - mzw;                   // exact, <= 8 significant bits
+        l[j][0] = __float_as_uint(r2xy.x); l[j][1] = __float_as_uint(r2xy.y);
+        l[j][2] = __float_as_uint(r2zw.x); l[j][3] = __float_as_uint(r2zw.y);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        H[c] = make_uint4(pack_hi16(h[0][c], h[1][c]), pack_hi16(h[2][c], h[3][c]), pack_hi16(h[4][c], h[5][c]), pack_hi16(h[6][c], h[7][c]));
+        M[c] = make_uint4(pack_hi16(m[0][c], m[1][c]), pack_hi16(m[2][c], m[3][c]), pack_hi16(m[4][c], m[5][c]), pack_hi16(m[6][c], m[7][c]));
+        L[c] = make_uint4(pack_hi16(l[0][c], l[1][c]), pack_hi16(l[2][c], l[3][c]), pack_hi16(l[4][c], l[5][c]), pack_hi16(l[6][c], l[7][c]));
+    }
+}
+
 __device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -705,16 +734,12 @@ __global__ __launch_bounds__(256, 1) void linear_wgrad_bf16x3_kernel(WgradGroup 
     auto mma_tile = [&](float4 (&aa)[8], const float4 (&bb)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dbs.x += aa[j].x; dbs.y += aa[j].y; dbs.z += aa[j].z; dbs.w += aa[j].w; }
-        uint4 bh[4], bm[4], bl[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            split8(make_float4(comp(bb[0], p), comp(bb[1], p), comp(bb[2], p), comp(bb[3], p)),
-                   make_float4(comp(bb[4], p), comp(bb[5], p), comp(bb[6], p), comp(bb[7], p)), bh[p], bm[p], bl[p]);
+        uint4 bh[4], bm[4], bl[4], ahs[4], ams[4], als[4];
+        split32(bb, bh, bm, bl);
+        split32(aa, ahs, ams, als);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            uint4 ah, am, al;
-            split8(make_float4(comp(aa[0], q), comp(aa[1], q), comp(aa[2], q), comp(aa[3], q)),
-                   make_float4(comp(aa[4], q), comp(aa[5], q), comp(aa[6], q), comp(aa[7], q)), ah, am, al);
+            const uint4 ah = ahs[q], am = ams[q], al = als[q];
             // smallest terms first (as in the forward)
 #pragma unroll
             for (int p = 0; p < 4; ++p) acc[q][p] = mfma_bf16(al, bh[p], acc[q][p]);
