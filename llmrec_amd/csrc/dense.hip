@@ -41,6 +41,22 @@ __device__ __forceinline__ float4 load4_fast(const float* row, int k, int K) {
     return v;
 }
 
+// a GLOBAL-memory pointer known to be the same in every lane, moved into scalar registers (so that loads can use the
+// scalar-base + 32-bit-lane-offset form); the address space is kept explicit - a pointer rebuilt from integers would
+// otherwise be generic and load through FLAT instructions
+typedef const char __attribute__((address_space(1))) * global_cptr;
+__device__ __forceinline__ global_cptr uniform_ptr(const void* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (global_cptr)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float4 load4_global(global_cptr base, uint32_t byte_off) {
+    typedef float raw4 __attribute__((ext_vector_type(4)));
+    typedef const raw4 __attribute__((address_space(1))) * graw4;
+    const raw4 v = *(graw4)(base + byte_off);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ float comp(const float4& v, int s) {
     return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w));
 }
@@ -176,8 +192,9 @@ struct LinearGroup {
 constexpr int GF_BK = 32;              // k per step
 constexpr int GF_WS = GF_BK + 4;       // LDS row stride in floats (144 B: spreads ds_read_b128 over the banks)
 
-template <int NT, int RT, bool FAST>
+template <int NT, int RT, int MODE>
 __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup g, int N) {
+    constexpr bool FAST = MODE >= 1;
     __shared__ __attribute__((aligned(16))) float w_lds[2][NT * 16 * GF_WS];
     int prob = 0;
     while (prob + 1 < g.n_problems && (int)blockIdx.x >= g.unit_begin[prob + 1]) ++prob;
@@ -323,13 +340,26 @@ __device__ __forceinline__ uint32_t pack_hi16(uint32_t e0, uint32_t e1) { return
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// 8 floats (two float4) -> three packed bf16x8 fragments
+// two register-adjacent floats -> their packed (hi, mid, lo) bf16 pairs: 2 + 2 masks, 2 packed subtractions, 3 v_perm_b32
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& H, uint32_t& M, uint32_t& L) {
+    const f32x2 x = {x0, x1};
+    const uint32_t h0 = __float_as_uint(x0) & 0xffff0000u, h1 = __float_as_uint(x1) & 0xffff0000u;
+    const f32x2 hf = {__uint_as_float(h0), __uint_as_float(h1)};
+    const f32x2 r1 = x - hf;                                   // exact
+    const uint32_t m0 = __float_as_uint(r1.x) & 0xffff0000u, m1 = __float_as_uint(r1.y) & 0xffff0000u;
+    const f32x2 mf = {__uint_as_float(m0), __uint_as_float(m1)};
+    const f32x2 r2 = r1 - mf;                                  // exact, <= 8 significant bits
+    H = pack_hi16(h0, h1);
+    M = pack_hi16(m0, m1);
+    L = pack_hi16(__float_as_uint(r2.x), __float_as_uint(r2.y));
+}
+
+// 8 floats (two float4, consecutive k of one row) -> three packed bf16x8 fragments
 __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& H, uint4& M, uint4& L) {
-    const Split3 s0 = split3(a.x), s1 = split3(a.y), s2 = split3(a.z), s3 = split3(a.w);
-    const Split3 s4 = split3(b.x), s5 = split3(b.y), s6 = split3(b.z), s7 = split3(b.w);
-    H = make_uint4(pack_hi16(s0.h, s1.h), pack_hi16(s2.h, s3.h), pack_hi16(s4.h, s5.h), pack_hi16(s6.h, s7.h));
-    M = make_uint4(pack_hi16(s0.m, s1.m), pack_hi16(s2.m, s3.m), pack_hi16(s4.m, s5.m), pack_hi16(s6.m, s7.m));
-    L = make_uint4(pack_hi16(s0.l, s1.l), pack_hi16(s2.l, s3.l), pack_hi16(s4.l, s5.l), pack_hi16(s6.l, s7.l));
+    split2(a.x, a.y, H.x, M.x, L.x);
+    split2(a.z, a.w, H.y, M.y, L.y);
+    split2(b.x, b.y, H.z, M.z, L.z);
+    split2(b.z, b.w, H.w, M.w, L.w);
 }
 // 8 float4 (rows j = 0..7 of one lane; component c belongs to tile c) -> the three bf16x8 fragments of all four
 // tiles. The residual arithmetic runs on the register pairs (x, y) and (z, w) exactly as they were loaded (packed
@@ -364,8 +394,14 @@ __device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4
 
 constexpr int GB_WS = 40;              // LDS row stride of one bf16 W tile in 2-byte units (32 k + 8 pad = 80 B)
 
-template <int NT, int RT, bool FAST>
+// MODE 0: guarded loads (any shape); 1: FAST (16-byte aligned rows, K % 4 == 0: branch-free clamped loads with a zero
+// select); 2: FAST and every K % 32 == 0 and all byte offsets < 2^32 - a k-step is then valid or invalid for the
+// whole wave, so the operand addresses are scalar base + one 32-bit lane offset + a SCALAR k offset (one v_add per
+// load, no clamps or selects on X: past K the staged W tile is zero and X is finite), W is zeroed by one select.
+template <int NT, int RT, int MODE>
 __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(LinearGroup g, int N) {
+    constexpr bool FAST = MODE >= 1;
+    constexpr bool K32 = MODE == 2;
     // [buffer][term h/m/l][n][k] bf16
     __shared__ __attribute__((aligned(16))) uint16_t w_lds[2][3][NT * 16 * GB_WS];
     int prob = 0;
@@ -381,12 +417,15 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
     const int64_t row0 = (int64_t)(blockIdx.x - g.unit_begin[prob]) * (64 * RT) + wave * (16 * RT);
 
     const float* xrow[RT];
+    uint32_t xoff[RT];                                                     // K32: byte offset of (row, k = 8 lq) from X
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
         int64_t r = row0 + t * 16 + li;
         if (r > M - 1) r = M - 1;
         xrow[t] = X + r * ldx;
+        xoff[t] = (uint32_t)(r * ldx + 8 * lq) * 4u;
     }
+    const global_cptr Xs = uniform_ptr(X), Ws = uniform_ptr(W);
     const int wn = threadIdx.x >> 3, wk = (threadIdx.x & 7) * 4;
     constexpr int WLOADS = (NT * 16 + 31) / 32;
     auto load_w = [&](int kb, float4 (&wr)[WLOADS]) {
@@ -395,7 +434,12 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
             int n = wn + 32 * j;
             const bool in = n < NT * 16;
             if (n > N - 1) n = N - 1;
-            if (FAST) {
+            if (K32) {
+                const int kbs = kb < K ? kb : K - 32;                      // wave-uniform: scalar
+                float4 v = load4_global(Ws, (uint32_t)(n * (int)ldw + wk) * 4u + (uint32_t)kbs * 4u);
+                if (!in || kb >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                wr[j] = v;
+            } else if (FAST) {
                 float4 v = load4_fast(W + (int64_t)n * ldw, kb + wk, K);
                 if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 wr[j] = v;
@@ -409,11 +453,13 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
         for (int j = 0; j < WLOADS; ++j) {
             const int n = wn + 32 * j;
             if (n >= NT * 16) continue;
-            const Split3 s0 = split3(wr[j].x), s1 = split3(wr[j].y), s2 = split3(wr[j].z), s3 = split3(wr[j].w);
+            uint2 wh, wm, wl;
+            split2(wr[j].x, wr[j].y, wh.x, wm.x, wl.x);
+            split2(wr[j].z, wr[j].w, wh.y, wm.y, wl.y);
             const int off = n * GB_WS + wk;
-            *reinterpret_cast<uint2*>(&w_lds[buf][0][off]) = make_uint2(pack_hi16(s0.h, s1.h), pack_hi16(s2.h, s3.h));
-            *reinterpret_cast<uint2*>(&w_lds[buf][1][off]) = make_uint2(pack_hi16(s0.m, s1.m), pack_hi16(s2.m, s3.m));
-            *reinterpret_cast<uint2*>(&w_lds[buf][2][off]) = make_uint2(pack_hi16(s0.l, s1.l), pack_hi16(s2.l, s3.l));
+            *reinterpret_cast<uint2*>(&w_lds[buf][0][off]) = wh;
+            *reinterpret_cast<uint2*>(&w_lds[buf][1][off]) = wm;
+            *reinterpret_cast<uint2*>(&w_lds[buf][2][off]) = wl;
         }
     };
     auto load_x = [&](int kb, float4 (&xr)[RT][2]) {                         // lane: k = kb + 8 lq + {0..3 | 4..7}
@@ -421,7 +467,12 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-                xr[t][h] = FAST ? load4_fast(xrow[t], kb + 8 * lq + 4 * h, K) : load4_guard(xrow[t], kb + 8 * lq + 4 * h, K, vec_ok);
+                if (K32) {
+                    const int kbs = kb < K ? kb : K - 32;                  // wave-uniform: scalar; past K the W tile is zero
+                    xr[t][h] = load4_global(Xs, xoff[t] + (uint32_t)kbs * 4u + 16u * h);
+                } else {
+                    xr[t][h] = FAST ? load4_fast(xrow[t], kb + 8 * lq + 4 * h, K) : load4_guard(xrow[t], kb + 8 * lq + 4 * h, K, vec_ok);
+                }
     };
 
     f32x4 acc[RT][NT];
@@ -518,22 +569,6 @@ __device__ __forceinline__ int xcd_logical_block(int bid, int nblocks) {
     const int per = nblocks / XCDS, rem = nblocks % XCDS;       // XCD x runs per + (x < rem) blocks
     const int x = bid % XCDS, local = bid / XCDS;
     return x * per + (x < rem ? x : rem) + local;
-}
-
-// a GLOBAL-memory pointer known to be the same in every lane, moved into scalar registers (so that loads can use the
-// scalar-base + 32-bit-lane-offset form); the address space is kept explicit - a pointer rebuilt from integers would
-// otherwise be generic and load through FLAT instructions
-typedef const char __attribute__((address_space(1))) * global_cptr;
-__device__ __forceinline__ global_cptr uniform_ptr(const void* p) {
-    const uint64_t v = (uint64_t)p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return (global_cptr)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ float4 load4_global(global_cptr base, uint32_t byte_off) {
-    typedef float raw4 __attribute__((ext_vector_type(4)));
-    typedef const raw4 __attribute__((address_space(1))) * graw4;
-    const raw4 v = *(graw4)(base + byte_off);
-    return make_float4(v.x, v.y, v.z, v.w);
 }
 
 struct WgradGroup {
@@ -933,10 +968,20 @@ static int linear_fwd_grouped_impl(int32_t n_problems, const llmrec_linear_probl
     if (units == 0) return LLMREC_OK;
     bool fast = true;                                  // every problem: 16-byte aligned rows, K % 4 == 0
     for (int i = 0; i < n_problems; ++i) fast = fast && g.vec_ok[i] && (g.K[i] % 4 == 0) && g.K[i] >= 4;
+    bool k32 = fast;                                   // scalar-k addressing of the bf16x3 kernel (MODE 2)
+    for (int i = 0; i < n_problems; ++i)
+        k32 = k32 && (g.K[i] % 32 == 0) && (p[i].M * p[i].ldx + g.K[i]) < (1ll << 30) && ((int64_t)N * p[i].ldw + g.K[i]) < (1ll << 30);
 #define GROUPED_LAUNCH(KERNEL, NT_)                                                         \
     do {                                                                                    \
-        if (rows_per_unit == 128) { if (fast) KERNEL<NT_, 2, true><<<units, 256, 0, stream>>>(g, N); else KERNEL<NT_, 2, false><<<units, 256, 0, stream>>>(g, N); } \
-        else { if (fast) KERNEL<NT_, 1, true><<<units, 256, 0, stream>>>(g, N); else KERNEL<NT_, 1, false><<<units, 256, 0, stream>>>(g, N); } \
+        if (rows_per_unit == 128) {                                                         \
+            if (k32) KERNEL<NT_, 2, 2><<<units, 256, 0, stream>>>(g, N);                     \
+            else if (fast) KERNEL<NT_, 2, 1><<<units, 256, 0, stream>>>(g, N);               \
+            else KERNEL<NT_, 2, 0><<<units, 256, 0, stream>>>(g, N);                         \
+        } else {                                                                            \
+            if (k32) KERNEL<NT_, 1, 2><<<units, 256, 0, stream>>>(g, N);                     \
+            else if (fast) KERNEL<NT_, 1, 1><<<units, 256, 0, stream>>>(g, N);               \
+            else KERNEL<NT_, 1, 0><<<units, 256, 0, stream>>>(g, N);                         \
+        }                                                                                   \
     } while (0)
     const int nt = (N + 15) / 16;
     if (bf16x3) {
