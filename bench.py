@@ -191,9 +191,9 @@ class NetflixShaped:
         byts_all = sum(4.0 * (x.shape[0] * x.shape[1] + d * x.shape[1] + x.shape[0] * d) for x in feats)
         ms = event_time_ms(self.fused._project_all, 20)
         bf = self.fused.gemm == "bf16x3"
-        out.append({"kernel": ("linear_fwd_grouped_bf16x3_kernel<4,2,true> (all 8 projections, one launch; 3-term bf16 split, 6 bf16 MFMAs: "
+        out.append({"kernel": ("linear_fwd_grouped_bf16x3_kernel (all 8 projections, one launch; 3-term bf16 split, 6 bf16 MFMAs: "
                                "HBM-bound on the X stream - tflops/frac_mfma_f32 are fp32-EQUIVALENT figures)") if bf else
-                              "linear_fwd_grouped_kernel<4,2,true> (all 8 projections of one forward, one launch, exact fp32 MFMA)",
+                              "linear_fwd_grouped_kernel (all 8 projections of one forward, one launch, exact fp32 MFMA)",
                     "pmc": [("linear_fwd_grouped_bf16x3_kernel" if bf else "linear_fwd_grouped_kernel", 1)],
                     "bound": "hbm" if bf else "mfma", "calls_per_step": 1, "ms": ms,
                     "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
