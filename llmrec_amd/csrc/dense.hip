@@ -882,13 +882,34 @@ __global__ void reduce_chunks_kernel(int64_t n_elem, int64_t n_chunks, const flo
     }
 }
 
-// rows per slab so that the launch has ~2048 waves over all problems (two full rounds of one wave per SIMD for
-// the bf16x3 kernel); a multiple of the kernel's rotation length: 48 rows (fp32, 3 x 16) or 96 (bf16x3, 3 x 32)
+// rows per slab of the fp32 kernel: ~2048 waves over all problems (one round at two waves per SIMD); a multiple of
+// its rotation length (48 rows = 3 x 16)
 static int64_t wgrad_slab_rows(int64_t M_total, int K, bool bf16x3) {
     const int64_t n_kslab = ceil_div(K, 64);
     const int64_t want_slabs = ceil_div(2048, n_kslab);
-    const int64_t mc = align_up(ceil_div(M_total > 0 ? M_total : 1, want_slabs), bf16x3 ? 96 : 48);
+    const int64_t mc = align_up(ceil_div(M_total > 0 ? M_total : 1, want_slabs), bf16x3 ? 64 : 48);
     return (!bf16x3 && mc < 144) ? 144 : mc;
+}
+
+// rows per slab of the bf16x3 kernel. It runs ONE block (4 waves = 4 slabs of one k slab) per CU at a time, so the
+// launch takes ceil(blocks / 256) rounds of (rows per slab + a fixed prologue / LDS-reduction cost): 528 blocks are
+// three rounds where 480 are two. Pick the slab length (a multiple of 32, at least half the nominal one so that the
+// workspace bound of the fp32 geometry still holds) that minimises rounds x length; ties go to the longer slab
+// (fewer partial slabs to reduce).
+static int64_t wgrad_slab_rows_bf16(int32_t n_problems, const llmrec_wgrad_problem_t* p, int64_t M_total, int K) {
+    const int64_t n_kslab = ceil_div(K, 64);
+    const int64_t lo = std::max<int64_t>(64, align_up(wgrad_slab_rows(M_total, K, true) / 2, 32));
+    int64_t m_max = 0;
+    for (int i = 0; i < n_problems; ++i) m_max = std::max(m_max, p[i].M);
+    int64_t best = lo, best_cost = -1;
+    for (int64_t mc = lo; mc <= align_up(m_max, 32) + 32; mc += 32) {
+        int64_t slabs = 0;
+        for (int i = 0; i < n_problems; ++i) slabs += ceil_div(p[i].M, mc);
+        const int64_t blocks = ceil_div(slabs, 4) * n_kslab;
+        const int64_t cost = ceil_div(blocks, 256) * (mc + 96);
+        if (best_cost < 0 || cost <= best_cost) { best = mc; best_cost = cost; }
+    }
+    return best;
 }
 
 }  // namespace llmrec
@@ -1053,7 +1074,7 @@ static int linear_wgrad_grouped_impl(int32_t n_problems, const llmrec_wgrad_prob
     for (int i = 0; i < n_problems; ++i)
         small_offsets = small_offsets && (p[i].M + 256) * std::max(p[i].lddy, p[i].ldx) < (1ll << 30);   // byte offsets < 2^32
     const bool use_bf16 = bf16x3 && fast_shape && small_offsets;
-    const int64_t MC = wgrad_slab_rows(M_total, K, use_bf16);
+    const int64_t MC = use_bf16 ? wgrad_slab_rows_bf16(n_problems, p, M_total, K) : wgrad_slab_rows(M_total, K, false);
     WgradGroup g = {};
     g.n_problems = n_problems;
     int n_slabs = 0;
