@@ -210,3 +210,44 @@ def test_two_rank_full_model_matches_single_process_oracle(tmp_path):
     assert rel(got_u, ref_params["user_id_embedding.weight"]) < 1e-4
     assert rel(np.concatenate([r0["E_u"], r1["E_u"]]), ref_eu) < 1e-4
     assert rel(r0["E_i"], ref_ei) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# the exchange helpers of the batch-sharded replicas (llmrec_amd/dp.py uses exactly these two)
+# ---------------------------------------------------------------------------------------------
+def _comm_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from llmrec_amd import dist as ld
+    comm = ld.Comm()
+    assert comm.rank == rank and comm.world == world
+    block = torch.arange(5, dtype=torch.float32) + 10 * rank            # this rank's gather block
+    gathered = comm.all_gather_into(torch.zeros(world * 5), block)
+    bucket = torch.full((7,), float(rank + 1))
+    comm.all_reduce_(bucket)
+    np.savez(os.path.join(out_dir, "c%d.npz" % rank), gathered=gathered.numpy(), bucket=bucket.numpy())
+    dist.destroy_process_group()
+
+
+def test_comm_exchange_helpers_two_ranks(tmp_path):
+    mp.spawn(_comm_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    want = np.concatenate([np.arange(5), np.arange(5) + 10]).astype(np.float32)
+    for r in range(2):
+        z = np.load(tmp_path / ("c%d.npz" % r))
+        assert np.array_equal(z["gathered"], want)                       # blocks in rank order on every rank
+        assert np.array_equal(z["bucket"], np.full(7, 3.0, dtype=np.float32))
+
+
+def test_device_batcher_slices_tile_the_global_batch_shape():
+    """engine.DeviceBatcher's rank / world bookkeeping (no kernel call): capacity and slice offsets."""
+    from llmrec_amd import engine
+    exist = torch.arange(100)
+    for world in (1, 2, 8):
+        caps = []
+        for rank in range(world):
+            b = engine.DeviceBatcher(None, exist, 50, 16, torch.zeros(100, dtype=torch.int64), torch.zeros(100, dtype=torch.int64), 0.25,
+                                     seed=3, rank=rank, world=world)
+            assert b.n_aug == 4 and b.capacity == 20 and b.rank * b.B == rank * 16
+            caps.append(b.capacity)
+        assert len(set(caps)) == 1
