@@ -20,8 +20,10 @@ through a loop-back exchange on one GPU against FusedStep on the concatenated ba
 Replicas stay bit-identical: both collectives deliver identical values to every rank, and every
 rank applies the same AdamW update.
 
-Between the exchanges the step is three HIP graphs (forward + scores | selection + backward |
-AdamW); the collectives run between them on the same stream (RCCL, or nothing when world == 1).
+Between the exchanges the step is HIP graphs (sampler + forward + scores | selection + backward | AdamW); the
+collectives run between them on the same stream (RCCL, or nothing when world == 1). The AdamW graph of a step is
+merged into the first graph of the next one (two graph boundaries per step instead of three; flush() applies the
+last one).
 """
 from __future__ import annotations
 
@@ -72,6 +74,8 @@ class DataParallelStep(FusedStep):
         import os
         # LLMREC_DP_FORCE_COLLECTIVES=1: issue the RCCL calls even in a world of one rank (plumbing check on a 1-GPU box)
         self.force = os.environ.get("LLMREC_DP_FORCE_COLLECTIVES", "0") == "1" and comm is not None and comm.dist is not None
+        self.lazy_update = os.environ.get("LLMREC_DP_LAZY", "1") == "1"   # defer AdamW into the next step's first graph (see step())
+        self._pending_update = False
 
     # -- the three compute phases -----------------------------------------------------------------
     def _bpr_phase(self, phase, users, pos, neg, n_valid):
@@ -151,16 +155,24 @@ class DataParallelStep(FusedStep):
             first(); self.exchange_scores(); self.phase_b(*args); self.exchange_grads(); self.phase_c()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        def first_with_update():                               # the previous step's AdamW opens the next step's first graph
+            self.phase_c()
+            first()
         graphs = []
-        for fn in (first, lambda: self.phase_b(*args), self.phase_c):
+        for fn in (first, lambda: self.phase_b(*args), self.phase_c, first_with_update):
             g = torch.cuda.CUDAGraph()                         # capturing records, it does not execute: one step ran (the warm-up)
             with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (the RCCL watchdog) may touch the runtime
                 fn()
             graphs.append(g)
         self.graphs = graphs
         self.graph_exec = graphs[0]
+        self._pending_update = False
 
     def step(self, users=None, pos=None, neg=None, n_valid=None):
+        """One step from the captured graphs. The AdamW update of a step is deferred into the first graph of the NEXT
+        step (two graph boundaries per step instead of three; a boundary costs ~50 us of launch latency): parameters
+        and the loss scalars therefore lag by one step until flush() - evaluation and any read of the parameters go
+        through flush() first (eval_topk does)."""
         if self.graphs is None:
             return self.step_eager(users, pos, neg, n_valid)
         if users is not None:
@@ -169,10 +181,27 @@ class DataParallelStep(FusedStep):
             self._load(users, pos, neg, n_valid)
         elif getattr(self, "batcher", None) is None:
             raise RuntimeError("DataParallelStep.step: a batch is needed (the graphs were captured without a sampler)")
-        ga, gb, gc = self.graphs
-        ga.replay()
-        self.exchange_scores()
-        gb.replay()
-        self.exchange_grads()
-        gc.replay()
+        ga, gb, gc, ga_upd = self.graphs
+        if self.lazy_update:
+            (ga_upd if self._pending_update else ga).replay()
+            self.exchange_scores()
+            gb.replay()
+            self.exchange_grads()
+            self._pending_update = True
+        else:
+            ga.replay()
+            self.exchange_scores()
+            gb.replay()
+            self.exchange_grads()
+            gc.replay()
         return self.scal[1], self.scal[2], self.scal[3]
+
+    def flush(self):
+        """Apply the deferred AdamW update of the last step (and its loss scalars)."""
+        if self.graphs is not None and getattr(self, "_pending_update", False):
+            self.graphs[2].replay()
+            self._pending_update = False
+
+    def eval_topk(self, query_users, train, K, use_graph=False):
+        self.flush()
+        return super().eval_topk(query_users, train, K, use_graph=use_graph)

@@ -353,6 +353,9 @@ class FusedStep:
         self.opt.step(advanced=True)
         return self.scal[1], self.scal[2], self.scal[3]
 
+    def flush(self):
+        """Nothing is deferred in the single-graph step (DataParallelStep defers its AdamW)."""
+
     # -- evaluation -------------------------------------------------------------------------------
     def eval_topk(self, query_users: torch.Tensor, train: Optional[ops.Csr], K: int, use_graph: bool = False):
         """Reference Trainer.test up to the ranked lists (main.py:297-303, batch_test.py:83-109): no-grad forward +

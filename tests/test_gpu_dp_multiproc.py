@@ -57,15 +57,22 @@ def _worker(rank, world, port, case, out_dir, use_graph):
     for s in range(STEPS):
         if use_graph:
             if step.graphs is None:
-                step.capture(batcher=batcher)
-                out = step.scal[1:4].clone()
+                step.capture(batcher=batcher)                   # the capture's warm-up is a complete step
+                losses.append(step.scal[1:4].clone().cpu().numpy())
             else:
-                out = torch.stack(step.step())
+                step.step()                                     # AdamW deferred into the next step's first graph:
+                if s >= 2:                                      # the scalars visible now are those of step s - 1
+                    losses.append(step.scal[1:4].clone().cpu().numpy())
         else:
             u, p, n, nv = batcher.next()
             out = torch.stack(step.step_eager(u, p, n, nv))
             seen.append((u.cpu(), p.cpu(), n.cpu(), int(nv)))
-        losses.append(out.cpu().numpy())
+            losses.append(out.cpu().numpy())
+    if use_graph:
+        step.flush()                                            # the last step's update and scalars
+        if STEPS >= 2:
+            losses.append(step.scal[1:4].clone().cpu().numpy())
+    assert len(losses) == STEPS
     params = dict(tr.model_mm.named_parameters())
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), losses=np.array(losses),
              **{k.replace(".", "_"): params[k].detach().cpu().numpy() for k in NAMES})
