@@ -37,6 +37,23 @@ def test_argument_errors_are_reported_not_thrown():
         _lib.call("llmrec_degree_scale", -1, None, None, None)
 
 
+def test_argument_errors_of_the_later_entry_points():
+    """Every entry point validates its arguments before touching the device (status code + llmrec_last_error, no throw,
+    no launch): exercised here without a GPU for the entry points added after the first ABI draft."""
+    lib = _lib.load()
+    cases = [
+        ("llmrec_sample_batch", (1, None, 10, None, 5, None, None, 8, 0, 16, 0, None, None, None, None, None, None, None), b"sample_batch"),   # slice larger than the global batch
+        ("llmrec_topk_metrics", (4, None, 50, None, None, None, 9, None, None, None), b"topk_metrics"),                                       # more than 8 cut-offs
+        ("llmrec_bpr_multi_fwd_sharded_f32", (1, None, 64, None, None, None, 8, None, 0.3, 1e-5, 64.0, 3, None, None, 1, 0, 0, None, None, None), b"bpr_multi_fwd_sharded"),
+        ("llmrec_linear_wgrad_grouped_bf16x3", (0, None, 64, 64, None, 64, None, 0, None, 0, None), b"linear_wgrad"),
+        ("llmrec_fuse_bwd_f32", (4, 8, None, 8, 2, None, None, None, None, None, 0, 5, 0.0, None), b"fuse_bwd"),                              # n_reg_terms > n_norm
+    ]
+    for name, args, needle in cases:
+        st = getattr(lib, name)(*args)
+        assert st != 0, name
+        assert needle in lib.llmrec_last_error(), (name, lib.llmrec_last_error())
+
+
 def test_ops_refuse_cpu_tensors():
     from llmrec_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
