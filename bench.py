@@ -1,6 +1,6 @@
 """bench.py - the driver's measurement contract for the LLMRec Stage-2 hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one mini-batch: on-device BPR sampling + LLM-augmented
@@ -41,14 +41,15 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="auto", help="auto | nf (cfg 2) | ml (cfg 3) | synth (user-sharded ID path, cfg 4 shape)")
     ap.add_argument("--synth-users", type=int, default=1_250_000, help="users PER GPU for --workload synth")
     ap.add_argument("--synth-items", type=int, default=1_000_000)
     ap.add_argument("--synth-edges", type=int, default=25_000_000, help="edges PER GPU for --workload synth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity gate that runs before the timed region")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -171,13 +172,51 @@ class NetflixShaped:
                 "embed_size": self.args.embed_size, "prop_layers": len(eval(self.args.weight_size)),
                 "batch_size": self.hp.batch_size, "aug_sample_rate": self.hp.aug_sample_rate,
                 "prune_loss_drop_rate": self.hp.prune_loss_drop_rate, "side_features": "image512+text768+llm1536x(1+5)",
-                "sampler": "device (llmrec_sample_bpr)", "global_batch": self.hp.batch_size * self.world,
+                "sampler": "device, inside the step graph (llmrec_sample_batch: BPR triples + LLM-augmented triples, device step counter)", "global_batch": self.hp.batch_size * self.world,
                 "parallelism": "single GPU" if not hasattr(self.fused, "gsz") else
                 ("dp%d: batch-sharded replicas (llmrec_amd/dp.py), graph + tables replicated, prune over the global batch "
                  "(1 all-gather of %d B) + 1 all-reduce of the %d B gradient bucket per step; eval shards the users"
                  % (self.world, 4 * self.fused.gsz, 4 * self.fused.bucket.numel())),
                 "step": ("fused (llmrec_amd/fused.py)" if not hasattr(self.fused, "gsz") else "fused, 3 segments between the 2 exchanges (llmrec_amd/dp.py)")
                         + (" + HIP graph replay" if self.use_graph else "")}
+
+
+    def _wgrad_concurrent_ms(self, dYi, dYu, ws, iters: int = 20):
+        """Durations of the step's four weight-gradient launches when they run concurrently on four streams (HIP events
+        recorded on each launch's own stream), and the wall time of the group."""
+        import torch
+        ops, d, m_ = self.ops, self.args.embed_size, self.model
+        pr = self.fused.gemm
+        f = self.fused
+        jobs = {
+            "item_trans_x5": (lambda: ops.linear_wgrad_grouped([(dYi[:, (2 + k) * d:(3 + k) * d], m_.item_feats[key]) for k, key in enumerate(self.keys)],
+                                                               m_.item_trans.weight.grad, m_.item_trans.bias.grad, False, ws, precision=pr)),
+            "user_trans": (lambda: ops.linear_wgrad_grouped([(dYu, m_.user_feats)], m_.user_trans.weight.grad, m_.user_trans.bias.grad, False, f.ws_wgrad_b, precision=pr)),
+            "text_trans": (lambda: ops.linear_wgrad_grouped([(dYi[:, d:2 * d], m_.text_feats)], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False, f.ws_wgrad_c, precision=pr)),
+            "image_trans": (lambda: ops.linear_wgrad_grouped([(dYi[:, 0:d], m_.image_feats)], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False, f.ws_wgrad_d, precision=pr)),
+        }
+        streams = {k: torch.cuda.Stream() for k in jobs}
+        acc = {k: 0.0 for k in jobs}
+        wall = 0.0
+        for it in range(iters + 3):
+            cur = torch.cuda.current_stream()
+            ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in jobs}
+            w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            w0.record()
+            for k in jobs:
+                streams[k].wait_stream(cur)
+            for k, fn in jobs.items():
+                with torch.cuda.stream(streams[k]):
+                    ev[k][0].record(); fn(); ev[k][1].record()
+            for k in jobs:
+                cur.wait_stream(streams[k])
+            w1.record()
+            torch.cuda.synchronize()
+            if it >= 3:
+                for k in jobs:
+                    acc[k] += ev[k][0].elapsed_time(ev[k][1])
+                wall += w0.elapsed_time(w1)
+        return {k: v / iters for k, v in acc.items()}, wall / iters
 
     # ---- per-kernel roofline (dominant kernels of this workload, timed in isolation) -------------
     def kernel_rooflines(self):
@@ -198,7 +237,8 @@ class NetflixShaped:
                     "bound": "hbm" if bf else "mfma", "calls_per_step": 1, "ms": ms,
                     "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                     "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
-                    "algorithmic_flop_per_launch": flop_all, "algorithmic_bytes_per_launch": byts_all})
+                    "algorithmic_flop_per_launch": flop_all, "algorithmic_bytes_per_launch": byts_all,
+                    "algorithmic_flop_per_step": flop_all, "algorithmic_bytes_per_step": byts_all, "launches": 1})
         flop = 2.0 * sh.n_items * sh.llm_dim * d
         byts = 4.0 * (sh.n_items * sh.llm_dim + d * sh.llm_dim + sh.n_items * d)
         # the step's four weight-gradient launches: item_trans (5 attribute streams grouped), user, text, image
@@ -213,15 +253,24 @@ class NetflixShaped:
             ops.linear_wgrad_grouped([(dYu, m_.user_feats)], m_.user_trans.weight.grad, m_.user_trans.bias.grad, False, ws, precision=pr)
             ops.linear_wgrad_grouped([(dYi[:, d:2 * d], m_.text_feats)], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False, ws, precision=pr)
             ops.linear_wgrad_grouped([(dYi[:, 0:d], m_.image_feats)], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False, ws, precision=pr)
-        ms = event_time_ms(wgrad_all, 20)
+        ms_serial = event_time_ms(wgrad_all, 20)
+        # IN SITU: the step runs the four weight-gradient launches on four streams at once (fused.py _backward); each
+        # launch's own duration under that concurrency is what a rocprofv3 kernel trace of the step reports as the
+        # kernel's average duration, and it is the denominator of the roofline figure below.
+        per_launch, wall = self._wgrad_concurrent_ms(dYi, dYu, ws)
+        ms = sum(per_launch.values())
         out.append({"kernel": ("linear_wgrad_bf16x3_kernel" if bf else "linear_wgrad_kernel<true>") +
                               " + reduce_chunks_kernel (the step's 4 launches: item_trans x5 grouped, user, text, image" +
                               ("; 3-term bf16 split: HBM-bound on the X stream, tflops are fp32-EQUIVALENT)" if bf else ")"),
-                    "pmc": [("linear_wgrad_bf16x3_kernel" if bf else "linear_wgrad_kernel", 4), ("reduce_chunks_kernel", 8)],
-                    "launches": 4, "avg_launch_ms": ms / 4,
+                    "pmc": [("linear_wgrad_bf16x3_kernel" if bf else "linear_wgrad_kernel", 4), ("reduce_chunks_kernel", 4)],
+                    "launches": 4, "avg_launch_ms": ms / 4, "per_launch_ms_concurrent": per_launch, "ms_wall_concurrent": wall,
+                    "ms_serial_isolated": ms_serial,
+                    "timing": "HIP events on each launch's own stream, the four launched concurrently as in the step; ms = their sum",
                     "bound": "hbm" if bf else "mfma", "calls_per_step": 1, "ms": ms, "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                     "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
-                    "algorithmic_flop_per_launch": flop_all, "algorithmic_bytes_per_launch": byts_all})
+                    "gbs_wall_concurrent": byts_all / wall / 1e6,
+                    "algorithmic_flop_per_launch": flop_all / 4, "algorithmic_bytes_per_launch": byts_all / 4,
+                    "algorithmic_flop_per_step": flop_all, "algorithmic_bytes_per_step": byts_all})
         Xi = torch.randn(sh.n_items, d, device=self.device)
         a = self.graph.ui.fwd
         ms = event_time_ms(lambda: ops.spmm_raw(a, Xi), 50)
@@ -232,25 +281,28 @@ class NetflixShaped:
 
 
 def pmc_traffic_bytes(parts):
-    """HBM-side bytes of one "launch" as the roofline defines it, from the committed PMC pass
-    (profiles/r01_pmc_bench_step.json: separate rocprofv3 --pmc runs of this bench with --kernel-trace only, as
+    """HBM-side bytes of one "launch" as the roofline defines it, from the newest committed PMC pass over THIS bench
+    (profiles/r*_pmc_bench_step.json: separate rocprofv3 --pmc runs with --kernel-trace only, as
     MI355X_MICROARCH.md prescribes; FETCH_SIZE is doubled per its gfx950 note, WRITE_SIZE taken as reported;
-    both in KB). parts: [(kernel-name substring, launches of it per roofline launch)]. None when a kernel
-    is missing from the pass."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_bench_step.json")
-    if not os.path.exists(path):
-        return None
+    both in KB). parts: [(kernel-name substring, launches of it per roofline launch)]. Returns
+    (bytes or None, {"file", "kernels"}): None when a kernel is missing from the pass."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_step.json")))
+    if not files:
+        return None, None
+    path = files[-1]
     try:
         data = json.load(open(path))
     except Exception:
-        return None
-    total = 0.0
+        return None, None
+    total, names = 0.0, []
     for key, launches in parts:
-        hit = [c for name, c in data.items() if key in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c]
+        hit = [(name, c) for name, c in data.items() if key in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c]
         if not hit:
-            return None
-        total += launches * (2.0 * hit[0]["FETCH_SIZE"]["mean"] + hit[0]["WRITE_SIZE"]["mean"]) * 1024.0
-    return total
+            return None, {"file": os.path.basename(path), "missing": key}
+        names.append(hit[0][0])
+        total += launches * (2.0 * hit[0][1]["FETCH_SIZE"]["mean"] + hit[0][1]["WRITE_SIZE"]["mean"]) * 1024.0
+    return total, {"file": os.path.basename(path), "kernels": names}
 
 
 def spmm_roofline_large(device, seed, n_users=2_000_000, n_items=1_000_000, n_edges=40_000_000, d=64):
@@ -276,32 +328,169 @@ def spmm_roofline_large(device, seed, n_users=2_000_000, n_items=1_000_000, n_ed
     return {"graph": {"n_users": n_users, "n_items": n_items, "nnz": int(nnz), "d": d}, **res}
 
 
-def cpu_baseline_nf(w: NetflixShaped, budget_s: float = 20.0):
-    """The oracle (CPU restatement of the reference, oracle/oracle.py) timed on this host on a
-    bounded number of steps of the SAME workload. kind = "port"."""
+ORACLE_PARAMS = ["image_trans.weight", "image_trans.bias", "text_trans.weight", "text_trans.bias", "user_trans.weight",
+                 "user_trans.bias", "item_trans.weight", "item_trans.bias", "user_id_embedding.weight", "item_id_embedding.weight"]
+
+
+def _oracle_state(w: "NetflixShaped"):
+    """CPU copies of everything the oracle needs for this workload (graph, features, current parameters)."""
     import numpy as np
     import scipy.sparse as sp
-    import torch
     from oracle import oracle as O
     sh = w.sh
     cfg = O.Config.from_args(vars(w.args), w.keys)
     R = sp.csr_matrix((np.ones(w.rows.size, dtype=np.float32), (w.rows, w.cols)), shape=(sh.n_users, sh.n_items))
     a_ui, a_iu = O.normalized_graphs(R)
     feats = {k: v.cpu() for k, v in w.feats.items()}
-    names = ["image_trans.weight", "image_trans.bias", "text_trans.weight", "text_trans.bias", "user_trans.weight",
-             "user_trans.bias", "item_trans.weight", "item_trans.bias", "user_id_embedding.weight", "item_id_embedding.weight"]
     sd = w.model.state_dict()
-    params = {k: sd[k].detach().cpu().clone().requires_grad_(True) for k in names}
+    params = {k: sd[k].detach().cpu().clone().requires_grad_(True) for k in ORACLE_PARAMS}
+    return O, cfg, R, a_ui, a_iu, feats, params
+
+
+def parity_check(w: "NetflixShaped", n_eval_users: int = 256, steps: int = 2, tol: float = 1e-4):
+    """The parity gate printed next to the timings: the first `steps` training steps of THIS
+    workload on the path that is timed (fused step, HIP-graph replay from the second step on, in-graph device
+    sampler) and one evaluation, against the CPU oracle (oracle/oracle.py = the reference's arithmetic,
+    Models.py:127-199, main.py:228-278, utility/batch_test.py:21-36) fed with the identical samples read back
+    from the device. Per step: the forward outputs of the reference's 14-tuple, the 8 (mf, emb) BPR pairs,
+    the loss, the 10 gradients and the post-AdamW parameters, as max |a - b| / max |b| per tensor. Evaluation:
+    E_u / E_i after the steps, and the ranked top-50 lists of `n_eval_users` users, which must EQUAL the
+    reference ranking rule (score desc, item id asc) applied to the kernel's bit-exact fp32 fma-chain scores;
+    the lists from the oracle's own embeddings are compared too (near-ties may swap there: reported, not gated)."""
+    import numpy as np
+    import torch
+    assert w.world == 1 and w.step_id == 0, "parity_check runs on a fresh single-GPU workload"
+    O, cfg, R, a_ui, a_iu, feats, params = _oracle_state(w)
+    sh = w.sh
     opt = O.AdamW(params, lr=cfg.lr)
-    rng = np.random.default_rng(0)
-    B = cfg.batch_size + int(cfg.batch_size * cfg.aug_sample_rate)
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        users = rng.integers(0, sh.n_users, size=B); pos = rng.integers(0, sh.n_items, size=B); neg = rng.integers(0, sh.n_items, size=B)
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+    worst = {"forward": 0.0, "bpr": 0.0, "loss": 0.0, "grad": 0.0, "param": 0.0}
+    worst_name = {}
+
+    def upd(kind, name, e):
+        if e > worst[kind]:
+            worst[kind], worst_name[kind] = e, name
+    f = w.fused
+    t0 = time.perf_counter()
+    for s in range(steps):
+        if w.use_graph:
+            w.step()                                             # step 1 = the capture's eager warm-up, then graph replays
+            torch.cuda.synchronize()
+            st = f.static
+            nv = int(st["n_valid"])
+            u, p, n = (st[k][:nv].cpu().numpy() for k in ("users", "pos", "neg"))
+        else:
+            ud, pd_, nd, nvd = w.batcher.next()
+            w.step_id += 1
+            f.step_eager(ud, pd_, nd, nvd)
+            torch.cuda.synchronize()
+            nv = int(nvd)
+            u, p, n = ud[:nv].cpu().numpy(), pd_[:nv].cpu().numpy(), nd[:nv].cpu().numpy()
+        fw = O.forward(params, feats, a_ui, a_iu, cfg)
+        loss, parts = O.step_loss(fw, u, p, n, sh.n_items, cfg)
+        grads = dict(zip(params, torch.autograd.grad(loss, list(params.values()))))
+        out = f.outputs()
+        named = dict(E_u=out[0], E_i=out[1], img_i=out[2], txt_i=out[3], img_u=out[4], txt_u=out[5], P_usr=out[6], prof_u=out[8], prof_i=out[9])
+        for nm, t in named.items():
+            upd("forward", "step%d/%s" % (s, nm), rel(t.detach().cpu(), fw[nm].detach()))
+        for k in w.keys:
+            upd("forward", "step%d/att_u/%s" % (s, k), rel(out[10][k].detach().cpu(), fw["att_u"][k].detach()))
+            upd("forward", "step%d/att_i/%s" % (s, k), rel(out[11][k].detach().cpu(), fw["att_i"][k].detach()))
+        got = f.out[: f.n_prob].detach().cpu().double()
+        want = torch.tensor([[float(a.detach()), float(b.detach())] for a, b in parts["bpr"]], dtype=torch.float64)
+        upd("bpr", "step%d" % s, float((got - want).abs().max() / want.abs().max()))
+        upd("loss", "step%d" % s, abs(float(f.scal[1]) - float(loss)) / abs(float(loss)))
+        gp = dict(w.model.named_parameters())
+        for nm in ORACLE_PARAMS:
+            upd("grad", "step%d/%s" % (s, nm), rel(gp[nm].grad.detach().cpu(), grads[nm]))
+        opt.step(grads)
+        for nm in ORACLE_PARAMS:
+            upd("param", "step%d/%s" % (s, nm), rel(gp[nm].detach().cpu(), params[nm].detach()))
+    # evaluation: forward with the post-step parameters + scoring + masked top-50
+    idx, _ = w.eval_once()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        fw = O.forward(params, feats, a_ui, a_iu, cfg)
+    e_u, e_i = f.E_u.detach().cpu(), f.E_i.detach().cpu()
+    upd("forward", "eval/E_u", rel(e_u, fw["E_u"])); upd("forward", "eval/E_i", rel(e_i, fw["E_i"]))
+    rng = np.random.default_rng(123)
+    users = np.sort(rng.choice(sh.n_users, size=min(n_eval_users, sh.n_users), replace=False))
+    K = idx.shape[1]
+    S = O.scores_fma_chain(e_u.numpy()[users], e_i.numpy(), order="mfma16x16x4")     # the kernel's scores, bit for bit
+    S_or = (fw["E_u"][torch.as_tensor(users)] @ fw["E_i"].t()).numpy()
+    Rc = R.tocsr()
+    idx_np = idx.cpu().numpy()
+    equal = equal_oracle = 0
+    test_items = rng.integers(0, sh.n_items, size=sh.n_users)                          # one synthetic held-out item per user
+    m_want = np.zeros((4, len(cfg.Ks)))
+    for r, uu in enumerate(users):
+        tr = Rc.indices[Rc.indptr[uu]:Rc.indptr[uu + 1]]
+        want = O.rank_topk_np(S[r], tr, K)
+        got = idx_np[uu][idx_np[uu] >= 0]
+        equal += int(got.tolist() == want.tolist())
+        equal_oracle += int(got.tolist() == O.rank_topk_np(S_or[r], tr, K).tolist())
+        mm = O.metrics_from_hits([1 if int(i) == int(test_items[uu]) else 0 for i in want], 1, cfg.Ks)
+        for j, kname in enumerate(("precision", "recall", "ndcg", "hit_ratio")):
+            m_want[j] += mm[kname] / len(users)
+    # R10 on the device for the same users (llmrec_topk_hits + llmrec_topk_metrics)
+    dev = w.device
+    q = torch.as_tensor(users, dtype=torch.int64, device=dev)
+    t_rp = torch.arange(sh.n_users + 1, dtype=torch.int32, device=dev)
+    t_ci = torch.as_tensor(test_items, dtype=torch.int32, device=dev)
+    idx_q = idx[q].contiguous()
+    hits = w.ops.topk_hits(idx_q, q, t_rp, t_ci)
+    m_got = w.ops.topk_metrics(idx_q, hits, q, t_rp, cfg.Ks).mean(dim=0).cpu().numpy()
+    metrics_abs = float(np.abs(m_got - m_want).max())
+    rep = {"against": "oracle/oracle.py (CPU restatement of the reference, pinned to tests/golden) on the identical device-sampled batches",
+           "path": "fused step%s, gemm=%s" % (" + HIP graph replay (step 1 = the capture's eager warm-up)" if w.use_graph else " (eager)", f.gemm),
+           "steps_checked": steps, "tolerance_rel": tol,
+           "forward_max_rel": worst["forward"], "bpr_max_rel": worst["bpr"], "loss_rel": worst["loss"],
+           "grad_max_rel": worst["grad"], "param_max_rel": worst["param"], "worst_tensor": worst_name,
+           "topk_lists_checked": int(len(users)), "topk_lists_equal": int(equal),
+           "topk_lists_equal_oracle_embeddings": int(equal_oracle), "metrics_max_abs": metrics_abs,
+           "seconds": time.perf_counter() - t0}
+    rep["ok"] = bool(max(worst.values()) < tol and equal == len(users) and metrics_abs < 1e-12)
+    return rep
+
+
+def cpu_baseline_nf(w: "NetflixShaped", budget_s: float = 20.0):
+    """The oracle (CPU restatement of the reference, oracle/oracle.py) timed on this host on a bounded number of
+    steps of the SAME workload, batches from the reference's host sampler restated in the oracle
+    (load_data.py:157-195 + main.py:216-224). kind = "port" (the reference tree does not travel to the GPU box).
+    Thread count: the best of {8, 16, 32, 64} (capped at the host's cores) on one calibration step each (the reference runs with
+    torch's default = all cores; BASELINE.md section 2 measured it on 8)."""
+    import random as _random
+    import numpy as np
+    import torch
+    O, cfg, R, a_ui, a_iu, feats, params = _oracle_state(w)
+    sh = w.sh
+    opt = O.AdamW(params, lr=cfg.lr)
+    Rc = R.tocsr()
+    train_items = {u: Rc.indices[Rc.indptr[u]:Rc.indptr[u + 1]].tolist() for u in range(sh.n_users) if Rc.indptr[u + 1] > Rc.indptr[u]}
+    exist = sorted(train_items)
+    aug_p, aug_n = w.aug_pos.cpu().numpy(), w.aug_neg.cpu().numpy()
+    aug = {u: (int(aug_p[u]), int(aug_n[u])) for u in range(sh.n_users)}
+    rd, nprng = _random.Random(2022), np.random.RandomState(2022)
+
+    def one_step():
+        users, pos, neg = O.sample_batch(exist, train_items, sh.n_items, sh.n_users, cfg.batch_size, rd=rd, nprng=nprng)
+        users, pos, neg = O.augment_batch(users, pos, neg, aug, sh.n_items, cfg.aug_sample_rate, rd=rd)
         fw = O.forward(params, feats, a_ui, a_iu, cfg)
         loss, _ = O.step_loss(fw, users, pos, neg, sh.n_items, cfg)
         grads = dict(zip(params, torch.autograd.grad(loss, list(params.values()))))
         opt.step(grads)
+    all_cores = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    cal = {}
+    one_step()                                               # warm the allocator / MKL
+    for nt in sorted({min(c, all_cores) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        t = time.perf_counter(); one_step(); cal[nt] = time.perf_counter() - t
+    best = min(cal, key=cal.get)
+    torch.set_num_threads(best)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        one_step()
         steps += 1
         if time.perf_counter() - t0 > budget_s or steps >= 64:
             break
@@ -309,14 +498,38 @@ def cpu_baseline_nf(w: NetflixShaped, budget_s: float = 20.0):
     # eval sample: 256 users, full ranking (the reference's per-user python ranking, batch_test.py:83-109)
     with torch.no_grad():
         fw = O.forward(params, feats, a_ui, a_iu, cfg)
-    train_items = {u: w.cols[w.rows == u].tolist() for u in range(256)}
+    rng = np.random.default_rng(0)
     test_set = {u: [int(rng.integers(0, sh.n_items))] for u in range(256)}
     t1 = time.perf_counter()
     O.evaluate(fw["E_u"].numpy(), fw["E_i"].numpy(), list(range(256)), train_items, test_set, cfg.Ks, batch_size=cfg.batch_size)
     de = time.perf_counter() - t1
-    return {"value": steps * cfg.batch_size / dt, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d full training steps of the same workload (oracle/oracle.py, torch-CPU fp32); eval on 256 users" % steps,
+    torch.set_num_threads(default_threads)
+    return {"value": steps * cfg.batch_size / dt, "unit": "edges/s", "cores": best, "host_cores": all_cores, "kind": "port",
+            "sample": "%d full training steps of the same workload (oracle/oracle.py, torch-CPU fp32, host sampler stream); eval on 256 users" % steps,
+            "threads_calibration_s_per_step": {str(k): round(v, 3) for k, v in cal.items()},
             "ms_per_step": dt / steps * 1e3, "eval_users_per_s": 256 / de}
+
+
+def exact_f32_step_time(w: "NetflixShaped", steps: int):
+    """The same step with the exact fp32 MFMA chain in the 12 GEMM launches (LLMREC_GEMM=f32) instead of the default
+    3-term bf16 split: a second FusedStep over the same model / optimizer, graph-captured like the timed one."""
+    import torch
+    from llmrec_amd.fused import FusedStep
+    a = w.args
+    f = FusedStep(w.model, w.graph, w.hp, (a.model_cat_rate, a.user_cat_rate, a.item_cat_rate), w.opt, w.hp.batch_size + w.batcher.n_aug)
+    f.gemm = "f32"
+    f.capture(batcher=w.batcher)
+    for _ in range(5):
+        f.step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); e0.record()
+    for _ in range(steps):
+        f.step()
+    e1.record(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"ms_per_step": dt / steps * 1e3, "ms_per_step_hip_events": e0.elapsed_time(e1) / steps, "value": steps * w.hp.batch_size / dt,
+            "unit": "edges/s", "steps": steps, "gemm": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32) in projections and weight-gradients"}
 
 
 def main():
@@ -364,17 +577,27 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    parity = None
+    if workload in ("nf", "ml") and world == 1 and not a.no_parity and os.environ.get("LLMREC_FORCE_DP", "0") != "1":
+        parity = parity_check(w)                             # BEFORE the timed region; its two steps count as extra warm-up
+        if rank == 0:
+            print("[bench] parity gate: %s" % json.dumps({k: v for k, v in parity.items() if k != "worst_tensor"}), file=sys.stderr, flush=True)
+
     finish = getattr(getattr(w, "fused", None), "flush", lambda: None)   # batch-sharded replicas defer the last AdamW
     for _ in range(a.warmup):
         step()
     finish()
     barrier(); torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()                                             # HIP events on the stream the step graphs are launched on
     for _ in range(a.steps):
         step()
     finish()                                                 # inside the timed region: every step's update is applied
+    ev1.record()
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
+    dt_events = ev0.elapsed_time(ev1) / 1e3
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -382,31 +605,54 @@ def main():
         dt = float(t.item())
 
     line = {"metric": "bpr_train_edges_per_sec", "value": a.steps * units / dt, "unit": "edges/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "ms_per_step_hip_events": dt_events / a.steps * 1e3,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": w.config()}
+    if workload in ("nf", "ml"):
+        gemm = getattr(w.fused, "gemm", "f32")
+        line["arithmetic"] = ("fp32 storage and accumulation everywhere; the 8 projections and 4 weight-gradients multiply exact 3-term bf16 "
+                              "splits of both fp32 operands on the bf16 MFMA (24 significant bits, 2e-6 vs fp64: fp32-class); "
+                              "LLMREC_GEMM=f32 selects the exact fp32 MFMA chain, timed below as exact_f32") if gemm == "bf16x3" else \
+                             "exact fp32 (fp32 MFMA fma chains in the projections / weight-gradients)"
+    if parity is not None:
+        line["parity"] = parity
 
     if workload in ("nf", "ml"):
         w.eval_once(); torch.cuda.synchronize(); barrier()
-        t1 = time.perf_counter(); w.eval_once(); torch.cuda.synchronize(); barrier()
-        te = time.perf_counter() - t1                        # every rank ranks its user block; the barrier makes it the slowest rank's time
+        t1 = time.perf_counter()
+        for _ in range(5):
+            w.eval_once()
+        torch.cuda.synchronize(); barrier()
+        te = (time.perf_counter() - t1) / 5                  # every rank ranks its user block; the barrier makes it the slowest rank's time
     if rank == 0 and workload in ("nf", "ml"):
         line["eval"] = {"metric": "full_rank_eval_users_per_sec", "value": w.sh.n_users / te, "ms": te * 1e3,
                         "n_users": w.sh.n_users, "users_per_rank": (w.sh.n_users + world - 1) // world,
                         "includes": "no-grad full-graph forward + fp32 MFMA scoring + masked top-50"}
+        if world == 1 and not a.no_kernel_roofline and getattr(w.fused, "gemm", "f32") == "bf16x3" and os.environ.get("LLMREC_FORCE_DP", "0") != "1":
+            line["exact_f32"] = exact_f32_step_time(w, min(a.steps, 100))
         if not a.no_kernel_roofline:
             ks = w.kernel_rooflines()
             line["kernels"] = ks
-            # dominant kernel = the longest single launch of the step (the grouped projection: one 0.2 ms launch; the four
-            # weight-gradient launches of different shapes are listed in "kernels" with their sum)
-            dom = max(ks[:2], key=lambda k: k["ms"] / k.get("launches", 1))
-            hbm = dom.get("bound") == "hbm"
-            line["roofline"] = {"kernel": dom["kernel"], "bound": dom.get("bound", "mfma"),
-                                "achieved": dom["gbs"] if hbm else dom["tflops"], "peak": HBM_PEAK_GBS if hbm else MFMA_F32_PEAK_TFLOPS,
-                                "unit": "GB/s" if hbm else "TFLOP/s", "frac": dom["frac_hbm"] if hbm else dom["frac_mfma_f32"],
-                                "traffic": pmc_traffic_bytes(dom["pmc"]),
-                                "algorithmic_flop_per_launch": dom["algorithmic_flop_per_launch"],
-                                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                                "ms_per_launch": dom["ms"], "hbm_gbs": dom["gbs"], "frac_hbm": dom["frac_hbm"]}
+            # dominant kernel = the largest share of the step's GPU time: the four weight-gradient launches (rocprofv3:
+            # 25 % of the step) ahead of the single grouped-projection launch; both are reported, the dominant one first
+            dom = max(ks[:2], key=lambda k: k["ms"])
+            other = min(ks[:2], key=lambda k: k["ms"])
+
+            def roof(k):
+                hbm = k.get("bound") == "hbm"
+                traffic, src = pmc_traffic_bytes(k["pmc"])
+                n = k.get("launches", 1)
+                return {"kernel": k["kernel"], "bound": k.get("bound", "mfma"),
+                        "achieved": k["gbs"] if hbm else k["tflops"], "peak": HBM_PEAK_GBS if hbm else MFMA_F32_PEAK_TFLOPS,
+                        "unit": "GB/s" if hbm else "TFLOP/s", "frac": k["frac_hbm"] if hbm else k["frac_mfma_f32"],
+                        "traffic": None if traffic is None else traffic / n, "traffic_source": src,
+                        "launches_per_step": n, "ms_per_launch": k["ms"] / n, "ms_per_step": k["ms"],
+                        "algorithmic_flop_per_launch": k["algorithmic_flop_per_launch"],
+                        "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"],
+                        "timing": k.get("timing", "HIP events around the launch on its stream, in isolation"),
+                        "hbm_gbs": k["gbs"], "frac_hbm": k["frac_hbm"]}
+            line["roofline"] = roof(dom)
+            line["roofline"]["second"] = roof(other)
             line["spmm_roofline"] = spmm_roofline_large(device, a.seed)
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline_nf(w)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LLMREC_ABI_VERSION 1
+#define LLMREC_ABI_VERSION 2
 
 enum {
     LLMREC_OK = 0,
@@ -267,6 +267,23 @@ int llmrec_sumsq_f32(int64_t rows, int32_t d, const float* X, int64_t ldx, float
 /* Y (+)= alpha_dev[0] * alpha * X   (gradient of the regulariser; alpha_dev may be NULL = 1) */
 int llmrec_axpy_f32(int64_t rows, int32_t d, float alpha, const float* alpha_dev, const float* X, int64_t ldx,
                     float* Y, int64_t ldy, int32_t accumulate, llmrec_stream_t stream);
+
+/* Clear up to LLMREC_ZERO_MAX_TENSORS fp32 buffers in ONE launch (the backward's scatter targets; replaces
+ * one aten::zero_ per tensor inside the captured step). */
+#define LLMREC_ZERO_MAX_TENSORS 8
+typedef struct { float* p; int64_t n; } llmrec_zero_tensor_t;
+int llmrec_zero_multi_f32(int32_t n_tensors, const llmrec_zero_tensor_t* tensors_host, llmrec_stream_t stream);
+
+/* Loss assembly of reference main.py:273 / :280-283 on the device, one single-wave launch (replaces the
+ * aten mul / sum / add / copy launches that assembled the logged scalars):
+ *   bpr_out [n_problems][2] = (mf, emb) of each BPR problem; w_mf_host[n_problems] = its weight in the loss;
+ *   scal[4] = [feat_reg (input), loss, mf, emb].
+ *   mode 0 (single GPU): scal[1] = sum_p w_mf[p] * mf_p + emb_0 + scal[0]; scal[2] = mf_0; scal[3] = emb_0
+ *   mode 1 (batch-sharded replica, before the gradient all-reduce): tail[p] = mf_p (this rank's share),
+ *          tail[n_problems] = (emb_0 + scal[0]) * inv_world
+ *   mode 2 (after it): scal[2] = tail[0]; scal[3] = emb_0; scal[1] = sum_p w_mf[p] * tail[p] + tail[n_problems] */
+int llmrec_loss_assemble_f32(int32_t mode, int32_t n_problems, const float* bpr_out, const float* w_mf_host,
+                             float* scal4, float* tail, float inv_world, llmrec_stream_t stream);
 
 /* state[0] = step count (as float bits of an int32), state[1] = lr / (1 - b1^t), state[2] = sqrt(1 - b2^t).
  * llmrec_adamw_advance increments t on the device and refreshes state[1..2]. */

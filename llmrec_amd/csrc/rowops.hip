@@ -330,6 +330,50 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
 using namespace llmrec;
 
+struct ZeroTensors {
+    float* p[LLMREC_ZERO_MAX_TENSORS];
+    int64_t n[LLMREC_ZERO_MAX_TENSORS];
+    int32_t block_begin[LLMREC_ZERO_MAX_TENSORS + 1];
+    int32_t n_tensors;
+};
+constexpr int ZERO_PER_BLOCK = 256 * 4 * 8;                 // 8 float4 stores per thread
+
+__global__ __launch_bounds__(256) void zero_multi_kernel(ZeroTensors t) {
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < LLMREC_ZERO_MAX_TENSORS; ++i) k += (i < t.n_tensors && (int)blockIdx.x >= t.block_begin[i]) ? 1 : 0;
+    float* p = t.p[k];
+    const int64_t n = t.n[k];
+    const int64_t base = (int64_t)(blockIdx.x - t.block_begin[k]) * ZERO_PER_BLOCK;
+    const bool vec = (((uintptr_t)p) % 16) == 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t i = base + ((int64_t)j * 256 + threadIdx.x) * 4;
+        if (vec && i + 4 <= n) *reinterpret_cast<float4*>(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        else for (int e = 0; e < 4; ++e) if (i + e < n) p[i + e] = 0.f;
+    }
+}
+
+struct LossWeights { float w[LLMREC_BPR_MAX_PROBLEMS]; };
+
+__global__ void loss_assemble_kernel(int mode, int n_prob, const float* __restrict__ out, LossWeights w, float* scal, float* tail, float inv_world) {
+    if (threadIdx.x != 0) return;
+    if (mode == 0) {
+        float s = 0.f;
+        for (int p = 0; p < n_prob; ++p) s += out[2 * p] * w.w[p];         // same order as (out[:, 0] * w).sum() over <= 8 terms
+        scal[2] = out[0]; scal[3] = out[1];
+        scal[1] = s + out[1] + scal[0];
+    } else if (mode == 1) {
+        for (int p = 0; p < n_prob; ++p) tail[p] = out[2 * p];
+        tail[n_prob] = (out[1] + scal[0]) * inv_world;
+    } else {
+        float s = 0.f;
+        for (int p = 0; p < n_prob; ++p) s += tail[p] * w.w[p];
+        scal[2] = tail[0]; scal[3] = out[1];
+        scal[1] = s + tail[n_prob];
+    }
+}
+
 extern "C" {
 
 int llmrec_softmax_rows_fwd_f32(int64_t rows, int32_t d, const float* Z, int64_t ldz, float* Y, int64_t ldy,
@@ -488,6 +532,37 @@ int llmrec_adamw_multi_f32(int32_t n_tensors, const llmrec_adamw_tensor_t* tenso
     if (blocks == 0) return LLMREC_OK;
     const float decay_mul = (float)(1.0 - (double)lr * (double)weight_decay);
     adamw_multi_kernel<<<blocks, 256, 0, (hipStream_t)stream_>>>(t, state3, decay_mul, beta1, beta2, eps);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_zero_multi_f32(int32_t n_tensors, const llmrec_zero_tensor_t* tensors_host, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_tensors >= 0 && n_tensors <= LLMREC_ZERO_MAX_TENSORS && (n_tensors == 0 || tensors_host),
+                     "zero_multi: bad argument (at most %d tensors)", LLMREC_ZERO_MAX_TENSORS);
+    ZeroTensors t = {};
+    t.n_tensors = n_tensors;
+    int64_t blocks = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        LLMREC_CHECK_ARG(tensors_host[i].n >= 0 && (tensors_host[i].n == 0 || tensors_host[i].p), "zero_multi: tensor %d has a null pointer", i);
+        t.p[i] = tensors_host[i].p; t.n[i] = tensors_host[i].n;
+        t.block_begin[i] = (int32_t)blocks;
+        blocks += ceil_div(tensors_host[i].n, ZERO_PER_BLOCK);
+        LLMREC_CHECK_ARG(blocks < 0x7fffffffll, "zero_multi: too many elements for one launch");
+    }
+    for (int i = n_tensors; i <= LLMREC_ZERO_MAX_TENSORS; ++i) t.block_begin[i] = (int32_t)blocks;
+    if (blocks == 0) return LLMREC_OK;
+    zero_multi_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream_>>>(t);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_loss_assemble_f32(int32_t mode, int32_t n_problems, const float* bpr_out, const float* w_mf_host,
+                             float* scal4, float* tail, float inv_world, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(mode >= 0 && mode <= 2 && n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS, "loss_assemble: bad mode / problem count");
+    LLMREC_CHECK_ARG(bpr_out && scal4 && (mode == 1 || w_mf_host) && (mode == 0 || tail), "loss_assemble: null pointer");
+    LossWeights w = {};
+    if (w_mf_host) for (int i = 0; i < n_problems; ++i) w.w[i] = w_mf_host[i];
+    loss_assemble_kernel<<<1, 64, 0, (hipStream_t)stream_>>>(mode, n_problems, bpr_out, w, scal4, tail, inv_world);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

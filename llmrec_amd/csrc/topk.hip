@@ -300,6 +300,10 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
                 for (int r = 0; r < 4; ++r) cnt_s[w][lq * 4 + r] = cntr[r];
             }
             __syncthreads();
+            // snapshot of the finished-quarter count, taken BETWEEN the drain's barriers: every increment of this cycle
+            // happened before the first barrier and the next cycle's cannot happen before the last one - reading it after
+            // the last barrier would race with a faster wave that has already finished its final round
+            const int done_quarters = flag_s[1];
             const long long tk_d1 = TK_NOW();
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
             TK_ADD(4, tk_d1);                                  // sort + merge
             __syncthreads();
             TK_ADD(2, tk_d0);                                  // whole drain
-            if (flag_s[1] == 4) break;    // all four quarters swept and drained
+            if (done_quarters == 4) break;    // all four quarters swept and drained
             continue;
         }
         const int64_t base = (t_begin + round) * TK_TILE;

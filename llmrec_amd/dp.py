@@ -101,17 +101,14 @@ class DataParallelStep(FusedStep):
         self._fork(self.s3)
         with self._on(self.s3):                                          # loss scalars for the bucket's tail, off the critical path
             self._feat_reg()
-            self.tail[:P] = self.out[:P, 0]                              # this rank's shares of the mf values
-            self.tail[P:P + 1] = (self.out[0, 1:2] + self.scal[0:1]) * (1.0 / self.world)   # emb + feat_reg: identical on all ranks
+            # tail[:P] = this rank's shares of the mf values; tail[P] = (emb + feat_reg) / world (identical on all ranks)
+            self._assemble_loss(1, self.tail, 1.0 / self.world)
         self._backward(self._problems(), users, pos, neg, n_valid, replicated_scale=1.0 / self.world)
         self._join(self.s3)
 
     def phase_c(self):
         """loss scalars from the reduced tail + AdamW."""
-        P = self.n_prob
-        self.scal[2:3] = self.tail[0:1]
-        self.scal[3:4] = self.out[0, 1:2]
-        self.scal[1:2] = (self.tail[:P] * self.w_mf_dev).sum() + self.tail[P]
+        self._assemble_loss(2, self.tail)
         self.opt.step(advanced=True)                             # the counter was advanced during the forward
 
     # -- the two exchanges ------------------------------------------------------------------------

@@ -100,6 +100,7 @@ class FusedStep:
         # MFMAs, fp32-roundoff-class error (2e-6 measured), HBM-bound; "f32" = the exact fp32 MFMA fma chain
         import os
         self.gemm = os.environ.get("LLMREC_GEMM", "bf16x3")
+        self.wgrad_serial = os.environ.get("LLMREC_WGRAD_SERIAL", "1") == "1"
 
     # -- raw kernel helpers -----------------------------------------------------------------------
     def _fork(self, *streams):
@@ -189,8 +190,7 @@ class FusedStep:
         self._fork(self.s2)
         with self._on(self.s2):                                          # ID chain: needs no projection
             if self._zero_in_forward:                                    # the backward's scatter targets, off the critical path
-                for t in self._bwd_accumulators:
-                    t.zero_()
+                self._zero_accumulators()
                 self.opt.advance()                                       # AdamW's step counter / bias corrections, likewise
             i_prev = m.item_id_embedding.weight
             for l in range(self.L):
@@ -257,11 +257,21 @@ class FusedStep:
         self._fork(self.s3)
         with self._on(self.s3):
             self._feat_reg()
-            self.scal[2:3] = self.out[0, 0:1]
-            self.scal[3:4] = self.out[0, 1:2]
-            self.scal[1:2] = (self.out[: self.n_prob, 0] * self.w_mf_dev).sum() + self.out[0, 1] + self.scal[0]
+            self._assemble_loss(0)
         self._backward(probs, users, pos, neg, n_valid)
         self._join(self.s3)
+
+    def _zero_accumulators(self):
+        """The six scatter targets of the backward, cleared by ONE launch (llmrec_zero_multi_f32)."""
+        arr = (ops.ZeroTensor * len(self._bwd_accumulators))()
+        for i, t in enumerate(self._bwd_accumulators):
+            arr[i].p, arr[i].n = t.data_ptr(), t.numel()
+        _call("llmrec_zero_multi_f32", len(self._bwd_accumulators), arr)
+
+    def _assemble_loss(self, mode: int, tail=None, inv_world: float = 1.0):
+        """Logged scalars (main.py:273,280-283) from the 8 BPR results + the regulariser: one single-wave launch."""
+        w = (_c.c_float * self.n_prob)(*self.w_mf)
+        _call("llmrec_loss_assemble_f32", mode, self.n_prob, _p(self.out), w, _p(self.scal), _p(tail), float(inv_world))
 
     def _feat_reg(self):
         """Feature regulariser (main.py:151-156) over the image/text columns of both cat buffers -> scal[0]."""
@@ -278,8 +288,7 @@ class FusedStep:
         B = users.numel()
         coef = hp.feat_reg_decay * 0.5 / self.I * replicated_scale
         if not self._zeroed:
-            for t in self._bwd_accumulators:
-                t.zero_()
+            self._zero_accumulators()
         self._zeroed = False
         _call("llmrec_bpr_multi_bwd_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), float(hp.decay),
               float(hp.batch_size), _p(self.saved))
@@ -323,6 +332,17 @@ class FusedStep:
         # side chain: I_cat = iu(U_cat), U_cat = ui(P_cat); then the item-side weight gradients
         self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
         self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
+        item_pairs = [(self._side(self.dP_cat, 2 + k), m.item_feats[key]) for k, key in enumerate(self.keys)]
+        if self.wgrad_serial:
+            # the weight-gradient kernels each fill the chip (one wave per SIMD, HBM-bound): launched side by side they only
+            # interleave their blocks and thrash (measured: 0.26 ms for the four at once vs 0.21 ms back to back), so
+            # item_trans', text's and image's run back to back on this stream; only the latency-bound SpMM chains and
+            # user_trans' gradient (ready earlier, on s1) overlap them
+            ops.linear_wgrad_grouped(item_pairs, m.item_trans.weight.grad, m.item_trans.bias.grad, False, self.ws_wgrad, precision=self.gemm)
+            self._wgrad(self._side(self.dP_cat, 1), m.text_feats, m.text_trans, False, ws=self.ws_wgrad_c)
+            self._wgrad(self._side(self.dP_cat, 0), m.image_feats, m.image_trans, False, ws=self.ws_wgrad_d)
+            self._join(self.s1, self.s2)
+            return
         # text / image weight gradients (and their partial-slab reductions) run beside item_trans' on their own streams
         self._fork(self.s3, self.s4)
         with self._on(self.s3):
@@ -330,8 +350,7 @@ class FusedStep:
         with self._on(self.s4):
             self._wgrad(self._side(self.dP_cat, 0), m.image_feats, m.image_trans, False, ws=self.ws_wgrad_d)
         # the shared item_trans receives all attribute streams in one grouped launch (features are constants: no dX)
-        ops.linear_wgrad_grouped([(self._side(self.dP_cat, 2 + k), m.item_feats[key]) for k, key in enumerate(self.keys)],
-                                 m.item_trans.weight.grad, m.item_trans.bias.grad, False, self.ws_wgrad, precision=self.gemm)
+        ops.linear_wgrad_grouped(item_pairs, m.item_trans.weight.grad, m.item_trans.bias.grad, False, self.ws_wgrad, precision=self.gemm)
         self._join(self.s1, self.s2, self.s3, self.s4)
 
     def _train_forward(self):

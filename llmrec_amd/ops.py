@@ -399,6 +399,11 @@ class LinearProblem(_c.Structure):
                 ("W", _c.c_void_p), ("ldw", _c.c_int64), ("bias", _c.c_void_p), ("Y", _c.c_void_p), ("ldy", _c.c_int64)]
 
 
+class ZeroTensor(_c.Structure):
+    """llmrec_zero_tensor_t"""
+    _fields_ = [("p", _c.c_void_p), ("n", _c.c_int64)]
+
+
 class WgradProblem(_c.Structure):
     """llmrec_wgrad_problem_t"""
     _fields_ = [("dY", _c.c_void_p), ("lddy", _c.c_int64), ("X", _c.c_void_p), ("ldx", _c.c_int64), ("M", _c.c_int64)]

@@ -35,8 +35,10 @@ from utility.batch_test import *          # data_generator, test_torch, Ks, ... 
 from utility.logging import Logger
 from llmrec_amd import engine, ops
 
-device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 args = parse_args()
+if torch.cuda.is_available():                              # --gpu_id (reference parser.py:22) selects the device
+    torch.cuda.set_device(args.gpu_id if 0 <= args.gpu_id < torch.cuda.device_count() else 0)
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 ATTRIBUTE_KEYS = {                                         # reference main.py:69-72
     'preprocessed_raw_MovieLens': ['title', 'genre', 'director', 'country', 'language'],
@@ -162,14 +164,20 @@ class Trainer(object):
         with torch.no_grad():
             if fused and os.environ.get("LLMREC_GRAPH", "0") == "1" and args.test_flag == 'part':
                 # forward + scoring + masked top-K as ONE graph replay per evaluation
-                key = (len(users_to_test), is_val)
-                cache = getattr(self, "_eval_queries", None) or {}
-                if key not in cache:
-                    cache[key] = torch.as_tensor(list(users_to_test), dtype=torch.int64, device=device)
-                    self._eval_queries = cache
+                # the query tensor is cached on the CONTENT of the user list (a different list of the same length
+                # must not reuse it); the evaluation graph is keyed on that tensor
+                users_key = tuple(int(u_) for u_ in users_to_test)
+                cache = getattr(self, "_eval_queries", None)
+                if cache is None:
+                    cache = self._eval_queries = {}
+                if users_key not in cache:
+                    if len(cache) >= 4:                        # bound the number of live evaluation graphs
+                        cache.pop(next(iter(cache)))
+                    cache[users_key] = torch.as_tensor(users_key, dtype=torch.int64, device=device)
+                q = cache[users_key]
                 st = data_generator.device_state(device)
-                idx, _ = fused.eval_topk(cache[key], st["train"], max(eval(args.Ks)), use_graph=True)
-                return test_torch(fused.E_u, fused.E_i, users_to_test, is_val, topk=(cache[key], idx))
+                idx, _ = fused.eval_topk(q, st["train"], max(eval(args.Ks)), use_graph=True)
+                return test_torch(fused.E_u, fused.E_i, users_to_test, is_val, topk=(q, idx))
             if fused:                                          # same forward, ~40 launches over preallocated buffers
                 fused.forward()
                 ua_embeddings, ia_embeddings = fused.E_u, fused.E_i
@@ -203,8 +211,10 @@ class Trainer(object):
         --mask. LLMREC_FUSED=0 forces the modular autograd path; LLMREC_GRAPH=1 additionally
         replays the step from one captured HIP graph."""
         if self._fused is None:
+            # the reference masks user features whenever mask_rate > 0, with or without --mask (Models.py:139-142):
+            # the fused path reads the unmasked features, so any of the three sends the step down the modular path
             ok = (os.environ.get("LLMREC_FUSED", "1") == "1" and not args.mask and args.drop_rate == 0
-                  and device.type == "cuda")
+                  and args.mask_rate == 0 and device.type == "cuda")
             if ok:
                 from llmrec_amd.fused import FusedStep
                 graph = type("G", (), {"ui": ops.operand_from_sparse_tensor(self.ui_graph),
@@ -272,7 +282,8 @@ class Trainer(object):
         """Attribute-restoration term (reference main.py:258-271); off unless --mask."""
         user_prof_feat, item_att_feats, i_mask_nodes, u_mask_nodes = fw[8], fw[11], fw[12], fw[13]
         input_i = {value: item_att_feats[value][i_mask_nodes] for value in item_att_feats.keys()}
-        decoded_u, decoded_i = self.decoder(user_prof_feat[u_mask_nodes], input_i)
+        # the reference wraps the user input in torch.tensor(...) (main.py:262), which detaches it
+        decoded_u, decoded_i = self.decoder(user_prof_feat[u_mask_nodes].detach(), input_i)
         crit = self.mse_criterion if args.feat_loss_type == 'mse' else self.sce_criterion
         loss = crit(decoded_u, torch.as_tensor(self.user_init_embedding[u_mask_nodes]).float().to(device), alpha=args.alpha_l)
         for index, value in enumerate(item_att_feats.keys()):

@@ -1,0 +1,175 @@
+"""GPU parity at the shapes bench.py TIMES (BASELINE.json configs[1], Netflix shape U=13187, I=17366):
+the kernel instantiations the small op tests cannot reach -
+
+* ``linear_fwd_grouped_bf16x3_kernel<4,2,2>`` / ``linear_fwd_grouped_kernel<4,2,2>``: every K % 32 == 0 and
+  >= 256 work units of 128 rows (llmrec_amd/csrc/dense.hip, linear_fwd_grouped_impl);
+* ``linear_wgrad_bf16x3_kernel`` at M = 5 x 17366 / 13187, K = 1536 / 768 / 512: XCD-ordered slabs, the 4-slab
+  LDS pre-reduction, ragged slab tails, dY as a column slice of the [I, 7d] buffer (ld = 448);
+* the scoring + top-K kernel at I = 17366 (about five buffer drains per user) and at I = 10^6, with
+  adversarial score orders;
+* one whole fused + graph-replayed training step and one evaluation at the bench's exact shape against the oracle
+  (reference Models.py:145-199, main.py:228-278, utility/batch_test.py:21-36).
+
+References are fp64 products (torch) or the CPU oracle; tolerances are written at each assert."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+
+DEV = "cuda"
+U_NF, I_NF, D = 13187, 17366, 64
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from llmrec_amd import ops as _ops
+    return _ops
+
+
+def relmax(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+
+# ------------------------------------------------------------------------------------------
+# R4: the grouped projection exactly as FusedStep._project_all launches it
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 3e-6), ("f32", 3e-6)])
+def test_grouped_projection_at_bench_shape(ops, precision, tol):
+    g = torch.Generator(device=DEV); g.manual_seed(11)
+    rn = lambda *s: torch.randn(*s, generator=g, device=DEV)
+    P_cat = torch.full((I_NF, 7 * D), 7.0, device=DEV)              # the 7 item-side streams as one [I, 7d] buffer
+    P_usr = torch.full((U_NF, D), 7.0, device=DEV)
+    shapes = [(I_NF, 1536)] * 5 + [(U_NF, 1536), (I_NF, 768), (I_NF, 512)]       # longest K first, as the step sorts them
+    outs = [P_cat[:, (2 + k) * D:(3 + k) * D] for k in range(5)] + [P_usr, P_cat[:, D:2 * D], P_cat[:, 0:D]]
+    W_item, b_item = rn(D, 1536) / 39.0, rn(D)
+    jobs = []
+    for i, ((M, K), out) in enumerate(zip(shapes, outs)):
+        W, b = (W_item, b_item) if i < 5 else (rn(D, K) / K ** 0.5, rn(D))      # ONE shared item_trans for the 5 attribute keys
+        jobs.append((rn(M, K), W, b, out))
+    assert sum((M + 127) // 128 for M, _ in shapes) >= 256 and all(K % 32 == 0 for _, K in shapes)   # -> the <4, 2, 2> instantiation
+    ops.linear_fwd_grouped(jobs, D, precision=precision)
+    for X, W, b, out in jobs:
+        want = X.double() @ W.double().t() + b.double()
+        e = relmax(out, want)
+        assert e < tol, (precision, tuple(X.shape), e)
+    # ragged K (not a multiple of 32) in the same launch geometry -> the <4, 2, 1> instantiation
+    jobs2 = [(rn(I_NF, 1540), rn(D, 1540) / 39.0, rn(D), torch.empty(I_NF, D, device=DEV)) for _ in range(2)] + jobs[5:]
+    ops.linear_fwd_grouped(jobs2, D, precision=precision)
+    for X, W, b, out in jobs2[:2]:
+        assert relmax(out, X.double() @ W.double().t() + b.double()) < tol
+
+
+# ------------------------------------------------------------------------------------------
+# R4: the step's four weight-gradient launches
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 3e-6), ("f32", 3e-6)])
+def test_weight_gradients_at_bench_shape(ops, precision, tol):
+    g = torch.Generator(device=DEV); g.manual_seed(12)
+    rn = lambda *s: torch.randn(*s, generator=g, device=DEV)
+    dP_cat = rn(I_NF, 7 * D)                                       # dY of stream s = columns [s d, (s+1) d): ld = 448
+    dP_usr = rn(U_NF, D)
+    feats = [rn(I_NF, 1536) for _ in range(5)]
+    cases = [("item_trans x5", [(dP_cat[:, (2 + k) * D:(3 + k) * D], feats[k]) for k in range(5)], 1536),
+             ("user_trans", [(dP_usr, rn(U_NF, 1536))], 1536),
+             ("text_trans", [(dP_cat[:, D:2 * D], rn(I_NF, 768))], 768),
+             ("image_trans", [(dP_cat[:, 0:D], rn(I_NF, 512))], 512)]
+    for name, pairs, K in cases:
+        dW = torch.full((D, K), 7.0, device=DEV); db = torch.full((D,), 7.0, device=DEV)
+        ops.linear_wgrad_grouped(pairs, dW, db, False, precision=precision)
+        want = sum(dy.double().t() @ x.double() for dy, x in pairs)
+        want_b = sum(dy.double().sum(0) for dy, _ in pairs)
+        e, eb = relmax(dW, want), relmax(db, want_b)
+        assert e < tol and eb < tol, (precision, name, e, eb)
+        dW2 = dW.clone()
+        ops.linear_wgrad_grouped(pairs, dW2, db, True, precision=precision)                      # accumulate
+        assert relmax(dW2, 2 * want) < 2 * tol, (precision, name)
+        ops.linear_wgrad_grouped(pairs, dW2, db, False, precision=precision)                     # deterministic (fixed reduction tree)
+        assert torch.equal(dW2, dW), (precision, name)
+
+
+# ------------------------------------------------------------------------------------------
+# R9: scoring + masked top-K at Netflix width and at 10^6 items, adversarial orders
+# ------------------------------------------------------------------------------------------
+def _check_topk(ops, eu, ei, q, train_rows, K, what):
+    """Lists against oracle.rank_topk_np on the kernel's own (bit-exact, separately tested) scores."""
+    from llmrec_amd.ops import Csr, SpmmPlan
+    n_items = ei.shape[0]
+    rp = np.zeros(eu.shape[0] + 1, dtype=np.int64)
+    for u, items in train_rows.items():
+        rp[u + 1] = len(items)
+    rp = np.cumsum(rp)
+    ci = np.concatenate([np.sort(np.asarray(train_rows[u], dtype=np.int64)) for u in sorted(train_rows)]) if train_rows else np.zeros(0, dtype=np.int64)
+    train = Csr(eu.shape[0], n_items, torch.tensor(rp, dtype=torch.int32, device=DEV), torch.tensor(ci, dtype=torch.int32, device=DEV),
+                None, None, None, SpmmPlan(0, 0, None, None, None))
+    qd = torch.tensor(q, dtype=torch.int64, device=DEV)
+    idx, sc = ops.score_topk(eu, ei, qd, train, K)
+    S = ops.scores(eu, ei, qd).cpu().numpy()
+    idx, sc = idx.cpu().numpy(), sc.cpu().numpy()
+    for r, u in enumerate(q):
+        want = O.rank_topk_np(S[r], train_rows.get(u, []), K)
+        got = idx[r][idx[r] >= 0]
+        assert got.tolist() == want.tolist(), (what, u, got[:8], want[:8])
+        assert np.array_equal(sc[r][: len(want)], S[r][want]), (what, u)
+        assert (idx[r][len(want):] == -1).all(), (what, u)
+
+
+@pytest.mark.parametrize("K", [50, 64])
+def test_topk_netflix_width_random_and_adversarial(ops, K):
+    rng = np.random.default_rng(K)
+    n_users, n_items = 96, I_NF
+    eu = torch.tensor(rng.standard_normal((n_users, D)).astype(np.float32), device=DEV)
+    ei_np = rng.standard_normal((n_items, D)).astype(np.float32)
+    train = {u: rng.choice(n_items, size=int(rng.integers(0, 60)), replace=False).tolist() for u in range(n_users)}
+    train[3] = rng.choice(n_items, size=n_items - (K - 1), replace=False).tolist()      # fewer than K candidates left
+    train[4] = list(range(n_items))                                                       # nothing left
+    q = list(range(n_users))
+    _check_topk(ops, eu, torch.tensor(ei_np, device=DEV), q, train, K, "random")
+    # scores strictly increasing with the item id for every user: each candidate beats the running K-th, the filter
+    # never rejects, every round appends - maximal buffer drains
+    eu1 = torch.zeros(n_users, D, device=DEV); eu1[:, 0] = torch.tensor(rng.uniform(0.5, 2.0, n_users).astype(np.float32))
+    ei1 = torch.zeros(n_items, D, device=DEV); ei1[:, 0] = torch.arange(n_items, device=DEV, dtype=torch.float32) / 8.0
+    _check_topk(ops, eu1, ei1, q, train, K, "ascending")
+    # strictly decreasing: the first K items win and nothing after passes (the opposite extreme)
+    ei2 = ei1.clone(); ei2[:, 0] = -ei1[:, 0]
+    _check_topk(ops, eu1, ei2, q, train, K, "descending")
+    # all scores equal: the tie rule alone (ascending item id) decides
+    ei3 = torch.zeros(n_items, D, device=DEV); ei3[:, 1] = 1.0
+    eu3 = torch.zeros(n_users, D, device=DEV); eu3[:, 1] = 0.25
+    _check_topk(ops, eu3, ei3, q, train, K, "all-equal")
+    # few distinct values: long runs of exact ties across tile and wave boundaries
+    ei4 = torch.zeros(n_items, D, device=DEV); ei4[:, 0] = torch.tensor(rng.integers(0, 4, n_items).astype(np.float32), device=DEV)
+    _check_topk(ops, eu1, ei4, q, train, K, "four-values")
+
+
+def test_topk_one_million_items(ops):
+    rng = np.random.default_rng(7)
+    n_users, n_items, K = 40, 1_000_000, 50
+    eu = torch.tensor(rng.standard_normal((n_users, D)).astype(np.float32), device=DEV)
+    ei = torch.randn(n_items, D, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    train = {u: rng.choice(n_items, size=int(rng.integers(1, 3000)), replace=False).tolist() for u in range(n_users)}
+    q = list(range(0, n_users, 3)) + [1, 1]                                               # repeated query user
+    _check_topk(ops, eu, ei, q, train, K, "1M random")
+    eu1 = torch.zeros(n_users, D, device=DEV); eu1[:, 5] = 1.0
+    ei1 = torch.zeros(n_items, D, device=DEV); ei1[:, 5] = torch.arange(n_items, device=DEV, dtype=torch.float32)
+    _check_topk(ops, eu1, ei1, q[:6], train, K, "1M ascending")
+
+
+# ------------------------------------------------------------------------------------------
+# the whole step and evaluation at the bench's shape (fused + HIP graph replay) against the oracle
+# ------------------------------------------------------------------------------------------
+def test_fused_graph_step_and_eval_at_netflix_shape_match_oracle():
+    import bench
+    dev = torch.device("cuda")
+    w = bench.NetflixShaped("nf", 0, dev)
+    rep = bench.parity_check(w, n_eval_users=192)
+    print(rep)
+    assert rep["forward_max_rel"] < 1e-4 and rep["bpr_max_rel"] < 1e-4 and rep["loss_rel"] < 1e-4, rep
+    assert rep["grad_max_rel"] < 1e-4 and rep["param_max_rel"] < 1e-4, rep
+    assert rep["topk_lists_equal"] == rep["topk_lists_checked"] > 0, rep
+    assert rep["ok"], rep

@@ -64,7 +64,7 @@ def test_training_steps_and_eval_match_reference(golden, path, monkeypatch):
             for nm in TRAINABLE:
                 e = rel(params[nm].grad.cpu().numpy(), golden.z["step%d/grad/%s" % (s, nm)])
                 worst["grad/" + nm] = max(worst.get("grad/" + nm, 0), e)
-                assert e < 5 * RTOL, (s, "grad", nm, e)
+                assert e < RTOL, (s, "grad", nm, e)
                 e = rel(params[nm].detach().cpu().numpy(), golden.z["step%d/param/%s" % (s, nm)])
                 assert e < RTOL, (s, "param", nm, e)
     print("worst relative errors:", {k: "%.2e" % v for k, v in sorted(worst.items())})
