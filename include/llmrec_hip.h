@@ -75,28 +75,54 @@ int llmrec_csr_row_constant(int64_t n_rows, const int32_t* rowptr, const float* 
  *                                        :153-157,162-163,166-167,176-180) and, with col_scale,
  *                                        the transposed SpMM autograd runs for dX = A^T dY.
  * val, row_scale, col_scale may each be NULL (= all ones). d = columns of X and Y.
- * Rows longer than LLMREC_SPMM_LONG_ROW are cut into segments handled by whole wavefronts and
- * summed by a second pass in a fixed order (results are run-to-run deterministic); the segment
- * lists come from the plan calls below and `partials` is caller scratch of
- * plan.n_segments * d floats.
+ * Rows are bucketed by length (the plan calls below) and all buckets run in ONE launch:
+ *   nnz <= LLMREC_SPMM_WAVE_ROW      one lane group (d/4 lanes) per row,
+ *   nnz <= LLMREC_SPMM_BLOCK_ROW     one wavefront per row            (list wave_rows),
+ *   nnz <= LLMREC_SPMM_SPLIT_ROW     one 256-thread block per row     (list block_rows),
+ *   longer                           segments of LLMREC_SPMM_SEGMENT nnz, one block each, partial sums in
+ *                                    `partials` (caller scratch, plan.n_segments * d floats) added in a fixed order by
+ *                                    a second launch (lists split_rows / split_seg_begin / seg_split).
+ * Every summation tree is fixed by (nnz, d): results are run-to-run deterministic, no float atomics.
+ * Epilogue on the finished row r (t = alpha * Z[r] + result[r], Z may be NULL or alias Y):
+ *   LLMREC_SPMM_EPI_NONE          Y[r] = t                       (Z = Y, alpha = 1: "Y += A X")
+ *   LLMREC_SPMM_EPI_SOFTMAX       Y[r] = softmax(t) over the d columns           (reference Models.py:176-177)
+ *   LLMREC_SPMM_EPI_SOFTMAX_BWD   Y[r] = S[r] * (t - sum(t * S[r]))              (its backward; S = the forward output)
  * ------------------------------------------------------------------------------------------ */
-#define LLMREC_SPMM_LONG_ROW 32    /* rows with more nnz are split              */
-#define LLMREC_SPMM_SEGMENT 128    /* ... into segments of this many nnz         */
+#define LLMREC_SPMM_WAVE_ROW 32
+#define LLMREC_SPMM_BLOCK_ROW 512
+#define LLMREC_SPMM_SPLIT_ROW 16384
+#define LLMREC_SPMM_SEGMENT 4096
 
-/* counts_host[0] = number of long rows, counts_host[1] = number of segments (synchronises). */
-int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t* scratch2 /* device, 2 ints */,
+typedef struct {
+    int32_t n_wave_rows;  const int32_t* wave_rows;        /* rows with WAVE_ROW < nnz <= BLOCK_ROW */
+    int32_t n_block_rows; const int32_t* block_rows;       /* rows with BLOCK_ROW < nnz <= SPLIT_ROW */
+    int32_t n_split_rows; const int32_t* split_rows;       /* rows with nnz > SPLIT_ROW */
+    const int32_t* split_seg_begin;                        /* [n_split_rows] first segment of each split row */
+    int32_t n_segments;   const int32_t* seg_split;        /* [n_segments] index into split_rows */
+} llmrec_spmm_plan_t;
+
+#define LLMREC_SPMM_EPI_NONE 0
+#define LLMREC_SPMM_EPI_SOFTMAX 1
+#define LLMREC_SPMM_EPI_SOFTMAX_BWD 2
+typedef struct {
+    int32_t op; float alpha;
+    const float* Z; int64_t ldz;
+    const float* S; int64_t lds;
+} llmrec_spmm_epilogue_t;
+
+/* counts_host[0..3] = n_wave_rows, n_block_rows, n_split_rows, n_segments (synchronises the stream). */
+int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t* scratch4 /* device, 4 ints */,
                            int32_t* counts_host, llmrec_stream_t stream);
-int llmrec_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, int32_t* scratch2,
-                          int32_t* long_rows /* n_long */, int32_t* long_seg_begin /* n_long */,
-                          int32_t* seg_long /* n_seg: index into long_rows */, llmrec_stream_t stream);
+int llmrec_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, int32_t* scratch4,
+                          int32_t* wave_rows, int32_t* block_rows, int32_t* split_rows,
+                          int32_t* split_seg_begin, int32_t* seg_split, llmrec_stream_t stream);
 
 int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
                     const int32_t* rowptr, const int32_t* colidx, const float* val,
                     const float* row_scale, const float* col_scale,
                     const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t d,
-                    int32_t n_long, const int32_t* long_rows, const int32_t* long_seg_begin,
-                    int32_t n_seg, const int32_t* seg_long, float* partials,
-                    int32_t accumulate /* 1: Y += result */, llmrec_stream_t stream);
+                    const llmrec_spmm_plan_t* plan_host, float* partials,
+                    const llmrec_spmm_epilogue_t* epilogue_host /* NULL = none */, llmrec_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * R4  side-feature projection            replaces nn.Linear forward / weight-grad

@@ -57,30 +57,41 @@ __global__ void row_constant_kernel(int64_t n_rows, const int32_t* __restrict__ 
 
 __global__ void flag_finish_kernel(int32_t* flag) { flag[0] = flag[0] ? 0 : 1; }
 
-__device__ __forceinline__ int32_t n_segments_of(int32_t deg) {
-    return deg > LLMREC_SPMM_LONG_ROW ? (deg + LLMREC_SPMM_SEGMENT - 1) / LLMREC_SPMM_SEGMENT : 0;
+// row classes of the SpMM (include/llmrec_hip.h): 0 lane group, 1 wavefront, 2 block, 3 split into segments
+__device__ __forceinline__ int row_class(int32_t deg) {
+    return deg <= LLMREC_SPMM_WAVE_ROW ? 0 : (deg <= LLMREC_SPMM_BLOCK_ROW ? 1 : (deg <= LLMREC_SPMM_SPLIT_ROW ? 2 : 3));
 }
 
 __global__ void plan_count_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t* __restrict__ counts) {
-    int32_t nl = 0, ns = 0;
+    int32_t n1 = 0, n2 = 0, n3 = 0, ns = 0;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
-        int32_t k = n_segments_of(rowptr[r + 1] - rowptr[r]);
-        if (k) { nl += 1; ns += k; }
+        const int32_t deg = rowptr[r + 1] - rowptr[r];
+        const int c = row_class(deg);
+        n1 += c == 1; n2 += c == 2;
+        if (c == 3) { n3 += 1; ns += (deg + LLMREC_SPMM_SEGMENT - 1) / LLMREC_SPMM_SEGMENT; }
     }
-    if (nl) { atomicAdd(&counts[0], nl); atomicAdd(&counts[1], ns); }
+    if (n1) atomicAdd(&counts[0], n1);
+    if (n2) atomicAdd(&counts[1], n2);
+    if (n3) { atomicAdd(&counts[2], n3); atomicAdd(&counts[3], ns); }
 }
 
 __global__ void plan_fill_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t* __restrict__ cursors,
-                                 int32_t* __restrict__ long_rows, int32_t* __restrict__ long_seg_begin,
-                                 int32_t* __restrict__ seg_long) {
+                                 int32_t* __restrict__ wave_rows, int32_t* __restrict__ block_rows,
+                                 int32_t* __restrict__ split_rows, int32_t* __restrict__ split_seg_begin,
+                                 int32_t* __restrict__ seg_split) {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
-        int32_t k = n_segments_of(rowptr[r + 1] - rowptr[r]);
-        if (!k) continue;
-        int32_t slot = atomicAdd(&cursors[0], 1);
-        int32_t base = atomicAdd(&cursors[1], k);
-        long_rows[slot] = (int32_t)r;
-        long_seg_begin[slot] = base;
-        for (int32_t s = 0; s < k; ++s) seg_long[base + s] = slot;
+        const int32_t deg = rowptr[r + 1] - rowptr[r];
+        const int c = row_class(deg);
+        if (c == 1) wave_rows[atomicAdd(&cursors[0], 1)] = (int32_t)r;
+        else if (c == 2) block_rows[atomicAdd(&cursors[1], 1)] = (int32_t)r;
+        else if (c == 3) {
+            const int32_t k = (deg + LLMREC_SPMM_SEGMENT - 1) / LLMREC_SPMM_SEGMENT;
+            const int32_t slot = atomicAdd(&cursors[2], 1);
+            const int32_t base = atomicAdd(&cursors[3], k);
+            split_rows[slot] = (int32_t)r;
+            split_seg_begin[slot] = base;
+            for (int32_t s = 0; s < k; ++s) seg_split[base + s] = slot;
+        }
     }
 }
 
@@ -186,27 +197,29 @@ int llmrec_csr_row_constant(int64_t n_rows, const int32_t* rowptr, const float* 
     return LLMREC_OK;
 }
 
-int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t* scratch2, int32_t* counts_host,
+int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t* scratch4, int32_t* counts_host,
                            llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    LLMREC_CHECK_ARG(n_rows >= 0 && rowptr && scratch2 && counts_host, "spmm_plan_count: bad argument");
-    LLMREC_HIP(hipMemsetAsync(scratch2, 0, 8, stream));
+    LLMREC_CHECK_ARG(n_rows >= 0 && rowptr && scratch4 && counts_host, "spmm_plan_count: bad argument");
+    LLMREC_HIP(hipMemsetAsync(scratch4, 0, 16, stream));
     if (n_rows > 0) {
-        plan_count_kernel<<<grid_for(n_rows, 256), 256, 0, stream>>>(n_rows, rowptr, scratch2);
+        plan_count_kernel<<<grid_for(n_rows, 256), 256, 0, stream>>>(n_rows, rowptr, scratch4);
         LLMREC_LAUNCH_CHECK();
     }
-    LLMREC_HIP(hipMemcpyAsync(counts_host, scratch2, 8, hipMemcpyDeviceToHost, stream));
+    LLMREC_HIP(hipMemcpyAsync(counts_host, scratch4, 16, hipMemcpyDeviceToHost, stream));
     LLMREC_HIP(hipStreamSynchronize(stream));
     return LLMREC_OK;
 }
 
-int llmrec_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, int32_t* scratch2,
-                          int32_t* long_rows, int32_t* long_seg_begin, int32_t* seg_long, llmrec_stream_t stream_) {
+int llmrec_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, int32_t* scratch4,
+                          int32_t* wave_rows, int32_t* block_rows, int32_t* split_rows,
+                          int32_t* split_seg_begin, int32_t* seg_split, llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    LLMREC_CHECK_ARG(n_rows >= 0 && rowptr && scratch2 && long_rows && long_seg_begin && seg_long, "spmm_plan_fill: bad argument");
-    LLMREC_HIP(hipMemsetAsync(scratch2, 0, 8, stream));
+    LLMREC_CHECK_ARG(n_rows >= 0 && rowptr && scratch4, "spmm_plan_fill: bad argument");
+    LLMREC_HIP(hipMemsetAsync(scratch4, 0, 16, stream));
     if (n_rows > 0) {
-        plan_fill_kernel<<<grid_for(n_rows, 256), 256, 0, stream>>>(n_rows, rowptr, scratch2, long_rows, long_seg_begin, seg_long);
+        plan_fill_kernel<<<grid_for(n_rows, 256), 256, 0, stream>>>(n_rows, rowptr, scratch4, wave_rows, block_rows, split_rows,
+                                                                    split_seg_begin, seg_split);
         LLMREC_LAUNCH_CHECK();
     }
     return LLMREC_OK;

@@ -1,20 +1,26 @@
-// spmm.hip - R2: Y = diag(row_scale) * (P (.) val) * diag(col_scale) * X, fp32, CSR.
+// spmm.hip - R2: Y = epilogue(alpha * Z + diag(row_scale) * (P (.) val) * diag(col_scale) * X), fp32, CSR.
 // Replaces torch.sparse.mm / torch.mm(sparse, dense) at reference Models.py:57-61 (call sites
-// :153-157,162-163,166-167,176-180) and the transposed SpMM autograd runs for the backward.
+// :153-157,162-163,166-167,176-180), the transposed SpMM autograd runs for the backward, and - as fused
+// epilogues on the finished row - the row softmax of the last propagation layer (Models.py:176-177), its
+// backward, and the "+ mean-term" additions of the hand-written backward (llmrec_amd/fused.py).
 //
-// HBM-bound gather kernel, organised for 64-lane wavefronts:
-//   * a row of X / Y is d floats; LPR = d/4 lanes (16 for d = 64) each own one float4 of the row,
-//     so one wavefront instruction moves 64/LPR complete rows as 16-byte-per-lane accesses
-//     (coalesced 256-B row segments);
-//   * "row buckets": rows with <= LLMREC_SPMM_LONG_ROW nnz are processed one lane-group per row
-//     (4 rows per wavefront at d = 64); longer rows are cut into LLMREC_SPMM_SEGMENT-nnz segments,
-//     one wavefront per segment, whose partial sums a third kernel adds in a fixed order
-//     (deterministic, no float atomics);
-//   * a lane group loads LPR column indices with one coalesced access and broadcasts them with
-//     ds_bpermute (__shfl), then issues UNROLL independent row gathers before accumulating, so
-//     each lane keeps UNROLL x 16 B in flight;
-//   * the adjacency values are not read at all in the reference's case (A = diag(s) R, R binary):
-//     a per-row scale is applied once at the end (4 B/nnz of traffic instead of 8-20 B/nnz).
+// HBM / fabric-bound gather kernel, organised for 64-lane wavefronts:
+//   * a row of X / Y is d floats; LPR = d/4 lanes (16 for d = 64) each own one float4 of the row, so one
+//     wavefront instruction moves 64/LPR complete rows as 16-byte-per-lane accesses (coalesced 256-B rows);
+//   * CSR row buckets by length (llmrec_spmm_plan_*), all in ONE launch, heaviest blocks first:
+//       <= 32 nnz            one lane group per row (4 rows per wavefront at d = 64),
+//       33 .. 512            one wavefront per row (lane groups take contiguous quarters, butterfly sum),
+//       513 .. 16384         one 256-thread block per row (waves summed through LDS in wave order),
+//       > 16384              4096-nnz segments, one block each, partial sums added in a fixed order by a second,
+//                            tiny launch (only graphs with such hubs pay for it);
+//     every summation tree is fixed by (nnz, d): results are run-to-run deterministic, no float atomics;
+//   * a lane group loads LPR column indices with one coalesced access and broadcasts them with ds_bpermute
+//     (__shfl), then issues UNROLL independent row gathers before accumulating (UNROLL x 16 B in flight per lane);
+//   * the adjacency values are not read at all in the reference's case (A = diag(s) R, R binary): a per-row
+//     scale is applied once at the end (4 B/nnz of traffic instead of 8-20 B/nnz).
+// What bounds it at scale (tools/gatherbench.py, profiles/r02_gatherbench_*.txt): the L2-miss path of the fabric,
+// ~7.4 TB/s of 128-B lines from the Infinity Cache or HBM alike, plus ~25 TB/s for the L2 hits; a constant-degree
+// graph without any imbalance reaches 35 G gathers/s on the synthetic graphs' popularity - this kernel's ceiling.
 #include "common.h"
 
 namespace llmrec {
@@ -36,6 +42,12 @@ template <> struct Vec<4> {
         v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64);
         v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
     }
+    __device__ __forceinline__ float hmax() const { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
+    __device__ __forceinline__ float hsum() const { return (v.x + v.y) + (v.z + v.w); }
+    __device__ __forceinline__ float dot(const Vec& o) const { return (v.x * o.v.x + v.y * o.v.y) + (v.z * o.v.z + v.w * o.v.w); }
+    __device__ __forceinline__ void exp_sub(float m) { v.x = expf(v.x - m); v.y = expf(v.y - m); v.z = expf(v.z - m); v.w = expf(v.w - m); }
+    // this = s * (this - c)    (softmax backward: y * (g - sum(g y)))
+    __device__ __forceinline__ void sub_mul(float c, const Vec& s) { v.x = s.v.x * (v.x - c); v.y = s.v.y * (v.y - c); v.z = s.v.z * (v.z - c); v.w = s.v.w * (v.w - c); }
 };
 template <> struct Vec<1> {
     float v;
@@ -46,6 +58,11 @@ template <> struct Vec<1> {
     __device__ __forceinline__ void fma(float w, const Vec& o) { v = fmaf(w, o.v, v); }
     __device__ __forceinline__ void scale(float s) { v *= s; }
     __device__ __forceinline__ void xor_add(int off) { v += __shfl_xor(v, off, 64); }
+    __device__ __forceinline__ float hmax() const { return v; }
+    __device__ __forceinline__ float hsum() const { return v; }
+    __device__ __forceinline__ float dot(const Vec& o) const { return v * o.v; }
+    __device__ __forceinline__ void exp_sub(float m) { v = expf(v - m); }
+    __device__ __forceinline__ void sub_mul(float c, const Vec& s) { v = s.v * (v - c); }
 };
 
 struct SpmmArgs {
@@ -60,12 +77,22 @@ struct SpmmArgs {
     float* Y;
     int64_t ldy;
     int32_t d;
-    int32_t accumulate;          // 1: Y += result
-    int32_t skip_long;           // 1: rows longer than LLMREC_SPMM_LONG_ROW are left to the segment pass
-    const int32_t* long_rows;
-    const int32_t* long_seg_begin;
-    const int32_t* seg_long;
+    // epilogue: t = alpha * Z[row] + result; Y[row] = op(t)
+    int32_t epi_op;
+    float alpha;
+    const float* Z;
+    int64_t ldz;
+    const float* S;              // softmax backward: rows of the forward softmax output
+    int64_t lds;
+    // plan
+    const int32_t* wave_rows;
+    const int32_t* block_rows;
+    const int32_t* split_rows;
+    const int32_t* split_seg_begin;
+    const int32_t* seg_split;
     float* partials;
+    int32_t n_wave_rows, n_block_rows, n_split_rows, n_segments;
+    int32_t blk_seg, blk_block, blk_wave;     // first block of the block-row / wave-row / short-row ranges
 };
 
 // Accumulate sum_{j in [s, e)} w_j * X[col_j, chunk columns] into acc, in ascending j order.
@@ -110,7 +137,53 @@ __device__ __forceinline__ void accumulate_range(const SpmmArgs& a, int32_t s, i
     }
 }
 
-// one lane group per row
+// The finished row (unscaled sum in acc, held by the LPR lanes of one lane group): scale, init term, epilogue, store.
+template <int LPR, int NCHUNK, int VEC>
+__device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t row, int gl, Vec<VEC> (&acc)[NCHUNK]) {
+    const float rs = a.row_scale ? a.row_scale[row] : 1.0f;
+    float* yr = a.Y + row * a.ldy;
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) {
+        const int col = (k * LPR + gl) * VEC;
+        if (a.row_scale) acc[k].scale(rs);
+        if (a.Z && col < a.d) { Vec<VEC> z; z.load(a.Z + row * a.ldz + col); acc[k].fma(a.alpha, z); }
+        if (col >= a.d) acc[k].zero();
+    }
+    if (a.epi_op == LLMREC_SPMM_EPI_SOFTMAX) {                   // wave-uniform
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k) if ((k * LPR + gl) * VEC < a.d) m = fmaxf(m, acc[k].hmax());
+        m = group_max<LPR>(m);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k) {
+            if ((k * LPR + gl) * VEC < a.d) { acc[k].exp_sub(m); s += acc[k].hsum(); }
+        }
+        s = group_sum<LPR>(s);
+        const float inv = 1.0f / s;
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k) acc[k].scale(inv);
+    } else if (a.epi_op == LLMREC_SPMM_EPI_SOFTMAX_BWD) {
+        Vec<VEC> y[NCHUNK];
+        float c = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k) {
+            const int col = (k * LPR + gl) * VEC;
+            if (col < a.d) { y[k].load(a.S + row * a.lds + col); c += acc[k].dot(y[k]); }
+            else y[k].zero();
+        }
+        c = group_sum<LPR>(c);
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k) acc[k].sub_mul(c, y[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) {
+        const int col = (k * LPR + gl) * VEC;
+        if (col < a.d) acc[k].store(yr + col);
+    }
+}
+
+// one lane group per row (rows with at most LLMREC_SPMM_WAVE_ROW nnz; longer rows belong to the other ranges)
 template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
 __device__ __forceinline__ void rows_body(const SpmmArgs& a, int64_t block) {
     constexpr int GPB = 256 / LPR;
@@ -118,47 +191,21 @@ __device__ __forceinline__ void rows_body(const SpmmArgs& a, int64_t block) {
     const int64_t row = block * GPB + (threadIdx.x / LPR);
     if (row >= a.n_rows) return;
     const int32_t s = a.rowptr[row], e = a.rowptr[row + 1];
-    if (a.skip_long && (e - s) > LLMREC_SPMM_LONG_ROW) return;
+    if ((e - s) > LLMREC_SPMM_WAVE_ROW) return;
     Vec<VEC> acc[NCHUNK];
 #pragma unroll
     for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
     accumulate_range<LPR, NCHUNK, VEC, WEIGHTED>(a, s, e, gl, acc);
-    const float rs = a.row_scale ? a.row_scale[row] : 1.0f;
-    float* yr = a.Y + row * a.ldy;
-#pragma unroll
-    for (int k = 0; k < NCHUNK; ++k) {
-        const int col = (k * LPR + gl) * VEC;
-        if (col < a.d) {
-            if (a.row_scale) acc[k].scale(rs);
-            if (a.accumulate) { Vec<VEC> old; old.load(yr + col); acc[k].add(old); }
-            acc[k].store(yr + col);
-        }
-    }
+    finish_row<LPR, NCHUNK, VEC>(a, row, gl, acc);
 }
 
+// one wavefront over [s, e): the 64/LPR lane groups take contiguous parts, butterfly sum -> every group holds the total
 template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
-__global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
-    rows_body<LPR, NCHUNK, VEC, WEIGHTED>(a, blockIdx.x);
-}
-
-// one wavefront per segment of a long row; the 64/LPR lane groups take contiguous quarters
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
-__device__ __forceinline__ void segments_body(const SpmmArgs& a, int32_t n_seg, int32_t block) {
-    constexpr int G = 64 / LPR;                       // lane groups per wavefront
-    const int lane = threadIdx.x & 63;
-    const int gl = lane & (LPR - 1);
-    const int g = lane / LPR;
-    const int32_t seg = block * 4 + (threadIdx.x >> 6);
-    if (seg >= n_seg) return;
-    const int32_t slot = a.seg_long[seg];
-    const int32_t row = a.long_rows[slot];
-    const int32_t k_in_row = seg - a.long_seg_begin[slot];
-    const int32_t rs_ = a.rowptr[row], re_ = a.rowptr[row + 1];
-    const int32_t s = rs_ + k_in_row * LLMREC_SPMM_SEGMENT;
-    const int32_t e = min(s + LLMREC_SPMM_SEGMENT, re_);
-    constexpr int PER_G = LLMREC_SPMM_SEGMENT / G;
-    const int32_t gs = min(s + g * PER_G, e), ge = min(gs + PER_G, e);
-    Vec<VEC> acc[NCHUNK];
+__device__ __forceinline__ void wave_range(const SpmmArgs& a, int32_t s, int32_t e, int lane, Vec<VEC> (&acc)[NCHUNK]) {
+    constexpr int G = 64 / LPR;
+    const int gl = lane & (LPR - 1), g = lane / LPR;
+    const int32_t per = (((e - s) + G - 1) / G + LPR - 1) / LPR * LPR;      // multiple of LPR: aligned index loads
+    const int32_t gs = min(s + g * per, e), ge = min(gs + per, e);
 #pragma unroll
     for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
     accumulate_range<LPR, NCHUNK, VEC, WEIGHTED>(a, gs, ge, gl, acc);
@@ -167,97 +214,127 @@ __device__ __forceinline__ void segments_body(const SpmmArgs& a, int32_t n_seg, 
 #pragma unroll
         for (int k = 0; k < NCHUNK; ++k) acc[k].xor_add(off);
     }
-    if (g == 0) {
-        float* pr = a.partials + (int64_t)seg * a.d;
+}
+
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
+__device__ __forceinline__ void wave_rows_body(const SpmmArgs& a, int32_t block) {
+    const int lane = threadIdx.x & 63;
+    const int32_t slot = block * 4 + (threadIdx.x >> 6);
+    if (slot >= a.n_wave_rows) return;
+    const int32_t row = a.wave_rows[slot];
+    Vec<VEC> acc[NCHUNK];
+    wave_range<LPR, NCHUNK, VEC, WEIGHTED>(a, a.rowptr[row], a.rowptr[row + 1], lane, acc);
+    if (lane < LPR) finish_row<LPR, NCHUNK, VEC>(a, row, lane, acc);
+}
+
+// one block over [s, e): the 4 waves take contiguous quarters, summed through LDS in wave order; the total ends up in
+// the first lane group of wave 0 (returns true there)
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
+__device__ __forceinline__ bool block_range(const SpmmArgs& a, int32_t s, int32_t e, float* lds, Vec<VEC> (&acc)[NCHUNK]) {
+    constexpr int ROWW = NCHUNK * LPR * VEC;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int32_t per = (((e - s) + 3) / 4 + 63) / 64 * 64;
+    const int32_t ws = min(s + w * per, e), we = min(ws + per, e);
+    wave_range<LPR, NCHUNK, VEC, WEIGHTED>(a, ws, we, lane, acc);
+    if (w > 0 && lane < LPR) {
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k) acc[k].store(lds + (w - 1) * ROWW + (k * LPR + lane) * VEC);
+    }
+    __syncthreads();
+    if (w != 0 || lane >= LPR) return false;
+#pragma unroll
+    for (int ww = 0; ww < 3; ++ww) {
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k) { Vec<VEC> o; o.load(lds + ww * ROWW + (k * LPR + lane) * VEC); acc[k].add(o); }
+    }
+    return true;
+}
+
+// ONE launch: [0, blk_seg) segments of the split rows, [blk_seg, blk_block) block rows, [blk_block, blk_wave) wave
+// rows (4 per block), the rest short rows. The heavy blocks come first.
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
+__global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a) {
+    constexpr int ROWW = NCHUNK * LPR * VEC;
+    __shared__ __attribute__((aligned(16))) float red_lds[3 * ROWW];
+    const int32_t b = blockIdx.x;
+    if (b >= a.blk_wave) { rows_body<LPR, NCHUNK, VEC, WEIGHTED>(a, (int64_t)b - a.blk_wave); return; }
+    if (b >= a.blk_block) { wave_rows_body<LPR, NCHUNK, VEC, WEIGHTED>(a, b - a.blk_block); return; }
+    Vec<VEC> acc[NCHUNK];
+    if (b >= a.blk_seg) {
+        const int32_t row = a.block_rows[b - a.blk_seg];
+        if (block_range<LPR, NCHUNK, VEC, WEIGHTED>(a, a.rowptr[row], a.rowptr[row + 1], red_lds, acc))
+            finish_row<LPR, NCHUNK, VEC>(a, row, threadIdx.x, acc);
+        return;
+    }
+    const int32_t slot = a.seg_split[b];
+    const int32_t row = a.split_rows[slot];
+    const int32_t k_in_row = b - a.split_seg_begin[slot];
+    const int32_t re = a.rowptr[row + 1];
+    const int32_t s = a.rowptr[row] + k_in_row * LLMREC_SPMM_SEGMENT;
+    const int32_t e = min(s + LLMREC_SPMM_SEGMENT, re);
+    if (block_range<LPR, NCHUNK, VEC, WEIGHTED>(a, s, e, red_lds, acc)) {
+        float* pr = a.partials + (int64_t)b * a.d;
 #pragma unroll
         for (int k = 0; k < NCHUNK; ++k) {
-            const int col = (k * LPR + gl) * VEC;
+            const int col = (k * LPR + (int)threadIdx.x) * VEC;
             if (col < a.d) acc[k].store(pr + col);
         }
     }
 }
 
-// rows and segments are independent: one launch, blocks [0, seg_blocks) take four segments each (the heavy
-// blocks first), the rest the short rows (the 20 SpMMs of a Netflix-scale step are latency-bound; a
-// dependent launch costs ~7 us)
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
-__global__ __launch_bounds__(256) void spmm_rows_segments_kernel(SpmmArgs a, int32_t seg_blocks, int32_t n_seg) {
-    if ((int32_t)blockIdx.x < seg_blocks) segments_body<LPR, NCHUNK, VEC, WEIGHTED>(a, n_seg, blockIdx.x);
-    else rows_body<LPR, NCHUNK, VEC, WEIGHTED>(a, (int64_t)blockIdx.x - seg_blocks);
-}
-
-// one block per long row: the 256/LPR lane groups each add every (256/LPR)-th segment partial
-// (ascending), then the groups are combined through LDS in group order - a fixed summation tree
+// one block per split row: the 256/LPR lane groups each add every (256/LPR)-th segment partial (ascending), then the
+// groups are combined through LDS in group order - a fixed summation tree; then the row's epilogue
 template <int LPR, int NCHUNK, int VEC>
 __global__ __launch_bounds__(256) void spmm_finalize_kernel(SpmmArgs a) {
     constexpr int G = 256 / LPR;
-    extern __shared__ __attribute__((aligned(16))) float fin_lds[];   // [G][NCHUNK * LPR * VEC]
     constexpr int ROWW = NCHUNK * LPR * VEC;
+    __shared__ __attribute__((aligned(16))) float fin_lds[G * ROWW];
     const int gl = threadIdx.x & (LPR - 1), g = threadIdx.x / LPR;
     const int32_t slot = blockIdx.x;
-    const int32_t row = a.long_rows[slot];
+    const int32_t row = a.split_rows[slot];
     const int32_t deg = a.rowptr[row + 1] - a.rowptr[row];
     const int32_t nseg = (deg + LLMREC_SPMM_SEGMENT - 1) / LLMREC_SPMM_SEGMENT;
-    const float* pr = a.partials + (int64_t)a.long_seg_begin[slot] * a.d;
+    const float* pr = a.partials + (int64_t)a.split_seg_begin[slot] * a.d;
     Vec<VEC> acc[NCHUNK];
 #pragma unroll
     for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
-    for (int s0 = g; s0 < nseg; s0 += 4 * G) {
-        Vec<VEC> v[4][NCHUNK];
+    for (int s0 = g; s0 < nseg; s0 += G) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int sidx = s0 + u * G;
-#pragma unroll
-            for (int k = 0; k < NCHUNK; ++k) {
-                const int col = (k * LPR + gl) * VEC;
-                if (sidx < nseg && col < a.d) v[u][k].load(pr + (int64_t)sidx * a.d + col);
-                else v[u][k].zero();
-            }
+        for (int k = 0; k < NCHUNK; ++k) {
+            const int col = (k * LPR + gl) * VEC;
+            if (col < a.d) { Vec<VEC> v; v.load(pr + (int64_t)s0 * a.d + col); acc[k].add(v); }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int k = 0; k < NCHUNK; ++k) acc[k].add(v[u][k]);
     }
 #pragma unroll
     for (int k = 0; k < NCHUNK; ++k) acc[k].store(fin_lds + g * ROWW + (k * LPR + gl) * VEC);
     __syncthreads();
-    if (g == 0) {
-        const float rs = a.row_scale ? a.row_scale[row] : 1.0f;
-        float* yr = a.Y + (int64_t)row * a.ldy;
+    if (g != 0) return;
 #pragma unroll
-        for (int k = 0; k < NCHUNK; ++k) {
-            const int col = (k * LPR + gl) * VEC;
-            if (col >= a.d) continue;
-            Vec<VEC> t;
-            t.zero();
-            for (int gg = 0; gg < G; ++gg) { Vec<VEC> o; o.load(fin_lds + gg * ROWW + col); t.add(o); }
-            if (a.row_scale) t.scale(rs);
-            if (a.accumulate) { Vec<VEC> old; old.load(yr + col); t.add(old); }
-            t.store(yr + col);
-        }
+    for (int k = 0; k < NCHUNK; ++k) {
+        acc[k].zero();
+        for (int gg = 0; gg < G; ++gg) { Vec<VEC> o; o.load(fin_lds + gg * ROWW + (k * LPR + gl) * VEC); acc[k].add(o); }
     }
+    finish_row<LPR, NCHUNK, VEC>(a, row, gl, acc);
 }
 
 template <int LPR, int NCHUNK, int VEC>
-static int launch_spmm(const SpmmArgs& a, int32_t n_long, int32_t n_seg, hipStream_t stream) {
+static int launch_spmm(SpmmArgs& a, hipStream_t stream) {
     const bool weighted = a.val != nullptr || a.col_scale != nullptr;
     constexpr int GPB = 256 / LPR;
-    const int64_t blocks = ceil_div(a.n_rows, GPB);
-    if (blocks > 0x7fffffffll) { set_error("spmm: too many rows for one launch"); return LLMREC_EUNSUPPORTED; }
-    const int sb = (int)ceil_div(n_seg, 4);
-    if (n_long > 0 && blocks + sb <= 0x7fffffffll) {
-        const int grid = (int)(blocks + sb);
-        if (weighted) spmm_rows_segments_kernel<LPR, NCHUNK, VEC, true><<<grid, 256, 0, stream>>>(a, sb, n_seg);
-        else spmm_rows_segments_kernel<LPR, NCHUNK, VEC, false><<<grid, 256, 0, stream>>>(a, sb, n_seg);
+    const int64_t row_blocks = ceil_div(a.n_rows, GPB);
+    const int64_t wave_blocks = ceil_div(a.n_wave_rows, 4);
+    const int64_t total = (int64_t)a.n_segments + a.n_block_rows + wave_blocks + row_blocks;
+    if (total > 0x7fffffffll) { set_error("spmm: too many rows for one launch"); return LLMREC_EUNSUPPORTED; }
+    a.blk_seg = a.n_segments;
+    a.blk_block = a.blk_seg + a.n_block_rows;
+    a.blk_wave = a.blk_block + (int32_t)wave_blocks;
+    if (total > 0) {
+        if (weighted) spmm_kernel<LPR, NCHUNK, VEC, true><<<(unsigned)total, 256, 0, stream>>>(a);
+        else spmm_kernel<LPR, NCHUNK, VEC, false><<<(unsigned)total, 256, 0, stream>>>(a);
         LLMREC_LAUNCH_CHECK();
-        spmm_finalize_kernel<LPR, NCHUNK, VEC><<<n_long, 256, sizeof(float) * (256 / LPR) * NCHUNK * LPR * VEC, stream>>>(a);
-        LLMREC_LAUNCH_CHECK();
-        return LLMREC_OK;
     }
-    if (blocks > 0) {
-        if (weighted) spmm_rows_kernel<LPR, NCHUNK, VEC, true><<<(int)blocks, 256, 0, stream>>>(a);
-        else spmm_rows_kernel<LPR, NCHUNK, VEC, false><<<(int)blocks, 256, 0, stream>>>(a);
+    if (a.n_split_rows > 0) {
+        spmm_finalize_kernel<LPR, NCHUNK, VEC><<<a.n_split_rows, 256, 0, stream>>>(a);
         LLMREC_LAUNCH_CHECK();
     }
     return LLMREC_OK;
@@ -271,34 +348,47 @@ extern "C" int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
                                const int32_t* rowptr, const int32_t* colidx, const float* val,
                                const float* row_scale, const float* col_scale,
                                const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t d,
-                               int32_t n_long, const int32_t* long_rows, const int32_t* long_seg_begin,
-                               int32_t n_seg, const int32_t* seg_long, float* partials,
-                               int32_t accumulate, llmrec_stream_t stream_) {
+                               const llmrec_spmm_plan_t* plan_host, float* partials,
+                               const llmrec_spmm_epilogue_t* epilogue_host, llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LLMREC_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && d >= 0, "spmm: negative size");
     if (n_rows == 0 || d == 0) return LLMREC_OK;
     LLMREC_CHECK_ARG(rowptr && Y && ldy >= d && ldx >= d, "spmm: null pointer or ld < d");
-    LLMREC_CHECK_ARG(n_long >= 0 && n_seg >= 0, "spmm: negative plan size");
-    LLMREC_CHECK_ARG(n_long == 0 || (long_rows && long_seg_begin && seg_long && partials), "spmm: long-row plan incomplete");
-    SpmmArgs a;
+    LLMREC_CHECK_ARG(plan_host, "spmm: a row plan is required (llmrec_spmm_plan_count / _fill)");
+    const llmrec_spmm_plan_t& p = *plan_host;
+    LLMREC_CHECK_ARG(p.n_wave_rows >= 0 && p.n_block_rows >= 0 && p.n_split_rows >= 0 && p.n_segments >= 0, "spmm: negative plan size");
+    LLMREC_CHECK_ARG((p.n_wave_rows == 0 || p.wave_rows) && (p.n_block_rows == 0 || p.block_rows) &&
+                     (p.n_split_rows == 0 || (p.split_rows && p.split_seg_begin && p.seg_split && partials)), "spmm: row plan incomplete");
+    SpmmArgs a = {};
     a.n_rows = n_rows; a.rowptr = rowptr; a.colidx = colidx; a.val = val; a.row_scale = row_scale;
     a.col_scale = col_scale; a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.d = d;
-    a.accumulate = accumulate; a.skip_long = n_long > 0; a.long_rows = long_rows; a.long_seg_begin = long_seg_begin;
-    a.seg_long = seg_long; a.partials = partials;
-    const bool vec4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
+    a.wave_rows = p.wave_rows; a.block_rows = p.block_rows; a.split_rows = p.split_rows; a.split_seg_begin = p.split_seg_begin;
+    a.seg_split = p.seg_split; a.partials = partials;
+    a.n_wave_rows = p.n_wave_rows; a.n_block_rows = p.n_block_rows; a.n_split_rows = p.n_split_rows; a.n_segments = p.n_segments;
+    a.epi_op = LLMREC_SPMM_EPI_NONE; a.alpha = 0.f;
+    bool epi_aligned = true;
+    if (epilogue_host) {
+        const llmrec_spmm_epilogue_t& e = *epilogue_host;
+        LLMREC_CHECK_ARG(e.op >= LLMREC_SPMM_EPI_NONE && e.op <= LLMREC_SPMM_EPI_SOFTMAX_BWD, "spmm: unknown epilogue op %d", e.op);
+        LLMREC_CHECK_ARG(!e.Z || e.ldz >= d, "spmm: epilogue Z with ld < d");
+        LLMREC_CHECK_ARG(e.op != LLMREC_SPMM_EPI_SOFTMAX_BWD || (e.S && e.lds >= d), "spmm: softmax backward needs S with ld >= d");
+        a.epi_op = e.op; a.alpha = e.alpha; a.Z = e.Z; a.ldz = e.ldz; a.S = e.S; a.lds = e.lds;
+        epi_aligned = (!e.Z || (e.ldz % 4 == 0 && (uintptr_t)e.Z % 16 == 0)) && (!e.S || (e.lds % 4 == 0 && (uintptr_t)e.S % 16 == 0));
+    }
+    const bool vec4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && epi_aligned &&
                       (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)partials) % 16 == 0);
     if (vec4) {
-        if (d <= 16) return launch_spmm<4, 1, 4>(a, n_long, n_seg, stream);
-        if (d <= 32) return launch_spmm<8, 1, 4>(a, n_long, n_seg, stream);
-        if (d <= 64) return launch_spmm<16, 1, 4>(a, n_long, n_seg, stream);
-        if (d <= 128) return launch_spmm<32, 1, 4>(a, n_long, n_seg, stream);
-        if (d <= 256) return launch_spmm<64, 1, 4>(a, n_long, n_seg, stream);
-        if (d <= 512) return launch_spmm<64, 2, 4>(a, n_long, n_seg, stream);
-        if (d <= 1024) return launch_spmm<64, 4, 4>(a, n_long, n_seg, stream);
+        if (d <= 16) return launch_spmm<4, 1, 4>(a, stream);
+        if (d <= 32) return launch_spmm<8, 1, 4>(a, stream);
+        if (d <= 64) return launch_spmm<16, 1, 4>(a, stream);
+        if (d <= 128) return launch_spmm<32, 1, 4>(a, stream);
+        if (d <= 256) return launch_spmm<64, 1, 4>(a, stream);
+        if (d <= 512) return launch_spmm<64, 2, 4>(a, stream);
+        if (d <= 1024) return launch_spmm<64, 4, 4>(a, stream);
     } else {
-        if (d <= 16) return launch_spmm<16, 1, 1>(a, n_long, n_seg, stream);
-        if (d <= 64) return launch_spmm<64, 1, 1>(a, n_long, n_seg, stream);
-        if (d <= 256) return launch_spmm<64, 4, 1>(a, n_long, n_seg, stream);
+        if (d <= 16) return launch_spmm<16, 1, 1>(a, stream);
+        if (d <= 64) return launch_spmm<64, 1, 1>(a, stream);
+        if (d <= 256) return launch_spmm<64, 4, 1>(a, stream);
     }
     set_error("spmm: d = %d outside the compiled kernel family (vec4 = %d)", d, (int)vec4);
     return LLMREC_EUNSUPPORTED;

@@ -119,17 +119,20 @@ class FusedStep:
         """Context: launch on side stream `st` (or stay on the current stream when disabled)."""
         return torch.cuda.stream(st) if self.multi_stream else torch.cuda.stream(torch.cuda.current_stream())
 
-    def _spmm(self, a: ops.Csr, X, Y, accumulate=False, tag=0):
+    def _spmm(self, a: ops.Csr, X, Y, accumulate=False, tag=0, epilogue=None):
+        """Y = epilogue(A X) (llmrec_spmm_f32); accumulate: Y += A X. tag: one segment scratch per concurrent chain."""
         pl = a.plan
         partials = None
-        if pl.n_long:
-            key = (id(pl), X.shape[1], tag)                   # one scratch per concurrent chain
+        if pl.n_seg:
+            key = (id(pl), X.shape[1], tag)
             partials = self._partials.get(key)
             if partials is None:
                 partials = self._partials[key] = torch.empty(pl.n_seg * X.shape[1], dtype=torch.float32, device=X.device)
+        if accumulate:
+            epilogue = ops.spmm_epilogue(ops.EPI_NONE, 1.0, Y)
         _call("llmrec_spmm_f32", a.n_rows, a.n_cols, _p(a.rowptr), _p(a.colidx), _p(a.val), _p(a.row_scale), _p(a.col_scale),
-              _p(X), _ld(X), _p(Y), _ld(Y), X.shape[1], pl.n_long, _p(pl.long_rows), _p(pl.long_seg_begin), pl.n_seg,
-              _p(pl.seg_long), _p(partials), 1 if accumulate else 0)
+              _p(X), _ld(X), _p(Y), _ld(Y), X.shape[1], _c.byref(pl.c_struct()), _p(partials),
+              _c.byref(epilogue) if epilogue is not None else None)
 
     def _linear(self, X, lin, out):
         _call("llmrec_linear_fwd_f32", X.shape[0], self.d, X.shape[1], _p(X), _ld(X), _p(lin.weight), _ld(lin.weight), _p(lin.bias),
@@ -195,9 +198,10 @@ class FusedStep:
             i_prev = m.item_id_embedding.weight
             for l in range(self.L):
                 last = l == self.L - 1
-                if last:
-                    self._spmm(self.ui.fwd, i_prev, self.tmpU, tag=2); self._softmax(self.tmpU, self.Ul[l])
-                    self._spmm(self.iu.fwd, self.Ul[l], self.tmpI, tag=2); self._softmax(self.tmpI, self.Il[l])
+                if last:                                                 # row softmax of the last layer = the SpMM's epilogue
+                    sm = ops.spmm_epilogue(ops.EPI_SOFTMAX)
+                    self._spmm(self.ui.fwd, i_prev, self.Ul[l], tag=2, epilogue=sm)
+                    self._spmm(self.iu.fwd, self.Ul[l], self.Il[l], tag=2, epilogue=sm)
                 else:
                     self._spmm(self.ui.fwd, i_prev, self.Ul[l], tag=2)
                     self._spmm(self.iu.fwd, self.Ul[l], self.Il[l], tag=2)
@@ -314,20 +318,28 @@ class FusedStep:
             self._wgrad(self.dP_usr, m.user_feats, m.user_trans, False, ws=self.ws_wgrad_b)
         with self._on(self.s2):
             # ID chain (items of layer l+1 from the new users; softmax on the last layer)
-            self._axpy(inv, self.dE_i, self.bufI, False)                  # dI[L] = mean part
+            # every "+ mean term" and every softmax backward below is an epilogue of the SpMM that produces the tensor:
+            #   dI[L] = inv dE_i                      -> g = softmax_bwd(I_L, dI[L])            (one row kernel, no SpMM feeds it)
+            #   dU[l+1] = inv dE_u + A_iu^T g         -> h = softmax_bwd(U_L, dU[l+1]) on the last layer
+            #   dI[l]   = inv dE_i + A_ui^T h         -> (l > 0) feeds the next round as g; (l = 0) IS the item table's gradient
+            g = self.bufI
+            if L >= 1:
+                self._axpy(inv, self.dE_i, self.bufI, False)                              # dI[L] = mean part
+                self._softmax_bwd(self.Il[L - 1], self.bufI, self.tmpI); g = self.tmpI
             for l in range(L - 1, -1, -1):
                 last = l == L - 1
+                if last:
+                    self._spmm(self.iu.bwd, g, self.tmpU, tag=2,
+                               epilogue=ops.spmm_epilogue(ops.EPI_SOFTMAX_BWD, inv, self.dE_u, self.Ul[l]))   # h
+                    h = self.tmpU
+                else:
+                    self._spmm(self.iu.bwd, g, self.bufU, tag=2, epilogue=ops.spmm_epilogue(ops.EPI_NONE, inv, self.dE_u))
+                    h = self.bufU
+                dst = m.item_id_embedding.weight.grad if l == 0 else self.bufI
+                self._spmm(self.ui.bwd, h, dst, tag=2, epilogue=ops.spmm_epilogue(ops.EPI_NONE, inv, self.dE_i))
                 g = self.bufI
-                if last:
-                    self._softmax_bwd(self.Il[l], self.bufI, self.tmpI); g = self.tmpI
-                self._axpy(inv, self.dE_u, self.bufU, False)
-                self._spmm(self.iu.bwd, g, self.bufU, accumulate=True, tag=2)     # dU[l+1] complete
-                h = self.bufU
-                if last:
-                    self._softmax_bwd(self.Ul[l], self.bufU, self.tmpU); h = self.tmpU
-                self._axpy(inv, self.dE_i, self.bufI, False)
-                self._spmm(self.ui.bwd, h, self.bufI, accumulate=True, tag=2)     # dI[l] complete
-            self._axpy(1.0, self.bufI, m.item_id_embedding.weight.grad, False)
+            if L == 0:
+                self._axpy(inv, self.dE_i, m.item_id_embedding.weight.grad, False)
             self._axpy(inv, self.dE_u, m.user_id_embedding.weight.grad, False)    # U^0 only enters the mean
         # side chain: I_cat = iu(U_cat), U_cat = ui(P_cat); then the item-side weight gradients
         self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)

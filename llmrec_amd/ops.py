@@ -53,29 +53,67 @@ def _ld(t: torch.Tensor) -> int:
 # ---------------------------------------------------------------------------------------------
 # R1: CSR operands
 # ---------------------------------------------------------------------------------------------
+class SpmmPlanC(_c.Structure):
+    """llmrec_spmm_plan_t"""
+    _fields_ = [("n_wave_rows", _c.c_int32), ("wave_rows", _c.c_void_p), ("n_block_rows", _c.c_int32), ("block_rows", _c.c_void_p),
+                ("n_split_rows", _c.c_int32), ("split_rows", _c.c_void_p), ("split_seg_begin", _c.c_void_p),
+                ("n_segments", _c.c_int32), ("seg_split", _c.c_void_p)]
+
+
+class SpmmEpilogueC(_c.Structure):
+    """llmrec_spmm_epilogue_t"""
+    _fields_ = [("op", _c.c_int32), ("alpha", _c.c_float), ("Z", _c.c_void_p), ("ldz", _c.c_int64), ("S", _c.c_void_p), ("lds", _c.c_int64)]
+
+
+EPI_NONE, EPI_SOFTMAX, EPI_SOFTMAX_BWD = 0, 1, 2
+
+
 @dataclass
 class SpmmPlan:
-    """Long-row segment lists for one rowptr (include/llmrec_hip.h, llmrec_spmm_plan_*)."""
-    n_long: int
-    n_seg: int
-    long_rows: Optional[torch.Tensor]
-    long_seg_begin: Optional[torch.Tensor]
-    seg_long: Optional[torch.Tensor]
+    """Row buckets of one rowptr (include/llmrec_hip.h, llmrec_spmm_plan_*): rows of 33..512 nnz get a wavefront, 513..16384 a
+    block, longer rows are cut into 4096-nnz segments whose partial sums a second launch adds."""
+    n_wave: int = 0
+    n_block: int = 0
+    n_split: int = 0
+    n_seg: int = 0
+    wave_rows: Optional[torch.Tensor] = None
+    block_rows: Optional[torch.Tensor] = None
+    split_rows: Optional[torch.Tensor] = None
+    split_seg_begin: Optional[torch.Tensor] = None
+    seg_split: Optional[torch.Tensor] = None
+
+    @property
+    def n_long(self) -> int:
+        return self.n_wave + self.n_block + self.n_split
+
+    def c_struct(self) -> SpmmPlanC:
+        c = getattr(self, "_c", None)
+        if c is None:
+            c = self._c = SpmmPlanC(self.n_wave, self.wave_rows.data_ptr() if self.n_wave else None,
+                                    self.n_block, self.block_rows.data_ptr() if self.n_block else None,
+                                    self.n_split, self.split_rows.data_ptr() if self.n_split else None,
+                                    self.split_seg_begin.data_ptr() if self.n_split else None,
+                                    self.n_seg, self.seg_split.data_ptr() if self.n_split else None)
+        return c
 
     @staticmethod
     def build(rowptr: torch.Tensor) -> "SpmmPlan":
         n_rows = rowptr.numel() - 1
-        scratch = torch.zeros(2, dtype=torch.int32, device=rowptr.device)
-        counts = (_c.c_int32 * 2)()
+        dev = rowptr.device
+        scratch = torch.zeros(4, dtype=torch.int32, device=dev)
+        counts = (_c.c_int32 * 4)()
         _lib.call("llmrec_spmm_plan_count", n_rows, _p(rowptr), _p(scratch), counts, _stream())
-        n_long, n_seg = int(counts[0]), int(counts[1])
-        if n_long == 0:
-            return SpmmPlan(0, 0, None, None, None)
-        lr = torch.empty(n_long, dtype=torch.int32, device=rowptr.device)
-        lb = torch.empty(n_long, dtype=torch.int32, device=rowptr.device)
-        sl = torch.empty(n_seg, dtype=torch.int32, device=rowptr.device)
-        _lib.call("llmrec_spmm_plan_fill", n_rows, _p(rowptr), _p(scratch), _p(lr), _p(lb), _p(sl), _stream())
-        return SpmmPlan(n_long, n_seg, lr, lb, sl)
+        nw, nb, nsp, nseg = (int(x) for x in counts)
+        if nw + nb + nsp == 0:
+            return SpmmPlan()
+        i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        wr, br, sr, sb, ss = i32(nw), i32(nb), i32(nsp), i32(nsp), i32(nseg)
+        _lib.call("llmrec_spmm_plan_fill", n_rows, _p(rowptr), _p(scratch), _p(wr), _p(br), _p(sr), _p(sb), _p(ss), _stream())
+        # the fill compacts with atomics: sort the two independent row lists so that the plan (and the order rows are
+        # visited in) is reproducible run to run; results never depend on the order
+        wr = torch.sort(wr[:nw]).values.contiguous() if nw else None
+        br = torch.sort(br[:nb]).values.contiguous() if nb else None
+        return SpmmPlan(nw, nb, nsp, nseg, wr, br, sr if nsp else None, sb if nsp else None, ss if nsp else None)
 
 
 @dataclass
@@ -199,7 +237,15 @@ class BipartiteGraph:
 # ---------------------------------------------------------------------------------------------
 # R2: SpMM
 # ---------------------------------------------------------------------------------------------
-def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+def spmm_epilogue(op: int = EPI_NONE, alpha: float = 0.0, Z: Optional[torch.Tensor] = None, S: Optional[torch.Tensor] = None):
+    """llmrec_spmm_epilogue_t: Y = op(alpha * Z + A X); S = forward softmax rows for EPI_SOFTMAX_BWD."""
+    return SpmmEpilogueC(op, float(alpha), Z.data_ptr() if Z is not None else None, _ld(Z) if Z is not None else 0,
+                         S.data_ptr() if S is not None else None, _ld(S) if S is not None else 0)
+
+
+def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False, epilogue=None,
+             partials: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Y = epilogue(A X) through llmrec_spmm_f32. accumulate: Y += A X (epilogue Z = Y, alpha = 1)."""
     _need_gpu(X, a.rowptr)
     X = _rowmajor(X)
     if X.shape[0] != a.n_cols:
@@ -207,10 +253,15 @@ def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumu
     d = X.shape[1]
     Y = out if out is not None else torch.empty(a.n_rows, d, dtype=torch.float32, device=X.device)
     pl = a.plan
-    partials = torch.empty(pl.n_seg * d, dtype=torch.float32, device=X.device) if pl.n_long else None
+    if pl.n_seg and (partials is None or partials.numel() < pl.n_seg * d):
+        partials = torch.empty(pl.n_seg * d, dtype=torch.float32, device=X.device)
+    if accumulate:
+        if epilogue is not None:
+            raise RuntimeError("spmm: accumulate and an explicit epilogue are exclusive (pass Z = Y, alpha = 1)")
+        epilogue = spmm_epilogue(EPI_NONE, 1.0, Y)
     _lib.call("llmrec_spmm_f32", a.n_rows, a.n_cols, _p(a.rowptr), _p(a.colidx), _p(a.val), _p(a.row_scale),
-              _p(a.col_scale), _p(X), _ld(X), _p(Y), _ld(Y), d, pl.n_long, _p(pl.long_rows), _p(pl.long_seg_begin),
-              pl.n_seg, _p(pl.seg_long), _p(partials), 1 if accumulate else 0, _stream())
+              _p(a.col_scale), _p(X), _ld(X), _p(Y), _ld(Y), d, _c.byref(pl.c_struct()), _p(partials) if pl.n_seg else None,
+              _c.byref(epilogue) if epilogue is not None else None, _stream())
     return Y
 
 

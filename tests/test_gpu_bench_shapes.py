@@ -106,7 +106,7 @@ def _check_topk(ops, eu, ei, q, train_rows, K, what):
     rp = np.cumsum(rp)
     ci = np.concatenate([np.sort(np.asarray(train_rows[u], dtype=np.int64)) for u in sorted(train_rows)]) if train_rows else np.zeros(0, dtype=np.int64)
     train = Csr(eu.shape[0], n_items, torch.tensor(rp, dtype=torch.int32, device=DEV), torch.tensor(ci, dtype=torch.int32, device=DEV),
-                None, None, None, SpmmPlan(0, 0, None, None, None))
+                None, None, None, SpmmPlan())
     qd = torch.tensor(q, dtype=torch.int64, device=DEV)
     idx, sc = ops.score_topk(eu, ei, qd, train, K)
     S = ops.scores(eu, ei, qd).cpu().numpy()

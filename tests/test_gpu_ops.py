@@ -110,6 +110,48 @@ def test_spmm_forward_backward_vs_torch_sparse(ops, d):
     assert torch.equal(ops.spmm(A, X).detach(), Y.detach())
 
 
+def test_spmm_row_buckets_split_rows_and_epilogues(ops):
+    """Every row bucket of the plan (lane group <= 32 nnz, wavefront <= 512, block <= 16384, split segments beyond) and the
+    fused epilogues: Y = alpha Z + A X, row softmax (reference Models.py:176-177) and its backward, each against torch."""
+    rng = np.random.default_rng(77)
+    n_rows, n_cols = 600, 45000
+    degs = rng.integers(0, 40, size=n_rows)
+    for k, dg in enumerate([0, 1, 32, 33, 511, 512, 513, 4095, 4096, 4097, 16384, 16385, 20000, 44000]):
+        degs[(k * 13 + 1) % n_rows] = dg
+    rows, cols = rand_graph(rng, n_rows, n_cols, degs)
+    deg = np.bincount(rows, minlength=n_rows)
+    s = np.where(deg > 0, 1.0 / np.sqrt(np.maximum(deg, 1)), 0).astype(np.float32)
+    A_cpu = torch.sparse_coo_tensor(torch.tensor(np.vstack([rows, cols])), torch.tensor(s[rows]), (n_rows, n_cols))
+    A = A_cpu.to(DEV)
+    op = ops.operand_from_sparse_tensor(A)
+    pl = op.fwd.plan
+    assert pl.n_wave >= 3 and pl.n_block >= 5 and pl.n_split == 3 and pl.n_seg == 5 + 5 + 11
+    for d in (64, 128, 448, 20):
+        X_cpu = torch.tensor(rng.standard_normal((n_cols, d)).astype(np.float32))
+        Z_cpu = torch.tensor(rng.standard_normal((n_rows, d)).astype(np.float32))
+        want = torch.sparse.mm(A_cpu, X_cpu)
+        X, Z = X_cpu.to(DEV), Z_cpu.to(DEV)
+        Y = ops.spmm_raw(op.fwd, X)
+        assert rel_err(Y.cpu(), want) < 2e-6, d
+        assert torch.equal(ops.spmm_raw(op.fwd, X), Y)                       # deterministic
+        Y2 = ops.spmm_raw(op.fwd, X, epilogue=ops.spmm_epilogue(ops.EPI_NONE, 0.25, Z))
+        assert rel_err(Y2.cpu(), 0.25 * Z_cpu + want) < 2e-6, d
+        Y3 = Z.clone(); ops.spmm_raw(op.fwd, X, out=Y3, accumulate=True)
+        assert rel_err(Y3.cpu(), Z_cpu + want) < 2e-6, d
+        Y4 = ops.spmm_raw(op.fwd, X, epilogue=ops.spmm_epilogue(ops.EPI_SOFTMAX))
+        sm = torch.softmax(want, dim=-1)
+        assert rel_err(Y4.cpu(), sm) < 3e-6, d
+        # backward of a softmax layer: t = 0.5 Z + A X is the incoming gradient, S the forward output
+        S_cpu = torch.softmax(torch.tensor(rng.standard_normal((n_rows, d)).astype(np.float32)), dim=-1)
+        t = 0.5 * Z_cpu + want
+        want_b = S_cpu * (t - (t * S_cpu).sum(-1, keepdim=True))
+        Y5 = ops.spmm_raw(op.fwd, X, epilogue=ops.spmm_epilogue(ops.EPI_SOFTMAX_BWD, 0.5, Z, S_cpu.to(DEV)))
+        assert rel_err(Y5.cpu(), want_b) < 1e-5, d
+    # the transposed operand (hub COLUMNS become many short rows gathering with col_scale)
+    G_cpu = torch.tensor(rng.standard_normal((n_rows, 64)).astype(np.float32))
+    assert rel_err(ops.spmm_raw(op.bwd, G_cpu.to(DEV)).cpu(), torch.sparse.mm(A_cpu.t(), G_cpu)) < 2e-6
+
+
 def test_spmm_general_values_and_strided_operands(ops):
     rng = np.random.default_rng(5)
     n_rows, n_cols, d = 120, 900, 64
@@ -413,7 +455,7 @@ def _train_csr(ops, train_items, U, I):
     rows = np.concatenate([np.full(len(v), u) for u, v in train_items.items()] + [np.zeros(0)]).astype(np.int64)
     cols = np.concatenate([np.asarray(v) for v in train_items.values()] + [np.zeros(0)]).astype(np.int64)
     rp, ci, _ = ops.csr_from_coo(torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV), None, U, I)
-    return ops.Csr(U, I, rp, ci, None, None, None, ops.SpmmPlan(0, 0, None, None, None))
+    return ops.Csr(U, I, rp, ci, None, None, None, ops.SpmmPlan())
 
 
 @pytest.mark.parametrize("U,I,d,K", [(150, 1000, 64, 50), (70, 130, 16, 50), (33, 64, 64, 20), (200, 777, 128, 64), (10, 45, 64, 50)])

@@ -64,7 +64,7 @@ if which in ("topk", "all"):
     Eu = torch.randn(U, d, device=dev); Ei = torch.randn(I, d, device=dev)
     rows, cols = synth.bipartite_edges(U, I, 55146, seed=0)
     rp, ci, _ = ops.csr_from_coo(torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev), None, U, I)
-    tr = ops.Csr(U, I, rp, ci, None, None, None, ops.SpmmPlan(0, 0, None, None, None))
+    tr = ops.Csr(U, I, rp, ci, None, None, None, ops.SpmmPlan())
     q = torch.arange(U, device=dev)
     ms = timeit(lambda: ops.score_topk(Eu, Ei, q, tr, 50))
     print("score_topk ms %.4f TF %.2f users/s %.0f" % (ms, 2.0 * U * I * d / ms / 1e9, U / ms * 1e3))

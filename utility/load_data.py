@@ -102,7 +102,7 @@ class Data(object):
                                          self.n_users, self.n_items)
             return rp, ci
         tr = csr_of(self.train_items)
-        train = ops.Csr(self.n_users, self.n_items, tr[0], tr[1], None, None, None, ops.SpmmPlan(0, 0, None, None, None))
+        train = ops.Csr(self.n_users, self.n_items, tr[0], tr[1], None, None, None, ops.SpmmPlan())
         self._device_state = {"device": device, "train": train, "test": csr_of(self.test_set), "val": csr_of(self.val_set),
                               "exist_users": torch.tensor(self.exist_users, dtype=torch.int64, device=device)}
         return self._device_state
