@@ -75,29 +75,30 @@ int llmrec_csr_row_constant(int64_t n_rows, const int32_t* rowptr, const float* 
  *                                        :153-157,162-163,166-167,176-180) and, with col_scale,
  *                                        the transposed SpMM autograd runs for dX = A^T dY.
  * val, row_scale, col_scale may each be NULL (= all ones). d = columns of X and Y.
- * Rows are bucketed by length (the plan calls below) and all buckets run in ONE launch:
- *   nnz <= LLMREC_SPMM_WAVE_ROW      one lane group (d/4 lanes) per row,
- *   nnz <= LLMREC_SPMM_BLOCK_ROW     one wavefront per row            (list wave_rows),
- *   nnz <= LLMREC_SPMM_SPLIT_ROW     one 256-thread block per row     (list block_rows),
- *   longer                           segments of LLMREC_SPMM_SEGMENT nnz, one block each, partial sums in
- *                                    `partials` (caller scratch, plan.n_segments * d floats) added in a fixed order by
- *                                    a second launch (lists split_rows / split_seg_begin / seg_split).
- * Every summation tree is fixed by (nnz, d): results are run-to-run deterministic, no float atomics.
+ * Rows are bucketed by length (the plan calls below; thresholds chosen by the host) and all buckets run in ONE launch:
+ *   nnz <= LLMREC_SPMM_LONG_ROW   one lane group (d/4 lanes) per row,
+ *   nnz <= t_wave                 one wavefront per row                  (list wave_rows),
+ *   nnz <= t_block                one 512-thread block per row           (list block_rows),
+ *   longer                        pieces of `segment` nnz, one block each, partial sums in `partials` (caller scratch,
+ *                                 plan.n_segments * d floats) added in a fixed order by a second launch
+ *                                 (lists split_rows / split_seg_begin / seg_split).
+ * Every summation tree is fixed by (nnz, thresholds, d): results are run-to-run deterministic, no float atomics.
+ * llmrec_amd/ops.py picks 32 nnz per lane group for launch-bound (L2-resident) graphs, 128 for HBM-bound ones.
+ * slice_width > 0 (must divide d; epilogue op NONE only): the operand is processed as d / slice_width independent
+ * column slices - (row, slice) tasks - which gives a launch-bound graph the parallelism and latency of a narrow product.
  * Epilogue on the finished row r (t = alpha * Z[r] + result[r], Z may be NULL or alias Y):
  *   LLMREC_SPMM_EPI_NONE          Y[r] = t                       (Z = Y, alpha = 1: "Y += A X")
  *   LLMREC_SPMM_EPI_SOFTMAX       Y[r] = softmax(t) over the d columns           (reference Models.py:176-177)
  *   LLMREC_SPMM_EPI_SOFTMAX_BWD   Y[r] = S[r] * (t - sum(t * S[r]))              (its backward; S = the forward output)
  * ------------------------------------------------------------------------------------------ */
-#define LLMREC_SPMM_WAVE_ROW 32
-#define LLMREC_SPMM_BLOCK_ROW 512
-#define LLMREC_SPMM_SPLIT_ROW 16384
-#define LLMREC_SPMM_SEGMENT 4096
+#define LLMREC_SPMM_LONG_ROW 32    /* rows with more nnz leave the lane-group bucket */
 
 typedef struct {
-    int32_t n_wave_rows;  const int32_t* wave_rows;        /* rows with WAVE_ROW < nnz <= BLOCK_ROW */
-    int32_t n_block_rows; const int32_t* block_rows;       /* rows with BLOCK_ROW < nnz <= SPLIT_ROW */
-    int32_t n_split_rows; const int32_t* split_rows;       /* rows with nnz > SPLIT_ROW */
-    const int32_t* split_seg_begin;                        /* [n_split_rows] first segment of each split row */
+    int32_t t_wave, t_block, segment;                      /* LONG_ROW <= t_wave <= t_block, segment >= LONG_ROW */
+    int32_t n_wave_rows;  const int32_t* wave_rows;        /* rows with LONG_ROW < nnz <= t_wave */
+    int32_t n_block_rows; const int32_t* block_rows;       /* rows with t_wave < nnz <= t_block */
+    int32_t n_split_rows; const int32_t* split_rows;       /* rows with nnz > t_block */
+    const int32_t* split_seg_begin;                        /* [n_split_rows] first piece of each split row */
     int32_t n_segments;   const int32_t* seg_split;        /* [n_segments] index into split_rows */
 } llmrec_spmm_plan_t;
 
@@ -111,16 +112,16 @@ typedef struct {
 } llmrec_spmm_epilogue_t;
 
 /* counts_host[0..3] = n_wave_rows, n_block_rows, n_split_rows, n_segments (synchronises the stream). */
-int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t* scratch4 /* device, 4 ints */,
-                           int32_t* counts_host, llmrec_stream_t stream);
-int llmrec_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, int32_t* scratch4,
-                          int32_t* wave_rows, int32_t* block_rows, int32_t* split_rows,
+int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t t_wave, int32_t t_block, int32_t segment,
+                           int32_t* scratch4 /* device, 4 ints */, int32_t* counts_host, llmrec_stream_t stream);
+int llmrec_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, int32_t t_wave, int32_t t_block, int32_t segment,
+                          int32_t* scratch4, int32_t* wave_rows, int32_t* block_rows, int32_t* split_rows,
                           int32_t* split_seg_begin, int32_t* seg_split, llmrec_stream_t stream);
 
 int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
                     const int32_t* rowptr, const int32_t* colidx, const float* val,
                     const float* row_scale, const float* col_scale,
-                    const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t d,
+                    const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t d, int32_t slice_width,
                     const llmrec_spmm_plan_t* plan_host, float* partials,
                     const llmrec_spmm_epilogue_t* epilogue_host /* NULL = none */, llmrec_stream_t stream);
 

@@ -58,34 +58,36 @@ __global__ void row_constant_kernel(int64_t n_rows, const int32_t* __restrict__ 
 __global__ void flag_finish_kernel(int32_t* flag) { flag[0] = flag[0] ? 0 : 1; }
 
 // row classes of the SpMM (include/llmrec_hip.h): 0 lane group, 1 wavefront, 2 block, 3 split into segments
-__device__ __forceinline__ int row_class(int32_t deg) {
-    return deg <= LLMREC_SPMM_WAVE_ROW ? 0 : (deg <= LLMREC_SPMM_BLOCK_ROW ? 1 : (deg <= LLMREC_SPMM_SPLIT_ROW ? 2 : 3));
+__device__ __forceinline__ int row_class(int32_t deg, int32_t t_wave, int32_t t_block) {
+    return deg <= LLMREC_SPMM_LONG_ROW ? 0 : (deg <= t_wave ? 1 : (deg <= t_block ? 2 : 3));
 }
 
-__global__ void plan_count_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t* __restrict__ counts) {
+__global__ void plan_count_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t t_wave, int32_t t_block, int32_t segment,
+                                  int32_t* __restrict__ counts) {
     int32_t n1 = 0, n2 = 0, n3 = 0, ns = 0;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
         const int32_t deg = rowptr[r + 1] - rowptr[r];
-        const int c = row_class(deg);
+        const int c = row_class(deg, t_wave, t_block);
         n1 += c == 1; n2 += c == 2;
-        if (c == 3) { n3 += 1; ns += (deg + LLMREC_SPMM_SEGMENT - 1) / LLMREC_SPMM_SEGMENT; }
+        if (c == 3) { n3 += 1; ns += (deg + segment - 1) / segment; }
     }
     if (n1) atomicAdd(&counts[0], n1);
     if (n2) atomicAdd(&counts[1], n2);
     if (n3) { atomicAdd(&counts[2], n3); atomicAdd(&counts[3], ns); }
 }
 
-__global__ void plan_fill_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t* __restrict__ cursors,
+__global__ void plan_fill_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, int32_t t_wave, int32_t t_block, int32_t segment,
+                                 int32_t* __restrict__ cursors,
                                  int32_t* __restrict__ wave_rows, int32_t* __restrict__ block_rows,
                                  int32_t* __restrict__ split_rows, int32_t* __restrict__ split_seg_begin,
                                  int32_t* __restrict__ seg_split) {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
         const int32_t deg = rowptr[r + 1] - rowptr[r];
-        const int c = row_class(deg);
+        const int c = row_class(deg, t_wave, t_block);
         if (c == 1) wave_rows[atomicAdd(&cursors[0], 1)] = (int32_t)r;
         else if (c == 2) block_rows[atomicAdd(&cursors[1], 1)] = (int32_t)r;
         else if (c == 3) {
-            const int32_t k = (deg + LLMREC_SPMM_SEGMENT - 1) / LLMREC_SPMM_SEGMENT;
+            const int32_t k = (deg + segment - 1) / segment;
             const int32_t slot = atomicAdd(&cursors[2], 1);
             const int32_t base = atomicAdd(&cursors[3], k);
             split_rows[slot] = (int32_t)r;
@@ -197,13 +199,14 @@ int llmrec_csr_row_constant(int64_t n_rows, const int32_t* rowptr, const float* 
     return LLMREC_OK;
 }
 
-int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t* scratch4, int32_t* counts_host,
-                           llmrec_stream_t stream_) {
+int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t t_wave, int32_t t_block, int32_t segment,
+                           int32_t* scratch4, int32_t* counts_host, llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LLMREC_CHECK_ARG(n_rows >= 0 && rowptr && scratch4 && counts_host, "spmm_plan_count: bad argument");
+    LLMREC_CHECK_ARG(t_wave >= LLMREC_SPMM_LONG_ROW && t_block >= t_wave && segment >= LLMREC_SPMM_LONG_ROW, "spmm_plan_count: bad thresholds");
     LLMREC_HIP(hipMemsetAsync(scratch4, 0, 16, stream));
     if (n_rows > 0) {
-        plan_count_kernel<<<grid_for(n_rows, 256), 256, 0, stream>>>(n_rows, rowptr, scratch4);
+        plan_count_kernel<<<grid_for(n_rows, 256), 256, 0, stream>>>(n_rows, rowptr, t_wave, t_block, segment, scratch4);
         LLMREC_LAUNCH_CHECK();
     }
     LLMREC_HIP(hipMemcpyAsync(counts_host, scratch4, 16, hipMemcpyDeviceToHost, stream));
@@ -211,14 +214,15 @@ int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t* scrat
     return LLMREC_OK;
 }
 
-int llmrec_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, int32_t* scratch4,
+int llmrec_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, int32_t t_wave, int32_t t_block, int32_t segment, int32_t* scratch4,
                           int32_t* wave_rows, int32_t* block_rows, int32_t* split_rows,
                           int32_t* split_seg_begin, int32_t* seg_split, llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LLMREC_CHECK_ARG(n_rows >= 0 && rowptr && scratch4, "spmm_plan_fill: bad argument");
+    LLMREC_CHECK_ARG(t_wave >= LLMREC_SPMM_LONG_ROW && t_block >= t_wave && segment >= LLMREC_SPMM_LONG_ROW, "spmm_plan_fill: bad thresholds");
     LLMREC_HIP(hipMemsetAsync(scratch4, 0, 16, stream));
     if (n_rows > 0) {
-        plan_fill_kernel<<<grid_for(n_rows, 256), 256, 0, stream>>>(n_rows, rowptr, scratch4, wave_rows, block_rows, split_rows,
+        plan_fill_kernel<<<grid_for(n_rows, 256), 256, 0, stream>>>(n_rows, rowptr, t_wave, t_block, segment, scratch4, wave_rows, block_rows, split_rows,
                                                                     split_seg_begin, seg_split);
         LLMREC_LAUNCH_CHECK();
     }

@@ -7,13 +7,19 @@
 // HBM / fabric-bound gather kernel, organised for 64-lane wavefronts:
 //   * a row of X / Y is d floats; LPR = d/4 lanes (16 for d = 64) each own one float4 of the row, so one
 //     wavefront instruction moves 64/LPR complete rows as 16-byte-per-lane accesses (coalesced 256-B rows);
-//   * CSR row buckets by length (llmrec_spmm_plan_*), all in ONE launch, heaviest blocks first:
+//   * CSR row buckets by length (llmrec_spmm_plan_*, thresholds chosen by the host), all in ONE launch of 512-thread
+//     blocks, heaviest blocks first:
 //       <= 32 nnz            one lane group per row (4 rows per wavefront at d = 64),
-//       33 .. 512            one wavefront per row (lane groups take contiguous quarters, butterfly sum),
-//       513 .. 16384         one 256-thread block per row (waves summed through LDS in wave order),
-//       > 16384              4096-nnz segments, one block each, partial sums added in a fixed order by a second,
+//       <= plan.t_wave       one wavefront per row (lane groups take contiguous parts, butterfly sum),
+//       <= plan.t_block      one block (8 wavefronts) per row, waves summed through LDS in wave order,
+//       longer               plan.segment-nnz segments, one block each, partial sums added in a fixed order by a second,
 //                            tiny launch (only graphs with such hubs pay for it);
-//     every summation tree is fixed by (nnz, d): results are run-to-run deterministic, no float atomics;
+//     every summation tree is fixed by (nnz, thresholds, d): results are run-to-run deterministic, no float atomics.
+//     (A ticket scheme - the last piece's wave sums the partials behind agent-scope fences, no second launch - was
+//     measured and dropped: buffer_wbl2 writes back EVERY dirty line of the XCD's L2, 2.4x slower at 36 M edges and
+//     3x slower in situ at Netflix scale, where concurrent kernels keep the L2 dirty.)
+//   * wide operands ([rows, 7 x 64] side-feature blocks) can be cut into 64-column SLICES: (row, slice) tasks, so a
+//     launch-bound graph gets 7x the parallelism and the latency of a d = 64 product instead of one wave per row;
 //   * a lane group loads LPR column indices with one coalesced access and broadcasts them with ds_bpermute
 //     (__shfl), then issues UNROLL independent row gathers before accumulating (UNROLL x 16 B in flight per lane);
 //   * the adjacency values are not read at all in the reference's case (A = diag(s) R, R binary): a per-row
@@ -76,7 +82,8 @@ struct SpmmArgs {
     int64_t ldx;
     float* Y;
     int64_t ldy;
-    int32_t d;
+    int32_t d;                   // columns handled per task (= the slice width when the operand is cut into column slices)
+    int32_t n_slices;            // column slices of width d: task (row, slice) reads / writes columns [slice d, (slice + 1) d)
     // epilogue: t = alpha * Z[row] + result; Y[row] = op(t)
     int32_t epi_op;
     float alpha;
@@ -90,14 +97,14 @@ struct SpmmArgs {
     const int32_t* split_rows;
     const int32_t* split_seg_begin;
     const int32_t* seg_split;
-    float* partials;
-    int32_t n_wave_rows, n_block_rows, n_split_rows, n_segments;
+    float* partials;             // [slice][segment][d]
+    int32_t n_wave_rows, n_block_rows, n_split_rows, n_segments, segment;
     int32_t blk_seg, blk_block, blk_wave;     // first block of the block-row / wave-row / short-row ranges
 };
 
 // Accumulate sum_{j in [s, e)} w_j * X[col_j, chunk columns] into acc, in ascending j order.
 template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
-__device__ __forceinline__ void accumulate_range(const SpmmArgs& a, int32_t s, int32_t e, int gl, Vec<VEC> (&acc)[NCHUNK]) {
+__device__ __forceinline__ void accumulate_range(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, int gl, Vec<VEC> (&acc)[NCHUNK]) {
     for (int32_t base = s; base < e; base += LPR) {
         const int n = min(LPR, e - base);
         int32_t myc = 0;
@@ -117,7 +124,7 @@ __device__ __forceinline__ void accumulate_range(const SpmmArgs& a, int32_t s, i
                 const int tt = t + u;
                 const int32_t c = __shfl(myc, tt & (LPR - 1), LPR);
                 if (WEIGHTED) w[u] = __shfl(myw, tt & (LPR - 1), LPR);
-                const float* xr = a.X + (int64_t)c * a.ldx;
+                const float* xr = a.X + (int64_t)c * a.ldx + col0;
 #pragma unroll
                 for (int k = 0; k < NCHUNK; ++k) {
                     const int col = (k * LPR + gl) * VEC;
@@ -139,14 +146,14 @@ __device__ __forceinline__ void accumulate_range(const SpmmArgs& a, int32_t s, i
 
 // The finished row (unscaled sum in acc, held by the LPR lanes of one lane group): scale, init term, epilogue, store.
 template <int LPR, int NCHUNK, int VEC>
-__device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t row, int gl, Vec<VEC> (&acc)[NCHUNK]) {
+__device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t col0, int64_t row, int gl, Vec<VEC> (&acc)[NCHUNK]) {
     const float rs = a.row_scale ? a.row_scale[row] : 1.0f;
-    float* yr = a.Y + row * a.ldy;
+    float* yr = a.Y + row * a.ldy + col0;
 #pragma unroll
     for (int k = 0; k < NCHUNK; ++k) {
         const int col = (k * LPR + gl) * VEC;
         if (a.row_scale) acc[k].scale(rs);
-        if (a.Z && col < a.d) { Vec<VEC> z; z.load(a.Z + row * a.ldz + col); acc[k].fma(a.alpha, z); }
+        if (a.Z && col < a.d) { Vec<VEC> z; z.load(a.Z + row * a.ldz + col0 + col); acc[k].fma(a.alpha, z); }
         if (col >= a.d) acc[k].zero();
     }
     if (a.epi_op == LLMREC_SPMM_EPI_SOFTMAX) {                   // wave-uniform
@@ -169,7 +176,7 @@ __device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t row, int g
 #pragma unroll
         for (int k = 0; k < NCHUNK; ++k) {
             const int col = (k * LPR + gl) * VEC;
-            if (col < a.d) { y[k].load(a.S + row * a.lds + col); c += acc[k].dot(y[k]); }
+            if (col < a.d) { y[k].load(a.S + row * a.lds + col0 + col); c += acc[k].dot(y[k]); }
             else y[k].zero();
         }
         c = group_sum<LPR>(c);
@@ -183,32 +190,36 @@ __device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t row, int g
     }
 }
 
-// one lane group per row (rows with at most LLMREC_SPMM_WAVE_ROW nnz; longer rows belong to the other ranges)
+constexpr int TPB = 512;                                        // threads per block: 8 wavefronts
+
+// one lane group per (row, slice) task; rows with more than LLMREC_SPMM_LONG_ROW nnz belong to the other ranges
 template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
 __device__ __forceinline__ void rows_body(const SpmmArgs& a, int64_t block) {
-    constexpr int GPB = 256 / LPR;
+    constexpr int GPB = TPB / LPR;
     const int gl = threadIdx.x & (LPR - 1);
-    const int64_t row = block * GPB + (threadIdx.x / LPR);
-    if (row >= a.n_rows) return;
+    const int64_t task = block * GPB + (threadIdx.x / LPR);
+    if (task >= a.n_rows * a.n_slices) return;
+    const int64_t slice = task / a.n_rows, row = task - slice * a.n_rows;      // slice-major: neighbouring lane groups take neighbouring rows
+    const int64_t col0 = slice * a.d;
     const int32_t s = a.rowptr[row], e = a.rowptr[row + 1];
-    if ((e - s) > LLMREC_SPMM_WAVE_ROW) return;
+    if ((e - s) > LLMREC_SPMM_LONG_ROW) return;
     Vec<VEC> acc[NCHUNK];
 #pragma unroll
     for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
-    accumulate_range<LPR, NCHUNK, VEC, WEIGHTED>(a, s, e, gl, acc);
-    finish_row<LPR, NCHUNK, VEC>(a, row, gl, acc);
+    accumulate_range<LPR, NCHUNK, VEC, WEIGHTED>(a, col0, s, e, gl, acc);
+    finish_row<LPR, NCHUNK, VEC>(a, col0, row, gl, acc);
 }
 
 // one wavefront over [s, e): the 64/LPR lane groups take contiguous parts, butterfly sum -> every group holds the total
 template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
-__device__ __forceinline__ void wave_range(const SpmmArgs& a, int32_t s, int32_t e, int lane, Vec<VEC> (&acc)[NCHUNK]) {
+__device__ __forceinline__ void wave_range(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, int lane, Vec<VEC> (&acc)[NCHUNK]) {
     constexpr int G = 64 / LPR;
     const int gl = lane & (LPR - 1), g = lane / LPR;
     const int32_t per = (((e - s) + G - 1) / G + LPR - 1) / LPR * LPR;      // multiple of LPR: aligned index loads
     const int32_t gs = min(s + g * per, e), ge = min(gs + per, e);
 #pragma unroll
     for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
-    accumulate_range<LPR, NCHUNK, VEC, WEIGHTED>(a, gs, ge, gl, acc);
+    accumulate_range<LPR, NCHUNK, VEC, WEIGHTED>(a, col0, gs, ge, gl, acc);
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
@@ -216,26 +227,37 @@ __device__ __forceinline__ void wave_range(const SpmmArgs& a, int32_t s, int32_t
     }
 }
 
+// (row, slice) tasks of a row list, slice-major
+__device__ __forceinline__ void list_task(const SpmmArgs& a, const int32_t* list, int32_t n_list, int64_t task, int32_t& row, int64_t& col0, int32_t& slot) {
+    const int64_t slice = task / n_list;
+    slot = (int32_t)(task - slice * n_list);
+    row = list[slot];
+    col0 = slice * a.d;
+}
+
+// one wavefront per (row, slice) of the wave-row list
 template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
 __device__ __forceinline__ void wave_rows_body(const SpmmArgs& a, int32_t block) {
     const int lane = threadIdx.x & 63;
-    const int32_t slot = block * 4 + (threadIdx.x >> 6);
-    if (slot >= a.n_wave_rows) return;
-    const int32_t row = a.wave_rows[slot];
+    const int64_t task = (int64_t)block * (TPB / 64) + (threadIdx.x >> 6);
+    if (task >= (int64_t)a.n_wave_rows * a.n_slices) return;
+    int32_t row, slot; int64_t col0;
+    list_task(a, a.wave_rows, a.n_wave_rows, task, row, col0, slot);
     Vec<VEC> acc[NCHUNK];
-    wave_range<LPR, NCHUNK, VEC, WEIGHTED>(a, a.rowptr[row], a.rowptr[row + 1], lane, acc);
-    if (lane < LPR) finish_row<LPR, NCHUNK, VEC>(a, row, lane, acc);
+    wave_range<LPR, NCHUNK, VEC, WEIGHTED>(a, col0, a.rowptr[row], a.rowptr[row + 1], lane, acc);
+    if (lane < LPR) finish_row<LPR, NCHUNK, VEC>(a, col0, row, lane, acc);
 }
 
-// one block over [s, e): the 4 waves take contiguous quarters, summed through LDS in wave order; the total ends up in
-// the first lane group of wave 0 (returns true there)
+// one block over [s, e): the 8 waves take contiguous parts, summed through LDS in wave order; the total ends up in the
+// first lane group of wave 0 (returns true there)
 template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
-__device__ __forceinline__ bool block_range(const SpmmArgs& a, int32_t s, int32_t e, float* lds, Vec<VEC> (&acc)[NCHUNK]) {
+__device__ __forceinline__ bool block_range(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, float* lds, Vec<VEC> (&acc)[NCHUNK]) {
     constexpr int ROWW = NCHUNK * LPR * VEC;
+    constexpr int NW = TPB / 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int32_t per = (((e - s) + 3) / 4 + 63) / 64 * 64;
+    const int32_t per = (((e - s) + NW - 1) / NW + 63) / 64 * 64;
     const int32_t ws = min(s + w * per, e), we = min(ws + per, e);
-    wave_range<LPR, NCHUNK, VEC, WEIGHTED>(a, ws, we, lane, acc);
+    wave_range<LPR, NCHUNK, VEC, WEIGHTED>(a, col0, ws, we, lane, acc);
     if (w > 0 && lane < LPR) {
 #pragma unroll
         for (int k = 0; k < NCHUNK; ++k) acc[k].store(lds + (w - 1) * ROWW + (k * LPR + lane) * VEC);
@@ -243,7 +265,7 @@ __device__ __forceinline__ bool block_range(const SpmmArgs& a, int32_t s, int32_
     __syncthreads();
     if (w != 0 || lane >= LPR) return false;
 #pragma unroll
-    for (int ww = 0; ww < 3; ++ww) {
+    for (int ww = 0; ww < NW - 1; ++ww) {
 #pragma unroll
         for (int k = 0; k < NCHUNK; ++k) { Vec<VEC> o; o.load(lds + ww * ROWW + (k * LPR + lane) * VEC); acc[k].add(o); }
     }
@@ -251,28 +273,31 @@ __device__ __forceinline__ bool block_range(const SpmmArgs& a, int32_t s, int32_
 }
 
 // ONE launch: [0, blk_seg) segments of the split rows, [blk_seg, blk_block) block rows, [blk_block, blk_wave) wave
-// rows (4 per block), the rest short rows. The heavy blocks come first.
+// rows (8 per block), the rest short rows. The heavy blocks come first.
 template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
-__global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a) {
+__global__ __launch_bounds__(TPB) void spmm_kernel(SpmmArgs a) {
     constexpr int ROWW = NCHUNK * LPR * VEC;
-    __shared__ __attribute__((aligned(16))) float red_lds[3 * ROWW];
+    __shared__ __attribute__((aligned(16))) float red_lds[(TPB / 64 - 1) * ROWW];
     const int32_t b = blockIdx.x;
     if (b >= a.blk_wave) { rows_body<LPR, NCHUNK, VEC, WEIGHTED>(a, (int64_t)b - a.blk_wave); return; }
     if (b >= a.blk_block) { wave_rows_body<LPR, NCHUNK, VEC, WEIGHTED>(a, b - a.blk_block); return; }
     Vec<VEC> acc[NCHUNK];
+    int32_t row, slot; int64_t col0;
     if (b >= a.blk_seg) {
-        const int32_t row = a.block_rows[b - a.blk_seg];
-        if (block_range<LPR, NCHUNK, VEC, WEIGHTED>(a, a.rowptr[row], a.rowptr[row + 1], red_lds, acc))
-            finish_row<LPR, NCHUNK, VEC>(a, row, threadIdx.x, acc);
+        list_task(a, a.block_rows, a.n_block_rows, b - a.blk_seg, row, col0, slot);
+        if (block_range<LPR, NCHUNK, VEC, WEIGHTED>(a, col0, a.rowptr[row], a.rowptr[row + 1], red_lds, acc))
+            finish_row<LPR, NCHUNK, VEC>(a, col0, row, threadIdx.x, acc);
         return;
     }
-    const int32_t slot = a.seg_split[b];
-    const int32_t row = a.split_rows[slot];
-    const int32_t k_in_row = b - a.split_seg_begin[slot];
+    const int32_t slice = b / a.n_segments, seg = b - slice * a.n_segments;
+    slot = a.seg_split[seg];
+    row = a.split_rows[slot];
+    col0 = (int64_t)slice * a.d;
+    const int32_t k_in_row = seg - a.split_seg_begin[slot];
     const int32_t re = a.rowptr[row + 1];
-    const int32_t s = a.rowptr[row] + k_in_row * LLMREC_SPMM_SEGMENT;
-    const int32_t e = min(s + LLMREC_SPMM_SEGMENT, re);
-    if (block_range<LPR, NCHUNK, VEC, WEIGHTED>(a, s, e, red_lds, acc)) {
+    const int32_t s = a.rowptr[row] + k_in_row * a.segment;
+    const int32_t e = min(s + a.segment, re);
+    if (block_range<LPR, NCHUNK, VEC, WEIGHTED>(a, col0, s, e, red_lds, acc)) {
         float* pr = a.partials + (int64_t)b * a.d;
 #pragma unroll
         for (int k = 0; k < NCHUNK; ++k) {
@@ -282,19 +307,19 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a) {
     }
 }
 
-// one block per split row: the 256/LPR lane groups each add every (256/LPR)-th segment partial (ascending), then the
-// groups are combined through LDS in group order - a fixed summation tree; then the row's epilogue
+// one block per (split row, slice): the 256/LPR lane groups each add every (256/LPR)-th segment partial (ascending),
+// then the groups are combined through LDS in group order - a fixed summation tree; then the row's epilogue
 template <int LPR, int NCHUNK, int VEC>
 __global__ __launch_bounds__(256) void spmm_finalize_kernel(SpmmArgs a) {
     constexpr int G = 256 / LPR;
     constexpr int ROWW = NCHUNK * LPR * VEC;
     __shared__ __attribute__((aligned(16))) float fin_lds[G * ROWW];
     const int gl = threadIdx.x & (LPR - 1), g = threadIdx.x / LPR;
-    const int32_t slot = blockIdx.x;
+    const int32_t slice = blockIdx.x / a.n_split_rows, slot = blockIdx.x - slice * a.n_split_rows;
     const int32_t row = a.split_rows[slot];
     const int32_t deg = a.rowptr[row + 1] - a.rowptr[row];
-    const int32_t nseg = (deg + LLMREC_SPMM_SEGMENT - 1) / LLMREC_SPMM_SEGMENT;
-    const float* pr = a.partials + (int64_t)a.split_seg_begin[slot] * a.d;
+    const int32_t nseg = (deg + a.segment - 1) / a.segment;
+    const float* pr = a.partials + ((int64_t)slice * a.n_segments + a.split_seg_begin[slot]) * a.d;
     Vec<VEC> acc[NCHUNK];
 #pragma unroll
     for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
@@ -314,27 +339,28 @@ __global__ __launch_bounds__(256) void spmm_finalize_kernel(SpmmArgs a) {
         acc[k].zero();
         for (int gg = 0; gg < G; ++gg) { Vec<VEC> o; o.load(fin_lds + gg * ROWW + (k * LPR + gl) * VEC); acc[k].add(o); }
     }
-    finish_row<LPR, NCHUNK, VEC>(a, row, gl, acc);
+    finish_row<LPR, NCHUNK, VEC>(a, (int64_t)slice * a.d, row, gl, acc);
 }
 
 template <int LPR, int NCHUNK, int VEC>
 static int launch_spmm(SpmmArgs& a, hipStream_t stream) {
     const bool weighted = a.val != nullptr || a.col_scale != nullptr;
-    constexpr int GPB = 256 / LPR;
-    const int64_t row_blocks = ceil_div(a.n_rows, GPB);
-    const int64_t wave_blocks = ceil_div(a.n_wave_rows, 4);
-    const int64_t total = (int64_t)a.n_segments + a.n_block_rows + wave_blocks + row_blocks;
+    constexpr int GPB = TPB / LPR;
+    const int64_t S = a.n_slices;
+    const int64_t row_blocks = ceil_div(a.n_rows * S, GPB);
+    const int64_t wave_blocks = ceil_div(a.n_wave_rows * S, TPB / 64);
+    const int64_t total = a.n_segments * S + a.n_block_rows * S + wave_blocks + row_blocks;
     if (total > 0x7fffffffll) { set_error("spmm: too many rows for one launch"); return LLMREC_EUNSUPPORTED; }
-    a.blk_seg = a.n_segments;
-    a.blk_block = a.blk_seg + a.n_block_rows;
+    a.blk_seg = (int32_t)(a.n_segments * S);
+    a.blk_block = a.blk_seg + (int32_t)(a.n_block_rows * S);
     a.blk_wave = a.blk_block + (int32_t)wave_blocks;
     if (total > 0) {
-        if (weighted) spmm_kernel<LPR, NCHUNK, VEC, true><<<(unsigned)total, 256, 0, stream>>>(a);
-        else spmm_kernel<LPR, NCHUNK, VEC, false><<<(unsigned)total, 256, 0, stream>>>(a);
+        if (weighted) spmm_kernel<LPR, NCHUNK, VEC, true><<<(unsigned)total, TPB, 0, stream>>>(a);
+        else spmm_kernel<LPR, NCHUNK, VEC, false><<<(unsigned)total, TPB, 0, stream>>>(a);
         LLMREC_LAUNCH_CHECK();
     }
     if (a.n_split_rows > 0) {
-        spmm_finalize_kernel<LPR, NCHUNK, VEC><<<a.n_split_rows, 256, 0, stream>>>(a);
+        spmm_finalize_kernel<LPR, NCHUNK, VEC><<<(unsigned)(a.n_split_rows * S), 256, 0, stream>>>(a);
         LLMREC_LAUNCH_CHECK();
     }
     return LLMREC_OK;
@@ -347,7 +373,7 @@ using namespace llmrec;
 extern "C" int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
                                const int32_t* rowptr, const int32_t* colidx, const float* val,
                                const float* row_scale, const float* col_scale,
-                               const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t d,
+                               const float* X, int64_t ldx, float* Y, int64_t ldy, int32_t d, int32_t slice_width,
                                const llmrec_spmm_plan_t* plan_host, float* partials,
                                const llmrec_spmm_epilogue_t* epilogue_host, llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -356,40 +382,47 @@ extern "C" int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
     LLMREC_CHECK_ARG(rowptr && Y && ldy >= d && ldx >= d, "spmm: null pointer or ld < d");
     LLMREC_CHECK_ARG(plan_host, "spmm: a row plan is required (llmrec_spmm_plan_count / _fill)");
     const llmrec_spmm_plan_t& p = *plan_host;
-    LLMREC_CHECK_ARG(p.n_wave_rows >= 0 && p.n_block_rows >= 0 && p.n_split_rows >= 0 && p.n_segments >= 0, "spmm: negative plan size");
+    LLMREC_CHECK_ARG(p.n_wave_rows >= 0 && p.n_block_rows >= 0 && p.n_split_rows >= 0 && p.n_segments >= 0 && p.segment >= LLMREC_SPMM_LONG_ROW,
+                     "spmm: bad plan sizes");
     LLMREC_CHECK_ARG((p.n_wave_rows == 0 || p.wave_rows) && (p.n_block_rows == 0 || p.block_rows) &&
                      (p.n_split_rows == 0 || (p.split_rows && p.split_seg_begin && p.seg_split && partials)), "spmm: row plan incomplete");
+    LLMREC_CHECK_ARG(slice_width == 0 || (slice_width > 0 && d % slice_width == 0), "spmm: slice_width must divide d");
     SpmmArgs a = {};
     a.n_rows = n_rows; a.rowptr = rowptr; a.colidx = colidx; a.val = val; a.row_scale = row_scale;
-    a.col_scale = col_scale; a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.d = d;
+    a.col_scale = col_scale; a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy;
+    a.d = slice_width > 0 ? slice_width : d;
+    a.n_slices = slice_width > 0 ? d / slice_width : 1;
     a.wave_rows = p.wave_rows; a.block_rows = p.block_rows; a.split_rows = p.split_rows; a.split_seg_begin = p.split_seg_begin;
     a.seg_split = p.seg_split; a.partials = partials;
     a.n_wave_rows = p.n_wave_rows; a.n_block_rows = p.n_block_rows; a.n_split_rows = p.n_split_rows; a.n_segments = p.n_segments;
+    a.segment = p.segment;
     a.epi_op = LLMREC_SPMM_EPI_NONE; a.alpha = 0.f;
     bool epi_aligned = true;
     if (epilogue_host) {
         const llmrec_spmm_epilogue_t& e = *epilogue_host;
         LLMREC_CHECK_ARG(e.op >= LLMREC_SPMM_EPI_NONE && e.op <= LLMREC_SPMM_EPI_SOFTMAX_BWD, "spmm: unknown epilogue op %d", e.op);
+        LLMREC_CHECK_ARG(e.op == LLMREC_SPMM_EPI_NONE || a.n_slices == 1, "spmm: the softmax epilogues need the whole row (slice_width = 0)");
         LLMREC_CHECK_ARG(!e.Z || e.ldz >= d, "spmm: epilogue Z with ld < d");
         LLMREC_CHECK_ARG(e.op != LLMREC_SPMM_EPI_SOFTMAX_BWD || (e.S && e.lds >= d), "spmm: softmax backward needs S with ld >= d");
         a.epi_op = e.op; a.alpha = e.alpha; a.Z = e.Z; a.ldz = e.ldz; a.S = e.S; a.lds = e.lds;
         epi_aligned = (!e.Z || (e.ldz % 4 == 0 && (uintptr_t)e.Z % 16 == 0)) && (!e.S || (e.lds % 4 == 0 && (uintptr_t)e.S % 16 == 0));
     }
-    const bool vec4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && epi_aligned &&
+    const int dd = a.d;
+    const bool vec4 = (dd % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && epi_aligned &&
                       (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)partials) % 16 == 0);
     if (vec4) {
-        if (d <= 16) return launch_spmm<4, 1, 4>(a, stream);
-        if (d <= 32) return launch_spmm<8, 1, 4>(a, stream);
-        if (d <= 64) return launch_spmm<16, 1, 4>(a, stream);
-        if (d <= 128) return launch_spmm<32, 1, 4>(a, stream);
-        if (d <= 256) return launch_spmm<64, 1, 4>(a, stream);
-        if (d <= 512) return launch_spmm<64, 2, 4>(a, stream);
-        if (d <= 1024) return launch_spmm<64, 4, 4>(a, stream);
+        if (dd <= 16) return launch_spmm<4, 1, 4>(a, stream);
+        if (dd <= 32) return launch_spmm<8, 1, 4>(a, stream);
+        if (dd <= 64) return launch_spmm<16, 1, 4>(a, stream);
+        if (dd <= 128) return launch_spmm<32, 1, 4>(a, stream);
+        if (dd <= 256) return launch_spmm<64, 1, 4>(a, stream);
+        if (dd <= 512) return launch_spmm<64, 2, 4>(a, stream);
+        if (dd <= 1024) return launch_spmm<64, 4, 4>(a, stream);
     } else {
-        if (d <= 16) return launch_spmm<16, 1, 1>(a, stream);
-        if (d <= 64) return launch_spmm<64, 1, 1>(a, stream);
-        if (d <= 256) return launch_spmm<64, 4, 1>(a, stream);
+        if (dd <= 16) return launch_spmm<16, 1, 1>(a, stream);
+        if (dd <= 64) return launch_spmm<64, 1, 1>(a, stream);
+        if (dd <= 256) return launch_spmm<64, 4, 1>(a, stream);
     }
-    set_error("spmm: d = %d outside the compiled kernel family (vec4 = %d)", d, (int)vec4);
+    set_error("spmm: d = %d outside the compiled kernel family (vec4 = %d)", dd, (int)vec4);
     return LLMREC_EUNSUPPORTED;
 }

@@ -90,11 +90,11 @@ class HipBackend:
 
     def pattern_csr(self, rows, cols, n_rows, n_cols):
         rp, ci, _ = self.ops.csr_from_coo(rows, cols, None, n_rows, n_cols)
-        return self.ops.Csr(n_rows, n_cols, rp, ci, None, None, None, self.ops.SpmmPlan.build(rp))
+        return self.ops.Csr(n_rows, n_cols, rp, ci, None, None, None, {})
 
     def with_scales(self, csr, row_scale, col_scale):
         o = self.ops
-        return o.Csr(csr.n_rows, csr.n_cols, csr.rowptr, csr.colidx, None, row_scale, col_scale, csr.plan)
+        return o.Csr(csr.n_rows, csr.n_cols, csr.rowptr, csr.colidx, None, row_scale, col_scale, csr.plans)
 
     def degrees(self, csr) -> torch.Tensor:
         return (csr.rowptr[1:] - csr.rowptr[:-1]).to(torch.float32)

@@ -120,18 +120,19 @@ class FusedStep:
         return torch.cuda.stream(st) if self.multi_stream else torch.cuda.stream(torch.cuda.current_stream())
 
     def _spmm(self, a: ops.Csr, X, Y, accumulate=False, tag=0, epilogue=None):
-        """Y = epilogue(A X) (llmrec_spmm_f32); accumulate: Y += A X. tag: one segment scratch per concurrent chain."""
-        pl = a.plan
+        """Y = epilogue(A X) (llmrec_spmm_f32); accumulate: Y += A X. tag: one partial-sum scratch per concurrent chain."""
+        d = X.shape[1]
+        sw, pl = a.plan_for(d, whole_row=epilogue is not None and epilogue.op != ops.EPI_NONE)
         partials = None
         if pl.n_seg:
-            key = (id(pl), X.shape[1], tag)
+            key = (id(pl), d, tag)
             partials = self._partials.get(key)
             if partials is None:
-                partials = self._partials[key] = torch.empty(pl.n_seg * X.shape[1], dtype=torch.float32, device=X.device)
+                partials = self._partials[key] = torch.empty(pl.n_seg * d, dtype=torch.float32, device=X.device)
         if accumulate:
             epilogue = ops.spmm_epilogue(ops.EPI_NONE, 1.0, Y)
         _call("llmrec_spmm_f32", a.n_rows, a.n_cols, _p(a.rowptr), _p(a.colidx), _p(a.val), _p(a.row_scale), _p(a.col_scale),
-              _p(X), _ld(X), _p(Y), _ld(Y), X.shape[1], _c.byref(pl.c_struct()), _p(partials),
+              _p(X), _ld(X), _p(Y), _ld(Y), d, sw, _c.byref(pl.c_struct()), _p(partials),
               _c.byref(epilogue) if epilogue is not None else None)
 
     def _linear(self, X, lin, out):

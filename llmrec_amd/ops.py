@@ -55,7 +55,8 @@ def _ld(t: torch.Tensor) -> int:
 # ---------------------------------------------------------------------------------------------
 class SpmmPlanC(_c.Structure):
     """llmrec_spmm_plan_t"""
-    _fields_ = [("n_wave_rows", _c.c_int32), ("wave_rows", _c.c_void_p), ("n_block_rows", _c.c_int32), ("block_rows", _c.c_void_p),
+    _fields_ = [("t_wave", _c.c_int32), ("t_block", _c.c_int32), ("segment", _c.c_int32),
+                ("n_wave_rows", _c.c_int32), ("wave_rows", _c.c_void_p), ("n_block_rows", _c.c_int32), ("block_rows", _c.c_void_p),
                 ("n_split_rows", _c.c_int32), ("split_rows", _c.c_void_p), ("split_seg_begin", _c.c_void_p),
                 ("n_segments", _c.c_int32), ("seg_split", _c.c_void_p)]
 
@@ -66,12 +67,35 @@ class SpmmEpilogueC(_c.Structure):
 
 
 EPI_NONE, EPI_SOFTMAX, EPI_SOFTMAX_BWD = 0, 1, 2
+SPMM_LATENCY_NNZ = 4_000_000      # below: the graph is L2-resident and a step is launch-bound (Netflix scale)
+
+
+def spmm_shape(d: int, nnz: int, whole_row: bool = False):
+    """(slice_width, (t_wave, t_block, segment)) for llmrec_spmm_f32: the latency / throughput policy.
+    Launch-bound graphs (nnz < SPMM_LATENCY_NNZ): the longest dependent gather chain of any wave sets a kernel's
+    duration, so a lane group gets at most 32 nnz (wavefront bucket) / 64 nnz (block bucket), and wide operands whose
+    width is a multiple of 64 are cut into 64-column slices ((row, slice) tasks) unless an epilogue needs the whole row.
+    HBM-bound graphs: 128 / 512 nnz per lane group (fewer, longer pieces; partial sums only for hubs)."""
+    small = nnz < SPMM_LATENCY_NNZ
+    sw = 64 if (small and not whole_row and d > 64 and d % 64 == 0) else 0
+    w = sw or d
+    lpr = 4
+    while lpr < 64 and lpr * 4 < w:
+        lpr *= 2
+    groups = 64 // lpr
+    if small:
+        t_wave, t_block = max(32, 32 * groups), 8 * groups * 64
+    else:
+        t_wave, t_block = 128 * groups, 8 * groups * 512
+    return sw, (t_wave, t_block, t_block)
 
 
 @dataclass
 class SpmmPlan:
-    """Row buckets of one rowptr (include/llmrec_hip.h, llmrec_spmm_plan_*): rows of 33..512 nnz get a wavefront, 513..16384 a
-    block, longer rows are cut into 4096-nnz segments whose partial sums a second launch adds."""
+    """Row buckets of one rowptr for one threshold triple (include/llmrec_hip.h, llmrec_spmm_plan_*)."""
+    t_wave: int = 128
+    t_block: int = 2048
+    segment: int = 2048
     n_wave: int = 0
     n_block: int = 0
     n_split: int = 0
@@ -89,31 +113,39 @@ class SpmmPlan:
     def c_struct(self) -> SpmmPlanC:
         c = getattr(self, "_c", None)
         if c is None:
-            c = self._c = SpmmPlanC(self.n_wave, self.wave_rows.data_ptr() if self.n_wave else None,
-                                    self.n_block, self.block_rows.data_ptr() if self.n_block else None,
-                                    self.n_split, self.split_rows.data_ptr() if self.n_split else None,
-                                    self.split_seg_begin.data_ptr() if self.n_split else None,
-                                    self.n_seg, self.seg_split.data_ptr() if self.n_split else None)
+            dp = lambda t, n: t.data_ptr() if n else None
+            c = self._c = SpmmPlanC(self.t_wave, self.t_block, self.segment, self.n_wave, dp(self.wave_rows, self.n_wave),
+                                    self.n_block, dp(self.block_rows, self.n_block), self.n_split, dp(self.split_rows, self.n_split),
+                                    dp(self.split_seg_begin, self.n_split), self.n_seg, dp(self.seg_split, self.n_split))
         return c
 
+    def scratch(self, d: int, device) -> Optional[torch.Tensor]:
+        """The plan's own partial-sum scratch for width d: for callers that run their SpMMs on ONE stream."""
+        if not self.n_seg:
+            return None
+        cache = self.__dict__.setdefault("_scratch", {})
+        if d not in cache:
+            cache[d] = torch.empty(self.n_seg * d, dtype=torch.float32, device=device)
+        return cache[d]
+
     @staticmethod
-    def build(rowptr: torch.Tensor) -> "SpmmPlan":
+    def build(rowptr: torch.Tensor, t_wave: int = 128, t_block: int = 2048, segment: int = 2048) -> "SpmmPlan":
         n_rows = rowptr.numel() - 1
         dev = rowptr.device
         scratch = torch.zeros(4, dtype=torch.int32, device=dev)
         counts = (_c.c_int32 * 4)()
-        _lib.call("llmrec_spmm_plan_count", n_rows, _p(rowptr), _p(scratch), counts, _stream())
+        _lib.call("llmrec_spmm_plan_count", n_rows, _p(rowptr), t_wave, t_block, segment, _p(scratch), counts, _stream())
         nw, nb, nsp, nseg = (int(x) for x in counts)
         if nw + nb + nsp == 0:
-            return SpmmPlan()
+            return SpmmPlan(t_wave, t_block, segment)
         i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         wr, br, sr, sb, ss = i32(nw), i32(nb), i32(nsp), i32(nsp), i32(nseg)
-        _lib.call("llmrec_spmm_plan_fill", n_rows, _p(rowptr), _p(scratch), _p(wr), _p(br), _p(sr), _p(sb), _p(ss), _stream())
+        _lib.call("llmrec_spmm_plan_fill", n_rows, _p(rowptr), t_wave, t_block, segment, _p(scratch), _p(wr), _p(br), _p(sr), _p(sb), _p(ss), _stream())
         # the fill compacts with atomics: sort the two independent row lists so that the plan (and the order rows are
         # visited in) is reproducible run to run; results never depend on the order
         wr = torch.sort(wr[:nw]).values.contiguous() if nw else None
         br = torch.sort(br[:nb]).values.contiguous() if nb else None
-        return SpmmPlan(nw, nb, nsp, nseg, wr, br, sr if nsp else None, sb if nsp else None, ss if nsp else None)
+        return SpmmPlan(t_wave, t_block, segment, nw, nb, nsp, nseg, wr, br, sr if nsp else None, sb if nsp else None, ss if nsp else None)
 
 
 @dataclass
@@ -126,11 +158,27 @@ class Csr:
     val: Optional[torch.Tensor]     # fp32 [nnz] or None (pattern only)
     row_scale: Optional[torch.Tensor]
     col_scale: Optional[torch.Tensor]
-    plan: SpmmPlan
+    plans: Optional[dict] = None    # {(t_wave, t_block, segment): SpmmPlan}, shared by the operands that share this rowptr
+
+    def __post_init__(self):
+        if not isinstance(self.plans, dict):
+            self.plans = {}
 
     @property
     def nnz(self) -> int:
         return self.colidx.numel()
+
+    def plan_for(self, d: int, whole_row: bool = False):
+        """(slice_width, SpmmPlan) for an operand of width d."""
+        sw, key = spmm_shape(d, self.nnz, whole_row)
+        pl = self.plans.get(key)
+        if pl is None:
+            pl = self.plans[key] = SpmmPlan.build(self.rowptr, *key)
+        return sw, pl
+
+    @property
+    def plan(self) -> SpmmPlan:
+        return self.plan_for(64)[1]
 
 
 def csr_from_coo(rows: torch.Tensor, cols: torch.Tensor, vals: Optional[torch.Tensor], n_rows: int, n_cols: int):
@@ -181,7 +229,7 @@ class SparseOperand:
             _lib.call("llmrec_csr_row_constant", n_rows, _p(rowptr), _p(val), _p(rc), _p(flag), _stream())
             if int(flag.item()) == 1:
                 row_const = rc
-        plan_f, plan_b = SpmmPlan.build(rowptr), SpmmPlan.build(t_rowptr)
+        plan_f, plan_b = {}, {}                                  # built lazily per piece length, shared by the operands below
         if val is None or row_const is not None:
             fwd = Csr(n_rows, n_cols, rowptr, colidx, None, row_const, None, plan_f)
             bwd = Csr(n_cols, n_rows, t_rowptr, t_colidx, None, None, row_const, plan_b)
@@ -228,7 +276,7 @@ class BipartiteGraph:
         ru, cu, _ = csr_from_coo(users, items, None, n_users, n_items)
         ri, ci, _ = csr_from_coo(items, users, None, n_items, n_users)
         s_u, s_i = degree_scale(ru), degree_scale(ri)
-        pu, pi = SpmmPlan.build(ru), SpmmPlan.build(ri)
+        pu, pi = {}, {}                                          # plan caches shared by the operands over ru / ri
         ui = SparseOperand(Csr(n_users, n_items, ru, cu, None, s_u, None, pu), Csr(n_items, n_users, ri, ci, None, None, s_u, pi))
         iu = SparseOperand(Csr(n_items, n_users, ri, ci, None, s_i, None, pi), Csr(n_users, n_items, ru, cu, None, None, s_i, pu))
         return BipartiteGraph(n_users, n_items, ui, iu, ui.fwd, s_u, s_i)
@@ -245,22 +293,23 @@ def spmm_epilogue(op: int = EPI_NONE, alpha: float = 0.0, Z: Optional[torch.Tens
 
 def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False, epilogue=None,
              partials: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Y = epilogue(A X) through llmrec_spmm_f32. accumulate: Y += A X (epilogue Z = Y, alpha = 1)."""
+    """Y = epilogue(A X) through llmrec_spmm_f32. accumulate: Y += A X (epilogue Z = Y, alpha = 1). partials: scratch of
+    plan.n_seg * d floats when the caller runs several SpMMs over this operand at once (default: the plan's own)."""
     _need_gpu(X, a.rowptr)
     X = _rowmajor(X)
     if X.shape[0] != a.n_cols:
         raise RuntimeError("spmm: X has %d rows, operand has %d columns" % (X.shape[0], a.n_cols))
     d = X.shape[1]
     Y = out if out is not None else torch.empty(a.n_rows, d, dtype=torch.float32, device=X.device)
-    pl = a.plan
-    if pl.n_seg and (partials is None or partials.numel() < pl.n_seg * d):
-        partials = torch.empty(pl.n_seg * d, dtype=torch.float32, device=X.device)
+    sw, pl = a.plan_for(d, whole_row=epilogue is not None and epilogue.op != EPI_NONE)
+    if partials is None:
+        partials = pl.scratch(d, X.device)
     if accumulate:
         if epilogue is not None:
             raise RuntimeError("spmm: accumulate and an explicit epilogue are exclusive (pass Z = Y, alpha = 1)")
         epilogue = spmm_epilogue(EPI_NONE, 1.0, Y)
     _lib.call("llmrec_spmm_f32", a.n_rows, a.n_cols, _p(a.rowptr), _p(a.colidx), _p(a.val), _p(a.row_scale),
-              _p(a.col_scale), _p(X), _ld(X), _p(Y), _ld(Y), d, _c.byref(pl.c_struct()), _p(partials) if pl.n_seg else None,
+              _p(a.col_scale), _p(X), _ld(X), _p(Y), _ld(Y), d, sw, _c.byref(pl.c_struct()), _p(partials),
               _c.byref(epilogue) if epilogue is not None else None, _stream())
     return Y
 

@@ -124,23 +124,31 @@ def test_spmm_row_buckets_split_rows_and_epilogues(ops):
     A_cpu = torch.sparse_coo_tensor(torch.tensor(np.vstack([rows, cols])), torch.tensor(s[rows]), (n_rows, n_cols))
     A = A_cpu.to(DEV)
     op = ops.operand_from_sparse_tensor(A)
-    pl = op.fwd.plan
-    assert pl.n_wave >= 3 and pl.n_block >= 5 and pl.n_split == 3 and pl.n_seg == 5 + 5 + 11
+    sw, pl = op.fwd.plan_for(64)
+    assert sw == 0 and (pl.t_wave, pl.t_block) == (128, 2048) and pl.n_wave >= 1 and pl.n_block >= 3 and pl.n_split == 7
+    assert op.fwd.plan_for(448)[0] == 64                                              # wide operands go slice by slice
     for d in (64, 128, 448, 20):
         X_cpu = torch.tensor(rng.standard_normal((n_cols, d)).astype(np.float32))
         Z_cpu = torch.tensor(rng.standard_normal((n_rows, d)).astype(np.float32))
-        want = torch.sparse.mm(A_cpu, X_cpu)
+        want = torch.sparse.mm(A_cpu.double(), X_cpu.double()).float()     # rows of up to 44000 terms: fp64 reference
         X, Z = X_cpu.to(DEV), Z_cpu.to(DEV)
         Y = ops.spmm_raw(op.fwd, X)
-        assert rel_err(Y.cpu(), want) < 2e-6, d
-        assert torch.equal(ops.spmm_raw(op.fwd, X), Y)                       # deterministic
+        assert rel_err(Y.cpu(), want) < 4e-6, d
+        for _ in range(3):
+            assert torch.equal(ops.spmm_raw(op.fwd, X), Y)                   # deterministic, whichever wave finishes a row
+        _, key = ops.spmm_shape(d, op.fwd.nnz)
+        keep = op.fwd.plans[key]
+        for alt in ((512, 16384, 16384), (32, 32, 64), (64, 256, 4096)):      # the HBM-regime thresholds; everything split; mixed
+            op.fwd.plans[key] = ops.SpmmPlan.build(op.fwd.rowptr, *alt)
+            assert rel_err(ops.spmm_raw(op.fwd, X).cpu(), want) < 4e-6, (d, alt)
+        op.fwd.plans[key] = keep
         Y2 = ops.spmm_raw(op.fwd, X, epilogue=ops.spmm_epilogue(ops.EPI_NONE, 0.25, Z))
-        assert rel_err(Y2.cpu(), 0.25 * Z_cpu + want) < 2e-6, d
+        assert rel_err(Y2.cpu(), 0.25 * Z_cpu + want) < 4e-6, d
         Y3 = Z.clone(); ops.spmm_raw(op.fwd, X, out=Y3, accumulate=True)
-        assert rel_err(Y3.cpu(), Z_cpu + want) < 2e-6, d
+        assert rel_err(Y3.cpu(), Z_cpu + want) < 4e-6, d
         Y4 = ops.spmm_raw(op.fwd, X, epilogue=ops.spmm_epilogue(ops.EPI_SOFTMAX))
         sm = torch.softmax(want, dim=-1)
-        assert rel_err(Y4.cpu(), sm) < 3e-6, d
+        assert rel_err(Y4.cpu(), sm) < 5e-6, d
         # backward of a softmax layer: t = 0.5 Z + A X is the incoming gradient, S the forward output
         S_cpu = torch.softmax(torch.tensor(rng.standard_normal((n_rows, d)).astype(np.float32)), dim=-1)
         t = 0.5 * Z_cpu + want

@@ -31,7 +31,7 @@ def test_workspace_queries_run_without_gpu():
 
 def test_argument_errors_are_reported_not_thrown():
     lib = _lib.load()
-    st = lib.llmrec_spmm_f32(4, 4, None, None, None, None, None, None, 8, None, 8, 8, None, None, None, None)
+    st = lib.llmrec_spmm_f32(4, 4, None, None, None, None, None, None, 8, None, 8, 8, 0, None, None, None, None)
     assert st == -1 and b"spmm" in lib.llmrec_last_error()
     with pytest.raises(RuntimeError, match="invalid argument"):
         _lib.call("llmrec_degree_scale", -1, None, None, None)
