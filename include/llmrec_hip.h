@@ -283,6 +283,22 @@ int llmrec_bpr_prune_bwd_f32(const float* Eu, int64_t ldu, const float* Ei, int6
                              const float* saved, const float* grads2,
                              float* dEu, int64_t lddu, float* dEi, int64_t lddi, llmrec_stream_t stream);
 
+/* The same gradient as COMPACT rows instead of a scatter (row-sharded step): rows3 = [3][B_max][d],
+ * block 0 = d/dEu[u_b], block 1 = d/dEi[p_b], block 2 = d/dEi[q_b]; rows of samples b >= B are zero. The item rows are
+ * what the ranks exchange (an all-gather of 2 B rows instead of an all-reduce of the dense I x d gradient). */
+int llmrec_bpr_prune_bwd_rows_f32(const float* Eu, int64_t ldu, const float* Ei, int64_t ldi, int32_t d,
+                                  const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                  int32_t B_max, const int32_t* n_valid_dev,
+                                  float decay, float batch_size_flag,
+                                  const float* saved, const float* grads2, float* rows3, llmrec_stream_t stream);
+
+/* dst[ids[j]] += alpha * rows[j] for j < n, ids[j] < 0 skipped. Rows with the same id are added in ascending j
+ * (radix sort of (id, j), one lane group per run): DETERMINISTIC, so ranks that scatter the same gathered rows keep
+ * bit-identical replicas - a float-atomic scatter would not. */
+int64_t llmrec_scatter_rows_workspace_bytes(int64_t n);
+int llmrec_scatter_rows_f32(int64_t n, const int64_t* ids, const float* rows, int64_t ldr, int32_t d, float alpha,
+                            float* dst, int64_t ldd, void* workspace, int64_t workspace_bytes, llmrec_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * R8  feature regulariser, optimiser     replaces (x**2).sum() x4 (reference main.py:151-156)
  *                                        and torch.optim.AdamW.step (main.py:100-104,278)

@@ -282,6 +282,43 @@ __global__ __launch_bounds__(256) void bpr_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// the same gradient as compact rows (row-sharded step): rows3[0][b] = d/dEu[u_b], rows3[1][b] = d/dEi[p_b], rows3[2][b] = d/dEi[q_b]
+__global__ __launch_bounds__(256) void bpr_bwd_rows_kernel(const float* __restrict__ Eu, int64_t ldu,
+                                                           const float* __restrict__ Ei, int64_t ldi, int d,
+                                                           const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
+                                                           const int64_t* __restrict__ neg, int B_max,
+                                                           const int32_t* __restrict__ n_valid_dev, float decay, float bsz,
+                                                           const float* __restrict__ saved, const float* __restrict__ grads2,
+                                                           float* __restrict__ rows3) {
+    int B = n_valid_dev ? n_valid_dev[0] : B_max;
+    if (B > B_max) B = B_max;
+    const float g_mf = grads2[0], g_emb = grads2[1];
+    const float Su = saved[B_max], Sp = saved[B_max + 1], Sq = saved[B_max + 2];
+    const float base = -4.0f * decay / bsz * g_emb;
+    const float du_ = 2.0f * Su + 1e-8f, dp_ = 2.0f * Sp + 1e-8f, dq_ = 2.0f * Sq + 1e-8f;
+    const float cu = base / (du_ * du_), cp = base / (dp_ * dp_), cq = base / (dq_ * dq_);
+    const int gl = threadIdx.x & 15;
+    const int groups = gridDim.x * (blockDim.x >> 4);
+    const int64_t plane = (int64_t)B_max * d;
+    for (int b = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); b < B_max; b += groups) {
+        float* ru = rows3 + (int64_t)b * d;
+        if (b >= B) {
+            for (int c = gl; c < d; c += 16) { ru[c] = 0.f; ru[plane + c] = 0.f; ru[2 * plane + c] = 0.f; }
+            continue;
+        }
+        const float ds = g_mf * saved[b];
+        const float* u = Eu + users[b] * ldu;
+        const float* p = Ei + pos[b] * ldi;
+        const float* q = Ei + neg[b] * ldi;
+        for (int c = gl; c < d; c += 16) {
+            const float uu = u[c], pp = p[c], qq = q[c];
+            ru[c] = fmaf(ds, pp - qq, cu * uu);
+            ru[plane + c] = fmaf(ds, uu, cp * pp);
+            ru[2 * plane + c] = fmaf(-ds, uu, cq * qq);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 counter-based generator (Salmon et al., SC'11)
 // ---------------------------------------------------------------------------------------------
@@ -576,6 +613,20 @@ int llmrec_bpr_prune_bwd_f32(const float* Eu, int64_t ldu, const float* Ei, int6
                      "bpr_bwd: null pointer or ld < d");
     bpr_bwd_kernel<<<grid_for(B_max, 16), 256, 0, stream>>>(Eu, ldu, Ei, ldi, d, users, pos, neg, B_max, n_valid_dev, decay,
                                                             batch_size_flag, saved, grads2, dEu, lddu, dEi, lddi);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_bpr_prune_bwd_rows_f32(const float* Eu, int64_t ldu, const float* Ei, int64_t ldi, int32_t d,
+                                  const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                  int32_t B_max, const int32_t* n_valid_dev, float decay, float batch_size_flag,
+                                  const float* saved, const float* grads2, float* rows3, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(B_max >= 0 && d > 0 && saved && grads2, "bpr_bwd_rows: bad argument");
+    if (B_max == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(Eu && Ei && users && pos && neg && rows3 && ldu >= d && ldi >= d, "bpr_bwd_rows: null pointer or ld < d");
+    bpr_bwd_rows_kernel<<<grid_for(B_max, 16), 256, 0, stream>>>(Eu, ldu, Ei, ldi, d, users, pos, neg, B_max, n_valid_dev, decay,
+                                                                 batch_size_flag, saved, grads2, rows3);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

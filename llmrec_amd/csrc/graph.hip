@@ -97,6 +97,34 @@ __global__ void plan_fill_kernel(int64_t n_rows, const int32_t* __restrict__ row
     }
 }
 
+// keys (id << 32 | j) of the rows to scatter; ids < 0 sort to the end (key = all ones) and are skipped
+__global__ void scatter_keys_kernel(int64_t n, const int64_t* __restrict__ ids, uint64_t* __restrict__ keys) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+        keys[j] = ids[j] < 0 ? ~0ull : (((uint64_t)ids[j] << 32) | (uint64_t)(uint32_t)j);
+}
+
+// one 16-lane group per sorted position; the head of a run of equal ids adds the run's rows in ascending j
+__global__ __launch_bounds__(256) void scatter_runs_kernel(int64_t n, const uint64_t* __restrict__ keys, const float* __restrict__ rows,
+                                                           int64_t ldr, int d, float alpha, float* __restrict__ dst, int64_t ldd) {
+    const int gl = threadIdx.x & 15;
+    const int64_t j0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (j0 >= n) return;
+    const uint64_t k0 = keys[j0];
+    if (k0 == ~0ull) return;
+    const uint64_t id = k0 >> 32;
+    if (j0 > 0 && (keys[j0 - 1] >> 32) == id) return;             // not the head of its run
+    float* out = dst + (int64_t)id * ldd;
+    for (int c = gl; c < d; c += 16) {
+        float s = out[c];
+        for (int64_t j = j0; j < n; ++j) {
+            const uint64_t k = keys[j];
+            if ((k >> 32) != id) break;
+            s = fmaf(alpha, rows[(int64_t)(uint32_t)k * ldr + c], s);
+        }
+        out[c] = s;
+    }
+}
+
 }  // namespace llmrec
 
 using namespace llmrec;
@@ -226,6 +254,37 @@ int llmrec_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, int32_t t_wave,
                                                                     split_seg_begin, seg_split);
         LLMREC_LAUNCH_CHECK();
     }
+    return LLMREC_OK;
+}
+
+int64_t llmrec_scatter_rows_workspace_bytes(int64_t n) {
+    if (n < 0) return -1;
+    return 2 * align_up(8 * n, 256) + align_up(n + (32ll << 20), 256);
+}
+
+int llmrec_scatter_rows_f32(int64_t n, const int64_t* ids, const float* rows, int64_t ldr, int32_t d, float alpha,
+                            float* dst, int64_t ldd, void* workspace, int64_t workspace_bytes, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(n >= 0 && d > 0 && n < (1ll << 31), "scatter_rows: bad sizes");
+    if (n == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(ids && rows && dst && ldr >= d && ldd >= d, "scatter_rows: null pointer or ld < d");
+    if (!workspace || workspace_bytes < llmrec_scatter_rows_workspace_bytes(n)) {
+        set_error("scatter_rows: workspace %lld < %lld", (long long)workspace_bytes, (long long)llmrec_scatter_rows_workspace_bytes(n));
+        return LLMREC_EWORKSPACE;
+    }
+    char* ws = (char*)workspace;
+    uint64_t* keys_a = (uint64_t*)ws;
+    uint64_t* keys_b = (uint64_t*)(ws + align_up(8 * n, 256));
+    void* temp = ws + 2 * align_up(8 * n, 256);
+    size_t temp_avail = (size_t)align_up(n + (32ll << 20), 256), need = 0;
+    scatter_keys_kernel<<<grid_for(n, 256), 256, 0, stream>>>(n, ids, keys_a);
+    LLMREC_LAUNCH_CHECK();
+    hipcub::DoubleBuffer<uint64_t> kbuf(keys_a, keys_b);
+    LLMREC_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, need, kbuf, (int)n, 0, 64, stream));
+    if (need > temp_avail) { set_error("scatter_rows: rocPRIM needs %zu B temp > %zu", need, temp_avail); return LLMREC_EWORKSPACE; }
+    LLMREC_HIP(hipcub::DeviceRadixSort::SortKeys(temp, need, kbuf, (int)n, 0, 64, stream));
+    scatter_runs_kernel<<<(unsigned)ceil_div(n, 16), 256, 0, stream>>>(n, kbuf.Current(), rows, ldr, d, alpha, dst, ldd);
+    LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }
 

@@ -99,8 +99,63 @@ class HipBackend:
     def degrees(self, csr) -> torch.Tensor:
         return (csr.rowptr[1:] - csr.rowptr[:-1]).to(torch.float32)
 
-    def spmm(self, csr, X):
-        return self.ops.spmm_raw(csr, X)
+    def spmm(self, csr, X, out=None, epilogue=None):
+        """Y = epilogue(A X); epilogue: None or {"op": "none" | "softmax" | "softmax_bwd", "alpha", "Z", "S"}."""
+        o = self.ops
+        epi = None
+        if epilogue is not None:
+            op = {"none": o.EPI_NONE, "softmax": o.EPI_SOFTMAX, "softmax_bwd": o.EPI_SOFTMAX_BWD}[epilogue.get("op", "none")]
+            epi = o.spmm_epilogue(op, epilogue.get("alpha", 0.0), epilogue.get("Z"), epilogue.get("S"))
+        return o.spmm_raw(csr, X, out=out, epilogue=epi)
+
+    def row_chunk(self, csr, r0, r1):
+        """The operand restricted to rows [r0, r1) (views; its own row plan)."""
+        o = self.ops
+        sl = lambda t: None if t is None else t[r0:r1]
+        return o.Csr(r1 - r0, csr.n_cols, csr.rowptr[r0:r1 + 1], csr.colidx, csr.val, sl(csr.row_scale), csr.col_scale, {})
+
+    def softmax_rows_into(self, Z, out):
+        o = self.ops
+        o._lib.call("llmrec_softmax_rows_fwd_f32", Z.shape[0], Z.shape[1], o._p(Z), o._ld(Z), o._p(out), o._ld(out), o._stream())
+
+    def softmax_bwd_into(self, Y, dY, out):
+        o = self.ops
+        o._lib.call("llmrec_softmax_rows_bwd_f32", Y.shape[0], Y.shape[1], o._p(Y), o._ld(Y), o._p(dY), o._ld(dY), o._p(out), o._ld(out), o._stream())
+
+    def axpy_into(self, alpha, X, out):
+        o = self.ops
+        o._lib.call("llmrec_axpy_f32", X.shape[0], X.shape[1], float(alpha), None, o._p(X), o._ld(X), o._p(out), o._ld(out), 0, o._stream())
+
+    def layer_mean_into(self, terms, out):
+        o = self.ops
+        mp, ml = o._ptr_table(list(terms))
+        npt, nl = o._ptr_table([])
+        r = (o._c.c_float * 1)(0.0)
+        o._lib.call("llmrec_fuse_fwd_f32", out.shape[0], out.shape[1], 1.0 / len(terms), len(terms), mp, ml, 0, npt, nl, r,
+                    o._p(out), o._ld(out), o._stream())
+
+    def zero_(self, tensors):
+        o = self.ops
+        arr = (o.ZeroTensor * len(tensors))()
+        for i, t in enumerate(tensors):
+            arr[i].p, arr[i].n = t.data_ptr(), t.numel()
+        o._lib.call("llmrec_zero_multi_f32", len(tensors), arr, o._stream())
+
+    def bpr_bwd_rows(self, Eu, Ei, u, p, n, decay, bsz, saved, grads2, rows3):
+        o = self.ops
+        o._lib.call("llmrec_bpr_prune_bwd_rows_f32", o._p(Eu), o._ld(Eu), o._p(Ei), o._ld(Ei), Eu.shape[1], o._p(u), o._p(p), o._p(n),
+                    u.numel(), None, float(decay), float(bsz), o._p(saved), o._p(grads2), o._p(rows3), o._stream())
+
+    def scatter_rows(self, ids, rows, dst, alpha):
+        """dst[ids[j]] += alpha * rows[j], duplicates in ascending j (deterministic)."""
+        o = self.ops
+        n = ids.numel()
+        need = o._lib.query("llmrec_scatter_rows_workspace_bytes", n)
+        ws = getattr(self, "_scatter_ws", None)
+        if ws is None or ws.numel() < need:
+            ws = self._scatter_ws = torch.empty(need, dtype=torch.uint8, device=dst.device)
+        o._lib.call("llmrec_scatter_rows_f32", n, o._p(ids), o._p(rows), o._ld(rows), rows.shape[1], float(alpha), o._p(dst), o._ld(dst),
+                    o._p(ws), ws.numel(), o._stream())
 
     def softmax_rows(self, Z):
         return self.ops.softmax_rows(Z)

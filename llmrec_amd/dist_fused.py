@@ -1,0 +1,195 @@
+"""Row-sharded FUSED step of the ID-embedding path (BASELINE.json configs 4 / 5).
+
+Same partition as llmrec_amd/dist.py - users (rows of A_ui, columns of A_iu) sharded over the ranks, every item-side
+tensor replicated - but the step is written out by hand like llmrec_amd/fused.py (no autograd graph, preallocated
+buffers, SpMM epilogues for the softmax / softmax-backward / "+ mean term" of reference Models.py:169-186), and the
+exchanges are organised for xGMI:
+
+  * per layer and direction ONE I x d message (forward: I^{l+1} = sum_r A_iu[:, blk_r] U^{l+1}[blk_r]; backward:
+    dI^l = sum_r A_ui[blk_r, :]^T dU^{l+1}[blk_r]). The SpMM that produces it runs in item-row CHUNKS; each chunk's
+    all-reduce is issued (async, on the communicator's stream) as soon as the chunk is computed, so the reduction of
+    chunk c overlaps the SpMM of chunk c + 1 - the per-layer message is then bound by max(compute, link time) instead
+    of their sum (RCCL picks reduce-scatter + all-gather inside each all-reduce; chunks are sized >= 32 MB so the
+    point-to-point xGMI links stay bandwidth- rather than latency-bound);
+  * the BPR gradient of the replicated fused item table has at most 2 B non-zero rows per rank: the ranks
+    ALL-GATHER those rows (ids + 2 B x d floats, 0.5 MB at B = 1024, d = 64) and every rank scatter-adds the same
+    list in the same order (llmrec_scatter_rows_f32: sorted, deterministic) - instead of the dense I x d all-reduce
+    of llmrec_amd/dist.py's per-op autograd path (256 MB at cfg 4) - so replicas stay bit-identical;
+  * prune threshold over the GLOBAL batch: all-gather of B floats (llmrec_bpr_prune_fwd_sharded_f32, two passes),
+    norms / mf share: one all-reduce of 4 floats.
+The item table's gradient is complete on every rank after the layer all-reduces, so its AdamW update is replicated.
+
+The local kernels come from a ``backend`` (llmrec_amd.dist.HipBackend = the C-ABI HIP library; tests inject the
+torch-CPU stand-in to run this file under gloo with two ranks against the single-process oracle).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from .dist import Comm, ShardedGraph
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def all_reduce_start(comm: Comm, t: torch.Tensor):
+    """Start an in-place sum all-reduce of t; returns a handle whose wait() orders the CURRENT stream after it.
+    nccl (= RCCL): asynchronous on the communicator's stream (it first waits for the work already queued on the
+    current stream, i.e. for the kernel that produced t); gloo / one rank: done on return."""
+    if comm.dist is None or comm.world == 1:
+        return _Done()
+    if comm._host_staged():
+        comm.all_reduce_(t)
+        return _Done()
+    return comm.dist.all_reduce(t, async_op=True)
+
+
+class ShardedFusedID:
+    """One rank's part of the fused ID-path training step."""
+
+    def __init__(self, graph: ShardedGraph, comm: Comm, backend, d: int, n_layers: int, n_users_global: int, seed: int,
+                 lr: float, batch_local: int, drop_rate: float, decay: float, n_chunks: Optional[int] = None,
+                 user_init: Optional[torch.Tensor] = None, item_init: Optional[torch.Tensor] = None):
+        self.g, self.comm, self.be = graph, comm, backend
+        self.d, self.L, self.B = d, n_layers, batch_local
+        self.remember, self.decay = 1.0 - drop_rate, decay
+        self.bsz_flag = float(batch_local * comm.world)
+        dev = graph.s_i.device
+        U, I = graph.n_users_local, graph.n_items
+        self.U, self.I = U, I
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        # parameters: xavier_uniform over the GLOBAL table shapes (reference Models.py:39-42); the item table is drawn
+        # identically on every rank, the user rows per rank
+        if item_init is None:
+            gen = torch.Generator(device="cpu"); gen.manual_seed(seed)
+            item_init = (torch.rand(I, d, generator=gen) * 2 - 1) * math.sqrt(6.0 / (I + d))
+        if user_init is None:
+            gu = torch.Generator(device="cpu"); gu.manual_seed(seed * 7919 + 1 + comm.rank)
+            user_init = (torch.rand(U, d, generator=gu) * 2 - 1) * math.sqrt(6.0 / (n_users_global + d))
+        self.item_tab = torch.nn.Parameter(item_init.to(dev).float().contiguous())
+        self.user_tab = torch.nn.Parameter(user_init.to(dev).float().contiguous())
+        self.item_tab.grad, self.user_tab.grad = f(I, d), f(U, d)
+        self.opt = backend.optimizer([self.user_tab, self.item_tab], lr)
+        # forward / backward buffers
+        self.Ul = [f(U, d) for _ in range(n_layers)]
+        self.Il = [f(I, d) for _ in range(n_layers)]
+        self.E_u, self.E_i = f(U, d), f(I, d)
+        self.dE_u, self.dE_i = f(U, d), f(I, d)
+        self.bufU, self.tmpU, self.bufI, self.tmpI = f(U, d), f(U, d), f(I, d), f(I, d)
+        self.rows3 = f(3, batch_local, d)
+        self.gat_rows = f(comm.world, 2, batch_local, d)
+        self.gat_ids = torch.empty(comm.world, 2, batch_local, dtype=torch.int64, device=dev)
+        self.my_ids = torch.empty(2, batch_local, dtype=torch.int64, device=dev)
+        # item-row chunks of the two SpMMs whose output is all-reduced (>= 32 MB per message unless told otherwise)
+        if n_chunks is None:
+            n_chunks = max(1, min(8, (4 * I * d) // (32 << 20)))
+        n_chunks = max(1, min(n_chunks, I))
+        per = (I + n_chunks - 1) // n_chunks
+        self.chunks = [(r0, min(r0 + per, I)) for r0 in range(0, I, per)]
+        self.iu_fwd_chunks = [backend.row_chunk(graph.iu_fwd, r0, r1) for r0, r1 in self.chunks]
+        self.ui_bwd_chunks = [backend.row_chunk(graph.ui_bwd, r0, r1) for r0, r1 in self.chunks]
+        deg = backend.degrees(graph.by_user)
+        self.exist = torch.nonzero(deg > 0).reshape(-1).to(torch.int64)
+        self.seed = seed * 1000003 + comm.rank
+        self.step_id = 0
+        self.allreduce_bytes = 0
+
+    def parameters(self):
+        return [self.user_tab, self.item_tab]
+
+    # -- the chunked, overlapped all-reduce ----------------------------------------------------------
+    def _reduced_spmm(self, chunk_ops, X, out, epilogue_for=None, after=None):
+        """out[rows_c] = sum over ranks of chunk_ops[c] @ X, chunk by chunk: the all-reduce of chunk c is in flight
+        while chunk c + 1 is computed. after(c, view): optional row-local op on the reduced chunk (the softmax)."""
+        pending = []
+        for c, (r0, r1) in enumerate(self.chunks):
+            view = out[r0:r1]
+            self.be.spmm(chunk_ops[c], X, out=view, epilogue=epilogue_for(r0, r1) if epilogue_for else None)
+            pending.append((all_reduce_start(self.comm, view), view))
+            self.allreduce_bytes += view.numel() * 4
+        for c, (h, view) in enumerate(pending):
+            h.wait()
+            if after is not None:
+                after(c, view)
+
+    # -- forward ---------------------------------------------------------------------------------------
+    def forward(self):
+        be, L = self.be, self.L
+        i_prev = self.item_tab.detach()
+        for l in range(L):
+            last = l == L - 1
+            be.spmm(self.g.ui_fwd, i_prev, out=self.Ul[l], epilogue={"op": "softmax"} if last else None)      # local users
+            self._reduced_spmm(self.iu_fwd_chunks, self.Ul[l], self.Il[l],
+                               after=(lambda c, view: be.softmax_rows_into(view, view)) if last else None)
+            i_prev = self.Il[l]
+        be.layer_mean_into([self.user_tab.detach()] + self.Ul, self.E_u)
+        be.layer_mean_into([self.item_tab.detach()] + self.Il, self.E_i)
+        return self.E_u, self.E_i
+
+    # -- one training step -------------------------------------------------------------------------------
+    def sample(self):
+        return self.be.sample(self.seed, self.step_id, self.exist, self.I, self.g.by_user, self.B)
+
+    def step(self, triples=None):
+        """triples: (users RELATIVE to this rank's block, pos, neg) int64 device vectors of length batch_local, or None
+        to draw them with the device sampler. Returns (loss, [mf, emb]) of the GLOBAL batch as device scalars."""
+        be, comm, L, B = self.be, self.comm, self.L, self.B
+        u, p, n = triples if triples is not None else self.sample()
+        self.step_id += 1
+        self.allreduce_bytes = 0
+        self.forward()
+        # BPR + prune over the global batch (reference main.py:158-165,330-342): two passes around an all-gather of B floats
+        _, s1 = be.bpr_fwd(self.E_u, self.E_i, u, p, n, self.remember, self.decay, self.bsz_flag, None, 0, 0, True)
+        global_m = comm.all_gather_cat(be.bpr_local_m(s1, B).contiguous())
+        out, saved = be.bpr_fwd(self.E_u, self.E_i, u, p, n, self.remember, self.decay, self.bsz_flag, global_m, global_m.numel(),
+                                comm.rank * B, False)
+        small = torch.cat([saved[B:B + 3], out[:1]])
+        comm.all_reduce_(small)                                   # the three squared norms + the mf shares
+        saved[B:B + 3] = small[:3]
+        mf = small[3:4]
+        emb = (self.decay * ((1.0 / (2.0 * small[:3] + 1e-8)).sum() / self.bsz_flag)).reshape(1)
+        # backward: compact gradient rows; users scatter locally, item rows are exchanged (all-gather of 2 B rows)
+        ones = torch.ones(2, dtype=torch.float32, device=out.device)
+        be.bpr_bwd_rows(self.E_u, self.E_i, u, p, n, self.decay, self.bsz_flag, saved, ones, self.rows3)
+        be.zero_([self.dE_u, self.dE_i])
+        be.scatter_rows(u, self.rows3[0], self.dE_u, 1.0)
+        self.my_ids[0].copy_(p); self.my_ids[1].copy_(n)
+        comm.all_gather_into(self.gat_rows.view(-1), self.rows3[1:3].reshape(-1))
+        comm.all_gather_into(self.gat_ids.view(-1), self.my_ids.view(-1))
+        be.scatter_rows(self.gat_ids.view(-1), self.gat_rows.view(-1, self.d), self.dE_i, 1.0)     # same list, same order on every rank
+        inv = 1.0 / (L + 1)
+        # dI[L] = inv dE_i -> g = softmax_bwd(I_L, dI[L]); then per layer
+        #   dU[l+1] = inv dE_u + A_iu[:, blk]^T g          (local; softmax backward as the epilogue on the last layer)
+        #   dI[l]   = inv dE_i + sum_r A_ui[blk_r, :]^T h  (chunked + all-reduced; every rank adds inv / world of the replicated dE_i)
+        g = self.bufI
+        if L >= 1:
+            be.axpy_into(inv, self.dE_i, self.bufI)
+            be.softmax_bwd_into(self.Il[L - 1], self.bufI, self.tmpI)
+            g = self.tmpI
+        for l in range(L - 1, -1, -1):
+            last = l == L - 1
+            if last:
+                be.spmm(self.g.iu_bwd, g, out=self.tmpU, epilogue={"op": "softmax_bwd", "alpha": inv, "Z": self.dE_u, "S": self.Ul[l]})
+                h = self.tmpU
+            else:
+                be.spmm(self.g.iu_bwd, g, out=self.bufU, epilogue={"op": "none", "alpha": inv, "Z": self.dE_u})
+                h = self.bufU
+            dst = self.item_tab.grad if l == 0 else self.bufI
+            w = inv / comm.world
+            self._reduced_spmm(self.ui_bwd_chunks, h, dst, epilogue_for=lambda r0, r1: {"op": "none", "alpha": w, "Z": self.dE_i[r0:r1]})
+            g = self.bufI
+        if L == 0:
+            be.axpy_into(inv, self.dE_i, self.item_tab.grad)
+        be.axpy_into(inv, self.dE_u, self.user_tab.grad)              # U^0 only enters the mean
+        self.opt.step()
+        return (mf + emb).reshape(()), torch.cat([mf, emb])
+
+    # -- accounting for bench.py -------------------------------------------------------------------------
+    def message_bytes_per_step(self) -> dict:
+        return {"allreduce_I_x_d_bytes": 4 * self.I * self.d * 2 * self.L, "allreduce_messages": 2 * self.L * len(self.chunks),
+                "bpr_rows_allgather_bytes_per_rank": 2 * self.B * (4 * self.d + 8), "prune_allgather_bytes_per_rank": 4 * self.B}

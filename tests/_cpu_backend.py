@@ -21,11 +21,63 @@ class CpuBackend:
     def degrees(self, p):
         return torch.bincount(p.rows, minlength=p.n_rows).float()
 
-    def spmm(self, p, X):
+    def spmm(self, p, X, out=None, epilogue=None):
         X = X if p.col_scale is None else X * p.col_scale[:, None]
         A = torch.sparse_coo_tensor(torch.stack([p.rows, p.cols]), torch.ones(p.rows.numel()), (p.n_rows, p.n_cols))
         Y = torch.sparse.mm(A, X)
-        return Y if p.row_scale is None else Y * p.row_scale[:, None]
+        Y = Y if p.row_scale is None else Y * p.row_scale[:, None]
+        if epilogue is not None:                                  # the contract of llmrec_spmm_epilogue_t
+            if epilogue.get("Z") is not None:
+                Y = epilogue.get("alpha", 0.0) * epilogue["Z"] + Y
+            op = epilogue.get("op", "none")
+            if op == "softmax":
+                Y = torch.softmax(Y, dim=-1)
+            elif op == "softmax_bwd":
+                S = epilogue["S"]
+                Y = S * (Y - (Y * S).sum(-1, keepdim=True))
+        if out is not None:
+            out.copy_(Y)
+            return out
+        return Y
+
+    def row_chunk(self, p, r0, r1):
+        sel = (p.rows >= r0) & (p.rows < r1)
+        return _Pattern(p.rows[sel] - r0, p.cols[sel], r1 - r0, p.n_cols,
+                        None if p.row_scale is None else p.row_scale[r0:r1], p.col_scale)
+
+    def softmax_rows_into(self, Z, out):
+        out.copy_(torch.softmax(Z, dim=-1))
+
+    def softmax_bwd_into(self, Y, dY, out):
+        out.copy_(Y * (dY - (dY * Y).sum(-1, keepdim=True)))
+
+    def axpy_into(self, alpha, X, out):
+        out.copy_(alpha * X)
+
+    def layer_mean_into(self, terms, out):
+        out.copy_(torch.mean(torch.stack(list(terms)), dim=0))
+
+    def zero_(self, tensors):
+        for t in tensors:
+            t.zero_()
+
+    def bpr_bwd_rows(self, Eu, Ei, u, p, n, decay, bsz, saved, grads2, rows3):
+        B = u.numel()
+        ds = grads2[0] * saved[:B]
+        Su, Sp, Sq = saved[B], saved[B + 1], saved[B + 2]
+        base = -4.0 * decay / bsz * grads2[1]
+        cu, cp, cq = (base / (2 * S + 1e-8) ** 2 for S in (Su, Sp, Sq))
+        eu, ep, en = Eu[u], Ei[p], Ei[n]
+        rows3[0].copy_(ds[:, None] * (ep - en) + cu * eu)
+        rows3[1].copy_(ds[:, None] * eu + cp * ep)
+        rows3[2].copy_(-ds[:, None] * eu + cq * en)
+
+    def scatter_rows(self, ids, rows, dst, alpha):
+        keep = ids >= 0
+        dst.index_add_(0, ids[keep], alpha * rows[keep])
+
+    def sample(self, seed, step, exist, n_items, by_user, B):
+        raise NotImplementedError("the CPU stand-in is driven with explicit triples")
 
     def softmax_rows(self, Z):
         return torch.softmax(Z, dim=-1)

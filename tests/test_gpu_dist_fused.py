@@ -1,0 +1,175 @@
+"""GPU tests of the row-sharded fused ID step (llmrec_amd/dist_fused.py) on the HIP backend:
+* one rank (collectives are identities) against the single-process oracle, with the item rows cut into chunks and
+  hub rows that cross every SpMM row bucket;
+* two PROCESSES on one GPU (torch.distributed gloo moving device tensors through the host) against the same oracle -
+  the code `bench.py --gpus N --workload synth` runs over RCCL;
+* the two kernels the step adds (compact BPR gradient rows, deterministic sorted row scatter) against torch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+
+U, I, D, L, B_LOCAL, STEPS = 900, 700, 64, 2, 128, 3
+DROP, DECAY, LR = 0.71, 1e-5, 1e-3
+
+
+def _problem(world):
+    rng = np.random.default_rng(4)
+    deg = rng.integers(1, 30, size=U); deg[7] = 600; deg[U - 3] = 200                     # hubs in both halves
+    rows = np.repeat(np.arange(U), deg)
+    cols = np.concatenate([rng.choice(I, size=c, replace=False) for c in deg])
+    hot = rng.integers(0, U, size=2500); rows = np.concatenate([rows, hot]); cols = np.concatenate([cols, np.full(hot.size, 5)])   # a hub item
+    key = np.unique(rows * I + cols); rows, cols = key // I, key % I
+    u_tab = (rng.standard_normal((U, D)) * 0.1).astype(np.float32)
+    i_tab = (rng.standard_normal((I, D)) * 0.1).astype(np.float32)
+    per = (U + world - 1) // world
+    batches = []
+    for s in range(STEPS):
+        per_rank = []
+        for r in range(world):
+            u0, u1 = r * per, min((r + 1) * per, U)
+            pos = rng.integers(0, I, size=B_LOCAL); pos[:40] = 5                           # duplicate gradient rows (>= 3 per id)
+            per_rank.append((rng.integers(u0, u1, size=B_LOCAL), pos, rng.integers(0, I, size=B_LOCAL)))
+        batches.append(per_rank)
+    return rows, cols, u_tab, i_tab, batches
+
+
+def _oracle_run(world):
+    import scipy.sparse as sp
+    rows, cols, u_tab, i_tab, batches = _problem(world)
+    R = sp.csr_matrix((np.ones(rows.size, dtype=np.float32), (rows, cols)), shape=(U, I))
+    a_ui, a_iu = O.normalized_graphs(R)
+    pu = torch.tensor(u_tab, requires_grad=True); pi = torch.tensor(i_tab, requires_grad=True)
+    opt = torch.optim.AdamW([{"params": [pu, pi]}], lr=LR)
+    cfg = O.Config(batch_size=world * B_LOCAL, decay=DECAY, prune_loss_drop_rate=DROP)
+    losses = []
+    for per_rank in batches:
+        us = np.concatenate([b[0] for b in per_rank]); ps = np.concatenate([b[1] for b in per_rank]); ns = np.concatenate([b[2] for b in per_rank])
+        u, i = pu, pi
+        ul, il = [u], [i]
+        for l in range(L):
+            u = torch.sparse.mm(a_ui, i)
+            if l == L - 1: u = torch.softmax(u, -1)
+            i = torch.sparse.mm(a_iu, u)
+            if l == L - 1: i = torch.softmax(i, -1)
+            ul.append(u); il.append(i)
+        eu, ei = torch.mean(torch.stack(ul), 0), torch.mean(torch.stack(il), 0)
+        mf, emb = O.bpr_loss(eu[torch.tensor(us)], ei[torch.tensor(ps)], ei[torch.tensor(ns)], cfg)
+        opt.zero_grad(); (mf + emb).backward(); opt.step()
+        losses.append(float(mf + emb))
+    return pu.detach().numpy(), pi.detach().numpy(), losses
+
+
+def _run_rank(rank, world, n_chunks):
+    from llmrec_amd import dist as ld
+    from llmrec_amd.dist_fused import ShardedFusedID
+    rows, cols, u_tab, i_tab, batches = _problem(world)
+    comm, be = ld.Comm(), ld.HipBackend()
+    u0, u1 = ld.user_block(U, rank, world)
+    sel = (rows >= u0) & (rows < u1)
+    g = ld.ShardedGraph.build(torch.tensor(rows[sel] - u0).cuda(), torch.tensor(cols[sel]).cuda(), u1 - u0, I, u0, comm, be)
+    st = ShardedFusedID(g, comm, be, D, L, U, seed=1, lr=LR, batch_local=B_LOCAL, drop_rate=DROP, decay=DECAY, n_chunks=n_chunks,
+                        user_init=torch.tensor(u_tab[u0:u1]), item_init=torch.tensor(i_tab))
+    losses = []
+    for per_rank in batches:
+        us, ps, ns = per_rank[rank]
+        loss, _ = st.step((torch.tensor(us - u0).cuda(), torch.tensor(ps).cuda(), torch.tensor(ns).cuda()))
+        losses.append(float(loss))
+    return st, losses
+
+
+@pytest.mark.parametrize("n_chunks", [1, 5])
+def test_fused_sharded_step_single_rank_matches_oracle(n_chunks):
+    ref_u, ref_i, ref_losses = _oracle_run(1)
+    st, losses = _run_rank(0, 1, n_chunks)
+    assert len(st.chunks) == n_chunks
+    assert np.allclose(losses, ref_losses, rtol=2e-5), (losses, ref_losses)
+    got_u, got_i = st.user_tab.detach().cpu().numpy(), st.item_tab.detach().cpu().numpy()
+    assert np.abs(got_u - ref_u).max() <= 1e-4 * np.abs(ref_u).max()
+    assert np.abs(got_i - ref_i).max() <= 1e-4 * np.abs(ref_i).max()
+    loss, _ = st.step()                                            # the device sampler path
+    assert np.isfinite(float(loss))
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    st, losses = _run_rank(rank, world, 3)
+    np.savez(os.path.join(out_dir, "g%d.npz" % rank), users=st.user_tab.detach().cpu().numpy(), items=st.item_tab.detach().cpu().numpy(),
+             losses=np.array(losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_fused_sharded_step_two_processes_one_gpu_match_oracle(tmp_path):
+    world = 2
+    ref_u, ref_i, ref_losses = _oracle_run(world)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / ("g%d.npz" % k)) for k in range(world)]
+    assert np.array_equal(r[0]["items"], r[1]["items"])                                   # replicas bit-identical (deterministic scatter)
+    assert np.allclose(r[0]["losses"], ref_losses, rtol=2e-5) and np.allclose(r[1]["losses"], ref_losses, rtol=2e-5)
+    got_u = np.concatenate([r[0]["users"], r[1]["users"]])
+    assert np.abs(got_u - ref_u).max() <= 1e-4 * np.abs(ref_u).max()
+    assert np.abs(r[0]["items"] - ref_i).max() <= 1e-4 * np.abs(ref_i).max()
+
+
+def test_scatter_rows_is_deterministic_and_matches_index_add():
+    from llmrec_amd import dist as ld
+    be = ld.HipBackend()
+    rng = np.random.default_rng(9)
+    n, rows_dst, d = 5000, 300, 64
+    ids = rng.integers(0, rows_dst, size=n); ids[:700] = 17; ids[rng.integers(0, n, size=200)] = -1      # a long run + skipped entries
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    base = rng.standard_normal((rows_dst, d)).astype(np.float32)
+    want = torch.tensor(base).double()
+    keep = ids >= 0
+    want.index_add_(0, torch.tensor(ids[keep]), 0.5 * torch.tensor(rows[keep]).double())
+    outs = []
+    for _ in range(3):
+        dst = torch.tensor(base).cuda()
+        be.scatter_rows(torch.tensor(ids).cuda(), torch.tensor(rows).cuda(), dst, 0.5)
+        outs.append(dst.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert float((outs[0].double() - want).abs().max() / want.abs().max()) < 2e-6
+    # strided source / destination (column slices)
+    big_src = torch.zeros(n, 3 * d).cuda(); big_src[:, d:2 * d] = torch.tensor(rows).cuda()
+    big_dst = torch.zeros(rows_dst, 2 * d).cuda(); big_dst[:, :d] = torch.tensor(base).cuda()
+    be.scatter_rows(torch.tensor(ids).cuda(), big_src[:, d:2 * d], big_dst[:, :d], 0.5)
+    assert torch.equal(big_dst[:, :d].cpu(), outs[0]) and float(big_dst[:, d:].abs().max()) == 0.0
+
+
+def test_bpr_gradient_rows_match_the_scatter_form():
+    """llmrec_bpr_prune_bwd_rows_f32 = the same per-sample gradients llmrec_bpr_prune_bwd_f32 scatters."""
+    from llmrec_amd import dist as ld
+    be = ld.HipBackend()
+    rng = np.random.default_rng(3)
+    Un, In, d, B = 50, 40, 64, 96
+    Eu = torch.tensor(rng.standard_normal((Un, d)).astype(np.float32)).cuda(); Ei = torch.tensor(rng.standard_normal((In, d)).astype(np.float32)).cuda()
+    u = torch.tensor(rng.integers(0, Un, size=B)).cuda(); p = torch.tensor(rng.integers(0, In, size=B)).cuda(); n = torch.tensor(rng.integers(0, In, size=B)).cuda()
+    _, s1 = be.bpr_fwd(Eu, Ei, u, p, n, 0.29, 1e-5, float(B), None, 0, 0, True)
+    gm = be.bpr_local_m(s1, B).contiguous().clone()
+    out, saved = be.bpr_fwd(Eu, Ei, u, p, n, 0.29, 1e-5, float(B), gm, B, 0, False)
+    g2 = torch.tensor([1.0, 2.0]).cuda()
+    dEu, dEi = be.bpr_bwd(Eu, Ei, u, p, n, 1e-5, float(B), saved, g2)
+    rows3 = torch.empty(3, B, d).cuda()
+    be.bpr_bwd_rows(Eu, Ei, u, p, n, 1e-5, float(B), saved, g2, rows3)
+    wu = torch.zeros(Un, d).cuda(); wi = torch.zeros(In, d).cuda()
+    be.scatter_rows(u, rows3[0], wu, 1.0)
+    be.scatter_rows(torch.cat([p, n]), rows3[1:3].reshape(-1, d), wi, 1.0)
+    assert float((wu - dEu).abs().max() / dEu.abs().max()) < 2e-6
+    assert float((wi - dEi).abs().max() / dEi.abs().max()) < 2e-6
