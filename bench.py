@@ -41,12 +41,15 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="auto", help="auto | nf (cfg 2) | ml (cfg 3) | synth (user-sharded ID path, cfg 4 shape)")
-    ap.add_argument("--synth-users", type=int, default=1_250_000, help="users PER GPU for --workload synth")
-    ap.add_argument("--synth-items", type=int, default=1_000_000)
-    ap.add_argument("--synth-edges", type=int, default=25_000_000, help="edges PER GPU for --workload synth")
+    ap.add_argument("--steps", type=int, default=None, help="default: 200 (nf / ml), 20 (cfg4), 5 (cfg5)")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 20 (nf / ml), 3 (cfg4), 1 (cfg5)")
+    ap.add_argument("--workload", default="auto", help="auto | nf (cfg 2) | ml (cfg 3) | synth = cfg4 (row-sharded ID path, 10 M x 1 M x 200 M, d = 64) | "
+                                                      "cfg5 (50 M x 5 M x 1.05 B, d = 128, + 5 % augmented triples)")
+    ap.add_argument("--synth-scaling", default="weak", help="weak: 2 of the config's 16 user blocks per GPU (cfg 4 / 5 exactly at 8 GPUs); "
+                                                           "strong: all 16 blocks = the whole config, split over the ranks")
+    ap.add_argument("--synth-blocks", type=int, default=0, help="override the number of user blocks per GPU (weak) / in total (strong)")
+    ap.add_argument("--synth-chunks", type=int, default=0, help="item-row chunks per all-reduced message (0 = automatic, >= 32 MB each)")
+    ap.add_argument("--no-row-sharded", action="store_true", help="nf / ml workloads: skip the cfg-4-shaped row-sharded measurements added to the line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity gate that runs before the timed region")
@@ -280,6 +283,158 @@ class NetflixShaped:
         return out
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3] / [4]: the ID-embedding path on a synthetic graph, users row-sharded over the ranks
+# ---------------------------------------------------------------------------------------------------------------
+SYNTH_CONFIGS = {
+    # 16 user blocks per config; one block = 1/16 of the users and of the edges
+    "cfg4": {"n_users": 10_000_000, "n_items": 1_000_000, "n_edges": 200_000_000, "d": 64, "layers": 2, "aug_rate": 0.0},
+    "cfg5": {"n_users": 50_000_000, "n_items": 5_000_000, "n_edges": 1_050_000_000, "d": 128, "layers": 2, "aug_rate": 0.05},
+}
+SYNTH_BLOCKS = 16
+
+
+class RowSharded:
+    """llmrec_amd/dist_fused.ShardedFusedID on cfg-4 / cfg-5-shaped synthetic graphs. The graph is generated in 16
+    user blocks with per-block seeds, so the GLOBAL graph does not depend on the number of ranks: weak scaling gives
+    every rank `blocks` of them (2 per GPU = the whole config at 8 GPUs), strong scaling splits all 16 over the ranks."""
+
+    def __init__(self, name, scaling, blocks, seed, device, rank, world, n_chunks=0, batch_local=1024):
+        import torch
+        from llmrec_amd import dist as ldist, synth
+        from llmrec_amd.dist_fused import ShardedFusedID
+        cfg = SYNTH_CONFIGS[name]
+        self.name, self.cfg, self.scaling, self.device, self.rank, self.world = name, cfg, scaling, device, rank, world
+        bu, be_ = cfg["n_users"] // SYNTH_BLOCKS, cfg["n_edges"] // SYNTH_BLOCKS
+        if scaling == "strong":
+            total = blocks or SYNTH_BLOCKS
+            if total % world:
+                raise SystemExit("strong scaling: %d blocks do not divide over %d ranks" % (total, world))
+            mine = list(range(rank * (total // world), (rank + 1) * (total // world)))
+        else:
+            per = blocks or 2
+            total = per * world
+            mine = list(range(rank * per, (rank + 1) * per))
+        self.blocks_total, self.blocks_mine = total, len(mine)
+        self.comm, self.backend = ldist.Comm(), ldist.HipBackend()
+        t0 = time.perf_counter()
+        rows, cols = [], []
+        for k, b in enumerate(mine):
+            r, c = synth.bipartite_edges_device(bu, cfg["n_items"], be_, seed * 131 + b, device)
+            rows.append(r + k * bu); cols.append(c)
+        rows, cols = torch.cat(rows), torch.cat(cols)
+        self.nnz_local = int(rows.numel())
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        n_local = bu * len(mine)
+        self.graph = ldist.ShardedGraph.build(rows, cols, n_local, cfg["n_items"], rank * n_local, self.comm, self.backend)
+        del rows, cols
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        self.n_aug = int(batch_local * cfg["aug_rate"])
+        self.B = batch_local + self.n_aug
+        self.batch_local = batch_local
+        self.step_obj = ShardedFusedID(self.graph, self.comm, self.backend, cfg["d"], cfg["layers"], bu * total, seed, 1e-4, self.B, 0.71, 1e-5,
+                                       n_chunks=n_chunks or None)
+        if self.n_aug:                                        # the LLM-augmented triples of main.py:216-224: a per-user (pos, neg) table
+            g = torch.Generator(device=device); g.manual_seed(seed + 17 + rank)
+            self.aug_pos = torch.randint(0, cfg["n_items"], (n_local,), generator=g, device=device)
+            self.aug_neg = torch.randint(0, cfg["n_items"], (n_local,), generator=g, device=device)
+        torch.cuda.synchronize()
+        self.ingest = {"generate_s": t1 - t0, "csr_build_and_plans_s": t2 - t1, "tables_s": time.perf_counter() - t2,
+                       "hbm_allocated_gb": torch.cuda.memory_allocated(device) / 1e9, "hbm_peak_gb": torch.cuda.max_memory_allocated(device) / 1e9}
+        self.units_per_step = batch_local * world              # the reference's timer counts batch_size per step (main.py:203)
+        self.last = None
+
+    def _triples(self):
+        import torch
+        st = self.step_obj
+        u, p, n = st.be.sample(st.seed, st.step_id, st.exist, st.I, st.g.by_user, self.batch_local)
+        if self.n_aug:                                        # extra triples for a sample of the batch's users
+            ua = u[: self.n_aug]
+            u, p, n = torch.cat([u, ua]), torch.cat([p, self.aug_pos[ua]]), torch.cat([n, self.aug_neg[ua]])
+        return u, p, n
+
+    def step(self):
+        self.last = self.step_obj.step(self._triples())
+        return self.last
+
+    def config(self):
+        c, st = self.cfg, self.step_obj
+        return {"workload": "synthetic_%s_shape_row_sharded_id_path" % self.name, "scaling": self.scaling,
+                "n_users_global": c["n_users"] // SYNTH_BLOCKS * self.blocks_total, "n_items": c["n_items"],
+                "users_per_gpu": st.U, "edges_per_gpu": self.nnz_local, "embed_size": c["d"], "prop_layers": c["layers"],
+                "batch_per_gpu": self.batch_local, "augmented_triples_per_gpu": self.n_aug, "global_batch": self.B * self.world,
+                "prune_loss_drop_rate": 0.71, "user_blocks_total": self.blocks_total,
+                "parallelism": ("user-row-sharded x%d (llmrec_amd/dist_fused.py): item tables replicated, per layer and direction one I x d "
+                                "all-reduce in %d asynchronous chunks behind the next chunk's SpMM, BPR gradient rows by all-gather"
+                                % (self.world, len(st.chunks)))}
+
+    def sampled_row_parity(self, n_rows=192):
+        """Every SpMM of one forward at FULL size, checked on sampled rows (plus the longest ones): row r of each layer's
+        output is recomputed on the CPU in fp64 from the previous layer's GPU tensor and the row's neighbour list."""
+        import numpy as np
+        import torch
+        st, g = self.step_obj, self.graph
+        if self.world != 1:
+            return None
+        st.forward()
+        torch.cuda.synchronize()
+        rng = np.random.default_rng(5)
+        worst = 0.0
+
+        def check(csr, X, Y, softmax):
+            nonlocal worst
+            deg = (csr.rowptr[1:] - csr.rowptr[:-1])
+            top = torch.topk(deg, 4).indices.cpu().numpy()
+            rows = np.unique(np.concatenate([rng.integers(0, csr.n_rows, size=n_rows), top]))
+            rp = csr.rowptr
+            for r in rows:
+                s, e = int(rp[r]), int(rp[r + 1])
+                cols = csr.colidx[s:e].long()
+                acc = X[cols].double().sum(0) * float(csr.row_scale[r]) if e > s else torch.zeros(X.shape[1], dtype=torch.float64, device=X.device)
+                if softmax:
+                    acc = torch.softmax(acc, dim=-1)
+                want = acc
+                got = Y[r].double()
+                worst = max(worst, float((got - want).abs().max() / max(float(want.abs().max()), 1e-30)))
+        prev = st.item_tab.detach()
+        for l in range(st.L):
+            last = l == st.L - 1
+            check(g.ui_fwd, prev, st.Ul[l], last)
+            check(g.iu_fwd, st.Ul[l], st.Il[l], last)
+            prev = st.Il[l]
+        return {"rows_per_spmm": n_rows + 4, "spmm_checked": 2 * st.L, "max_rel_err_vs_fp64": worst, "ok": bool(worst < 1e-4)}
+
+    def extras(self, ms_per_step):
+        import torch
+        st, c = self.step_obj, self.cfg
+        nnz = torch.tensor([self.nnz_local], dtype=torch.float64, device=self.device)
+        self.comm.all_reduce_(nnz)
+        nnz = float(nnz.item())
+        L, d = c["layers"], c["d"]
+        # algorithmic bytes of the step's 4 L SpMMs (SURVEY.md 8(d): 4 nnz + 8 rows + 4 d (rows + cols) each; here per rank)
+        U, I = st.U, st.I
+        per_pair = 2 * (4.0 * self.nnz_local + 8.0 * (U + I) / 2 + 4.0 * d * (U + I))
+        out = {"propagated_edges_per_step": nnz * 4 * L, "propagated_edges_per_sec": nnz * 4 * L / ms_per_step * 1e3,
+               "spmm_algorithmic_bytes_per_step_per_gpu": per_pair * 2 * L, "ingest": self.ingest, "messages": st.message_bytes_per_step()}
+        if self.last is not None:
+            out["loss"] = float(self.last[0]); out["mf_emb"] = [float(x) for x in self.last[1]]
+        return out
+
+    def spmm_times_ms(self, iters=3):
+        """In-situ size, each direction alone: the numbers the SpMM roofline is computed from."""
+        import torch
+        st, g = self.step_obj, self.graph
+        d = self.cfg["d"]
+        res = {}
+        Xi, Xu = st.item_tab.detach(), st.Ul[0]
+        for name, csr, X, Y in (("ui_fwd", g.ui_fwd, Xi, st.tmpU), ("iu_fwd", g.iu_fwd, Xu, st.tmpI), ("iu_bwd", g.iu_bwd, Xi, st.tmpU), ("ui_bwd", g.ui_bwd, Xu, st.tmpI)):
+            ms = event_time_ms(lambda: self.backend.spmm(csr, X, out=Y), iters, warmup=1)
+            alg = 4.0 * csr.nnz + 8.0 * csr.n_rows + 4.0 * d * (csr.n_cols + csr.n_rows)
+            res[name] = {"ms": ms, "edges_per_s": csr.nnz / ms * 1e3, "algorithmic_gbs": alg / ms / 1e6, "frac_hbm_algorithmic": alg / ms / 1e6 / HBM_PEAK_GBS,
+                         "gather_gbs": csr.nnz * 4.0 * d / ms / 1e6}
+        return res
+
+
 def pmc_traffic_bytes(parts):
     """HBM-side bytes of one "launch" as the roofline defines it, from the newest committed PMC pass over THIS bench
     (profiles/r*_pmc_bench_step.json: separate rocprofv3 --pmc runs with --kernel-trace only, as
@@ -510,6 +665,33 @@ def cpu_baseline_nf(w: "NetflixShaped", budget_s: float = 20.0):
             "ms_per_step": dt / steps * 1e3, "eval_users_per_s": 256 / de}
 
 
+def row_sharded_measure(name, scaling, seed, device, rank, world, steps, barrier):
+    """Time `steps` steps of the row-sharded ID path (all ranks call this; max over ranks; result on every rank)."""
+    import gc
+    import torch
+    w = RowSharded(name, scaling, 0, seed, device, rank, world)
+    for _ in range(2):
+        w.step()
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        w.step()
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / steps * 1e3
+    out = {"metric": "bpr_train_edges_per_sec", "value": steps * w.units_per_step / dt, "unit": "edges/s", "ms_per_step": ms, "steps": steps,
+           "n_gpus": world, "scaling": scaling, "config": w.config()}
+    out.update(w.extras(ms))
+    del w
+    gc.collect(); torch.cuda.empty_cache()
+    return out
+
+
 def exact_f32_step_time(w: "NetflixShaped", steps: int):
     """The same step with the exact fp32 MFMA chain in the 12 GEMM launches (LLMREC_GEMM=f32) instead of the default
     3-term bf16 split: a second FusedStep over the same model / optimizer, graph-captured like the timed one."""
@@ -562,14 +744,19 @@ def main():
     workload = a.workload
     if workload == "auto":
         workload = "nf"
+    dflt = {"nf": (200, 20), "ml": (200, 20), "cfg5": (5, 1)}.get(workload, (20, 3))
+    a.steps = dflt[0] if a.steps is None else a.steps
+    a.warmup = dflt[1] if a.warmup is None else a.warmup
 
     if workload in ("nf", "ml"):
         from llmrec_amd import dist as ldist
         w = NetflixShaped(workload, a.seed, device, rank, world, ldist.Comm() if use_pg else None)
         step, units = w.step, w.units_per_step * world      # global batch = world x batch_size
     else:
-        from llmrec_amd import dist as ldist
-        w = ldist.ShardedBench(a.synth_users, a.synth_items, a.synth_edges, a.seed, device, rank, world)
+        name = "cfg4" if workload in ("synth", "cfg4") else workload
+        if name not in SYNTH_CONFIGS:
+            raise SystemExit("unknown --workload %s" % workload)
+        w = RowSharded(name, a.synth_scaling, a.synth_blocks, a.seed, device, rank, world, n_chunks=a.synth_chunks)
         step, units = w.step, w.units_per_step              # global batch per step
 
     def barrier():
@@ -656,8 +843,26 @@ def main():
             line["spmm_roofline"] = spmm_roofline_large(device, a.seed)
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline_nf(w)
-    elif rank == 0:
-        line.update(w.extras())
+    if workload in ("nf", "ml") and not a.no_row_sharded:
+        # north_star's split (configs[3]): the row-sharded ID path on the cfg-4-shaped graph, next to the replica line above -
+        # weak (2 of the 16 user blocks per GPU: cfg 4 exactly at 8 GPUs) and strong (all 16 blocks = cfg 4, split over the ranks)
+        rs = {}
+        for scaling, steps_rs in (("weak", 20), ("strong", 8)):
+            try:
+                rs[scaling] = row_sharded_measure("cfg4", scaling, a.seed, device, rank, world, steps_rs, barrier)
+            except torch.OutOfMemoryError as e:               # pragma: no cover
+                rs[scaling] = {"error": "out of memory: %s" % str(e)[:120]}
+        if rank == 0:
+            line["row_sharded"] = rs
+    if workload not in ("nf", "ml"):
+        line["scaling"] = w.scaling
+        ex = w.extras(dt / a.steps * 1e3)                    # (collective inside: every rank calls it)
+        if rank == 0:
+            line.update(ex)
+            if world == 1 and not a.no_parity:
+                line["parity"] = w.sampled_row_parity()
+            if world == 1 and not a.no_kernel_roofline:
+                line["spmm_in_situ"] = w.spmm_times_ms()
     if rank == 0:
         print(json.dumps(line), flush=True)
     if use_pg:
