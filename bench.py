@@ -427,7 +427,7 @@ class RowSharded:
         d = self.cfg["d"]
         res = {}
         Xi, Xu = st.item_tab.detach(), st.Ul[0]
-        for name, csr, X, Y in (("ui_fwd", g.ui_fwd, Xi, st.tmpU), ("iu_fwd", g.iu_fwd, Xu, st.tmpI), ("iu_bwd", g.iu_bwd, Xi, st.tmpU), ("ui_bwd", g.ui_bwd, Xu, st.tmpI)):
+        for name, csr, X, Y in (("ui_fwd", g.ui_fwd, Xi, st.hU), ("iu_fwd", g.iu_fwd, Xu, st.tmpI), ("iu_bwd_pattern", st.R_user, Xi, st.hU), ("ui_bwd_weighted_not_on_the_path", g.ui_bwd, Xu, st.tmpI)):
             ms = event_time_ms(lambda: self.backend.spmm(csr, X, out=Y), iters, warmup=1)
             alg = 4.0 * csr.nnz + 8.0 * csr.n_rows + 4.0 * d * (csr.n_cols + csr.n_rows)
             res[name] = {"ms": ms, "edges_per_s": csr.nnz / ms * 1e3, "algorithmic_gbs": alg / ms / 1e6, "frac_hbm_algorithmic": alg / ms / 1e6 / HBM_PEAK_GBS,

@@ -90,6 +90,7 @@ int llmrec_csr_row_constant(int64_t n_rows, const int32_t* rowptr, const float* 
  *   LLMREC_SPMM_EPI_NONE          Y[r] = t                       (Z = Y, alpha = 1: "Y += A X")
  *   LLMREC_SPMM_EPI_SOFTMAX       Y[r] = softmax(t) over the d columns           (reference Models.py:176-177)
  *   LLMREC_SPMM_EPI_SOFTMAX_BWD   Y[r] = S[r] * (t - sum(t * S[r]))              (its backward; S = the forward output)
+ * and finally an optional per-row scale of the OUTPUT (epilogue.post_scale).
  * ------------------------------------------------------------------------------------------ */
 #define LLMREC_SPMM_LONG_ROW 32    /* rows with more nnz leave the lane-group bucket */
 
@@ -109,6 +110,8 @@ typedef struct {
     int32_t op; float alpha;
     const float* Z; int64_t ldz;
     const float* S; int64_t lds;
+    const float* post_scale;     /* [n_rows] or NULL: Y[r] = post_scale[r] * op(t) - lets the CONSUMER of Y run without a per-edge
+                                    col_scale gather (dX = R diag(s) g is computed as R (s . g)) */
 } llmrec_spmm_epilogue_t;
 
 /* counts_host[0..3] = n_wave_rows, n_block_rows, n_split_rows, n_segments (synchronises the stream). */
@@ -327,6 +330,10 @@ int llmrec_zero_multi_f32(int32_t n_tensors, const llmrec_zero_tensor_t* tensors
  *   mode 2 (after it): scal[2] = tail[0]; scal[3] = emb_0; scal[1] = sum_p w_mf[p] * tail[p] + tail[n_problems] */
 int llmrec_loss_assemble_f32(int32_t mode, int32_t n_problems, const float* bpr_out, const float* w_mf_host,
                              float* scal4, float* tail, float inv_world, llmrec_stream_t stream);
+
+/* Y[r] = s[r] * X[r] (Y may alias X) */
+int llmrec_scale_rows_f32(int64_t rows, int32_t d, const float* s, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                          llmrec_stream_t stream);
 
 /* state[0] = step count (as float bits of an int32), state[1] = lr / (1 - b1^t), state[2] = sqrt(1 - b2^t).
  * llmrec_adamw_advance increments t on the device and refreshes state[1..2]. */

@@ -374,6 +374,15 @@ __global__ void loss_assemble_kernel(int mode, int n_prob, const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void scale_rows_kernel(int64_t rows, int d, const float* __restrict__ s, const float* __restrict__ X, int64_t ldx,
+                                                         float* __restrict__ Y, int64_t ldy) {
+    const int64_t n = rows * d;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / d; const int c = (int)(e - r * d);
+        Y[r * ldy + c] = s[r] * X[r * ldx + c];
+    }
+}
+
 extern "C" {
 
 int llmrec_softmax_rows_fwd_f32(int64_t rows, int32_t d, const float* Z, int64_t ldz, float* Y, int64_t ldy,
@@ -563,6 +572,16 @@ int llmrec_loss_assemble_f32(int32_t mode, int32_t n_problems, const float* bpr_
     LossWeights w = {};
     if (w_mf_host) for (int i = 0; i < n_problems; ++i) w.w[i] = w_mf_host[i];
     loss_assemble_kernel<<<1, 64, 0, (hipStream_t)stream_>>>(mode, n_problems, bpr_out, w, scal4, tail, inv_world);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_scale_rows_f32(int64_t rows, int32_t d, const float* s, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                          llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(rows >= 0 && d >= 0, "scale_rows: bad sizes");
+    if (rows * d == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(s && X && Y && ldx >= d && ldy >= d, "scale_rows: null pointer or ld < d");
+    scale_rows_kernel<<<grid_for(rows * d, 256 * 4), 256, 0, (hipStream_t)stream_>>>(rows, d, s, X, ldx, Y, ldy);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

@@ -91,6 +91,7 @@ struct SpmmArgs {
     int64_t ldz;
     const float* S;              // softmax backward: rows of the forward softmax output
     int64_t lds;
+    const float* post_scale;     // per-row scale of the output, applied last
     // plan
     const int32_t* wave_rows;
     const int32_t* block_rows;
@@ -182,6 +183,11 @@ __device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t col0, int6
         c = group_sum<LPR>(c);
 #pragma unroll
         for (int k = 0; k < NCHUNK; ++k) acc[k].sub_mul(c, y[k]);
+    }
+    if (a.post_scale) {
+        const float ps = a.post_scale[row];
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k) acc[k].scale(ps);
     }
 #pragma unroll
     for (int k = 0; k < NCHUNK; ++k) {
@@ -404,7 +410,7 @@ extern "C" int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
         LLMREC_CHECK_ARG(e.op == LLMREC_SPMM_EPI_NONE || a.n_slices == 1, "spmm: the softmax epilogues need the whole row (slice_width = 0)");
         LLMREC_CHECK_ARG(!e.Z || e.ldz >= d, "spmm: epilogue Z with ld < d");
         LLMREC_CHECK_ARG(e.op != LLMREC_SPMM_EPI_SOFTMAX_BWD || (e.S && e.lds >= d), "spmm: softmax backward needs S with ld >= d");
-        a.epi_op = e.op; a.alpha = e.alpha; a.Z = e.Z; a.ldz = e.ldz; a.S = e.S; a.lds = e.lds;
+        a.epi_op = e.op; a.alpha = e.alpha; a.Z = e.Z; a.ldz = e.ldz; a.S = e.S; a.lds = e.lds; a.post_scale = e.post_scale;
         epi_aligned = (!e.Z || (e.ldz % 4 == 0 && (uintptr_t)e.Z % 16 == 0)) && (!e.S || (e.lds % 4 == 0 && (uintptr_t)e.S % 16 == 0));
     }
     const int dd = a.d;

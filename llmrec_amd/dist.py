@@ -105,7 +105,7 @@ class HipBackend:
         epi = None
         if epilogue is not None:
             op = {"none": o.EPI_NONE, "softmax": o.EPI_SOFTMAX, "softmax_bwd": o.EPI_SOFTMAX_BWD}[epilogue.get("op", "none")]
-            epi = o.spmm_epilogue(op, epilogue.get("alpha", 0.0), epilogue.get("Z"), epilogue.get("S"))
+            epi = o.spmm_epilogue(op, epilogue.get("alpha", 0.0), epilogue.get("Z"), epilogue.get("S"), epilogue.get("post_scale"))
         return o.spmm_raw(csr, X, out=out, epilogue=epi)
 
     def row_chunk(self, csr, r0, r1):
@@ -121,6 +121,10 @@ class HipBackend:
     def softmax_bwd_into(self, Y, dY, out):
         o = self.ops
         o._lib.call("llmrec_softmax_rows_bwd_f32", Y.shape[0], Y.shape[1], o._p(Y), o._ld(Y), o._p(dY), o._ld(dY), o._p(out), o._ld(out), o._stream())
+
+    def scale_rows_into(self, s, X, out):
+        o = self.ops
+        o._lib.call("llmrec_scale_rows_f32", X.shape[0], X.shape[1], o._p(s), o._p(X), o._ld(X), o._p(out), o._ld(out), o._stream())
 
     def axpy_into(self, alpha, X, out):
         o = self.ops

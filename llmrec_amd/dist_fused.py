@@ -73,14 +73,21 @@ class ShardedFusedID:
             user_init = (torch.rand(U, d, generator=gu) * 2 - 1) * math.sqrt(6.0 / (n_users_global + d))
         self.item_tab = torch.nn.Parameter(item_init.to(dev).float().contiguous())
         self.user_tab = torch.nn.Parameter(user_init.to(dev).float().contiguous())
-        self.item_tab.grad, self.user_tab.grad = f(I, d), f(U, d)
-        self.opt = backend.optimizer([self.user_tab, self.item_tab], lr)
-        # forward / backward buffers
+        # forward / backward buffers. The user side is the big one (25.6 GB per [U, d] tensor at cfg 5): besides the table
+        # and its two AdamW moments it holds L layer outputs and TWO work tensors - dE_u, which ends the step as the table's
+        # gradient (scaled in place), and hU, which is E_u until the BPR gradient rows are formed and dU / h afterwards
         self.Ul = [f(U, d) for _ in range(n_layers)]
         self.Il = [f(I, d) for _ in range(n_layers)]
-        self.E_u, self.E_i = f(U, d), f(I, d)
         self.dE_u, self.dE_i = f(U, d), f(I, d)
-        self.bufU, self.tmpU, self.bufI, self.tmpI = f(U, d), f(U, d), f(I, d), f(I, d)
+        self.hU = f(U, d)
+        self.E_u, self.E_i = self.hU, f(I, d)
+        self.bufI, self.tmpI = f(I, d), f(I, d)
+        self.item_tab.grad, self.user_tab.grad = f(I, d), self.dE_u
+        self.opt = backend.optimizer([self.user_tab, self.item_tab], lr)
+        # the backward runs the PATTERN operands (no per-edge col_scale gather): the tensor an SpMM gathers from is scaled by
+        # its rows' s once, where it is produced (epilogue post_scale / llmrec_scale_rows_f32): A_iu^T g = R (s_i . g)
+        self.R_user = backend.with_scales(graph.iu_bwd, None, None)       # rows = local users, gathers item rows
+        self.s_u, self.s_i = graph.ui_fwd.row_scale, graph.s_i
         self.rows3 = f(3, batch_local, d)
         self.gat_rows = f(comm.world, 2, batch_local, d)
         self.gat_ids = torch.empty(comm.world, 2, batch_local, dtype=torch.int64, device=dev)
@@ -92,7 +99,7 @@ class ShardedFusedID:
         per = (I + n_chunks - 1) // n_chunks
         self.chunks = [(r0, min(r0 + per, I)) for r0 in range(0, I, per)]
         self.iu_fwd_chunks = [backend.row_chunk(graph.iu_fwd, r0, r1) for r0, r1 in self.chunks]
-        self.ui_bwd_chunks = [backend.row_chunk(graph.ui_bwd, r0, r1) for r0, r1 in self.chunks]
+        self.ui_bwd_chunks = [backend.row_chunk(backend.with_scales(graph.ui_bwd, None, None), r0, r1) for r0, r1 in self.chunks]   # R^T pattern
         deg = backend.degrees(graph.by_user)
         self.exist = torch.nonzero(deg > 0).reshape(-1).to(torch.int64)
         self.seed = seed * 1000003 + comm.rank
@@ -166,26 +173,28 @@ class ShardedFusedID:
         # dI[L] = inv dE_i -> g = softmax_bwd(I_L, dI[L]); then per layer
         #   dU[l+1] = inv dE_u + A_iu[:, blk]^T g          (local; softmax backward as the epilogue on the last layer)
         #   dI[l]   = inv dE_i + sum_r A_ui[blk_r, :]^T h  (chunked + all-reduced; every rank adds inv / world of the replicated dE_i)
+        #   (g and h below are stored PRE-SCALED by s_i / s_u, see __init__)
         g = self.bufI
         if L >= 1:
             be.axpy_into(inv, self.dE_i, self.bufI)
             be.softmax_bwd_into(self.Il[L - 1], self.bufI, self.tmpI)
+            be.scale_rows_into(self.s_i, self.tmpI, self.tmpI)
             g = self.tmpI
         for l in range(L - 1, -1, -1):
             last = l == L - 1
+            epi = {"op": "softmax_bwd" if last else "none", "alpha": inv, "Z": self.dE_u, "post_scale": self.s_u}
             if last:
-                be.spmm(self.g.iu_bwd, g, out=self.tmpU, epilogue={"op": "softmax_bwd", "alpha": inv, "Z": self.dE_u, "S": self.Ul[l]})
-                h = self.tmpU
-            else:
-                be.spmm(self.g.iu_bwd, g, out=self.bufU, epilogue={"op": "none", "alpha": inv, "Z": self.dE_u})
-                h = self.bufU
+                epi["S"] = self.Ul[l]
+            be.spmm(self.R_user, g, out=self.hU, epilogue=epi)                           # h = s_u . dU[l+1] (softmax backward on the last layer)
             dst = self.item_tab.grad if l == 0 else self.bufI
             w = inv / comm.world
-            self._reduced_spmm(self.ui_bwd_chunks, h, dst, epilogue_for=lambda r0, r1: {"op": "none", "alpha": w, "Z": self.dE_i[r0:r1]})
+            self._reduced_spmm(self.ui_bwd_chunks, self.hU, dst,
+                               epilogue_for=lambda r0, r1: {"op": "none", "alpha": w, "Z": self.dE_i[r0:r1],
+                                                            "post_scale": None if l == 0 else self.s_i[r0:r1]})
             g = self.bufI
         if L == 0:
             be.axpy_into(inv, self.dE_i, self.item_tab.grad)
-        be.axpy_into(inv, self.dE_u, self.user_tab.grad)              # U^0 only enters the mean
+        be.axpy_into(inv, self.dE_u, self.dE_u)                       # = user_tab.grad (U^0 only enters the mean), scaled in place
         self.opt.step()
         return (mf + emb).reshape(()), torch.cat([mf, emb])
 

@@ -63,7 +63,8 @@ class SpmmPlanC(_c.Structure):
 
 class SpmmEpilogueC(_c.Structure):
     """llmrec_spmm_epilogue_t"""
-    _fields_ = [("op", _c.c_int32), ("alpha", _c.c_float), ("Z", _c.c_void_p), ("ldz", _c.c_int64), ("S", _c.c_void_p), ("lds", _c.c_int64)]
+    _fields_ = [("op", _c.c_int32), ("alpha", _c.c_float), ("Z", _c.c_void_p), ("ldz", _c.c_int64), ("S", _c.c_void_p), ("lds", _c.c_int64),
+                ("post_scale", _c.c_void_p)]
 
 
 EPI_NONE, EPI_SOFTMAX, EPI_SOFTMAX_BWD = 0, 1, 2
@@ -285,10 +286,12 @@ class BipartiteGraph:
 # ---------------------------------------------------------------------------------------------
 # R2: SpMM
 # ---------------------------------------------------------------------------------------------
-def spmm_epilogue(op: int = EPI_NONE, alpha: float = 0.0, Z: Optional[torch.Tensor] = None, S: Optional[torch.Tensor] = None):
-    """llmrec_spmm_epilogue_t: Y = op(alpha * Z + A X); S = forward softmax rows for EPI_SOFTMAX_BWD."""
+def spmm_epilogue(op: int = EPI_NONE, alpha: float = 0.0, Z: Optional[torch.Tensor] = None, S: Optional[torch.Tensor] = None,
+                  post_scale: Optional[torch.Tensor] = None):
+    """llmrec_spmm_epilogue_t: Y = post_scale . op(alpha * Z + A X); S = forward softmax rows for EPI_SOFTMAX_BWD."""
     return SpmmEpilogueC(op, float(alpha), Z.data_ptr() if Z is not None else None, _ld(Z) if Z is not None else 0,
-                         S.data_ptr() if S is not None else None, _ld(S) if S is not None else 0)
+                         S.data_ptr() if S is not None else None, _ld(S) if S is not None else 0,
+                         post_scale.data_ptr() if post_scale is not None else None)
 
 
 def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False, epilogue=None,

@@ -35,6 +35,8 @@ class CpuBackend:
             elif op == "softmax_bwd":
                 S = epilogue["S"]
                 Y = S * (Y - (Y * S).sum(-1, keepdim=True))
+            if epilogue.get("post_scale") is not None:
+                Y = Y * epilogue["post_scale"][:, None]
         if out is not None:
             out.copy_(Y)
             return out
@@ -53,6 +55,9 @@ class CpuBackend:
 
     def axpy_into(self, alpha, X, out):
         out.copy_(alpha * X)
+
+    def scale_rows_into(self, s, X, out):
+        out.copy_(X * s[:, None])
 
     def layer_mean_into(self, terms, out):
         out.copy_(torch.mean(torch.stack(list(terms)), dim=0))
