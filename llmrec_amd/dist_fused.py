@@ -65,12 +65,16 @@ class ShardedFusedID:
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         # parameters: xavier_uniform over the GLOBAL table shapes (reference Models.py:39-42); the item table is drawn
         # identically on every rank, the user rows per rank
+        def xavier(rows, bound, gen_seed):
+            # drawn ON the device (25.6 GB tables at cfg 5); the same seed gives the same table on every rank
+            gen = torch.Generator(device=dev); gen.manual_seed(gen_seed)
+            t = torch.empty(rows, d, dtype=torch.float32, device=dev)
+            t.uniform_(-bound, bound, generator=gen)
+            return t
         if item_init is None:
-            gen = torch.Generator(device="cpu"); gen.manual_seed(seed)
-            item_init = (torch.rand(I, d, generator=gen) * 2 - 1) * math.sqrt(6.0 / (I + d))
+            item_init = xavier(I, math.sqrt(6.0 / (I + d)), seed)
         if user_init is None:
-            gu = torch.Generator(device="cpu"); gu.manual_seed(seed * 7919 + 1 + comm.rank)
-            user_init = (torch.rand(U, d, generator=gu) * 2 - 1) * math.sqrt(6.0 / (n_users_global + d))
+            user_init = xavier(U, math.sqrt(6.0 / (n_users_global + d)), seed * 7919 + 1 + comm.rank)
         self.item_tab = torch.nn.Parameter(item_init.to(dev).float().contiguous())
         self.user_tab = torch.nn.Parameter(user_init.to(dev).float().contiguous())
         # forward / backward buffers. The user side is the big one (25.6 GB per [U, d] tensor at cfg 5): besides the table
