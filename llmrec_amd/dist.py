@@ -34,13 +34,17 @@ class Comm:
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.rank = self.dist.get_rank() if self.dist else 0
         self.world = self.dist.get_world_size() if self.dist else 1
+        import os
+        # LLMREC_FORCE_COLLECTIVES=1: issue every collective even in a world of one rank (plumbing check of the RCCL calls
+        # on a 1-GPU box: `torch.distributed.run --nproc-per-node 1 bench.py ...`)
+        self.force = self.dist is not None and os.environ.get("LLMREC_FORCE_COLLECTIVES", "0") == "1"
 
     def _host_staged(self) -> bool:
         """gloo (the CPU-test backend) moves device tensors through host copies and lacks some fused collectives."""
         return self.dist is not None and self.dist.get_backend() == "gloo"
 
     def all_reduce_(self, t: torch.Tensor, force: bool = False) -> torch.Tensor:
-        if self.dist and (self.world > 1 or force):
+        if self.dist and (self.world > 1 or force or self.force):
             if self._host_staged() and t.is_cuda:
                 h = t.cpu()
                 self.dist.all_reduce(h)
@@ -51,7 +55,7 @@ class Comm:
 
     def all_gather_into(self, out: torch.Tensor, t: torch.Tensor, force: bool = False) -> torch.Tensor:
         """out[world * n] <- the ranks' t[n] in rank order (preallocated, graph-step friendly)."""
-        if self.dist and (self.world > 1 or force):
+        if self.dist and (self.world > 1 or force or self.force):
             if self._host_staged() and t.is_cuda:
                 parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(self.world)]
                 self.dist.all_gather(parts, t.cpu())
@@ -63,7 +67,7 @@ class Comm:
         return out
 
     def all_gather_cat(self, t: torch.Tensor) -> torch.Tensor:
-        if not (self.dist and self.world > 1):
+        if not (self.dist and (self.world > 1 or self.force)):
             return t
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         self.dist.all_gather_into_tensor(out, t.contiguous())

@@ -41,7 +41,7 @@ def all_reduce_start(comm: Comm, t: torch.Tensor):
     """Start an in-place sum all-reduce of t; returns a handle whose wait() orders the CURRENT stream after it.
     nccl (= RCCL): asynchronous on the communicator's stream (it first waits for the work already queued on the
     current stream, i.e. for the kernel that produced t); gloo / one rank: done on return."""
-    if comm.dist is None or comm.world == 1:
+    if comm.dist is None or (comm.world == 1 and not comm.force):
         return _Done()
     if comm._host_staged():
         comm.all_reduce_(t)
