@@ -21,6 +21,7 @@ Falls outside its scope (use the modular path): dropout > 0 and the --mask branc
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional
 
 import torch
@@ -189,10 +190,12 @@ class FusedStep:
         return (_c.c_float * len(r))(*r)
 
     # -- forward ----------------------------------------------------------------------------------
-    def forward(self):
+    def forward(self, sampler=None):
         m, d = self.m, self.d
         self._fork(self.s2)
         with self._on(self.s2):                                          # ID chain: needs no projection
+            if sampler is not None and self.multi_stream:                # the batch is first read by the losses, after the join below:
+                sampler()                                                # sampling rides beside the projection instead of ahead of it
             if self._zero_in_forward:                                    # the backward's scatter targets, off the critical path
                 self._zero_accumulators()
                 self.opt.advance()                                       # AdamW's step counter / bias corrections, likewise
@@ -366,11 +369,11 @@ class FusedStep:
         ops.linear_wgrad_grouped(item_pairs, m.item_trans.weight.grad, m.item_trans.bias.grad, False, self.ws_wgrad, precision=self.gemm)
         self._join(self.s1, self.s2, self.s3, self.s4)
 
-    def _train_forward(self):
-        """forward() of a training step: also clears the backward's scatter targets on a side stream."""
+    def _train_forward(self, sampler=None):
+        """forward() of a training step: also clears the backward's scatter targets (and samples the batch) on a side stream."""
         self._zero_in_forward = True
         try:
-            self.forward()
+            self.forward(sampler)
         finally:
             self._zero_in_forward = False
         self._zeroed = True
@@ -378,9 +381,10 @@ class FusedStep:
     def step_eager(self, users, pos, neg, n_valid=None, sampler=None):
         """sampler: optional callable that fills (users, pos, neg, n_valid) on the current stream first (inside the same
         graph when captured; running it on a side stream beside the forward measured no faster)."""
-        if sampler is not None:
+        side = os.environ.get("LLMREC_SAMPLER_SIDE", "1") == "1" and self.multi_stream
+        if sampler is not None and not side:
             sampler()
-        self._train_forward()
+        self._train_forward(sampler if side else None)
         self.loss_backward(users, pos, neg, n_valid)
         self.opt.step(advanced=True)
         return self.scal[1], self.scal[2], self.scal[3]
