@@ -170,6 +170,6 @@ def test_fused_graph_step_and_eval_at_netflix_shape_match_oracle():
     rep = bench.parity_check(w, n_eval_users=192)
     print(rep)
     assert rep["forward_max_rel"] < 1e-4 and rep["bpr_max_rel"] < 1e-4 and rep["loss_rel"] < 1e-4, rep
-    assert rep["grad_max_rel"] < 1e-4 and rep["param_max_rel"] < 1e-4, rep
+    assert rep["grad_max_rel"] < 1e-4 and rep["adamw_given_gpu_grads_max_rel"] < 1e-5 and rep["param_max_rel"] < 2e-4, rep
     assert rep["topk_lists_equal"] == rep["topk_lists_checked"] > 0, rep
     assert rep["ok"], rep
