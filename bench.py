@@ -530,7 +530,11 @@ def parity_check(w: "NetflixShaped", n_eval_users: int = 256, steps: int = 2, to
             worst[kind], worst_name[kind] = e, name
     f = w.fused
     t0 = time.perf_counter()
+    gp = dict(w.model.named_parameters())
     for s in range(steps):
+        # the GPU's own optimiser inputs before this step (parameters, moments), for the AdamW-in-isolation check below
+        pre = {nm: gp[nm].detach().cpu().clone() for nm in ORACLE_PARAMS}
+        pre_mv = {nm: tuple(t.detach().cpu().clone() for t in w.opt.state[gp[nm]]) if gp[nm] in w.opt.state else None for nm in ORACLE_PARAMS}
         if w.use_graph:
             w.step()                                             # step 1 = the capture's eager warm-up, then graph replays
             torch.cuda.synchronize()
@@ -558,17 +562,18 @@ def parity_check(w: "NetflixShaped", n_eval_users: int = 256, steps: int = 2, to
         want = torch.tensor([[float(a.detach()), float(b.detach())] for a, b in parts["bpr"]], dtype=torch.float64)
         upd("bpr", "step%d" % s, float((got - want).abs().max() / want.abs().max()))
         upd("loss", "step%d" % s, abs(float(f.scal[1]) - float(loss)) / abs(float(loss)))
-        gp = dict(w.model.named_parameters())
         for nm in ORACLE_PARAMS:
             upd("grad", "step%d/%s" % (s, nm), rel(gp[nm].grad.detach().cpu(), grads[nm]))
         # the optimiser kernel in isolation: the oracle's AdamW fed with the GPU's OWN gradients must land on the GPU's
         # parameters (the end-to-end comparison below also carries Adam's amplification of gradient noise: in the first
         # steps the update is lr * g / (|g| + 1e-8), ill-conditioned where |g| is of the order of the gradient's
         # absolute error)
-        iso = {k: v.detach().clone() for k, v in params.items()}
+        iso = {nm: pre[nm].clone() for nm in ORACLE_PARAMS}
         opt_iso = O.AdamW(iso, lr=cfg.lr)
-        opt_iso.t = opt.t
-        opt_iso.m = {k: v.clone() for k, v in opt.m.items()}; opt_iso.v = {k: v.clone() for k, v in opt.v.items()}
+        opt_iso.t = s
+        for nm in ORACLE_PARAMS:
+            if pre_mv[nm] is not None:
+                opt_iso.m[nm], opt_iso.v[nm] = pre_mv[nm][0].clone(), pre_mv[nm][1].clone()
         opt_iso.step({nm: gp[nm].grad.detach().cpu() for nm in ORACLE_PARAMS})
         for nm in ORACLE_PARAMS:
             upd("adamw", "step%d/%s" % (s, nm), rel(gp[nm].detach().cpu(), iso[nm]))
