@@ -76,3 +76,50 @@ int run_stream(const float* X, int64_t n4, int blocks, float* out, void* stream)
     return (int)hipGetLastError();
 }
 }
+
+// The weight-gradient kernel's X stream alone: one wave per SIMD (a 100 KB LDS array forces one block per CU), each wave
+// walks a slab of rows for one 64-column k slab, 32 rows per tile, lane (li, lq) loads the float4 at row m0 + 4 j + lq,
+// column k0 + 4 li (j = 0..7); STAGES tiles in flight. What this reaches is the kernel's memory-latency ceiling.
+template <int STAGES>
+__global__ __launch_bounds__(256, 1) void wgradx_kernel(const float* __restrict__ X, int64_t ldx, int64_t M, int n_kslab, int64_t MC, float* out) {
+    __shared__ float pad[25000];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+    const int kslab = blockIdx.x % n_kslab, group = blockIdx.x / n_kslab;
+    const int64_t m_begin = (int64_t)(group * 4 + wave) * MC;
+    int64_t m_end = m_begin + MC; if (m_end > M) m_end = M;
+    if (threadIdx.x == 0 && M < 0) pad[0] = 1.f;
+    const float* base = X + kslab * 64 + 4 * li;
+    float4 acc = make_float4(0, 0, 0, 0);
+    float4 st[STAGES][8];
+    auto load = [&](int64_t m0, float4 (&v)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { int64_t r = m0 + 4 * j + lq; if (r > m_end - 1) r = m_end - 1; v[j] = *reinterpret_cast<const float4*>(base + r * ldx); }
+    };
+    auto use = [&](const float4 (&v)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+    };
+    if (m_begin >= M) return;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) load(m_begin + 32 * s, st[s]);
+    for (int64_t m0 = m_begin; m0 < m_end; m0 += 32 * STAGES) {
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s) {
+            load(m0 + 32 * (s + STAGES - 1), st[(s + STAGES - 1) % STAGES]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m0 + 32 * s < m_end) use(st[s]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x + pad[1];
+}
+extern "C" int run_wgradx(const float* X, int64_t ldx, int64_t M, int K, int64_t MC, int stages, float* out, void* stream) {
+    const int n_kslab = K / 64;
+    const int groups = (int)((M + 4 * MC - 1) / (4 * MC));
+    dim3 grid(n_kslab * groups);
+    if (stages == 2) wgradx_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(X, ldx, M, n_kslab, MC, out);
+    else if (stages == 3) wgradx_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>(X, ldx, M, n_kslab, MC, out);
+    else if (stages == 4) wgradx_kernel<4><<<grid, 256, 0, (hipStream_t)stream>>>(X, ldx, M, n_kslab, MC, out);
+    else wgradx_kernel<6><<<grid, 256, 0, (hipStream_t)stream>>>(X, ldx, M, n_kslab, MC, out);
+    return (int)hipGetLastError();
+}

@@ -32,3 +32,10 @@ for contig in (0, 1):
     for barrier in (0, 1):
         ms = timeit(lambda: lib.run_gemmx(p(X), ctypes.c_int64(K), K, blocks, contig, barrier, p(out), st))
         print("projection X pattern (32 k per step, 3 stages) contiguous-64B=%d barrier=%d: %.3f ms  %.0f GB/s" % (contig, barrier, ms, byts / ms / 1e6))
+
+# the weight-gradient kernel's X stream alone (one wave per SIMD, 240 blocks): how the rate depends on the tiles in flight
+lib.run_wgradx.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+MC = 2176                                            # 5 x 17366 rows in 40 slabs -> 10 groups x 24 k slabs = 240 blocks
+for stages in (2, 3, 4, 6):
+    ms = timeit(lambda: lib.run_wgradx(p(X), K, M, K, MC, stages, p(out), st))
+    print("wgrad X stream alone, %d tiles (of 8 KB per wave) rotating, one wave per SIMD: %.3f ms  %.0f GB/s" % (stages, ms, 4.0 * M * K / ms / 1e6))
