@@ -76,7 +76,6 @@ class DataParallelStep(FusedStep):
         self.force = os.environ.get("LLMREC_DP_FORCE_COLLECTIVES", "0") == "1" and comm is not None and comm.dist is not None
         self.lazy_update = os.environ.get("LLMREC_DP_LAZY", "1") == "1"   # defer AdamW into the next step's first graph (see step())
         self._pending_update = False
-        self.one_graph = os.environ.get("LLMREC_DP_ONE_GRAPH", "0") == "1"
 
     # -- the three compute phases -----------------------------------------------------------------
     def _bpr_phase(self, phase, users, pos, neg, n_valid):
@@ -153,17 +152,6 @@ class DataParallelStep(FusedStep):
             first(); self.exchange_scores(); self.phase_b(*args); self.exchange_grads(); self.phase_c()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        if self.one_graph:
-            # EXPERIMENTAL (LLMREC_DP_ONE_GRAPH=1, not the default): the two RCCL collectives captured inside ONE graph with
-            # the compute, so a replica step is a single graph launch like the single-GPU step. Only exercised in a world of
-            # one rank so far; the default keeps the collectives outside the graphs.
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                first(); self.exchange_scores(); self.phase_b(*args); self.exchange_grads(); self.phase_c()
-            self.graphs = [g]
-            self.graph_exec = g
-            return
-
         def first_with_update():                               # the previous step's AdamW opens the next step's first graph
             self.phase_c()
             first()
@@ -190,9 +178,6 @@ class DataParallelStep(FusedStep):
             self._load(users, pos, neg, n_valid)
         elif getattr(self, "batcher", None) is None:
             raise RuntimeError("DataParallelStep.step: a batch is needed (the graphs were captured without a sampler)")
-        if self.one_graph:
-            self.graphs[0].replay()
-            return self.scal[1], self.scal[2], self.scal[3]
         ga, gb, gc, ga_upd = self.graphs
         if self.lazy_update:
             (ga_upd if self._pending_update else ga).replay()
@@ -210,7 +195,7 @@ class DataParallelStep(FusedStep):
 
     def flush(self):
         """Apply the deferred AdamW update of the last step (and its loss scalars)."""
-        if self.graphs is not None and not self.one_graph and getattr(self, "_pending_update", False):
+        if self.graphs is not None and getattr(self, "_pending_update", False):
             self.graphs[2].replay()
             self._pending_update = False
 

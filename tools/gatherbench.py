@@ -104,3 +104,9 @@ run("D uniform 2M rows d=64 deg36 write", 64, 2_000_000, uniform_idx(2_000_000, 
 run("D uniform 10M rows d=64 deg36 write", 64, 10_000_000, uniform_idx(10_000_000, N), 36, 1)
 if len(sys.argv) > 1:
     json.dump(results, open(sys.argv[1], "w"), indent=1)
+# E: rows per lane group matter? the same 36 M gathers cut into rows of deg nnz (each row also writes its 256-B output)
+for deg in (1, 2, 4, 8, 18, 64):
+    n = N // deg * deg
+    run("E zipf0.8 1M rows d=64 write deg=%d" % deg, 64, 1_000_000, zi[:n], deg, 1)
+if len(sys.argv) > 1:
+    json.dump(results, open(sys.argv[1], "w"), indent=1)
