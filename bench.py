@@ -421,6 +421,21 @@ class RowSharded:
             out["loss"] = float(self.last[0]); out["mf_emb"] = [float(x) for x in self.last[1]]
         return out
 
+    def eval_sample(self, n_users=65536, K=50):
+        """Full-rank scoring + masked top-50 of a sample of this rank's users against all items (R9 at the config's size)."""
+        import torch
+        st = self.step_obj
+        n = min(n_users, st.U)
+        q = torch.arange(0, st.U, max(1, st.U // n), device=self.device, dtype=torch.int64)[:n]
+        st.forward(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx, _ = st.eval_topk(q, K, forward=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        flop = 2.0 * q.numel() * st.I * self.cfg["d"]
+        return {"users": int(q.numel()), "items": st.I, "K": K, "ms": dt * 1e3, "users_per_s": q.numel() / dt, "tflops": flop / dt / 1e12,
+                "frac_mfma_f32": flop / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, "lists_full": bool((idx[:, K - 1] >= 0).all())}
+
     def spmm_times_ms(self, iters=3):
         """In-situ size, each direction alone: the numbers the SpMM roofline is computed from."""
         import torch
@@ -886,6 +901,7 @@ def main():
                 line["parity"] = w.sampled_row_parity()
             if world == 1 and not a.no_kernel_roofline:
                 line["spmm_in_situ"] = w.spmm_times_ms()
+                line["eval_sample"] = w.eval_sample()
     if rank == 0:
         print(json.dumps(line), flush=True)
     if use_pg:

@@ -202,6 +202,15 @@ class ShardedFusedID:
         self.opt.step()
         return (mf + emb).reshape(()), torch.cat([mf, emb])
 
+    # -- evaluation ------------------------------------------------------------------------------------------
+    def eval_topk(self, query_users_local: torch.Tensor, K: int = 50, forward: bool = True):
+        """Full-rank evaluation of this rank's users (reference utility/batch_test.py:112-169): users shard, the item table
+        is replicated, so ranks are independent - no-grad forward (with its layer all-reduces) + scoring + masked top-K
+        against the local training rows. Returns (idx int32 [n, K], scores)."""
+        if forward:
+            self.forward()
+        return self.be.score_topk(self.E_u, self.E_i, query_users_local, self.g.by_user, K)
+
     # -- accounting for bench.py -------------------------------------------------------------------------
     def message_bytes_per_step(self) -> dict:
         return {"allreduce_I_x_d_bytes": 4 * self.I * self.d * 2 * self.L, "allreduce_messages": 2 * self.L * len(self.chunks),
