@@ -331,6 +331,10 @@ int llmrec_zero_multi_f32(int32_t n_tensors, const llmrec_zero_tensor_t* tensors
 int llmrec_loss_assemble_f32(int32_t mode, int32_t n_problems, const float* bpr_out, const float* w_mf_host,
                              float* scal4, float* tail, float inv_world, llmrec_stream_t stream);
 
+/* out[b] = scale * sum_t terms[t][idx[b]] for b < n: the layer mean of reference Models.py:185-186 for the rows a batch
+ * needs only (row-sharded step: B rows instead of a pass over the 10^7-row user tables) */
+int llmrec_gather_mean_f32(int64_t n, const int64_t* idx, int32_t d, float scale, int32_t n_terms,
+                           const float* const* terms, const int64_t* term_ld, float* out, int64_t ldo, llmrec_stream_t stream);
 /* Y[r] = s[r] * X[r] (Y may alias X) */
 int llmrec_scale_rows_f32(int64_t rows, int32_t d, const float* s, const float* X, int64_t ldx, float* Y, int64_t ldy,
                           llmrec_stream_t stream);
@@ -344,7 +348,9 @@ int llmrec_adamw_f32(int64_t n, float* p, const float* g, float* m, float* v, co
 
 /* the same update for up to LLMREC_ADAMW_MAX_TENSORS parameters in one launch */
 #define LLMREC_ADAMW_MAX_TENSORS 16
-typedef struct { float* p; const float* g; float* m; float* v; int64_t n; } llmrec_adamw_tensor_t;
+typedef struct { float* p; const float* g; float* m; float* v; int64_t n;
+                 float g_scale;   /* the gradient is g_scale * g (non-zero; 1 = plain): saves a scaling pass over a large table */
+} llmrec_adamw_tensor_t;
 int llmrec_adamw_multi_f32(int32_t n_tensors, const llmrec_adamw_tensor_t* tensors_host, const float* state3,
                            float lr, float beta1, float beta2, float eps, float weight_decay, llmrec_stream_t stream);
 

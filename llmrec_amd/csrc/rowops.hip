@@ -277,6 +277,7 @@ struct AdamwTensors {
     float* m[LLMREC_ADAMW_MAX_TENSORS];
     float* v[LLMREC_ADAMW_MAX_TENSORS];
     int64_t n[LLMREC_ADAMW_MAX_TENSORS];
+    float gscale[LLMREC_ADAMW_MAX_TENSORS];
     int32_t block_begin[LLMREC_ADAMW_MAX_TENSORS + 1];
     int32_t n_tensors;
 };
@@ -291,13 +292,14 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamwTensors t, const 
     float* __restrict__ p = t.p[k]; const float* __restrict__ g = t.g[k];
     float* __restrict__ m = t.m[k]; float* __restrict__ v = t.v[k];
     const int64_t n = t.n[k];
+    const float gs = t.gscale[k];
     const float step_size = state[1], bc2s = state[2];
     const float w1 = 1.0f - b1, w2 = 1.0f - b2;
 #pragma unroll 4
     for (int j = 0; j < 16; ++j) {
         const int64_t i = base + j * 256 + threadIdx.x;
         if (i >= n) break;
-        const float gi = g[i];
+        const float gi = gs == 1.0f ? g[i] : gs * g[i];
         float pi = p[i] * decay_mul;
         const float mi = m[i] + w1 * (gi - m[i]);
         const float vi = fmaf(w2 * gi, gi, v[i] * b2);
@@ -380,6 +382,21 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(int64_t rows, int d, co
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = e / d; const int c = (int)(e - r * d);
         Y[r * ldy + c] = s[r] * X[r * ldx + c];
+    }
+}
+
+struct GatherTerms { const float* t[LLMREC_MAX_TERMS]; int64_t ld[LLMREC_MAX_TERMS]; int n; };
+
+__global__ __launch_bounds__(256) void gather_mean_kernel(int64_t n, const int64_t* __restrict__ idx, int d, float scale, GatherTerms g,
+                                                          float* __restrict__ out, int64_t ldo) {
+    const int gl = threadIdx.x & 15;
+    const int64_t b = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (b >= n) return;
+    const int64_t row = idx[b];
+    for (int c = gl; c < d; c += 16) {
+        float s = 0.f;
+        for (int t = 0; t < g.n; ++t) s += g.t[t][row * g.ld[t] + c];
+        out[b * ldo + c] = scale * s;
     }
 }
 
@@ -533,7 +550,8 @@ int llmrec_adamw_multi_f32(int32_t n_tensors, const llmrec_adamw_tensor_t* tenso
     for (int i = 0; i < n_tensors; ++i) {
         const llmrec_adamw_tensor_t& x = tensors_host[i];
         LLMREC_CHECK_ARG(x.n >= 0 && (x.n == 0 || (x.p && x.g && x.m && x.v)), "adamw_multi: tensor %d has a null pointer", i);
-        t.p[i] = x.p; t.g[i] = x.g; t.m[i] = x.m; t.v[i] = x.v; t.n[i] = x.n;
+        LLMREC_CHECK_ARG(x.g_scale != 0.0f, "adamw_multi: tensor %d has g_scale 0 (set 1 for a plain gradient)", i);
+        t.p[i] = x.p; t.g[i] = x.g; t.m[i] = x.m; t.v[i] = x.v; t.n[i] = x.n; t.gscale[i] = x.g_scale;
         t.block_begin[i] = blocks;
         blocks += (int)ceil_div(x.n, ADAMW_PER_BLOCK);
     }
@@ -582,6 +600,22 @@ int llmrec_scale_rows_f32(int64_t rows, int32_t d, const float* s, const float* 
     if (rows * d == 0) return LLMREC_OK;
     LLMREC_CHECK_ARG(s && X && Y && ldx >= d && ldy >= d, "scale_rows: null pointer or ld < d");
     scale_rows_kernel<<<grid_for(rows * d, 256 * 4), 256, 0, (hipStream_t)stream_>>>(rows, d, s, X, ldx, Y, ldy);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_gather_mean_f32(int64_t n, const int64_t* idx, int32_t d, float scale, int32_t n_terms,
+                           const float* const* terms, const int64_t* term_ld, float* out, int64_t ldo, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n >= 0 && d > 0 && n_terms >= 1 && n_terms <= LLMREC_MAX_TERMS, "gather_mean: bad sizes");
+    if (n == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(idx && terms && term_ld && out && ldo >= d, "gather_mean: null pointer or ld < d");
+    GatherTerms g = {};
+    g.n = n_terms;
+    for (int t = 0; t < n_terms; ++t) {
+        LLMREC_CHECK_ARG(terms[t] && term_ld[t] >= d, "gather_mean: bad term %d", t);
+        g.t[t] = terms[t]; g.ld[t] = term_ld[t];
+    }
+    gather_mean_kernel<<<(unsigned)ceil_div(n, 16), 256, 0, (hipStream_t)stream_>>>(n, idx, d, scale, g, out, ldo);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

@@ -142,6 +142,17 @@ class HipBackend:
         o._lib.call("llmrec_fuse_fwd_f32", out.shape[0], out.shape[1], 1.0 / len(terms), len(terms), mp, ml, 0, npt, nl, r,
                     o._p(out), o._ld(out), o._stream())
 
+    def gather_mean_into(self, terms, idx, out):
+        """out[b] = mean_t terms[t][idx[b]] (llmrec_gather_mean_f32)."""
+        o = self.ops
+        tp, tl = o._ptr_table(list(terms))
+        o._lib.call("llmrec_gather_mean_f32", idx.numel(), o._p(idx), out.shape[1], 1.0 / len(terms), len(terms), tp, tl, o._p(out), o._ld(out), o._stream())
+
+    def optimizer_step(self, opt, grad_scales):
+        """AdamW over opt's parameters; grad_scales {param: s}: that parameter's gradient is s * param.grad."""
+        opt.grad_scale = dict(grad_scales)
+        opt.step()
+
     def zero_(self, tensors):
         o = self.ops
         arr = (o.ZeroTensor * len(tensors))()

@@ -78,8 +78,10 @@ class ShardedFusedID:
         self.item_tab = torch.nn.Parameter(item_init.to(dev).float().contiguous())
         self.user_tab = torch.nn.Parameter(user_init.to(dev).float().contiguous())
         # forward / backward buffers. The user side is the big one (25.6 GB per [U, d] tensor at cfg 5): besides the table
-        # and its two AdamW moments it holds L layer outputs and TWO work tensors - dE_u, which ends the step as the table's
-        # gradient (scaled in place), and hU, which is E_u until the BPR gradient rows are formed and dU / h afterwards
+        # and its two AdamW moments it holds L layer outputs and TWO work tensors - dE_u, which IS the table's gradient up
+        # to the factor 1 / (L + 1) that AdamW applies on the fly (grad_scale), and hU = dU / h in the backward (and the
+        # dense E_u of an evaluation). A training step never forms the dense E_u: the BPR loss needs its B batch rows only
+        # (llmrec_gather_mean_f32)
         self.Ul = [f(U, d) for _ in range(n_layers)]
         self.Il = [f(I, d) for _ in range(n_layers)]
         self.dE_u, self.dE_i = f(U, d), f(I, d)
@@ -93,6 +95,8 @@ class ShardedFusedID:
         self.R_user = backend.with_scales(graph.iu_bwd, None, None)       # rows = local users, gathers item rows
         self.s_u, self.s_i = graph.ui_fwd.row_scale, graph.s_i
         self.rows3 = f(3, batch_local, d)
+        self.Eu_rows = f(batch_local, d)
+        self.arange_b = torch.arange(batch_local, dtype=torch.int64, device=dev)
         self.gat_rows = f(comm.world, 2, batch_local, d)
         self.gat_ids = torch.empty(comm.world, 2, batch_local, dtype=torch.int64, device=dev)
         self.my_ids = torch.empty(2, batch_local, dtype=torch.int64, device=dev)
@@ -129,7 +133,8 @@ class ShardedFusedID:
                 after(c, view)
 
     # -- forward ---------------------------------------------------------------------------------------
-    def forward(self):
+    def forward(self, dense_users: bool = True):
+        """dense_users = False (training): E_u is not materialised (the loss gathers its batch rows)."""
         be, L = self.be, self.L
         i_prev = self.item_tab.detach()
         for l in range(L):
@@ -138,7 +143,8 @@ class ShardedFusedID:
             self._reduced_spmm(self.iu_fwd_chunks, self.Ul[l], self.Il[l],
                                after=(lambda c, view: be.softmax_rows_into(view, view)) if last else None)
             i_prev = self.Il[l]
-        be.layer_mean_into([self.user_tab.detach()] + self.Ul, self.E_u)
+        if dense_users:
+            be.layer_mean_into([self.user_tab.detach()] + self.Ul, self.E_u)
         be.layer_mean_into([self.item_tab.detach()] + self.Il, self.E_i)
         return self.E_u, self.E_i
 
@@ -153,11 +159,14 @@ class ShardedFusedID:
         u, p, n = triples if triples is not None else self.sample()
         self.step_id += 1
         self.allreduce_bytes = 0
-        self.forward()
-        # BPR + prune over the global batch (reference main.py:158-165,330-342): two passes around an all-gather of B floats
-        _, s1 = be.bpr_fwd(self.E_u, self.E_i, u, p, n, self.remember, self.decay, self.bsz_flag, None, 0, 0, True)
+        self.forward(dense_users=False)
+        # BPR + prune over the global batch (reference main.py:158-165,330-342): two passes around an all-gather of B floats;
+        # the user side of the loss is the B x d block of layer-mean rows, indexed 0..B-1
+        be.gather_mean_into([self.user_tab.detach()] + self.Ul, u, self.Eu_rows)
+        ar = self.arange_b
+        _, s1 = be.bpr_fwd(self.Eu_rows, self.E_i, ar, p, n, self.remember, self.decay, self.bsz_flag, None, 0, 0, True)
         global_m = comm.all_gather_cat(be.bpr_local_m(s1, B).contiguous())
-        out, saved = be.bpr_fwd(self.E_u, self.E_i, u, p, n, self.remember, self.decay, self.bsz_flag, global_m, global_m.numel(),
+        out, saved = be.bpr_fwd(self.Eu_rows, self.E_i, ar, p, n, self.remember, self.decay, self.bsz_flag, global_m, global_m.numel(),
                                 comm.rank * B, False)
         small = torch.cat([saved[B:B + 3], out[:1]])
         comm.all_reduce_(small)                                   # the three squared norms + the mf shares
@@ -166,7 +175,7 @@ class ShardedFusedID:
         emb = (self.decay * ((1.0 / (2.0 * small[:3] + 1e-8)).sum() / self.bsz_flag)).reshape(1)
         # backward: compact gradient rows; users scatter locally, item rows are exchanged (all-gather of 2 B rows)
         ones = torch.ones(2, dtype=torch.float32, device=out.device)
-        be.bpr_bwd_rows(self.E_u, self.E_i, u, p, n, self.decay, self.bsz_flag, saved, ones, self.rows3)
+        be.bpr_bwd_rows(self.Eu_rows, self.E_i, ar, p, n, self.decay, self.bsz_flag, saved, ones, self.rows3)
         be.zero_([self.dE_u, self.dE_i])
         be.scatter_rows(u, self.rows3[0], self.dE_u, 1.0)
         self.my_ids[0].copy_(p); self.my_ids[1].copy_(n)
@@ -198,8 +207,8 @@ class ShardedFusedID:
             g = self.bufI
         if L == 0:
             be.axpy_into(inv, self.dE_i, self.item_tab.grad)
-        be.axpy_into(inv, self.dE_u, self.dE_u)                       # = user_tab.grad (U^0 only enters the mean), scaled in place
-        self.opt.step()
+        # user_tab.grad = inv * dE_u (U^0 only enters the mean): the factor rides in AdamW instead of a pass over the table
+        be.optimizer_step(self.opt, {self.user_tab: inv})
         return (mf + emb).reshape(()), torch.cat([mf, emb])
 
     # -- evaluation ------------------------------------------------------------------------------------------

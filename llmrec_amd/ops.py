@@ -618,7 +618,7 @@ def sumsq(coef: float, Xs: Sequence[torch.Tensor]):
 # ---------------------------------------------------------------------------------------------
 class AdamwTensor(_c.Structure):
     """llmrec_adamw_tensor_t"""
-    _fields_ = [("p", _c.c_void_p), ("g", _c.c_void_p), ("m", _c.c_void_p), ("v", _c.c_void_p), ("n", _c.c_int64)]
+    _fields_ = [("p", _c.c_void_p), ("g", _c.c_void_p), ("m", _c.c_void_p), ("v", _c.c_void_p), ("n", _c.c_int64), ("g_scale", _c.c_float)]
 
 
 class FusedAdamW:
@@ -631,6 +631,7 @@ class FusedAdamW:
         self.lr, self.betas, self.eps, self.wd = float(lr), betas, float(eps), float(weight_decay)
         self.state = {}
         self.dev_state = None
+        self.grad_scale = {}                    # {param: s}: the gradient of that parameter is s * param.grad (default 1)
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -670,6 +671,7 @@ class FusedAdamW:
                 g = p.grad.contiguous()
                 keep.append(g)
                 arr[i].p, arr[i].g, arr[i].m, arr[i].v, arr[i].n = p.data_ptr(), g.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), p.numel()
+                arr[i].g_scale = float(self.grad_scale.get(p, 1.0))
             _lib.call("llmrec_adamw_multi_f32", len(group), arr, _p(self.dev_state), self.lr, self.betas[0], self.betas[1],
                       self.eps, self.wd, _stream())
 

@@ -62,6 +62,15 @@ class CpuBackend:
     def layer_mean_into(self, terms, out):
         out.copy_(torch.mean(torch.stack(list(terms)), dim=0))
 
+    def gather_mean_into(self, terms, idx, out):
+        out.copy_(torch.mean(torch.stack([t[idx] for t in terms]), dim=0))
+
+    def optimizer_step(self, opt, grad_scales):
+        with torch.no_grad():
+            for p, s in grad_scales.items():
+                p.grad.mul_(s)
+        opt.step()
+
     def zero_(self, tensors):
         for t in tensors:
             t.zero_()
