@@ -101,8 +101,8 @@ class ShardedFusedID:
         self.gat_ids = torch.empty(comm.world, 2, batch_local, dtype=torch.int64, device=dev)
         self.my_ids = torch.empty(2, batch_local, dtype=torch.int64, device=dev)
         # item-row chunks of the two SpMMs whose output is all-reduced (>= 32 MB per message unless told otherwise)
-        if n_chunks is None:
-            n_chunks = max(1, min(8, (4 * I * d) // (32 << 20)))
+        if n_chunks is None:                                  # nothing to overlap in a world of one rank
+            n_chunks = 1 if (comm.world == 1 and not comm.force) else max(1, min(8, (4 * I * d) // (32 << 20)))
         n_chunks = max(1, min(n_chunks, I))
         per = (I + n_chunks - 1) // n_chunks
         self.chunks = [(r0, min(r0 + per, I)) for r0 in range(0, I, per)]
