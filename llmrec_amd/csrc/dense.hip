@@ -392,6 +392,23 @@ __device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+#ifdef LLMREC_FWD_PROFILE
+__device__ unsigned long long g_fwd_prof[8];
+#define FP_DECL() long long fp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long fp_t = clock64()
+#define FP_MARK(slot) do { const long long n_ = clock64(); fp_acc[slot] += n_ - fp_t; fp_t = n_; } while (0)
+#define FP_TOUCH(x) asm volatile("" :: "v"(x))
+#define FP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define FP_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define FP_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_fwd_prof[i_], (unsigned long long)fp_acc[i_]); } while (0)
+#else
+#define FP_DECL() do {} while (0)
+#define FP_MARK(slot) do {} while (0)
+#define FP_TOUCH(x) do {} while (0)
+#define FP_WAIT_VM(n) do {} while (0)
+#define FP_WAIT_LGKM() do {} while (0)
+#define FP_FLUSH() do {} while (0)
+#endif
+
 constexpr int GB_WS = 40;              // LDS row stride of one bf16 W tile in 2-byte units (32 k + 8 pad = 80 B)
 
 // MODE 0: guarded loads (any shape); 1: FAST (16-byte aligned rows, K % 4 == 0: branch-free clamped loads with a zero
@@ -490,12 +507,17 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
     store_w(0, w0);
     __syncthreads();
     int cur = 0;
+    FP_DECL();
     auto kstep = [&](int kb, const float4 (&xc)[RT][2], float4 (&xl)[RT][2], const float4 (&ws)[WLOADS], float4 (&wl)[WLOADS]) {
         load_w(kb + 2 * GF_BK, wl);                                        // zeros beyond K (guarded)
         load_x(kb + 2 * GF_BK, xl);
+        FP_MARK(0);                                                        // issuing the loads of step k + 2
+        FP_WAIT_VM(12);                                                    // (profile build, RT = 2, NT = 4: the 12 younger loads may stay in flight)
+        FP_MARK(1);                                                        // waiting for this step's X rows
         uint4 ah[RT], am[RT], al[RT];
 #pragma unroll
         for (int t = 0; t < RT; ++t) split8(xc[t][0], xc[t][1], ah[t], am[t], al[t]);
+        FP_TOUCH(al[RT - 1].w); FP_MARK(2);                                // the X split (VALU)
         uint4 bh[NT], bm[NT], bl[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -504,6 +526,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
             bm[n] = *reinterpret_cast<const uint4*>(&w_lds[cur][1][off]);
             bl[n] = *reinterpret_cast<const uint4*>(&w_lds[cur][2][off]);
         }
+        FP_WAIT_LGKM(); FP_MARK(3);                                        // the W fragments from LDS
         // smallest terms first; consecutive MFMAs hit different accumulators
 #pragma unroll
         for (int t = 0; t < RT; ++t)
@@ -529,8 +552,11 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(ah[t], bh[n], acc[t][n]);
+        FP_TOUCH(acc[RT - 1][NT - 1][0]); FP_MARK(4);                      // the 6 x RT x NT MFMAs
         store_w(cur ^ 1, ws);
+        FP_WAIT_LGKM(); FP_MARK(5);                                        // waiting for W of step k + 1, its split, the LDS stores
         __syncthreads();
+        FP_MARK(6);                                                        // the block barrier
         cur ^= 1;
     };
     for (int kb = 0; kb < K; kb += 3 * GF_BK) {                          // steps past K multiply zeros
@@ -538,6 +564,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
         kstep(kb + GF_BK, x1, x0, w2, w0);
         kstep(kb + 2 * GF_BK, x2, x1, w0, w1);
     }
+    FP_MARK(7); FP_FLUSH();
     float* __restrict__ Y = g.Y[prob];
     const int64_t ldy = g.ldy[prob];
     const float* bias = g.bias[prob];
