@@ -141,13 +141,19 @@ __device__ __forceinline__ void sort64(float (&s)[NV], int (&i)[NV], int lane) {
     bitonic_net<32, NV>(s, i, lane, 0);
 }
 
-// cycle accounting for tools/topk_prof.hip (compiled out of the library)
+// cycle accounting for tools/topk_prof.hip (compiled out of the library). The TK_ABL_* switches (also tools-only) take one part of
+// the sweep away at a time: TK_ABL_THR = a filter that is final from the first round on (1000.0f: nothing ever passes),
+// TK_ABL_NOMFMA = the tile is consumed by plain adds, TK_ABL_NOLOAD = the same tile is reused.
 #ifdef LLMREC_TOPK_PROFILE
-__device__ unsigned long long g_topk_prof[8];
+__device__ unsigned long long g_topk_prof[10];   // [8] sweep in 100 MHz wall-clock ticks, [9] longest sweep
+__device__ unsigned long long g_topk_place[4096][4];   // per block: HW_ID, XCC_ID, start, end (100 MHz wall clock)
 #define TK_NOW() clock64()
 #define TK_ADD(slot, since) do { tk_acc[slot] += clock64() - (since); } while (0)
-#define TK_DECL() long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define TK_FLUSH() do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_topk_prof[i_], (unsigned long long)tk_acc[i_]); } while (0)
+#define TK_DECL() long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long tk_wall0 = wall_clock64()
+#define TK_FLUSH() do { if (lane == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_topk_prof[i_], (unsigned long long)tk_acc[i_]); \
+        atomicAdd(&g_topk_prof[8], wall_clock64() - tk_wall0); atomicMax(&g_topk_prof[9], (unsigned long long)tk_acc[0]); \
+        if (w == 0 && blockIdx.x < 4096) { g_topk_place[blockIdx.x][0] = __builtin_amdgcn_s_getreg(63492); g_topk_place[blockIdx.x][1] = __builtin_amdgcn_s_getreg(63508); \
+            g_topk_place[blockIdx.x][2] = tk_wall0; g_topk_place[blockIdx.x][3] = wall_clock64(); } } } while (0)
 #else
 #define TK_DECL() do {} while (0)
 #define TK_FLUSH() do {} while (0)
@@ -212,7 +218,11 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     const int li = lane & 15, lq = lane >> 4;
     const int q0 = blockIdx.x * 16;
     if (q0 >= a.n_query) return;                               // block-uniform
+#if defined(TK_ABL_THR)
+    if (threadIdx.x < 16) thr_s[threadIdx.x] = TK_ABL_THR;
+#else
     if (threadIdx.x < 16) thr_s[threadIdx.x] = -INFINITY;
+#endif
     if (threadIdx.x < 2) flag_s[threadIdx.x] = 0;             // [0] drain requested, [1] waves that finished their quarter
     __syncthreads();
 
@@ -343,6 +353,10 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
 #endif
         f32x4 acc[2];
         acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+#if defined(TK_ABL_NOMFMA)
+#pragma unroll
+        for (int c = 0; c < DK; ++c) { acc[0][0] += b[0][c].x + b[0][c].y + b[0][c].z + b[0][c].w; acc[1][0] += b[1][c].x + b[1][c].y + b[1][c].z + b[1][c].w; }
+#else
 #pragma unroll
         for (int c = 0; c < DK; ++c)
 #pragma unroll
@@ -350,9 +364,14 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(cmp4(ua[c], s), cmp4(b[n][c], s), acc[n], 0, 0, 0);
+#endif
         // the next tile's operands go into the registers the MFMAs have just read: the loads fly during the selection
         __builtin_amdgcn_sched_barrier(0);
+#if defined(TK_ABL_NOLOAD)
+        if (round + 1 < my_rounds) { asm volatile("" : "+v"(b[0][0].x), "+v"(b[1][0].x)); }
+#else
         if (round + 1 < my_rounds) load_tile(t_begin + round + 1);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #ifdef LLMREC_TOPK_PROFILE
         { const float touch = acc[0][0] + acc[1][0]; asm volatile("" :: "v"(touch)); }   // MFMA results have landed

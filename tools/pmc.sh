@@ -3,7 +3,7 @@
 # usage: bash tools/pmc.sh <probe: fwd|wgrad|spmm|topk|all> <out.json>
 PROBE=${1:-topk}; OUT=${2:-gpurun_out/pmc_$PROBE.json}
 REPO=$PWD; export TMPDIR=/tmp
-rm -rf /tmp/pmc_runs; mkdir -p /tmp/pmc_runs gpurun_out
+rm -rf /tmp/pmc_runs; mkdir -p /tmp/pmc_runs gpurun_out $(dirname $OUT)
 i=0
 for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" \

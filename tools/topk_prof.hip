@@ -26,19 +26,47 @@ int main() {
     hipMemcpy(dci, ci.data(), ci.size() * 4, hipMemcpyHostToDevice);
     for (int it = 0; it < 3; ++it) llmrec_score_topk_f32(U, dq, dEu, d, dEi, d, I, d, drp, dci, K, dI, dS, nullptr);
     hipDeviceSynchronize();
-    unsigned long long zero[8] = {0};
+#ifdef LLMREC_TOPK_PROFILE
+    unsigned long long zero[10] = {0};
     hipMemcpyToSymbol(HIP_SYMBOL(llmrec::g_topk_prof), zero, sizeof(zero));
+#endif
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 10;
     hipEventRecord(e0, nullptr);
     for (int it = 0; it < iters; ++it) llmrec_score_topk_f32(U, dq, dEu, d, dEi, d, I, d, drp, dci, K, dI, dS, nullptr);
     hipEventRecord(e1, nullptr); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    unsigned long long p[8];
+    printf("kernel %.4f ms%s\n", ms / iters, 
+#ifdef LLMREC_TOPK_PROFILE
+        " (with the instrumentation)");
+#else
+        "");
+#endif
+#ifdef LLMREC_TOPK_PROFILE
+    unsigned long long p[10];
     hipMemcpyFromSymbol(p, HIP_SYMBOL(llmrec::g_topk_prof), sizeof(p));
     const double waves = (double)((U + 15) / 16) * 4 * iters;
     const char* names[8] = {"sweep", "rounds", "drains", "rendezvous wait", "sort+merge", "round: tile wait", "round: mfma", "round: mask+select"};
-    printf("kernel %.4f ms (with the instrumentation)\n", ms / iters);
     for (int i = 0; i < 8; ++i) printf("%-22s %10.0f memtime ticks per wave\n", names[i], p[i] / waves);
+    printf("sweep, wall clock      %10.1f us per wave (100 MHz counter) -> %.3f memtime ticks per ns\n", p[8] / waves / 100.0, (p[0] / waves) / (p[8] / waves * 10.0));
+    {
+        static unsigned long long place[4096][4];
+        hipMemcpyFromSymbol(place, HIP_SYMBOL(llmrec::g_topk_place), sizeof(place));
+        const int nb = (U + 15) / 16;
+        unsigned long long t0 = ~0ull; for (int b = 0; b < nb; ++b) if (place[b][2] < t0) t0 = place[b][2];
+        // blocks per CU (key = xcc, se, sh, cu) and the span of each block of the LAST launch
+        std::vector<int> per_cu(8 * 8 * 2 * 16, 0);
+        for (int b = 0; b < nb; ++b) { const unsigned h = (unsigned)place[b][0]; const int cu = (h >> 8) & 15, sh = (h >> 12) & 1, se = (h >> 13) & 7, xcc = (int)place[b][1] & 7; per_cu[((xcc * 8 + se) * 2 + sh) * 16 + cu]++; }
+        int hist[16] = {0}; for (int c : per_cu) hist[c < 15 ? c : 15]++;
+        printf("CUs by number of blocks placed on them:"); for (int i = 0; i < 16; ++i) if (hist[i]) printf("  %d blocks: %d CUs", i, hist[i]); printf("\n");
+        double span_by[16] = {0}; int n_by[16] = {0}; double start_max = 0, end_max = 0;
+        for (int b = 0; b < nb; ++b) { const unsigned h = (unsigned)place[b][0]; const int cu = (h >> 8) & 15, sh = (h >> 12) & 1, se = (h >> 13) & 7, xcc = (int)place[b][1] & 7;
+            const int c = per_cu[((xcc * 8 + se) * 2 + sh) * 16 + cu]; span_by[c < 15 ? c : 15] += (place[b][3] - place[b][2]) / 100.0; n_by[c < 15 ? c : 15]++;
+            if ((place[b][2] - t0) / 100.0 > start_max) start_max = (place[b][2] - t0) / 100.0; if ((place[b][3] - t0) / 100.0 > end_max) end_max = (place[b][3] - t0) / 100.0; }
+        for (int i = 0; i < 16; ++i) if (n_by[i]) printf("  blocks on a CU with %d blocks: mean span %.1f us (%d blocks)\n", i, span_by[i] / n_by[i], n_by[i]);
+        printf("latest block start %.1f us, latest end %.1f us after the first start\n", start_max, end_max);
+    }
+    printf("longest sweep          %10.0f memtime ticks\n", (double)p[9]);
+#endif
     return 0;
 }
