@@ -418,9 +418,12 @@ constexpr int GB_WS = 40;              // LDS row stride of one bf16 W tile in 2
 template <int NT, int RT, int MODE>
 __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(LinearGroup g, int N) {
     constexpr bool FAST = MODE >= 1;
-    constexpr bool K32 = MODE == 2;
+    constexpr bool K32 = MODE >= 2;
+    constexpr bool XPOSE = MODE == 3;
     // [buffer][term h/m/l][n][k] bf16
     __shared__ __attribute__((aligned(16))) uint16_t w_lds[2][3][NT * 16 * GB_WS];
+    // MODE 3: each wave's 16 RT rows x 128 B of a k-step, as loaded (full 128-B lines), for the fragment-shaped re-read
+    __shared__ float4 x_lds[XPOSE ? 4 : 1][XPOSE ? 16 * RT * 8 : 1];
     int prob = 0;
     while (prob + 1 < g.n_problems && (int)blockIdx.x >= g.unit_begin[prob + 1]) ++prob;
     const int64_t M = g.M[prob];
@@ -441,6 +444,32 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
         if (r > M - 1) r = M - 1;
         xrow[t] = X + r * ldx;
         xoff[t] = (uint32_t)(r * ldx + 8 * lq) * 4u;
+    }
+    // MODE 3 (XPOSE). A fragment-shaped load touches 16 rows x 4 pieces of 16 B per instruction; the CU's address path
+    // serves such an instruction one lane per cycle and the wave sits at load issue for 60 % of its cycles
+    // (tools/fwd_prof.hip). Here a k-step's rows are loaded as full 128-B lines - instruction j: lane l reads piece l & 7
+    // of row 8 j + (l >> 3) - into the same register stages, and pass through the wave's private 4-KB LDS image on their
+    // way to the split: ds_write_b128 as loaded, ds_read_b128 in fragment shape (row li, pieces 2 lq and 2 lq + 1).
+    // The image is XOR-swizzled so that both sides are bank-conflict-free: piece p of row r sits at slot
+    // 8 r + (p ^ f(r)), f(r) = ((r >> 1) & 7) ^ 2 [(r & 15) in 4..11] (the b128 read groups are the lane sets
+    // {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: f maps the 16 (row, piece) pairs of each onto 16 different slots).
+    auto swz = [](int r) { return ((r >> 1) & 7) ^ ((((r >> 2) ^ (r >> 3)) & 1) << 1); };
+    uint32_t xoffc[2 * RT];                                                // byte offset of (row 8 j + (l >> 3), piece l & 7)
+    int wslot[2], rslot[2];
+    if (XPOSE) {
+#pragma unroll
+        for (int j = 0; j < 2 * RT; ++j) {
+            int64_t r = row0 + 8 * j + (lane >> 3);
+            if (r > M - 1) r = M - 1;
+            xoffc[j] = (uint32_t)(r * ldx + 4 * (lane & 7)) * 4u;
+        }
+#pragma unroll
+        for (int bpar = 0; bpar < 2; ++bpar) {                             // rows 8 j + (l >> 3): f depends on j only through j & 1
+            const int r = 8 * bpar + (lane >> 3);
+            wslot[bpar] = (lane >> 3) * 8 + ((lane & 7) ^ swz(r));         // + 64 j at use
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) rslot[h] = li * 8 + ((2 * lq + h) ^ swz(li));   // + 128 t at use
     }
     const global_cptr Xs = uniform_ptr(X), Ws = uniform_ptr(W);
     const int wn = threadIdx.x >> 3, wk = (threadIdx.x & 7) * 4;
@@ -484,7 +513,10 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-                if (K32) {
+                if (XPOSE) {
+                    const int kbs = kb < K ? kb : K - 32;
+                    xr[t][h] = load4_global(Xs, xoffc[2 * t + h] + (uint32_t)kbs * 4u);      // instruction j = 2 t + h
+                } else if (K32) {
                     const int kbs = kb < K ? kb : K - 32;                  // wave-uniform: scalar; past K the W tile is zero
                     xr[t][h] = load4_global(Xs, xoff[t] + (uint32_t)kbs * 4u + 16u * h);
                 } else {
@@ -515,8 +547,21 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
         FP_WAIT_VM(12);                                                    // (profile build, RT = 2, NT = 4: the 12 younger loads may stay in flight)
         FP_MARK(1);                                                        // waiting for this step's X rows
         uint4 ah[RT], am[RT], al[RT];
+        if (XPOSE) {
+            float4* xw = x_lds[XPOSE ? wave : 0];
 #pragma unroll
-        for (int t = 0; t < RT; ++t) split8(xc[t][0], xc[t][1], ah[t], am[t], al[t]);
+            for (int j = 0; j < 2 * RT; ++j) xw[wslot[j & 1] + 64 * j] = xc[j >> 1][j & 1];
+            float4 xf[RT][2];
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) xf[t][h] = xw[rslot[h] + 128 * t];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) split8(xf[t][0], xf[t][1], ah[t], am[t], al[t]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) split8(xc[t][0], xc[t][1], ah[t], am[t], al[t]);
+        }
         FP_TOUCH(al[RT - 1].w); FP_MARK(2);                                // the X split (VALU)
         uint4 bh[NT], bm[NT], bl[NT];
 #pragma unroll
@@ -1019,29 +1064,37 @@ static int linear_fwd_grouped_impl(int32_t n_problems, const llmrec_linear_probl
     bool k32 = fast;                                   // scalar-k addressing of the bf16x3 kernel (MODE 2)
     for (int i = 0; i < n_problems; ++i)
         k32 = k32 && (g.K[i] % 32 == 0) && (p[i].M * p[i].ldx + g.K[i]) < (1ll << 30) && ((int64_t)N * p[i].ldw + g.K[i]) < (1ll << 30);
+    // LLMREC_FWD_XPOSE=0 keeps the fragment-shaped X loads of round 1 (MODE 2) for A/B runs
+    static const bool xpose = [] { const char* e = getenv("LLMREC_FWD_XPOSE"); return !(e && e[0] == '0'); }();
 #define GROUPED_LAUNCH(KERNEL, NT_)                                                         \
     do {                                                                                    \
         if (rows_per_unit == 128) {                                                         \
-            if (k32) KERNEL<NT_, 2, 2><<<units, 256, 0, stream>>>(g, N);                     \
+            if (k32 && xpose) KERNEL<NT_, 2, K32MODE><<<units, 256, 0, stream>>>(g, N);      \
+            else if (k32) KERNEL<NT_, 2, 2><<<units, 256, 0, stream>>>(g, N);                \
             else if (fast) KERNEL<NT_, 2, 1><<<units, 256, 0, stream>>>(g, N);               \
             else KERNEL<NT_, 2, 0><<<units, 256, 0, stream>>>(g, N);                         \
         } else {                                                                            \
-            if (k32) KERNEL<NT_, 1, 2><<<units, 256, 0, stream>>>(g, N);                     \
+            if (k32 && xpose) KERNEL<NT_, 1, K32MODE><<<units, 256, 0, stream>>>(g, N);      \
+            else if (k32) KERNEL<NT_, 1, 2><<<units, 256, 0, stream>>>(g, N);                \
             else if (fast) KERNEL<NT_, 1, 1><<<units, 256, 0, stream>>>(g, N);               \
             else KERNEL<NT_, 1, 0><<<units, 256, 0, stream>>>(g, N);                         \
         }                                                                                   \
     } while (0)
     const int nt = (N + 15) / 16;
     if (bf16x3) {
+#define K32MODE 3
         if (nt == 1) GROUPED_LAUNCH(linear_fwd_grouped_bf16x3_kernel, 1);
         else if (nt == 2) GROUPED_LAUNCH(linear_fwd_grouped_bf16x3_kernel, 2);
         else if (nt == 3) GROUPED_LAUNCH(linear_fwd_grouped_bf16x3_kernel, 3);
         else GROUPED_LAUNCH(linear_fwd_grouped_bf16x3_kernel, 4);
+#undef K32MODE
     } else {
+#define K32MODE 2
         if (nt == 1) GROUPED_LAUNCH(linear_fwd_grouped_kernel, 1);
         else if (nt == 2) GROUPED_LAUNCH(linear_fwd_grouped_kernel, 2);
         else if (nt == 3) GROUPED_LAUNCH(linear_fwd_grouped_kernel, 3);
         else GROUPED_LAUNCH(linear_fwd_grouped_kernel, 4);
+#undef K32MODE
     }
 #undef GROUPED_LAUNCH
     LLMREC_LAUNCH_CHECK();
