@@ -54,6 +54,10 @@ struct TopkArgs {
     int32_t* out_idx; float* out_score;
     float* S; int64_t lds;
     int vec_ok;
+    // user tiles from split_from on are swept by n_parts blocks each (a part = a contiguous range of item tiles); their
+    // 64-slot lists go to ws_idx / ws_score [(tile - split_from) * n_parts + part][16][64] and are merged by topk_merge_kernel
+    int split_from, n_parts;
+    int32_t* ws_idx; float* ws_score;
 };
 
 template <int DK>
@@ -216,7 +220,13 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     // branches live in SGPRs / scalar branches instead of 64-bit VGPR arithmetic under exec masks
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lq = lane >> 4;
-    const int q0 = blockIdx.x * 16;
+    int tile = blockIdx.x, part = 0, n_parts = 1;
+    if ((int)blockIdx.x >= a.split_from) {                     // block-uniform
+        n_parts = a.n_parts;
+        tile = a.split_from + ((int)blockIdx.x - a.split_from) / n_parts;
+        part = ((int)blockIdx.x - a.split_from) % n_parts;
+    }
+    const int q0 = tile * 16;
     if (q0 >= a.n_query) return;                               // block-uniform
 #if defined(TK_ABL_THR)
     if (threadIdx.x < 16) thr_s[threadIdx.x] = TK_ABL_THR;
@@ -236,9 +246,10 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
         ua[c] = FAST ? *reinterpret_cast<const float4*>(a.Eu + user_a * a.ldu + 16 * c + 4 * lq)
                      : ld4g(a.Eu + user_a * a.ldu, 16 * c + 4 * lq, a.d, a.vec_ok);
 
-    const int64_t tiles_total = (a.n_items + TK_TILE - 1) / TK_TILE;
-    const int64_t tiles_per_wave = (tiles_total + 3) / 4;
-    const int64_t t_begin = w * tiles_per_wave;
+    const int64_t tiles_all = (a.n_items + TK_TILE - 1) / TK_TILE;
+    const int64_t part_begin = tiles_all * part / n_parts, tiles_total = tiles_all * (part + 1) / n_parts;   // this block's item tiles
+    const int64_t tiles_per_wave = (tiles_total - part_begin + 3) / 4;
+    const int64_t t_begin = part_begin + w * tiles_per_wave < tiles_total ? part_begin + w * tiles_per_wave : tiles_total;
     const int64_t t_end = t_begin + tiles_per_wave < tiles_total ? t_begin + tiles_per_wave : tiles_total;
 
     // lanes 0..15 own one user each for the train-row cursor: position of the first train item inside this
@@ -420,12 +431,42 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     }
     TK_ADD(0, tk_start);
     TK_FLUSH();
+    if (n_parts > 1) {                                         // a part's lists: all 64 slots, merged by topk_merge_kernel
+        const int64_t base = ((int64_t)(tile - a.split_from) * n_parts + part) * 16;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            a.ws_idx[(base + 4 * w + rr) * 64 + lane] = lid[rr];
+            a.ws_score[(base + 4 * w + rr) * 64 + lane] = ls[rr];
+        }
+        return;
+    }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int q = q0 + 4 * w + rr;
         if (q < a.n_query && lane < a.K) {
             a.out_idx[(int64_t)q * a.K + lane] = lid[rr] == INT_MAX ? -1 : lid[rr];
             a.out_score[(int64_t)q * a.K + lane] = ls[rr];
+        }
+    }
+}
+
+// the lists of a split tile's parts -> the tile's top K (one wave per four users, as in the sweep)
+__global__ __launch_bounds__(256) void topk_merge_kernel(TopkArgs a) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int tile = a.split_from + blockIdx.x;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int q = tile * 16 + 4 * w + rr;
+        if (q >= a.n_query) continue;                          // wave-uniform
+        float l1[1] = {-INFINITY}; int32_t i1[1] = {INT_MAX};
+        for (int p = 0; p < a.n_parts; ++p) {
+            const int64_t row = ((int64_t)blockIdx.x * a.n_parts + p) * 16 + 4 * w + rr;
+            const float bs[1] = {a.ws_score[row * 64 + lane]}; const int32_t bi[1] = {a.ws_idx[row * 64 + lane]};
+            merge64<1>(l1, i1, bs, bi, lane);
+        }
+        if (lane < a.K) {
+            a.out_idx[(int64_t)q * a.K + lane] = i1[0] == INT_MAX ? -1 : i1[0];
+            a.out_score[(int64_t)q * a.K + lane] = l1[0];
         }
     }
 }
@@ -481,10 +522,29 @@ __global__ void topk_metrics_kernel(int n_query, const int64_t* __restrict__ que
     }
 }
 
+static int device_cus() {
+    static const int n = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+                              return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }();
+    return n;
+}
+// The user tiles beyond the last full round of one tile per CU leave most CUs one block short (825 tiles on 256 CUs: 57 CUs
+// sweep four blocks, 199 three, and the kernel lasts as long as the four). Those left-over tiles are cut into parts along
+// the items, one block per part, so that every CU gets at most one short extra block.
+static void plan_split(int n_query, int64_t n_items, int* split_from, int* n_parts) {
+    const int n_tiles = (int)ceil_div(n_query, 16), cus = device_cus();
+    const int full = n_tiles / cus * cus, left = n_tiles - full;
+    int parts = left > 0 ? cus / left : 1;
+    if (parts > 8) parts = 8;
+    const int64_t item_tiles = (n_items + TK_TILE - 1) / TK_TILE;
+    while (parts > 1 && item_tiles / parts < 64) --parts;      // at least 16 rounds per wave of a part
+    *split_from = parts > 1 ? full : n_tiles; *n_parts = parts > 1 ? parts : 1;
+}
+
 template <bool SELECT>
 static int launch_topk(const TopkArgs& a, hipStream_t stream) {
     const int DK = (a.d + 15) / 16;
-    const int grid = (int)ceil_div(a.n_query, 16);
+    const int n_tiles = (int)ceil_div(a.n_query, 16);
+    const int grid = a.split_from + (n_tiles - a.split_from) * a.n_parts;
     const bool fast = a.vec_ok && a.d == 16 * DK;
 #define LLMREC_TOPK_CASE(D) case D: \
         if (!SELECT) scores_kernel<D><<<grid, 256, 0, stream>>>(a); \
@@ -498,6 +558,10 @@ static int launch_topk(const TopkArgs& a, hipStream_t stream) {
     }
 #undef LLMREC_TOPK_CASE
     LLMREC_LAUNCH_CHECK();
+    if (SELECT && a.n_parts > 1) {
+        topk_merge_kernel<<<n_tiles - a.split_from, 256, 0, stream>>>(a);
+        LLMREC_LAUNCH_CHECK();
+    }
     return LLMREC_OK;
 }
 
@@ -507,11 +571,29 @@ using namespace llmrec;
 
 extern "C" {
 
+int64_t llmrec_score_topk_workspace_bytes(int32_t n_query, int64_t n_items) {
+    if (n_query < 0 || n_items <= 0) return -1;
+    int split_from = 0, n_parts = 1;
+    plan_split(n_query, n_items, &split_from, &n_parts);
+    if (n_parts == 1) return 0;
+    return ((int64_t)ceil_div(n_query, 16) - split_from) * n_parts * 16 * 64 * 8;
+}
+
 int llmrec_score_topk_f32(int32_t n_query, const int64_t* query_users,
                           const float* Eu, int64_t ldu, const float* Ei, int64_t ldi,
                           int64_t n_items, int32_t d,
                           const int32_t* train_rowptr, const int32_t* train_colidx,
                           int32_t K, int32_t* out_idx, float* out_score, llmrec_stream_t stream_) {
+    return llmrec_score_topk_ws_f32(n_query, query_users, Eu, ldu, Ei, ldi, n_items, d, train_rowptr, train_colidx, K, out_idx, out_score,
+                                    nullptr, 0, stream_);
+}
+
+int llmrec_score_topk_ws_f32(int32_t n_query, const int64_t* query_users,
+                             const float* Eu, int64_t ldu, const float* Ei, int64_t ldi,
+                             int64_t n_items, int32_t d,
+                             const int32_t* train_rowptr, const int32_t* train_colidx,
+                             int32_t K, int32_t* out_idx, float* out_score,
+                             void* workspace, int64_t workspace_bytes, llmrec_stream_t stream_) {
     LLMREC_CHECK_ARG(n_query >= 0 && n_items > 0 && d > 0 && K > 0 && K <= LLMREC_TOPK_MAX, "score_topk: bad sizes (K <= %d)", LLMREC_TOPK_MAX);
     if (n_query == 0) return LLMREC_OK;
     LLMREC_CHECK_ARG(query_users && Eu && Ei && out_idx && out_score && ldu >= d && ldi >= d, "score_topk: null pointer or ld < d");
@@ -522,6 +604,14 @@ int llmrec_score_topk_f32(int32_t n_query, const int64_t* query_users,
     a.n_items = n_items; a.d = d; a.train_rowptr = train_rowptr; a.train_colidx = train_colidx; a.K = K;
     a.out_idx = out_idx; a.out_score = out_score; a.S = nullptr; a.lds = 0;
     a.vec_ok = (ldu % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)Eu | (uintptr_t)Ei) % 16 == 0);
+    a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr;
+    const int64_t need = llmrec_score_topk_workspace_bytes(n_query, n_items);
+    if (workspace && need > 0) {                               // without a workspace every tile is swept by one block
+        LLMREC_CHECK_ARG(workspace_bytes >= need && (uintptr_t)workspace % 16 == 0, "score_topk: workspace of %lld bytes needed (16-byte aligned)", (long long)need);
+        plan_split(n_query, n_items, &a.split_from, &a.n_parts);
+        a.ws_score = (float*)workspace;
+        a.ws_idx = (int32_t*)((char*)workspace + need / 2);
+    }
     return launch_topk<true>(a, (hipStream_t)stream_);
 }
 
@@ -536,6 +626,7 @@ int llmrec_scores_f32(int32_t n_query, const int64_t* query_users,
     a.n_items = n_items; a.d = d; a.train_rowptr = nullptr; a.train_colidx = nullptr; a.K = 1;
     a.out_idx = nullptr; a.out_score = nullptr; a.S = S; a.lds = lds;
     a.vec_ok = (ldu % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)Eu | (uintptr_t)Ei) % 16 == 0);
+    a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr;
     return launch_topk<false>(a, (hipStream_t)stream_);
 }
 

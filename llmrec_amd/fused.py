@@ -422,12 +422,13 @@ class FusedStep:
             n = q.numel()
             idx = torch.empty(n, K, dtype=torch.int32, device=q.device)
             sc = torch.empty(n, K, dtype=torch.float32, device=q.device)
+            ws = ops.topk_workspace(n, self.I, q.device)
 
             def run():
                 self.forward()
-                _call("llmrec_score_topk_f32", n, _p(q), _p(self.E_u), _ld(self.E_u), _p(self.E_i), _ld(self.E_i), self.I, self.d,
+                _call("llmrec_score_topk_ws_f32", n, _p(q), _p(self.E_u), _ld(self.E_u), _p(self.E_i), _ld(self.E_i), self.I, self.d,
                       _p(train.rowptr) if train is not None else None, _p(train.colidx) if train is not None else None,
-                      K, _p(idx), _p(sc))
+                      K, _p(idx), _p(sc), _p(ws), ws.numel() if ws is not None else 0)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -437,7 +438,7 @@ class FusedStep:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (the RCCL watchdog) may touch the runtime
                 run()
-            ev = self._eval_graphs[key] = (g, idx, sc, q, train)         # keeps the captured operands alive
+            ev = self._eval_graphs[key] = (g, idx, sc, q, train, ws)     # keeps the captured operands alive
         ev[0].replay()
         return ev[1], ev[2]
 

@@ -173,3 +173,46 @@ def test_fused_graph_step_and_eval_at_netflix_shape_match_oracle():
     assert rep["grad_max_rel"] < 1e-4 and rep["adamw_given_gpu_grads_max_rel"] < 1e-5 and rep["param_max_rel"] < 2e-4, rep
     assert rep["topk_lists_equal"] == rep["topk_lists_checked"] > 0, rep
     assert rep["ok"], rep
+
+
+@pytest.mark.parametrize("n_users", [U_NF, 300, 4096 + 16 * 57])
+def test_topk_split_left_over_tiles_equal_the_unsplit_sweep(ops, n_users):
+    """llmrec_score_topk_ws_f32 cuts the user tiles beyond the last full round of one tile per CU into item parts and
+    merges their lists: the result is the unsplit kernel's, bit for bit (ids and scores), including users whose train
+    rows leave fewer than K candidates in a part."""
+    from llmrec_amd import _lib
+    from llmrec_amd.ops import _p, _ld
+    g = torch.Generator(device=DEV); g.manual_seed(n_users)
+    K = 50
+    eu = torch.randn(n_users, D, generator=g, device=DEV)
+    ei = torch.randn(I_NF, D, generator=g, device=DEV)
+    ei[::7] = ei[3]                                                       # exact ties across the item parts
+    q = torch.arange(n_users, dtype=torch.int64, device=DEV)
+    deg = torch.randint(0, 12, (n_users,), generator=g, device=DEV)
+    deg[-5] = I_NF - 20                                                   # fewer than K candidates in total
+    rp = torch.zeros(n_users + 1, dtype=torch.int64, device=DEV); rp[1:] = torch.cumsum(deg, 0)
+    ci = torch.empty(int(rp[-1]), dtype=torch.int32, device=DEV)
+    rp_h, deg_h = rp.cpu().numpy(), deg.cpu().numpy()
+    rng = np.random.default_rng(n_users)
+    ci_h = np.empty(int(rp_h[-1]), dtype=np.int32)
+    for u in range(n_users):
+        if deg_h[u]:
+            ci_h[rp_h[u]:rp_h[u + 1]] = np.sort(rng.choice(I_NF, size=int(deg_h[u]), replace=False))
+    ci.copy_(torch.from_numpy(ci_h))
+    rp32 = rp.to(torch.int32)
+    need = _lib.query("llmrec_score_topk_workspace_bytes", n_users, I_NF)
+    assert need > 0, "these shapes leave user tiles over"
+    out = []
+    for ws in (None, torch.empty(need, dtype=torch.uint8, device=DEV)):
+        idx = torch.empty(n_users, K, dtype=torch.int32, device=DEV)
+        sc = torch.empty(n_users, K, dtype=torch.float32, device=DEV)
+        _lib.call("llmrec_score_topk_ws_f32", n_users, _p(q), _p(eu), _ld(eu), _p(ei), _ld(ei), I_NF, D, _p(rp32), _p(ci), K, _p(idx), _p(sc),
+                  _p(ws), need if ws is not None else 0, None)
+        torch.cuda.synchronize()
+        out.append((idx, sc))
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
+    assert int((out[0][0][n_users - 5] >= 0).sum()) == 20
+    with pytest.raises(RuntimeError):                                      # a workspace that is too small is refused
+        _lib.call("llmrec_score_topk_ws_f32", n_users, _p(q), _p(eu), _ld(eu), _p(ei), _ld(ei), I_NF, D, _p(rp32), _p(ci), K, _p(out[0][0]), _p(out[0][1]),
+                  _p(torch.empty(need, dtype=torch.uint8, device=DEV)), need - 16, None)
