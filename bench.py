@@ -198,10 +198,14 @@ class NetflixShaped:
             "text_trans": (lambda: ops.linear_wgrad_grouped([(dYi[:, d:2 * d], m_.text_feats)], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False, f.ws_wgrad_c, precision=pr)),
             "image_trans": (lambda: ops.linear_wgrad_grouped([(dYi[:, 0:d], m_.image_feats)], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False, f.ws_wgrad_d, precision=pr)),
         }
-        # as the step launches them (llmrec_amd/fused.py _backward): item_trans', text's and image's back to back on one
-        # stream, user_trans' on another (in the step it runs beside the SpMM chains)
+        # as the step launches them (llmrec_amd/fused.py _backward): user_trans' on its own stream (in the step it runs beside
+        # the SpMM chains); item_trans', text's and image's side by side on three streams, or back to back on one with
+        # LLMREC_WGRAD_SERIAL=1
         main_s, side_s = torch.cuda.Stream(), torch.cuda.Stream()
-        order = {"item_trans_x5": main_s, "text_trans": main_s, "image_trans": main_s, "user_trans": side_s}
+        if f.wgrad_serial:
+            order = {"item_trans_x5": main_s, "text_trans": main_s, "image_trans": main_s, "user_trans": side_s}
+        else:
+            order = {"item_trans_x5": main_s, "text_trans": torch.cuda.Stream(), "image_trans": torch.cuda.Stream(), "user_trans": side_s}
         acc = {k: 0.0 for k in jobs}
         wall = 0.0
         for it in range(iters + 3):
@@ -209,11 +213,13 @@ class NetflixShaped:
             ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in jobs}
             w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             w0.record()
-            main_s.wait_stream(cur); side_s.wait_stream(cur)
+            for st in set(order.values()):
+                st.wait_stream(cur)
             for k in ("user_trans", "item_trans_x5", "text_trans", "image_trans"):
                 with torch.cuda.stream(order[k]):
                     ev[k][0].record(); jobs[k](); ev[k][1].record()
-            cur.wait_stream(main_s); cur.wait_stream(side_s)
+            for st in set(order.values()):
+                cur.wait_stream(st)
             w1.record()
             torch.cuda.synchronize()
             if it >= 3:
@@ -269,7 +275,7 @@ class NetflixShaped:
                     "pmc": [("linear_wgrad_bf16x3_kernel" if bf else "linear_wgrad_kernel", 4), ("reduce_chunks_kernel", 4)],
                     "launches": 4, "avg_launch_ms": ms / 4, "per_launch_ms_in_situ": per_launch, "ms_wall_group": wall,
                     "ms_serial_isolated": ms_serial,
-                    "timing": "HIP events on each launch's own stream, launched as in the step (3 back to back + user_trans' beside them); ms = their sum",
+                    "timing": "HIP events on each launch's own stream, launched as in the step (item_trans' / text's / image's side by side unless LLMREC_WGRAD_SERIAL=1, user_trans' on a fourth stream); ms = the sum of the four durations",
                     "bound": "hbm" if bf else "mfma", "calls_per_step": 1, "ms": ms, "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                     "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
                     "gbs_wall_group": byts_all / wall / 1e6,

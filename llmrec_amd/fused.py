@@ -365,10 +365,12 @@ class FusedStep:
                 id_chain()
         item_pairs = [(self._side(self.dP_cat, 2 + k), m.item_feats[key]) for k, key in enumerate(self.keys)]
         if self.wgrad_serial:
-            # the weight-gradient kernels each fill the chip (one wave per SIMD, HBM-bound): launched side by side they only
-            # interleave their blocks and thrash (measured: 0.26 ms for the four at once vs 0.21 ms back to back), so
-            # item_trans', text's and image's run back to back on this stream; only the latency-bound SpMM chains and
-            # user_trans' gradient (ready earlier, on s1) overlap them
+            # Default (LLMREC_WGRAD_SERIAL=1): item_trans', text's and image's weight gradients back to back on this stream. Each
+            # fills the chip (one wave per SIMD, HBM-bound); side by side (LLMREC_WGRAD_SERIAL=0, below) they interleave their
+            # blocks: every launch then lasts 2-3x longer (47 / 125 / 141 us against 17 / 19 / 130 us) while the step gains
+            # 2.7 % (0.652 vs 0.670 ms) from the short launches' ramp-up and tail hiding under the long one. The serial form
+            # stays the default so that a launch's duration - what the bench's roofline and a rocprof summary report - is the
+            # kernel's own.
             ops.linear_wgrad_grouped(item_pairs, m.item_trans.weight.grad, m.item_trans.bias.grad, False, self.ws_wgrad, precision=self.gemm)
             self._wgrad(self._side(self.dP_cat, 1), m.text_feats, m.text_trans, False, ws=self.ws_wgrad_c)
             self._wgrad(self._side(self.dP_cat, 0), m.image_feats, m.image_trans, False, ws=self.ws_wgrad_d)
