@@ -191,18 +191,27 @@ class NetflixShaped:
         ops, d, m_ = self.ops, self.args.embed_size, self.model
         pr = self.fused.gemm
         f = self.fused
+        item_pairs = [(dYi[:, (2 + k) * d:(3 + k) * d], m_.item_feats[key]) for k, key in enumerate(self.keys)]
         jobs = {
-            "item_trans_x5": (lambda: ops.linear_wgrad_grouped([(dYi[:, (2 + k) * d:(3 + k) * d], m_.item_feats[key]) for k, key in enumerate(self.keys)],
-                                                               m_.item_trans.weight.grad, m_.item_trans.bias.grad, False, ws, precision=pr)),
+            "item_trans_x5": (lambda: ops.linear_wgrad_grouped(item_pairs, m_.item_trans.weight.grad, m_.item_trans.bias.grad, False, ws, precision=pr)),
             "user_trans": (lambda: ops.linear_wgrad_grouped([(dYu, m_.user_feats)], m_.user_trans.weight.grad, m_.user_trans.bias.grad, False, f.ws_wgrad_b, precision=pr)),
             "text_trans": (lambda: ops.linear_wgrad_grouped([(dYi[:, d:2 * d], m_.text_feats)], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False, f.ws_wgrad_c, precision=pr)),
             "image_trans": (lambda: ops.linear_wgrad_grouped([(dYi[:, 0:d], m_.image_feats)], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False, f.ws_wgrad_d, precision=pr)),
         }
+        multi = getattr(f, "wgrad_multi", False)
+        if multi:                                             # item_trans', text's and image's gradients are ONE launch in the step
+            targets = [(item_pairs, m_.item_trans.weight.grad, m_.item_trans.bias.grad, False),
+                       ([(dYi[:, d:2 * d], m_.text_feats)], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False),
+                       ([(dYi[:, 0:d], m_.image_feats)], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False)]
+            ws_multi = torch.empty(max(ops.linear_wgrad_multi_workspace(targets), 16), dtype=torch.uint8, device=dYi.device)
+            jobs = {"item+text+image_trans (one launch)": (lambda: ops.linear_wgrad_multi(targets, ws_multi)), "user_trans": jobs["user_trans"]}
         # as the step launches them (llmrec_amd/fused.py _backward): user_trans' on its own stream (in the step it runs beside
-        # the SpMM chains); item_trans', text's and image's side by side on three streams, or back to back on one with
-        # LLMREC_WGRAD_SERIAL=1
+        # the SpMM chains); the item-side gradients as one multi-target launch (default), or with LLMREC_WGRAD_MULTI=0 as three
+        # launches back to back on one stream (LLMREC_WGRAD_SERIAL=1) / side by side on three
         main_s, side_s = torch.cuda.Stream(), torch.cuda.Stream()
-        if f.wgrad_serial:
+        if multi:
+            order = {k: (side_s if k == "user_trans" else main_s) for k in jobs}
+        elif f.wgrad_serial:
             order = {"item_trans_x5": main_s, "text_trans": main_s, "image_trans": main_s, "user_trans": side_s}
         else:
             order = {"item_trans_x5": main_s, "text_trans": torch.cuda.Stream(), "image_trans": torch.cuda.Stream(), "user_trans": side_s}
@@ -215,7 +224,7 @@ class NetflixShaped:
             w0.record()
             for st in set(order.values()):
                 st.wait_stream(cur)
-            for k in ("user_trans", "item_trans_x5", "text_trans", "image_trans"):
+            for k in sorted(jobs, key=lambda k: k != "user_trans"):        # user_trans' first, as in the step
                 with torch.cuda.stream(order[k]):
                     ev[k][0].record(); jobs[k](); ev[k][1].record()
             for st in set(order.values()):
@@ -269,17 +278,22 @@ class NetflixShaped:
         # duration (profiles/r02_bench_nf_kernel_stats_*.csv), and it is the denominator of the roofline figure below.
         per_launch, wall = self._wgrad_in_situ_ms(dYi, dYu, ws)
         ms = sum(per_launch.values())
-        out.append({"kernel": ("linear_wgrad_bf16x3_kernel" if bf else "linear_wgrad_kernel<true>") +
-                              " + reduce_chunks_kernel (the step's 4 launches: item_trans x5 grouped, user, text, image" +
-                              ("; 3-term bf16 split: HBM-bound on the X stream, tflops are fp32-EQUIVALENT)" if bf else ")"),
-                    "pmc": [("linear_wgrad_bf16x3_kernel" if bf else "linear_wgrad_kernel", 4), ("reduce_chunks_kernel", 4)],
-                    "launches": 4, "avg_launch_ms": ms / 4, "per_launch_ms_in_situ": per_launch, "ms_wall_group": wall,
+        n_l = len(per_launch)
+        multi = n_l == 2
+        out.append({"kernel": (("linear_wgrad_bf16x3_multi_kernel + reduce_chunks_multi_kernel (item_trans x5 + text + image in one launch) and "
+                                "linear_wgrad_bf16x3_kernel + reduce_chunks_kernel (user_trans)") if multi else
+                               (("linear_wgrad_bf16x3_kernel" if bf else "linear_wgrad_kernel<true>") +
+                                " + reduce_chunks_kernel (the step's 4 launches: item_trans x5 grouped, user, text, image")) +
+                              ("; 3-term bf16 split: HBM-bound on the X stream, tflops are fp32-EQUIVALENT" if bf else "") + (")" if not multi else ""),
+                    "pmc": ([("linear_wgrad_bf16x3_multi_kernel", 1), ("reduce_chunks_multi_kernel", 1), ("linear_wgrad_bf16x3_kernel", 1), ("reduce_chunks_kernel", 1)]
+                            if multi else [("linear_wgrad_bf16x3_kernel" if bf else "linear_wgrad_kernel", 4), ("reduce_chunks_kernel", 4)]),
+                    "launches": n_l, "avg_launch_ms": ms / n_l, "per_launch_ms_in_situ": per_launch, "ms_wall_group": wall,
                     "ms_serial_isolated": ms_serial,
-                    "timing": "HIP events on each launch's own stream, launched as in the step (item_trans' / text's / image's side by side unless LLMREC_WGRAD_SERIAL=1, user_trans' on a fourth stream); ms = the sum of the four durations",
+                    "timing": "HIP events on each launch's own stream, launched as in the step (item_trans' + text's + image's as one multi-target launch unless LLMREC_WGRAD_MULTI=0, user_trans' on a second stream); ms = the sum of the launches' durations",
                     "bound": "hbm" if bf else "mfma", "calls_per_step": 1, "ms": ms, "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                     "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
                     "gbs_wall_group": byts_all / wall / 1e6,
-                    "algorithmic_flop_per_launch": flop_all / 4, "algorithmic_bytes_per_launch": byts_all / 4,
+                    "algorithmic_flop_per_launch": flop_all / n_l, "algorithmic_bytes_per_launch": byts_all / n_l,
                     "algorithmic_flop_per_step": flop_all, "algorithmic_bytes_per_step": byts_all})
         Xi = torch.randn(sh.n_items, d, device=self.device)
         a = self.graph.ui.fwd

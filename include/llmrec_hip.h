@@ -162,6 +162,18 @@ int llmrec_linear_wgrad_grouped_f32(int32_t n_problems, const llmrec_wgrad_probl
 int llmrec_linear_wgrad_grouped_bf16x3(int32_t n_problems, const llmrec_wgrad_problem_t* problems_host, int32_t N, int32_t K,
                                        float* dW, int64_t lddw, float* db, int32_t accumulate,
                                        void* workspace, int64_t workspace_bytes, llmrec_stream_t stream);
+/* The weight gradients of several Linears (targets) in ONE launch + one reduction launch, split-precision arithmetic as above:
+ * target t has its own K, dW, db and (dY_p, X_p) pairs; N is common. All targets are cut into slabs of one length, chosen so
+ * that the launch is whole rounds of equal blocks (three back-to-back launches each pay their own ramp-up and ragged last
+ * round). Fast path only - N % 64 == 0, K_t % 64 == 0, non-empty problems with 16-byte aligned rows and byte offsets below
+ * 2^32 - otherwise LLMREC_EUNSUPPORTED (workspace query: -1) and the caller issues llmrec_linear_wgrad_grouped_bf16x3 per
+ * target. Deterministic (fixed slab order); the slab length differs from the single-target launches', so the sums are
+ * equal to those only up to fp32 rounding. */
+#define LLMREC_WGRAD_MAX_TARGETS 4
+typedef struct { int32_t n_problems; const llmrec_wgrad_problem_t* problems; int32_t K; float* dW; int64_t lddw; float* db; int32_t accumulate; } llmrec_wgrad_target_t;
+int64_t llmrec_linear_wgrad_multi_workspace_bytes(int32_t n_targets, const llmrec_wgrad_target_t* targets_host, int32_t N);
+int llmrec_linear_wgrad_multi_bf16x3(int32_t n_targets, const llmrec_wgrad_target_t* targets_host, int32_t N,
+                                     void* workspace, int64_t workspace_bytes, llmrec_stream_t stream);
 /* Same contract, split precision: each fp32 operand = exact sum of three bf16 numbers, product by the
  * six bf16 MFMAs (v_mfma_f32_16x16x32_bf16, fp32 accumulate) whose terms are >= 2^-24 relative.
  * fp32-roundoff-class error (not the bit-identical fma chain); 3/8 of the fp32 matrix time, so the

@@ -786,16 +786,15 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(WgradGroup g, int 
 // split in registers into hi + mid + lo bf16 (exact), six MFMAs per tile pair keep every term >= 2^-24: 96 MFMAs
 // x 16 cycles per 32 rows instead of 128 x 32 cycles per 32 rows in the fp32 chain, so the kernel is bound by
 // the X stream from HBM instead of the matrix pipe. One wave per SIMD (stages + split need > 256 registers).
-template <bool UNUSED = true>
-__global__ __launch_bounds__(256, 1) void linear_wgrad_bf16x3_kernel(WgradGroup g, int N, int K, float* __restrict__ partial,
-                                                                   float* __restrict__ partial_db, int64_t MC, int n_kslab, int n_slabs) {
+// lb = the block's logical index among the launch's (or, in a multi-target launch, the target's) blocks
+__device__ __forceinline__ void wgrad_bf16x3_body(const WgradGroup& g, int N, int K, float* __restrict__ partial,
+                                                  float* __restrict__ partial_db, int64_t MC, int n_kslab, int n_slabs, int lb) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lq = lane >> 4;
     // the four waves of a block take four consecutive slabs of ONE k slab and are summed through LDS in wave
     // order before anything is written: a quarter of the partial-slab traffic (all problems feed the same dW)
     __shared__ __attribute__((aligned(16))) float red[3][64 * 64 + 64];
-    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
     const int kslab = lb % n_kslab;
     const int group = lb / n_kslab;
     const int slab_raw = group * 4 + wave;
@@ -926,6 +925,66 @@ __global__ __launch_bounds__(256, 1) void linear_wgrad_bf16x3_kernel(WgradGroup 
         float* pd = partial_db + (int64_t)group * N;
         pd[n_base + 0] = dbs.x; pd[n_base + 1] = dbs.y; pd[n_base + 2] = dbs.z; pd[n_base + 3] = dbs.w;
     }
+}
+
+template <bool UNUSED = true>
+__global__ __launch_bounds__(256, 1) void linear_wgrad_bf16x3_kernel(WgradGroup g, int N, int K, float* __restrict__ partial,
+                                                                   float* __restrict__ partial_db, int64_t MC, int n_kslab, int n_slabs) {
+    wgrad_bf16x3_body(g, N, K, partial, partial_db, MC, n_kslab, n_slabs, xcd_logical_block(blockIdx.x, gridDim.x));
+}
+
+// Several Linears' weight gradients in one launch (llmrec_linear_wgrad_multi_bf16x3): target t owns the logical blocks
+// [block_begin[t], block_begin[t + 1]), its own K, slab count and partial buffers; one slab length for all of them, so every
+// block of the launch has the same amount of work.
+struct WgradMulti {
+    WgradGroup g[LLMREC_WGRAD_MAX_TARGETS];
+    float* partial[LLMREC_WGRAD_MAX_TARGETS];
+    float* partial_db[LLMREC_WGRAD_MAX_TARGETS];
+    int32_t K[LLMREC_WGRAD_MAX_TARGETS], n_kslab[LLMREC_WGRAD_MAX_TARGETS], n_slabs[LLMREC_WGRAD_MAX_TARGETS];
+    int32_t block_begin[LLMREC_WGRAD_MAX_TARGETS + 1];
+    int32_t n_targets;
+    int64_t MC;
+};
+__global__ __launch_bounds__(256, 1) void linear_wgrad_bf16x3_multi_kernel(WgradMulti m, int N) {
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    int t = 0;
+    while (t + 1 < m.n_targets && lb >= m.block_begin[t + 1]) ++t;
+    wgrad_bf16x3_body(m.g[t], N, m.K[t], m.partial[t], m.partial_db[t], m.MC, m.n_kslab[t], m.n_slabs[t], lb - m.block_begin[t]);
+}
+
+struct ReduceMulti {
+    const float* partial[LLMREC_WGRAD_MAX_TARGETS]; const float* partial_b[LLMREC_WGRAD_MAX_TARGETS];
+    float* out[LLMREC_WGRAD_MAX_TARGETS]; float* out_b[LLMREC_WGRAD_MAX_TARGETS];
+    int64_t ld_out[LLMREC_WGRAD_MAX_TARGETS], n_elem[LLMREC_WGRAD_MAX_TARGETS], n_chunks[LLMREC_WGRAD_MAX_TARGETS];
+    int32_t row_len[LLMREC_WGRAD_MAX_TARGETS], n_b[LLMREC_WGRAD_MAX_TARGETS], accumulate[LLMREC_WGRAD_MAX_TARGETS];
+    int32_t block_begin[LLMREC_WGRAD_MAX_TARGETS + 1];
+    int32_t n_targets;
+};
+// reduce_chunks_kernel for every target of a multi-target launch (same chunk order, same four-way summation)
+__global__ void reduce_chunks_multi_kernel(ReduceMulti m) {
+    int t = 0;
+    while (t + 1 < m.n_targets && (int)blockIdx.x >= m.block_begin[t + 1]) ++t;
+    const int64_t e = (int64_t)(blockIdx.x - m.block_begin[t]) * blockDim.x + threadIdx.x;
+    const int64_t n_elem = m.n_elem[t], n_chunks = m.n_chunks[t];
+    const int n_b = m.n_b[t];
+    if (e >= n_elem + n_b) return;
+    const bool second = e >= n_elem;
+    const float* src = second ? m.partial_b[t] + (e - n_elem) : m.partial[t] + e;
+    const int64_t stride = second ? n_b : n_elem;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t c = 0;
+    for (; c + 4 <= n_chunks; c += 4) {
+        s0 += src[c * stride];
+        s1 += src[(c + 1) * stride];
+        s2 += src[(c + 2) * stride];
+        s3 += src[(c + 3) * stride];
+    }
+    for (; c < n_chunks; ++c) s0 += src[c * stride];
+    const float s = (s0 + s1) + (s2 + s3);
+    float* o;
+    if (second) o = m.out_b[t] + (e - n_elem);
+    else { const int64_t r = e / m.row_len[t], col = e % m.row_len[t]; o = m.out[t] + r * m.ld_out[t] + col; }
+    *o = m.accumulate[t] ? (*o + s) : s;
 }
 
 // out[e] (+)= sum over chunks of partial[chunk][e], chunks in ascending order (deterministic); a second, short
@@ -1188,6 +1247,100 @@ static int linear_wgrad_grouped_impl(int32_t n_problems, const llmrec_wgrad_prob
     const int64_t ne = (int64_t)N * K;
     reduce_chunks_kernel<<<grid_for(ne + (db ? N : 0), 256), 256, 0, stream>>>(ne, n_chunks, partial, dW, lddw, K, accumulate,
                                                                               db ? N : 0, partial_db, db);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+// one slab length for every target of a multi-target launch: the launch is ceil(blocks / 256) rounds of (mc + a fixed cost)
+static int64_t wgrad_multi_slab_rows(int32_t n_targets, const llmrec_wgrad_target_t* t) {
+    int64_t m_max = 0, work = 0;
+    for (int i = 0; i < n_targets; ++i)
+        for (int j = 0; j < t[i].n_problems; ++j) { m_max = std::max(m_max, t[i].problems[j].M); work += t[i].problems[j].M * ceil_div(t[i].K, 64); }
+    const int64_t lo = std::max<int64_t>(64, align_up(ceil_div(work, 4 * 512), 32));       // never more than ~2 rounds of blocks
+    int64_t best = lo, best_cost = -1;
+    for (int64_t mc = lo; mc <= align_up(m_max, 32) + 32; mc += 32) {
+        int64_t blocks = 0;
+        for (int i = 0; i < n_targets; ++i) {
+            int64_t slabs = 0;
+            for (int j = 0; j < t[i].n_problems; ++j) slabs += ceil_div(t[i].problems[j].M, mc);
+            blocks += ceil_div(slabs, 4) * ceil_div(t[i].K, 64);
+        }
+        const int64_t cost = ceil_div(blocks, 256) * (mc + 96);
+        if (best_cost < 0 || cost <= best_cost) { best = mc; best_cost = cost; }
+    }
+    return best;
+}
+static bool wgrad_multi_ok(int32_t n_targets, const llmrec_wgrad_target_t* t, int32_t N) {
+    if (n_targets < 1 || n_targets > LLMREC_WGRAD_MAX_TARGETS || !t || N <= 0 || N % 64) return false;
+    for (int i = 0; i < n_targets; ++i) {
+        if (t[i].n_problems < 1 || t[i].n_problems > LLMREC_LINEAR_MAX_PROBLEMS || !t[i].problems || t[i].K <= 0 || t[i].K % 64 || !t[i].dW || t[i].lddw < t[i].K) return false;
+        for (int j = 0; j < t[i].n_problems; ++j) {
+            const llmrec_wgrad_problem_t& q = t[i].problems[j];
+            if (q.M <= 0 || !q.dY || !q.X || q.lddy < N || q.ldx < t[i].K || q.lddy % 4 || q.ldx % 4 || ((uintptr_t)q.dY | (uintptr_t)q.X) % 16) return false;
+            if ((q.M + 256) * std::max(q.lddy, q.ldx) >= (1ll << 30)) return false;
+        }
+    }
+    return true;
+}
+
+int64_t llmrec_linear_wgrad_multi_workspace_bytes(int32_t n_targets, const llmrec_wgrad_target_t* t, int32_t N) {
+    if (!wgrad_multi_ok(n_targets, t, N)) return -1;
+    const int64_t mc = wgrad_multi_slab_rows(n_targets, t);
+    int64_t bytes = 0;
+    for (int i = 0; i < n_targets; ++i) {
+        int64_t slabs = 0;
+        for (int j = 0; j < t[i].n_problems; ++j) slabs += ceil_div(t[i].problems[j].M, mc);
+        bytes += wgrad_ws_bytes(ceil_div(slabs, 4), N, t[i].K);
+    }
+    return bytes;
+}
+
+int llmrec_linear_wgrad_multi_bf16x3(int32_t n_targets, const llmrec_wgrad_target_t* t, int32_t N,
+                                     void* workspace, int64_t workspace_bytes, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!wgrad_multi_ok(n_targets, t, N)) {
+        set_error("linear_wgrad_multi: outside the fast path (1..%d targets, N %% 64 == 0, K %% 64 == 0, non-empty 16-byte aligned problems, 32-bit offsets)",
+                  LLMREC_WGRAD_MAX_TARGETS);
+        return LLMREC_EUNSUPPORTED;
+    }
+    const int64_t need = llmrec_linear_wgrad_multi_workspace_bytes(n_targets, t, N);
+    if (!workspace || workspace_bytes < need || (uintptr_t)workspace % 16) {
+        set_error("linear_wgrad_multi: workspace %lld < %lld (16-byte aligned)", (long long)workspace_bytes, (long long)need);
+        return LLMREC_EWORKSPACE;
+    }
+    WgradMulti m = {};
+    ReduceMulti r = {};
+    m.n_targets = r.n_targets = n_targets;
+    m.MC = wgrad_multi_slab_rows(n_targets, t);
+    char* ws = (char*)workspace;
+    int blocks = 0, rblocks = 0;
+    for (int i = 0; i < n_targets; ++i) {
+        WgradGroup& g = m.g[i];
+        g.n_problems = t[i].n_problems;
+        int n_slabs = 0;
+        for (int j = 0; j < t[i].n_problems; ++j) {
+            const llmrec_wgrad_problem_t& q = t[i].problems[j];
+            g.dY[j] = q.dY; g.X[j] = q.X; g.lddy[j] = q.lddy; g.ldx[j] = q.ldx; g.M[j] = q.M; g.vec_ok[j] = 1;
+            g.chunk_begin[j] = n_slabs;
+            n_slabs += (int)ceil_div(q.M, m.MC);
+        }
+        for (int j = t[i].n_problems; j <= LLMREC_LINEAR_MAX_PROBLEMS; ++j) g.chunk_begin[j] = n_slabs;
+        const int64_t n_chunks = ceil_div(n_slabs, 4);
+        m.K[i] = t[i].K; m.n_kslab[i] = t[i].K / 64; m.n_slabs[i] = n_slabs;
+        m.partial[i] = (float*)ws;
+        m.partial_db[i] = t[i].db ? (float*)(ws + align_up(4 * n_chunks * N * t[i].K, 256)) : nullptr;
+        ws += wgrad_ws_bytes(n_chunks, N, t[i].K);
+        m.block_begin[i] = blocks;
+        blocks += (int)(n_chunks * m.n_kslab[i]);
+        r.partial[i] = m.partial[i]; r.partial_b[i] = m.partial_db[i]; r.out[i] = t[i].dW; r.out_b[i] = t[i].db; r.ld_out[i] = t[i].lddw;
+        r.n_elem[i] = (int64_t)N * t[i].K; r.n_chunks[i] = n_chunks; r.row_len[i] = t[i].K; r.n_b[i] = t[i].db ? N : 0; r.accumulate[i] = t[i].accumulate;
+        r.block_begin[i] = rblocks;
+        rblocks += (int)ceil_div(r.n_elem[i] + r.n_b[i], 256);
+    }
+    for (int i = n_targets; i <= LLMREC_WGRAD_MAX_TARGETS; ++i) { m.block_begin[i] = blocks; r.block_begin[i] = rblocks; }
+    linear_wgrad_bf16x3_multi_kernel<<<dim3((unsigned)blocks, (unsigned)(N / 64)), 256, 0, stream>>>(m, N);
+    LLMREC_LAUNCH_CHECK();
+    reduce_chunks_multi_kernel<<<rblocks, 256, 0, stream>>>(r);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

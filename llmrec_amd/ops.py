@@ -512,6 +512,46 @@ class WgradProblem(_c.Structure):
     _fields_ = [("dY", _c.c_void_p), ("lddy", _c.c_int64), ("X", _c.c_void_p), ("ldx", _c.c_int64), ("M", _c.c_int64)]
 
 
+class WgradTarget(_c.Structure):
+    """llmrec_wgrad_target_t"""
+    _fields_ = [("n_problems", _c.c_int32), ("problems", _c.c_void_p), ("K", _c.c_int32), ("dW", _c.c_void_p), ("lddw", _c.c_int64),
+                ("db", _c.c_void_p), ("accumulate", _c.c_int32)]
+
+
+def _wgrad_targets(targets):
+    """targets: [(pairs, dW, db, accumulate)] -> (ctypes array, keep-alive list, N)"""
+    arr = (WgradTarget * len(targets))()
+    keep = []
+    N = targets[0][1].shape[0]
+    for i, (pairs, dW, db, accumulate) in enumerate(targets):
+        probs = (WgradProblem * len(pairs))()
+        for j, (dY, X) in enumerate(pairs):
+            _need_gpu(dY, X)
+            probs[j].dY, probs[j].lddy, probs[j].X, probs[j].ldx, probs[j].M = dY.data_ptr(), _ld(dY), X.data_ptr(), _ld(X), X.shape[0]
+        keep.append(probs)
+        arr[i].n_problems, arr[i].problems, arr[i].K = len(pairs), _c.cast(probs, _c.c_void_p), dW.shape[1]
+        arr[i].dW, arr[i].lddw, arr[i].db, arr[i].accumulate = dW.data_ptr(), _ld(dW), (db.data_ptr() if db is not None else None), 1 if accumulate else 0
+    return arr, keep, N
+
+
+def linear_wgrad_multi_workspace(targets) -> int:
+    """Bytes of workspace llmrec_linear_wgrad_multi_bf16x3 needs for these targets; -1 = outside its fast path."""
+    arr, keep, N = _wgrad_targets(targets)
+    return _lib.query("llmrec_linear_wgrad_multi_workspace_bytes", len(targets), arr, N)
+
+
+def linear_wgrad_multi(targets, ws: Optional[torch.Tensor] = None):
+    """The bf16x3 weight gradients of several Linears in one launch + one reduction launch (llmrec_linear_wgrad_multi_bf16x3).
+    targets: [(pairs, dW, db, accumulate)], pairs = [(dY, X)] as in linear_wgrad_grouped; all dW have N rows."""
+    arr, keep, N = _wgrad_targets(targets)
+    need = _lib.query("llmrec_linear_wgrad_multi_workspace_bytes", len(targets), arr, N)
+    if need < 0:
+        raise RuntimeError("linear_wgrad_multi: shapes outside the fast path (use linear_wgrad_grouped per target)")
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=targets[0][1].device)
+    _lib.call("llmrec_linear_wgrad_multi_bf16x3", len(targets), arr, N, _p(ws), ws.numel(), _stream())
+
+
 def linear_wgrad_grouped(pairs, dW, db, accumulate: bool, ws: Optional[torch.Tensor] = None, precision: str = "f32"):
     """dW (+)= sum_p dY_p^T X_p for several (dY, X) pairs sharing one weight (one launch + reduce).
     precision "bf16x3": llmrec_linear_wgrad_grouped_bf16x3 (three-term bf16 split, fp32-class error)."""

@@ -93,6 +93,44 @@ def test_weight_gradients_at_bench_shape(ops, precision, tol):
         assert torch.equal(dW2, dW), (precision, name)
 
 
+def test_multi_target_weight_gradient_at_bench_shape(ops):
+    """llmrec_linear_wgrad_multi_bf16x3: item_trans' (5 pairs), text's and image's gradients in one launch - each target against
+    the fp64 product (3e-6), against its single-target launch (other slab length: equal up to rounding), accumulate,
+    determinism, ragged problem sizes, and the refusal of shapes outside the fast path."""
+    g = torch.Generator(device=DEV); g.manual_seed(13)
+    rn = lambda *s: torch.randn(*s, generator=g, device=DEV)
+    for n_items in (I_NF, 1000, 33):
+        dP_cat = rn(n_items, 7 * D)
+        feats = [rn(n_items, 1536) for _ in range(5)]
+        text, image = rn(n_items, 768), rn(n_items, 512)
+        pairs = [[(dP_cat[:, (2 + k) * D:(3 + k) * D], feats[k]) for k in range(5)], [(dP_cat[:, D:2 * D], text)], [(dP_cat[:, 0:D], image)]]
+        Ks = [1536, 768, 512]
+        dWs = [torch.full((D, K), 7.0, device=DEV) for K in Ks]
+        dbs = [torch.full((D,), 7.0, device=DEV) for _ in Ks]
+        targets = [(pairs[t], dWs[t], dbs[t], False) for t in range(3)]
+        assert ops.linear_wgrad_multi_workspace(targets) > 0
+        ops.linear_wgrad_multi(targets)
+        for t in range(3):
+            want = sum(dy.double().t() @ x.double() for dy, x in pairs[t])
+            want_b = sum(dy.double().sum(0) for dy, _ in pairs[t])
+            e, eb = relmax(dWs[t], want), relmax(dbs[t], want_b)
+            assert e < 3e-6 and eb < 3e-6, (n_items, t, e, eb)
+            single = torch.empty_like(dWs[t]); single_b = torch.empty_like(dbs[t])
+            ops.linear_wgrad_grouped(pairs[t], single, single_b, False, precision="bf16x3")
+            assert relmax(dWs[t], single.double()) < 3e-6, (n_items, t)
+        first = [w.clone() for w in dWs]
+        ops.linear_wgrad_multi([(pairs[t], dWs[t], dbs[t], True) for t in range(3)])           # accumulate
+        for t in range(3):
+            assert relmax(dWs[t], 2 * first[t].double()) < 1e-6, (n_items, t)
+        ops.linear_wgrad_multi(targets)                                                          # deterministic
+        for t in range(3):
+            assert torch.equal(dWs[t], first[t]), (n_items, t)
+    bad = [([(rn(64, D), rn(64, 100))], torch.empty(D, 100, device=DEV), None, False)]          # K % 64 != 0
+    assert ops.linear_wgrad_multi_workspace(bad) == -1
+    with pytest.raises(RuntimeError):
+        ops.linear_wgrad_multi(bad)
+
+
 # ------------------------------------------------------------------------------------------
 # R9: scoring + masked top-K at Netflix width and at 10^6 items, adversarial orders
 # ------------------------------------------------------------------------------------------
