@@ -105,7 +105,7 @@ class FusedStep:
         self.wgrad_serial = os.environ.get("LLMREC_WGRAD_SERIAL", "1") == "1"
         # LLMREC_WGRAD_MULTI=1 (default): item_trans', text's and image's weight gradients as ONE launch (bf16x3 only)
         self.wgrad_multi = os.environ.get("LLMREC_WGRAD_MULTI", "1") == "1" and self.gemm == "bf16x3"
-        self.id_chain_late = os.environ.get("LLMREC_ID_CHAIN_LATE", "1") == "1"
+        self.id_chain_late = os.environ.get("LLMREC_ID_CHAIN_LATE", "0") == "1"
 
     # -- raw kernel helpers -----------------------------------------------------------------------
     def _fork(self, *streams):
@@ -359,10 +359,11 @@ class FusedStep:
         self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
         self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
         if self.id_chain_late:
-            # The side chain ends in the item-side weight gradients, 0.19 ms of serial HBM streaming - the step's critical
-            # path; the ID chain's six small launches only have to be done before AdamW. Started here they run beside the
-            # weight gradients (346 of a SIMD's 512 registers: an SpMM wave fits next to a weight-gradient wave) instead
-            # of competing with the side chain's two products.
+            # LLMREC_ID_CHAIN_LATE=1: the ID chain's six small launches only have to be done before AdamW; started here they
+            # run beside the weight gradients (346 of a SIMD's 512 registers: an SpMM wave fits next to a weight-gradient
+            # wave) instead of competing with the side chain's two products. Worth 1-2 % with three weight-gradient
+            # launches back to back; with the single multi-target launch the chain then ends AFTER it (its SpMMs stretch
+            # to 50-70 us beside the gradient) and the step time is the same either way, so the default starts it early.
             self._fork(self.s2)
             with self._on(self.s2):
                 id_chain()
