@@ -27,6 +27,30 @@ def test_workspace_queries_run_without_gpu():
     assert _lib.query("llmrec_csr_build_workspace_bytes", 10, 1000) > 16 * 1000
     assert _lib.query("llmrec_linear_wgrad_workspace_bytes", 1000, 64, 512) >= 4 * 64 * 512
     assert _lib.query("llmrec_sumsq_workspace_bytes", 10, 10) > 0
+    # top-K: 825 user tiles on 256 compute units (the default when no device answers) leave 57 tiles, cut in 4 parts each
+    assert _lib.query("llmrec_score_topk_workspace_bytes", 13187, 17366) == 57 * 4 * 16 * 64 * 8
+    assert _lib.query("llmrec_score_topk_workspace_bytes", 4096 * 16, 1_000_000) == 0          # whole rounds: nothing is split
+    assert _lib.query("llmrec_score_topk_workspace_bytes", 100, 500) == 0                       # too few items to cut
+    assert _lib.query("llmrec_score_topk_workspace_bytes", -1, 10) == -1
+
+
+def test_multi_target_weight_gradient_plan_without_gpu():
+    """llmrec_linear_wgrad_multi_*: the fast-path test and the workspace size are host arithmetic on the argument block."""
+    from llmrec_amd import ops
+    lib = _lib.load()
+    probs = (ops.WgradProblem * 2)()
+    for j in range(2):
+        probs[j].dY, probs[j].lddy, probs[j].X, probs[j].ldx, probs[j].M = 0x1000, 448, 0x2000, 1536, 17366
+    tg = (ops.WgradTarget * 2)()
+    tg[0].n_problems, tg[0].problems, tg[0].K, tg[0].dW, tg[0].lddw, tg[0].db, tg[0].accumulate = 2, ctypes.cast(probs, ctypes.c_void_p), 1536, 0x3000, 1536, 0x4000, 0
+    tg[1].n_problems, tg[1].problems, tg[1].K, tg[1].dW, tg[1].lddw, tg[1].db, tg[1].accumulate = 1, ctypes.cast(probs, ctypes.c_void_p), 1536, 0x5000, 1536, None, 1
+    need = _lib.query("llmrec_linear_wgrad_multi_workspace_bytes", 2, tg, 64)
+    assert need >= 2 * 4 * 64 * 1536
+    assert lib.llmrec_linear_wgrad_multi_bf16x3(2, tg, 64, None, 0, None) == -3                  # workspace too small
+    tg[1].K = 100                                                                               # K % 64 != 0: outside the fast path
+    assert _lib.query("llmrec_linear_wgrad_multi_workspace_bytes", 2, tg, 64) == -1
+    assert lib.llmrec_linear_wgrad_multi_bf16x3(2, tg, 64, None, 0, None) == -4 and b"linear_wgrad_multi" in lib.llmrec_last_error()
+    assert _lib.query("llmrec_linear_wgrad_multi_workspace_bytes", 5, tg, 64) == -1            # more than LLMREC_WGRAD_MAX_TARGETS
 
 
 def test_argument_errors_are_reported_not_thrown():
