@@ -106,6 +106,14 @@ class FusedStep:
         # LLMREC_WGRAD_MULTI=1 (default): item_trans', text's and image's weight gradients as ONE launch (bf16x3 only)
         self.wgrad_multi = os.environ.get("LLMREC_WGRAD_MULTI", "1") == "1" and self.gemm == "bf16x3"
         self.id_chain_late = os.environ.get("LLMREC_ID_CHAIN_LATE", "0") == "1"
+        # Launch (= capture) order at the fork points. Where a bit is set, the critical path's next launch is issued BEFORE the
+        # side stream's work and the side stream waits for an event recorded at the fork point; the order decides which branch
+        # the graph runs behind its parent without a cross-queue hand-off. Bits: 1 projection before the ID chain / sampler,
+        # 2 the forward's side-feature SpMMs before the profile chain, 4 fuse(user) before fuse(item), 8 the BPR backward
+        # before the feature regulariser / loss assembly, 16 fuse_bwd(item) before fuse_bwd(user), 32 the backward's side
+        # chain before the profile / ID chains. Measured one at a time and interleaved with the baseline on one box
+        # (0.6552-0.6576 ms per step): 2 -> 0.6435, 8 -> 0.6471, 2 + 8 -> 0.6297-0.6344; 1 and 32 lose 2-7 %, 4 and 16 are neutral.
+        self.critical_first = int(os.environ.get("LLMREC_CRITICAL_FIRST", "10"))
 
     # -- raw kernel helpers -----------------------------------------------------------------------
     def _fork(self, *streams):
@@ -113,6 +121,19 @@ class FusedStep:
             cur = torch.cuda.current_stream()
             for st in streams:
                 st.wait_stream(cur)
+
+    def _mark(self):
+        """An event at the current point of the current stream (a fork point that side streams may wait for later)."""
+        if not self.multi_stream:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def _fork_from(self, ev, *streams):
+        if self.multi_stream:
+            for st in streams:
+                st.wait_event(ev)
 
     def _join(self, *streams):
         if self.multi_stream:
@@ -196,7 +217,14 @@ class FusedStep:
     # -- forward ----------------------------------------------------------------------------------
     def forward(self, sampler=None):
         m, d = self.m, self.d
-        self._fork(self.s2)
+        cfm = self.critical_first
+        cf = cfm & 1
+        if cf:
+            ev0 = self._mark()
+            self._project_all()
+            self._fork_from(ev0, self.s2)
+        else:
+            self._fork(self.s2)
         with self._on(self.s2):                                          # ID chain: needs no projection
             if sampler is not None and self.multi_stream:                # the batch is first read by the losses, after the join below:
                 sampler()                                                # sampling rides beside the projection instead of ahead of it
@@ -214,14 +242,24 @@ class FusedStep:
                     self._spmm(self.ui.fwd, i_prev, self.Ul[l], tag=2)
                     self._spmm(self.iu.fwd, self.Ul[l], self.Il[l], tag=2)
                 i_prev = self.Il[l]
-        self._project_all()
-        self._fork(self.s1)
+        if not cf:
+            self._project_all()
+        cf1 = cfm & 2
+        if not cf1:
+            self._fork(self.s1)
+        else:
+            ev1 = self._mark()
+            self._spmm(self.ui.fwd, self.P_cat, self.U_cat)
+            self._spmm(self.iu.fwd, self.U_cat, self.I_cat)
+            self._fork_from(ev1, self.s1)
         with self._on(self.s1):                                          # profile stream: items first
             self._spmm(self.iu.fwd, self.P_usr, self.prof_i, tag=1)
             self._spmm(self.ui.fwd, self.prof_i, self.prof_u, tag=1)
-        self._spmm(self.ui.fwd, self.P_cat, self.U_cat)                  # 7 streams, one adjacency pass
-        self._spmm(self.iu.fwd, self.U_cat, self.I_cat)
+        if not cf1:
+            self._spmm(self.ui.fwd, self.P_cat, self.U_cat)              # 7 streams, one adjacency pass
+            self._spmm(self.iu.fwd, self.U_cat, self.I_cat)
         self._join(self.s1, self.s2)
+        cf = cfm & 4
 
         def fuse(out, base, layers, cat, prof):
             means = [base] + layers
@@ -230,10 +268,16 @@ class FusedStep:
             npt, nl = self._tables(norms)
             _call("llmrec_fuse_fwd_f32", out.shape[0], d, 1.0 / len(means), len(means), mp, ml, len(norms), npt, nl, self._rates(),
                   _p(out), _ld(out))
-        self._fork(self.s3)
+        if cf:
+            ev2 = self._mark()
+            fuse(self.E_u, m.user_id_embedding.weight, self.Ul, self.U_cat, self.prof_u)
+            self._fork_from(ev2, self.s3)
+        else:
+            self._fork(self.s3)
         with self._on(self.s3):                                          # the item table beside the user table
             fuse(self.E_i, m.item_id_embedding.weight, self.Il, self.I_cat, self.prof_i)
-        fuse(self.E_u, m.user_id_embedding.weight, self.Ul, self.U_cat, self.prof_u)
+        if not cf:
+            fuse(self.E_u, m.user_id_embedding.weight, self.Ul, self.U_cat, self.prof_u)
         self._join(self.s3)
 
     def outputs(self):
@@ -266,11 +310,17 @@ class FusedStep:
         _call("llmrec_bpr_multi_fwd_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid),
               float(1 - hp.prune_loss_drop_rate), float(hp.decay), float(hp.batch_size), _p(self.out), _p(self.saved))
         # feature regulariser value + loss values for logging, off the critical path: loss = sum_p w_mf[p] * mf_p + emb_0 + feat_reg
-        self._fork(self.s3)
-        with self._on(self.s3):
-            self._feat_reg()
-            self._assemble_loss(0)
-        self._backward(probs, users, pos, neg, n_valid)
+        def side():
+            with self._on(self.s3):
+                self._feat_reg()
+                self._assemble_loss(0)
+        if self.critical_first & 8:
+            ev = self._mark()
+            self._backward(probs, users, pos, neg, n_valid, after_first=lambda: (self._fork_from(ev, self.s3), side()))
+        else:
+            self._fork(self.s3)
+            side()
+            self._backward(probs, users, pos, neg, n_valid)
         self._join(self.s3)
 
     def _zero_accumulators(self):
@@ -292,7 +342,7 @@ class FusedStep:
             _call("llmrec_sumsq_f32", blk.shape[0], 2 * self.d, _p(blk), _ld(blk), float(coef), k, _p(self.scal), _p(self.ws_sumsq),
                   self.ws_sumsq.numel())
 
-    def _backward(self, probs, users, pos, neg, n_valid, replicated_scale: float = 1.0):
+    def _backward(self, probs, users, pos, neg, n_valid, replicated_scale: float = 1.0, after_first=None):
         """Hand-written backward from the saved BPR state to the parameter gradients. replicated_scale
         weights the batch-independent loss terms (1 / world on batch-sharded replicas, whose
         gradients are summed over ranks afterwards)."""
@@ -304,6 +354,9 @@ class FusedStep:
         self._zeroed = False
         _call("llmrec_bpr_multi_bwd_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), float(hp.decay),
               float(hp.batch_size), _p(self.saved))
+        if after_first is not None:
+            after_first()
+        cf = self.critical_first & 16
         def fuse_bwd(dout, cat, prof, dcat, dprof):
             norms, dnorms = self._norm_terms(cat, prof), self._norm_terms(dcat, dprof)
             npt, nl = self._tables(norms)
@@ -311,14 +364,30 @@ class FusedStep:
             # the feature regulariser's gradient on the image / text streams (terms 0, 1) rides along: 2 coef x
             _call("llmrec_fuse_bwd_f32", dout.shape[0], d, _p(dout), _ld(dout), len(norms), npt, nl, self._rates(), dp, dl, 1,
                   2, float(2.0 * coef))
-        self._fork(self.s4)
-        with self._on(self.s4):                                          # item side beside the user side
+        if cf:                                                           # the item side feeds the side chain = the critical path
+            ev4 = self._mark()
             fuse_bwd(self.dE_i, self.I_cat, self.prof_i, self.dI_cat, self.dprof_i)
-        fuse_bwd(self.dE_u, self.U_cat, self.prof_u, self.dU_cat, self.dprof_u)
+            self._fork_from(ev4, self.s4)
+            with self._on(self.s4):
+                fuse_bwd(self.dE_u, self.U_cat, self.prof_u, self.dU_cat, self.dprof_u)
+        else:
+            self._fork(self.s4)
+            with self._on(self.s4):                                      # item side beside the user side
+                fuse_bwd(self.dE_i, self.I_cat, self.prof_i, self.dI_cat, self.dprof_i)
+            fuse_bwd(self.dE_u, self.U_cat, self.prof_u, self.dU_cat, self.dprof_u)
         self._join(self.s4)
         m = self.m
         inv = 1.0 / (L + 1)
-        self._fork(self.s1)
+        side_done = False
+        cf = self.critical_first & 32
+        if cf:                                                           # the side chain's two products first, then the side streams
+            ev5 = self._mark()
+            self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
+            self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
+            side_done = True
+            self._fork_from(ev5, self.s1)
+        else:
+            self._fork(self.s1)
         with self._on(self.s1):
             # profile chain: prof_u = ui(prof_i), prof_i = iu(P_usr); then user_trans' weight gradient
             self._spmm(self.ui.bwd, self.dprof_u, self.dprof_i, accumulate=True, tag=1)
@@ -352,12 +421,16 @@ class FusedStep:
             self._axpy(inv, self.dE_u, m.user_id_embedding.weight.grad, False)    # U^0 only enters the mean
 
         if not self.id_chain_late:
-            self._fork(self.s2)
+            if cf:
+                self._fork_from(ev5, self.s2)
+            else:
+                self._fork(self.s2)
             with self._on(self.s2):
                 id_chain()
         # side chain: I_cat = iu(U_cat), U_cat = ui(P_cat); then the item-side weight gradients
-        self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
-        self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
+        if not side_done:
+            self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
+            self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
         if self.id_chain_late:
             # LLMREC_ID_CHAIN_LATE=1: the ID chain's six small launches only have to be done before AdamW; started here they
             # run beside the weight gradients (346 of a SIMD's 512 registers: an SpMM wave fits next to a weight-gradient
