@@ -185,7 +185,7 @@ class NetflixShaped:
 
 
     def _wgrad_in_situ_ms(self, dYi, dYu, ws, iters: int = 20):
-        """Durations of the step's four weight-gradient launches (each = the GEMM + its slab reduction), launched as the
+        """Durations of the step's weight-gradient launches (each = the GEMM + its slab reduction; two with the multi-target launch, four without), launched as the
         step launches them, HIP events on each launch's own stream; and the wall time of the group."""
         import torch
         ops, d, m_ = self.ops, self.args.embed_size, self.model
@@ -260,7 +260,8 @@ class NetflixShaped:
                     "algorithmic_flop_per_step": flop_all, "algorithmic_bytes_per_step": byts_all, "launches": 1})
         flop = 2.0 * sh.n_items * sh.llm_dim * d
         byts = 4.0 * (sh.n_items * sh.llm_dim + d * sh.llm_dim + sh.n_items * d)
-        # the step's four weight-gradient launches: item_trans (5 attribute streams grouped), user, text, image
+        # the step's weight gradients: item_trans (5 attribute streams grouped), user, text, image - four single-target launches here
+        # (the isolated serial figure), the step's own layout (multi-target launch + user_trans') in _wgrad_in_situ_ms below
         dYi = torch.randn(sh.n_items, 7 * d, device=self.device); dYu = torch.randn(sh.n_users, d, device=self.device)
         m_ = self.model
         ws = self.fused.ws_wgrad
@@ -273,7 +274,7 @@ class NetflixShaped:
             ops.linear_wgrad_grouped([(dYi[:, d:2 * d], m_.text_feats)], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False, ws, precision=pr)
             ops.linear_wgrad_grouped([(dYi[:, 0:d], m_.image_feats)], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False, ws, precision=pr)
         ms_serial = event_time_ms(wgrad_all, 20)
-        # IN SITU: the launches as the step issues them (three back to back on one stream, user_trans' on a second one);
+        # IN SITU: the launches as the step issues them (the multi-target launch on one stream, user_trans' on a second one);
         # each launch's own duration is what a rocprofv3 kernel trace of the step reports as the kernel's average
         # duration (profiles/r02_bench_nf_kernel_stats_*.csv), and it is the denominator of the roofline figure below.
         per_launch, wall = self._wgrad_in_situ_ms(dYi, dYu, ws)
@@ -878,7 +879,7 @@ def main():
         if not a.no_kernel_roofline:
             ks = w.kernel_rooflines()
             line["kernels"] = ks
-            # dominant kernel = the largest share of the step's GPU time: the four weight-gradient launches (rocprofv3:
+            # dominant kernel = the largest share of the step's GPU time: the weight-gradient launches (rocprofv3 round 1:
             # 25 % of the step) ahead of the single grouped-projection launch; both are reported, the dominant one first
             dom = max(ks[:2], key=lambda k: k["ms"])
             other = min(ks[:2], key=lambda k: k["ms"])

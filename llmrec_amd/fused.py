@@ -78,7 +78,7 @@ class FusedStep:
         self._partials = {}
         # Three independent chains (7-stream side features / LLM profile / ID embeddings) run on three
         # HIP streams in forward and in backward; under capture the fork/join becomes graph edges, so
-        # the latency-bound Netflix-scale SpMMs and the four weight-gradient GEMMs overlap.
+        # the latency-bound Netflix-scale SpMMs and the weight-gradient GEMMs overlap.
         import os as _os
         self.multi_stream = _os.environ.get("LLMREC_STREAMS", "1") == "1"
         self.s1, self.s2, self.s3, self.s4 = (torch.cuda.Stream(device=dev) for _ in range(4))
