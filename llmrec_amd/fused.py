@@ -217,9 +217,9 @@ class FusedStep:
     # -- forward ----------------------------------------------------------------------------------
     def forward(self, sampler=None):
         m, d = self.m, self.d
-        cfm = self.critical_first
-        cf = cfm & 1
-        if cf:
+        order = self.critical_first                                      # capture order at the fork points (see __init__)
+        proj_first, side_first, fuse_user_first = order & 1, order & 2, order & 4
+        if proj_first:
             ev0 = self._mark()
             self._project_all()
             self._fork_from(ev0, self.s2)
@@ -242,10 +242,9 @@ class FusedStep:
                     self._spmm(self.ui.fwd, i_prev, self.Ul[l], tag=2)
                     self._spmm(self.iu.fwd, self.Ul[l], self.Il[l], tag=2)
                 i_prev = self.Il[l]
-        if not cf:
+        if not proj_first:
             self._project_all()
-        cf1 = cfm & 2
-        if not cf1:
+        if not side_first:
             self._fork(self.s1)
         else:
             ev1 = self._mark()
@@ -255,11 +254,10 @@ class FusedStep:
         with self._on(self.s1):                                          # profile stream: items first
             self._spmm(self.iu.fwd, self.P_usr, self.prof_i, tag=1)
             self._spmm(self.ui.fwd, self.prof_i, self.prof_u, tag=1)
-        if not cf1:
+        if not side_first:
             self._spmm(self.ui.fwd, self.P_cat, self.U_cat)              # 7 streams, one adjacency pass
             self._spmm(self.iu.fwd, self.U_cat, self.I_cat)
         self._join(self.s1, self.s2)
-        cf = cfm & 4
 
         def fuse(out, base, layers, cat, prof):
             means = [base] + layers
@@ -268,7 +266,7 @@ class FusedStep:
             npt, nl = self._tables(norms)
             _call("llmrec_fuse_fwd_f32", out.shape[0], d, 1.0 / len(means), len(means), mp, ml, len(norms), npt, nl, self._rates(),
                   _p(out), _ld(out))
-        if cf:
+        if fuse_user_first:
             ev2 = self._mark()
             fuse(self.E_u, m.user_id_embedding.weight, self.Ul, self.U_cat, self.prof_u)
             self._fork_from(ev2, self.s3)
@@ -276,7 +274,7 @@ class FusedStep:
             self._fork(self.s3)
         with self._on(self.s3):                                          # the item table beside the user table
             fuse(self.E_i, m.item_id_embedding.weight, self.Il, self.I_cat, self.prof_i)
-        if not cf:
+        if not fuse_user_first:
             fuse(self.E_u, m.user_id_embedding.weight, self.Ul, self.U_cat, self.prof_u)
         self._join(self.s3)
 
@@ -356,7 +354,7 @@ class FusedStep:
               float(hp.batch_size), _p(self.saved))
         if after_first is not None:
             after_first()
-        cf = self.critical_first & 16
+        fuse_item_first, side_chain_first = self.critical_first & 16, self.critical_first & 32
         def fuse_bwd(dout, cat, prof, dcat, dprof):
             norms, dnorms = self._norm_terms(cat, prof), self._norm_terms(dcat, dprof)
             npt, nl = self._tables(norms)
@@ -364,7 +362,7 @@ class FusedStep:
             # the feature regulariser's gradient on the image / text streams (terms 0, 1) rides along: 2 coef x
             _call("llmrec_fuse_bwd_f32", dout.shape[0], d, _p(dout), _ld(dout), len(norms), npt, nl, self._rates(), dp, dl, 1,
                   2, float(2.0 * coef))
-        if cf:                                                           # the item side feeds the side chain = the critical path
+        if fuse_item_first:                                              # the item side feeds the side chain = the critical path
             ev4 = self._mark()
             fuse_bwd(self.dE_i, self.I_cat, self.prof_i, self.dI_cat, self.dprof_i)
             self._fork_from(ev4, self.s4)
@@ -379,8 +377,7 @@ class FusedStep:
         m = self.m
         inv = 1.0 / (L + 1)
         side_done = False
-        cf = self.critical_first & 32
-        if cf:                                                           # the side chain's two products first, then the side streams
+        if side_chain_first:                                             # the side chain's two products first, then the side streams
             ev5 = self._mark()
             self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
             self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
@@ -421,7 +418,7 @@ class FusedStep:
             self._axpy(inv, self.dE_u, m.user_id_embedding.weight.grad, False)    # U^0 only enters the mean
 
         if not self.id_chain_late:
-            if cf:
+            if side_chain_first:
                 self._fork_from(ev5, self.s2)
             else:
                 self._fork(self.s2)
