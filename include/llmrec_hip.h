@@ -216,6 +216,15 @@ int llmrec_fuse_bwd_f32(int64_t rows, int32_t d, const float* dOut, int64_t lddo
                         int32_t n_norm, const float* const* norm_terms_host, const int64_t* norm_ld_host,
                         const float* rates_host, float* const* d_terms_host, const int64_t* d_ld_host,
                         int32_t accumulate, int32_t n_reg_terms, float reg_two_coef, llmrec_stream_t stream);
+/* The same with a SOURCE per term: d_terms[t] = src_terms[t] (or 0 where src_terms[t] is NULL) + the term's gradient, written
+ * without reading d_terms. With the loss backward scattering into separate, otherwise all-zero source buffers
+ * (llmrec_bpr_multi_bwd_f32) and llmrec_bpr_multi_zero_rows_f32 clearing the touched rows afterwards, a training step needs no
+ * dense memset of its gradient buffers. */
+int llmrec_fuse_bwd_src_f32(int64_t rows, int32_t d, const float* dOut, int64_t lddo,
+                            int32_t n_norm, const float* const* norm_terms_host, const int64_t* norm_ld_host,
+                            const float* rates_host, float* const* d_terms_host, const int64_t* d_ld_host,
+                            const float* const* src_terms_host, const int64_t* src_ld_host,
+                            int32_t n_reg_terms, float reg_two_coef, llmrec_stream_t stream);
 /* n_reg_terms / reg_two_coef: the first n_reg_terms terms additionally receive reg_two_coef * x - the gradient of a
  * sum-of-squares regulariser coef * sum x^2 on them (reference main.py:151-156 on the image / text streams), folded in
  * because the kernel has x in registers anyway; pass 0, 0 for the plain backward. */
@@ -288,6 +297,11 @@ int llmrec_bpr_multi_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* pro
                              const int64_t* users, const int64_t* pos, const int64_t* neg,
                              int32_t B_max, const int32_t* n_valid_dev, float decay, float batch_size_flag,
                              const float* saved, llmrec_stream_t stream);
+/* Clears exactly the rows llmrec_bpr_multi_bwd_f32 added into (dEu[u_b], dEi[p_b], dEi[q_b] of every problem, b < n_valid),
+ * so scatter targets that start all-zero are all-zero again. */
+int llmrec_bpr_multi_zero_rows_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
+                                   const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                   int32_t B_max, const int32_t* n_valid_dev, llmrec_stream_t stream);
 /* dEu[u_b] += g_mf * ds_b * (Ei[p_b] - Ei[q_b]) + g_emb * c_u * Eu[u_b]   (atomic scatter-add)
  * dEi[p_b] += g_mf * ds_b * Eu[u_b] + g_emb * c_p * Ei[p_b] ; dEi[q_b] likewise with -ds_b, c_q
  * g_mf / g_emb are upstream gradients read from device memory (grads2[0], grads2[1]). */

@@ -250,6 +250,22 @@ __global__ __launch_bounds__(256) void bpr_bwd_multi_kernel(BprTables t, int d, 
     }
 }
 
+// the rows bpr_bwd_multi_kernel added into are cleared again (same grid): the scatter targets stay all-zero between steps
+// without a dense memset
+__global__ __launch_bounds__(256) void bpr_zero_rows_kernel(BprTables t, int d, const int64_t* __restrict__ users,
+                                                            const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
+                                                            int B_max, const int32_t* __restrict__ n_valid_dev) {
+    const int B = bpr_batch(n_valid_dev, B_max);
+    const int prob = blockIdx.y;
+    const int gl = threadIdx.x & 15;
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (b >= B) return;
+    float* du = t.dEu[prob] + users[b] * t.lddu[prob];
+    float* dpp = t.dEi[prob] + pos[b] * t.lddi[prob];
+    float* dqq = t.dEi[prob] + neg[b] * t.lddi[prob];
+    for (int c = gl; c < d; c += 16) { du[c] = 0.f; dpp[c] = 0.f; dqq[c] = 0.f; }
+}
+
 __global__ __launch_bounds__(256) void bpr_bwd_kernel(const float* __restrict__ Eu, int64_t ldu,
                                                       const float* __restrict__ Ei, int64_t ldi, int d,
                                                       const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
@@ -597,6 +613,20 @@ int llmrec_bpr_multi_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* pro
     dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_problems);
     bpr_bwd_multi_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(t, d, users, pos, neg, B_max, n_valid_dev, decay, batch_size_flag,
                                                                 saved, LLMREC_BPR_SAVED_FLOATS(B_max));
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_bpr_multi_zero_rows_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
+                                   const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                   int32_t B_max, const int32_t* n_valid_dev, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && problems_host && d > 0, "bpr_multi_zero_rows: bad argument");
+    if (B_max == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(users && pos && neg, "bpr_multi_zero_rows: null index pointer");
+    BprTables t = {};
+    LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, true), "bpr_multi_zero_rows: bad problem table");
+    dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_problems);
+    bpr_zero_rows_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(t, d, users, pos, neg, B_max, n_valid_dev);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

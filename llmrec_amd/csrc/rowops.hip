@@ -120,6 +120,8 @@ struct FuseArgs {
     int64_t norm_ld[LLMREC_MAX_TERMS];
     float* d_terms[LLMREC_MAX_TERMS];
     int64_t d_ld[LLMREC_MAX_TERMS];
+    const float* s_terms[LLMREC_MAX_TERMS];   // backward, accumulate == 2: d_terms[t] = s_terms[t] (or 0 if null) + the term's gradient
+    int64_t s_ld[LLMREC_MAX_TERMS];
     float rates[LLMREC_MAX_TERMS];
     int n_mean, n_norm;
     float mean_scale;
@@ -166,7 +168,9 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(int64_t rows, int d, Fuse
             t.load(a.norm_terms[i] + row * a.norm_ld[i], gl, d);
             const float nn = sqrtf(t.dot(t));
             float* dst = a.d_terms[i] + row * a.d_ld[i];
-            if (accumulate) o.load(dst, gl, d); else o.fill(0.f);
+            if (accumulate == 1) o.load(dst, gl, d);
+            else if (accumulate == 2 && a.s_terms[i]) o.load(a.s_terms[i] + row * a.s_ld[i], gl, d);
+            else o.fill(0.f);
             if (nn >= 1e-12f) {
                 const float inv = 1.0f / nn;
                 const float proj = t.dot(g) * inv * inv;                 // <n, g> / ||x||
@@ -465,10 +469,35 @@ int llmrec_fuse_fwd_f32(int64_t rows, int32_t d, float mean_scale,
     return LLMREC_OK;
 }
 
+static int fuse_bwd_impl(int64_t rows, int32_t d, const float* dOut, int64_t lddo,
+                         int32_t n_norm, const float* const* norm_terms, const int64_t* norm_ld,
+                         const float* rates, float* const* d_terms, const int64_t* d_ld,
+                         const float* const* src_terms, const int64_t* src_ld,
+                         int32_t accumulate, int32_t n_reg_terms, float reg_two_coef, llmrec_stream_t stream_);
+
 int llmrec_fuse_bwd_f32(int64_t rows, int32_t d, const float* dOut, int64_t lddo,
                         int32_t n_norm, const float* const* norm_terms, const int64_t* norm_ld,
                         const float* rates, float* const* d_terms, const int64_t* d_ld,
                         int32_t accumulate, int32_t n_reg_terms, float reg_two_coef, llmrec_stream_t stream_) {
+    return fuse_bwd_impl(rows, d, dOut, lddo, n_norm, norm_terms, norm_ld, rates, d_terms, d_ld, nullptr, nullptr, accumulate ? 1 : 0,
+                         n_reg_terms, reg_two_coef, stream_);
+}
+
+int llmrec_fuse_bwd_src_f32(int64_t rows, int32_t d, const float* dOut, int64_t lddo,
+                            int32_t n_norm, const float* const* norm_terms, const int64_t* norm_ld,
+                            const float* rates, float* const* d_terms, const int64_t* d_ld,
+                            const float* const* src_terms, const int64_t* src_ld,
+                            int32_t n_reg_terms, float reg_two_coef, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(src_terms && src_ld, "fuse_bwd_src: null source tables");
+    return fuse_bwd_impl(rows, d, dOut, lddo, n_norm, norm_terms, norm_ld, rates, d_terms, d_ld, src_terms, src_ld, 2,
+                         n_reg_terms, reg_two_coef, stream_);
+}
+
+static int fuse_bwd_impl(int64_t rows, int32_t d, const float* dOut, int64_t lddo,
+                         int32_t n_norm, const float* const* norm_terms, const int64_t* norm_ld,
+                         const float* rates, float* const* d_terms, const int64_t* d_ld,
+                         const float* const* src_terms, const int64_t* src_ld,
+                         int32_t accumulate, int32_t n_reg_terms, float reg_two_coef, llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LLMREC_CHECK_ARG(rows >= 0 && d > 0 && n_norm >= 0 && n_norm <= LLMREC_MAX_TERMS && n_reg_terms >= 0 && n_reg_terms <= n_norm,
                      "fuse_bwd: bad sizes");
@@ -481,7 +510,10 @@ int llmrec_fuse_bwd_f32(int64_t rows, int32_t d, const float* dOut, int64_t lddo
         LLMREC_CHECK_ARG(norm_terms[i] && d_terms[i] && norm_ld[i] >= d && d_ld[i] >= d, "fuse_bwd: bad term %d", i);
         a.norm_terms[i] = norm_terms[i]; a.norm_ld[i] = norm_ld[i]; a.rates[i] = rates[i];
         a.d_terms[i] = d_terms[i]; a.d_ld[i] = d_ld[i];
-        vec4 = vec4 && norm_ld[i] % 4 == 0 && d_ld[i] % 4 == 0 && aligned16(norm_terms[i]) && aligned16(d_terms[i]);
+        a.s_terms[i] = src_terms ? src_terms[i] : nullptr; a.s_ld[i] = src_terms ? src_ld[i] : 0;
+        LLMREC_CHECK_ARG(!a.s_terms[i] || a.s_ld[i] >= d, "fuse_bwd: source term %d has ld < d", i);
+        vec4 = vec4 && norm_ld[i] % 4 == 0 && d_ld[i] % 4 == 0 && aligned16(norm_terms[i]) && aligned16(d_terms[i]) &&
+               (!a.s_terms[i] || (a.s_ld[i] % 4 == 0 && aligned16(a.s_terms[i])));
     }
     const int grid = grid_for(rows, ROWS_PER_BLOCK);
     int rc = dispatch_rows(d, vec4,

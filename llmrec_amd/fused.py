@@ -59,7 +59,15 @@ class FusedStep:
         self.Il = [f(I, d) for _ in range(self.L)]
         self.E_u, self.E_i = f(U, d), f(I, d)
         # backward buffers
-        self.dE_u, self.dE_i = f(U, d), f(I, d)
+        # LLMREC_SPARSE_ZERO=1 (default): the loss backward scatters into buffers that are all-zero between steps - dE_u / dE_i and
+        # the sc_* sources of the fusion backward - and clears exactly the rows it touched afterwards
+        # (llmrec_bpr_multi_zero_rows_f32); the fusion backward writes d*_cat = source + its own term
+        # (llmrec_fuse_bwd_src_f32). No dense memset of the six gradient buffers (70 MB per step at the Netflix shape).
+        self.sparse_zero = os.environ.get("LLMREC_SPARSE_ZERO", "1") == "1"
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.dE_u, self.dE_i = z(U, d), z(I, d)
+        if self.sparse_zero:
+            self.sc_U, self.sc_I, self.sc_prof = z(U, 2 * d), z(I, S * d), z(U, d)
         self.dU_cat, self.dI_cat, self.dP_cat = f(U, S * d), f(I, S * d), f(I, S * d)
         self.dprof_u, self.dprof_i, self.dP_usr = f(U, d), f(I, d), f(U, d)
         self.bufU, self.bufI, self.tmpU, self.tmpI = f(U, d), f(I, d), f(U, d), f(I, d)
@@ -100,7 +108,7 @@ class FusedStep:
         self._zero_in_forward = False                         # set by step_eager: forward() alone (evaluation) must not pay for it
         # projection / weight-gradient arithmetic: "bf16x3" (default) = exact 3-term bf16 split of both operands, six bf16
         # MFMAs, fp32-roundoff-class error (2e-6 measured), HBM-bound; "f32" = the exact fp32 MFMA fma chain
-        import os
+
         self.gemm = os.environ.get("LLMREC_GEMM", "bf16x3")
         self.wgrad_serial = os.environ.get("LLMREC_WGRAD_SERIAL", "1") == "1"
         # LLMREC_WGRAD_MULTI=1 (default): item_trans', text's and image's weight gradients as ONE launch (bf16x3 only)
@@ -229,7 +237,8 @@ class FusedStep:
             if sampler is not None and self.multi_stream:                # the batch is first read by the losses, after the join below:
                 sampler()                                                # sampling rides beside the projection instead of ahead of it
             if self._zero_in_forward:                                    # the backward's scatter targets, off the critical path
-                self._zero_accumulators()
+                if not self.sparse_zero:
+                    self._zero_accumulators()
                 self.opt.advance()                                       # AdamW's step counter / bias corrections, likewise
             i_prev = m.item_id_embedding.weight
             for l in range(self.L):
@@ -289,10 +298,11 @@ class FusedStep:
     def _problems(self):
         arr = (ops.BprProblem * self.n_prob)()
         tabs = [(self.E_u, self.E_i, self.dE_u, self.dE_i)]
+        tU, tI, tP = (self.sc_U, self.sc_I, self.sc_prof) if self.sparse_zero else (self.dU_cat, self.dI_cat, self.dprof_u)
         for s in range(2):
-            tabs.append((self._side(self.U_cat, s), self._side(self.I_cat, s), self._side(self.dU_cat, s), self._side(self.dI_cat, s)))
+            tabs.append((self._side(self.U_cat, s), self._side(self.I_cat, s), self._side(tU, s), self._side(tI, s)))
         for k in range(len(self.keys)):
-            tabs.append((self.prof_u, self._side(self.I_cat, 2 + k), self.dprof_u, self._side(self.dI_cat, 2 + k)))
+            tabs.append((self.prof_u, self._side(self.I_cat, 2 + k), tP, self._side(tI, 2 + k)))
         for i, (eu, ei, deu, dei) in enumerate(tabs):
             arr[i].Eu, arr[i].ldu, arr[i].Ei, arr[i].ldi = eu.data_ptr(), _ld(eu), ei.data_ptr(), _ld(ei)
             arr[i].dEu, arr[i].lddu, arr[i].dEi, arr[i].lddi = deu.data_ptr(), _ld(deu), dei.data_ptr(), _ld(dei)
@@ -347,7 +357,7 @@ class FusedStep:
         hp, d, L, S = self.hp, self.d, self.L, self.S
         B = users.numel()
         coef = hp.feat_reg_decay * 0.5 / self.I * replicated_scale
-        if not self._zeroed:
+        if not self._zeroed and not self.sparse_zero:
             self._zero_accumulators()
         self._zeroed = False
         _call("llmrec_bpr_multi_bwd_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), float(hp.decay),
@@ -360,7 +370,18 @@ class FusedStep:
             npt, nl = self._tables(norms)
             dp, dl = self._tables(dnorms)
             # the feature regulariser's gradient on the image / text streams (terms 0, 1) rides along: 2 coef x
-            _call("llmrec_fuse_bwd_f32", dout.shape[0], d, _p(dout), _ld(dout), len(norms), npt, nl, self._rates(), dp, dl, 1,
+            if not self.sparse_zero:
+                _call("llmrec_fuse_bwd_f32", dout.shape[0], d, _p(dout), _ld(dout), len(norms), npt, nl, self._rates(), dp, dl, 1,
+                      2, float(2.0 * coef))
+                return
+            # sources = what the loss backward scattered for this side (terms in _norm_terms order: image, text, profile, attributes)
+            if dcat is self.dI_cat:
+                srcs = [self._side(self.sc_I, 0), self._side(self.sc_I, 1), None] + [self._side(self.sc_I, 2 + k) for k in range(len(self.keys))]
+            else:
+                srcs = [self._side(self.sc_U, 0), self._side(self.sc_U, 1), self.sc_prof] + [None] * len(self.keys)
+            sp = (_c.c_void_p * len(srcs))(*[t.data_ptr() if t is not None else None for t in srcs])
+            sl = (_c.c_int64 * len(srcs))(*[_ld(t) if t is not None else 0 for t in srcs])
+            _call("llmrec_fuse_bwd_src_f32", dout.shape[0], d, _p(dout), _ld(dout), len(norms), npt, nl, self._rates(), dp, dl, sp, sl,
                   2, float(2.0 * coef))
         if fuse_item_first:                                              # the item side feeds the side chain = the critical path
             ev4 = self._mark()
@@ -416,6 +437,8 @@ class FusedStep:
             if L == 0:
                 self._axpy(inv, self.dE_i, m.item_id_embedding.weight.grad, False)
             self._axpy(inv, self.dE_u, m.user_id_embedding.weight.grad, False)    # U^0 only enters the mean
+            if self.sparse_zero:                                                  # last reader of dE_u / dE_i: clear the touched rows
+                _call("llmrec_bpr_multi_zero_rows_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid))
 
         if not self.id_chain_late:
             if side_chain_first:

@@ -634,3 +634,54 @@ def test_topk_metrics_match_host_formulae(ops):
     want = metrics_from_hit_matrix(hits.cpu().numpy(), n_pos, Ks, (topk >= 0).sum(1))
     for j, k in enumerate(("precision", "recall", "ndcg", "hit_ratio")):
         assert np.allclose(got[:, j, :], want[k], rtol=0, atol=1e-13), k
+
+
+def test_fuse_bwd_source_mode_and_zero_rows(ops):
+    """llmrec_fuse_bwd_src_f32: d_terms = source (or 0) + the term's gradient, identical to scatter-then-accumulate with
+    llmrec_fuse_bwd_f32; llmrec_bpr_multi_zero_rows_f32 clears exactly the rows the multi-problem backward touched."""
+    import ctypes as C
+    from llmrec_amd import _lib
+    from llmrec_amd.ops import _p, _ld, BprProblem
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    rn = lambda *s: torch.randn(*s, generator=g, device=DEV)
+    rows, d, T = 301, 64, 4
+    dout = rn(rows, d)
+    cat = rn(rows, 3 * d); prof = rn(rows, d)
+    cat[7] = 0.0                                                            # a zero row: the clamp branch
+    terms = [cat[:, 0:d], cat[:, d:2 * d], prof, cat[:, 2 * d:3 * d]]
+    rates = (C.c_float * T)(0.3, 0.2, 0.5, 0.1)
+    tab = lambda ts: ((C.c_void_p * len(ts))(*[t.data_ptr() if t is not None else None for t in ts]),
+                      (C.c_int64 * len(ts))(*[_ld(t) if t is not None else 0 for t in ts]))
+    src_cat = torch.zeros(rows, 3 * d, device=DEV); src_cat[::5] = rn((rows + 4) // 5, 3 * d)   # what a scatter would have left
+    srcs = [src_cat[:, 0:d], src_cat[:, d:2 * d], None, src_cat[:, 2 * d:3 * d]]
+    # reference: accumulate into a copy of the sources (profile term: into zeros)
+    ref_cat = src_cat.clone(); ref_prof = torch.zeros(rows, d, device=DEV)
+    d_ref = [ref_cat[:, 0:d], ref_cat[:, d:2 * d], ref_prof, ref_cat[:, 2 * d:3 * d]]
+    npt, nl = tab(terms); dp, dl = tab(d_ref)
+    _lib.call("llmrec_fuse_bwd_f32", rows, d, _p(dout), _ld(dout), T, npt, nl, rates, dp, dl, 1, 2, 0.01, None)
+    out_cat = torch.full((rows, 3 * d), 9.0, device=DEV); out_prof = torch.full((rows, d), 9.0, device=DEV)   # garbage: must be overwritten
+    d_out = [out_cat[:, 0:d], out_cat[:, d:2 * d], out_prof, out_cat[:, 2 * d:3 * d]]
+    dp2, dl2 = tab(d_out); sp, sl = tab(srcs)
+    _lib.call("llmrec_fuse_bwd_src_f32", rows, d, _p(dout), _ld(dout), T, npt, nl, rates, dp2, dl2, sp, sl, 2, 0.01, None)
+    torch.cuda.synchronize()
+    assert torch.equal(out_cat, ref_cat) and torch.equal(out_prof, ref_prof)
+
+    # zero_rows: two problems sharing index vectors, n_valid < B
+    U, I, B, nv = 50, 70, 32, 20
+    Eu, Ei = rn(U, d), rn(I, d)
+    dEu = [torch.ones(U, d, device=DEV) for _ in range(2)]; dEi = [torch.ones(I, 2 * d, device=DEV) for _ in range(2)]
+    users = torch.randperm(U, generator=g, device=DEV)[:B].to(torch.int64)
+    pos = torch.randint(0, I, (B,), generator=g, device=DEV); neg = torch.randint(0, I, (B,), generator=g, device=DEV)
+    n_valid = torch.tensor([nv], dtype=torch.int32, device=DEV)
+    probs = (BprProblem * 2)()
+    for i in range(2):
+        probs[i].Eu, probs[i].ldu, probs[i].Ei, probs[i].ldi = Eu.data_ptr(), d, Ei.data_ptr(), d
+        tgt = dEi[i][:, d:2 * d]                                             # a column slice: ld = 2 d
+        probs[i].dEu, probs[i].lddu, probs[i].dEi, probs[i].lddi = dEu[i].data_ptr(), d, tgt.data_ptr(), 2 * d
+        probs[i].g_mf, probs[i].g_emb = 1.0, 1.0
+    _lib.call("llmrec_bpr_multi_zero_rows_f32", 2, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), None)
+    torch.cuda.synchronize()
+    for i in range(2):
+        want_u = torch.ones(U, d, device=DEV); want_u[users[:nv]] = 0
+        want_i = torch.ones(I, 2 * d, device=DEV); want_i[pos[:nv], d:] = 0; want_i[neg[:nv], d:] = 0
+        assert torch.equal(dEu[i], want_u) and torch.equal(dEi[i], want_i)
