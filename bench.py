@@ -911,6 +911,8 @@ def main():
                 rs[scaling] = row_sharded_measure("cfg4", scaling, a.seed, device, rank, world, steps_rs, barrier)
             except torch.OutOfMemoryError as e:               # pragma: no cover
                 rs[scaling] = {"error": "out of memory: %s" % str(e)[:120]}
+            except Exception as e:                            # pragma: no cover - the replica line above must still be printed
+                rs[scaling] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if rank == 0:
             line["row_sharded"] = rs
     if workload not in ("nf", "ml"):
