@@ -49,6 +49,8 @@ def parse():
                                                            "strong: all 16 blocks = the whole config, split over the ranks")
     ap.add_argument("--synth-blocks", type=int, default=0, help="override the number of user blocks per GPU (weak) / in total (strong)")
     ap.add_argument("--synth-chunks", type=int, default=0, help="item-row chunks per all-reduced message (0 = automatic, >= 32 MB each)")
+    ap.add_argument("--synth-exchange", default="all_reduce", help="all_reduce | rs_ag: the per-chunk exchange of the row-sharded step (llmrec_amd/dist_fused.py)")
+    ap.add_argument("--no-single-gpu-reference", action="store_true", help="N > 1, row-sharded strong scaling: skip rank 0's run of the same workload on one GPU")
     ap.add_argument("--no-row-sharded", action="store_true", help="nf / ml workloads: skip the cfg-4-shaped row-sharded measurements added to the line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
@@ -321,7 +323,7 @@ class RowSharded:
     user blocks with per-block seeds, so the GLOBAL graph does not depend on the number of ranks: weak scaling gives
     every rank `blocks` of them (2 per GPU = the whole config at 8 GPUs), strong scaling splits all 16 over the ranks."""
 
-    def __init__(self, name, scaling, blocks, seed, device, rank, world, n_chunks=0, batch_local=1024):
+    def __init__(self, name, scaling, blocks, seed, device, rank, world, n_chunks=0, batch_local=1024, exchange="all_reduce", single=False):
         import torch
         from llmrec_amd import dist as ldist, synth
         from llmrec_amd.dist_fused import ShardedFusedID
@@ -338,7 +340,7 @@ class RowSharded:
             total = per * world
             mine = list(range(rank * per, (rank + 1) * per))
         self.blocks_total, self.blocks_mine = total, len(mine)
-        self.comm, self.backend = ldist.Comm(), ldist.HipBackend()
+        self.comm, self.backend = ldist.Comm(single=single), ldist.HipBackend()
         t0 = time.perf_counter()
         rows, cols = [], []
         for k, b in enumerate(mine):
@@ -355,7 +357,8 @@ class RowSharded:
         self.B = batch_local + self.n_aug
         self.batch_local = batch_local
         self.step_obj = ShardedFusedID(self.graph, self.comm, self.backend, cfg["d"], cfg["layers"], bu * total, seed, 1e-4, self.B, 0.71, 1e-5,
-                                       n_chunks=n_chunks or None)
+                                       n_chunks=n_chunks or None, batch_size_flag=float(batch_local * world),      # the FLAG, not B + aug (main.py:340)
+                                       exchange=exchange)
         if self.n_aug:                                        # the LLM-augmented triples of main.py:216-224: a per-user (pos, neg) table
             g = torch.Generator(device=device); g.manual_seed(seed + 17 + rank)
             self.aug_pos = torch.randint(0, cfg["n_items"], (n_local,), generator=g, device=device)
@@ -472,6 +475,39 @@ class RowSharded:
         return res
 
 
+def kernel_time_shares():
+    """Per-kernel summed GPU time per step from the newest committed rocprofv3 --kernel-trace --stats summary of THIS bench
+    (profiles/r*_bench_nf_kernel_stats*.csv, written by tools/rocpd_stats.py): the line then shows the same ranking as the
+    summary - e.g. the SpMM class, whose launches overlap the GEMMs on side streams, next to the roofline's dominant
+    kernel on the critical path. None when no summary is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_nf_kernel_stats*.csv")), key=os.path.getmtime)
+    if not files:
+        return None
+    path = files[-1]
+    rows = []
+    try:
+        with open(path) as f:
+            for rec in csv.reader(line for line in f if not line.startswith("#")):
+                if rec and rec[0] != "name":
+                    rows.append((rec[0], int(rec[1]), float(rec[5])))
+    except Exception:
+        return None
+    classes = {}
+    for name, calls, per_step in rows:
+        short = name.split("(")[0].replace("void ", "").replace("llmrec::", "")
+        cls = short.split("<")[0]
+        c = classes.setdefault(cls, {"per_step_us": 0.0, "kernels": []})
+        c["per_step_us"] += per_step
+        c["kernels"].append(short)
+    total = sum(c["per_step_us"] for c in classes.values())
+    top = sorted(classes.items(), key=lambda kv: -kv[1]["per_step_us"])[:8]
+    return {"file": os.path.basename(path), "sum_of_kernel_time_per_step_us": total,
+            "note": "summed launch durations per step; launches on the step's five streams overlap, so the sum exceeds the step time",
+            "classes": {k: {"per_step_us": round(v["per_step_us"], 2), "share_of_kernel_time": round(v["per_step_us"] / total, 4)} for k, v in top}}
+
+
 def pmc_traffic_bytes(parts):
     """HBM-side bytes of one "launch" as the roofline defines it, from the newest committed PMC pass over THIS bench
     (profiles/r*_pmc_bench_step.json: separate rocprofv3 --pmc runs with --kernel-trace only, as
@@ -546,8 +582,8 @@ def parity_check(w: "NetflixShaped", n_eval_users: int = 256, steps: int = 2, to
     Models.py:127-199, main.py:228-278, utility/batch_test.py:21-36) fed with the identical samples read back
     from the device. Per step: the forward outputs of the reference's 14-tuple, the 8 (mf, emb) BPR pairs,
     the loss, the 10 gradients and the post-AdamW parameters, as max |a - b| / max |b| per tensor (gate: 1e-4 on every stage
-    given the previous one - forward, losses, gradients; 1e-5 on the AdamW kernel given the GPU's own gradients; the end-to-end
-    parameters are reported and bounded at 5e-4, see param_note). Evaluation:
+    given the previous one - forward, losses, gradients; 1e-5 on the AdamW kernel given the GPU's own gradients; 1e-4 end to end
+    on E_u / E_i after the steps; the per-entry end-to-end parameter figure is reported, see param_note). Evaluation:
     E_u / E_i after the steps, and the ranked top-50 lists of `n_eval_users` users, which must EQUAL the
     reference ranking rule (score desc, item id asc) applied to the kernel's bit-exact fp32 fma-chain scores;
     the lists from the oracle's own embeddings are compared too (near-ties may swap there: reported, not gated)."""
@@ -622,6 +658,10 @@ def parity_check(w: "NetflixShaped", n_eval_users: int = 256, steps: int = 2, to
     with torch.no_grad():
         fw = O.forward(params, feats, a_ui, a_iu, cfg)
     e_u, e_i = f.E_u.detach().cpu(), f.E_i.detach().cpu()
+    # E_u / E_i of the evaluation = the model after `steps` optimiser steps on each side: the end-to-end check that is not
+    # ill-conditioned by Adam's first updates (a parameter entry whose gradient is of the order of the gradient's absolute
+    # error moves by lr in either direction; the embeddings the loss and the ranking read do not notice)
+    eval_E = max(rel(e_u, fw["E_u"]), rel(e_i, fw["E_i"]))
     upd("forward", "eval/E_u", rel(e_u, fw["E_u"])); upd("forward", "eval/E_i", rel(e_i, fw["E_i"]))
     rng = np.random.default_rng(123)
     users = np.sort(rng.choice(sh.n_users, size=min(n_eval_users, sh.n_users), replace=False))
@@ -655,15 +695,17 @@ def parity_check(w: "NetflixShaped", n_eval_users: int = 256, steps: int = 2, to
            "path": "fused step%s, gemm=%s" % (" + HIP graph replay (step 1 = the capture's eager warm-up)" if w.use_graph else " (eager)", f.gemm),
            "steps_checked": steps, "tolerance_rel": tol,
            "forward_max_rel": worst["forward"], "bpr_max_rel": worst["bpr"], "loss_rel": worst["loss"],
-           "grad_max_rel": worst["grad"], "adamw_given_gpu_grads_max_rel": worst["adamw"], "param_max_rel": worst["param"],
-           "param_note": "param_max_rel is end to end (oracle gradients -> oracle AdamW vs GPU gradients -> GPU AdamW): in Adam's first steps "
-                         "the update lr * g / (|g| + 1e-8) amplifies the gradients' absolute error on near-zero entries; "
-                         "adamw_given_gpu_grads isolates the optimiser kernel", "worst_tensor": worst_name,
+           "grad_max_rel": worst["grad"], "adamw_given_gpu_grads_max_rel": worst["adamw"], "embeddings_after_steps_max_rel": eval_E,
+           "param_max_rel": worst["param"],
+           "param_note": "gated end to end: embeddings_after_steps_max_rel (E_u / E_i of the evaluation after the optimiser steps on both sides) "
+                         "and adamw_given_gpu_grads (the optimiser kernel fed with the GPU's own gradients and moments); param_max_rel "
+                         "(oracle gradients -> oracle AdamW vs GPU gradients -> GPU AdamW, per entry) is reported, not gated: in Adam's first steps "
+                         "the update lr * g / (|g| + 1e-8) turns an absolute gradient error on a near-zero entry into a full lr step", "worst_tensor": worst_name,
            "topk_lists_checked": int(len(users)), "topk_lists_equal": int(equal),
            "topk_lists_equal_oracle_embeddings": int(equal_oracle), "metrics_max_abs": metrics_abs,
            "seconds": time.perf_counter() - t0}
     stagewise = max(worst[k] for k in ("forward", "bpr", "loss", "grad"))
-    rep["ok"] = bool(stagewise < tol and worst["adamw"] < 1e-5 and worst["param"] < 5 * tol and equal == len(users) and metrics_abs < 1e-12)
+    rep["ok"] = bool(stagewise < tol and worst["adamw"] < 1e-5 and eval_E < tol and equal == len(users) and metrics_abs < 1e-12)
     return rep
 
 
@@ -724,11 +766,12 @@ def cpu_baseline_nf(w: "NetflixShaped", budget_s: float = 20.0):
             "ms_per_step": dt / steps * 1e3, "eval_users_per_s": 256 / de}
 
 
-def row_sharded_measure(name, scaling, seed, device, rank, world, steps, barrier):
-    """Time `steps` steps of the row-sharded ID path (all ranks call this; max over ranks; result on every rank)."""
+def row_sharded_measure(name, scaling, seed, device, rank, world, steps, barrier, exchange="all_reduce", single=False):
+    """Time `steps` steps of the row-sharded ID path (all ranks call this; max over ranks; result on every rank).
+    single: this process alone runs the WHOLE workload (a communicator of one rank) - the 1-GPU reference of a strong-scaling line."""
     import gc
     import torch
-    w = RowSharded(name, scaling, 0, seed, device, rank, world)
+    w = RowSharded(name, scaling, 0, seed, device, rank, world, exchange=exchange, single=single)
     for _ in range(2):
         w.step()
     barrier(); torch.cuda.synchronize()
@@ -800,9 +843,26 @@ def main():
         else:
             dist.init_process_group(backend)
         dist.barrier()                                       # the library exists before any rank loads it
+    n_ranks_seen = 1
+    if use_pg:                                               # what the communicator itself reports, and how many distinct devices answered
+        import torch.distributed as dist
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        ids = [None] * dist.get_world_size()
+        dist.all_gather_object(ids, "%s/%d" % (os.uname().nodename, torch.cuda.current_device()))
+        n_ranks_seen = int(ones.item())
+        n_devices_seen = len(set(ids))
+    else:
+        n_devices_seen = 1
     workload = a.workload
-    if workload == "auto":
-        workload = "nf"
+    auto = workload == "auto"
+    if auto:
+        # N = 1: BASELINE.json configs[1] (Netflix shape). N > 1: north_star's multi-GPU split - configs[3], the user-row-sharded ID
+        # path with one I x d exchange per layer and direction, STRONG scaling (the same 10 M x 1 M x 200 M graph over the ranks);
+        # the batch-sharded Netflix replicas ride along as `netflix_replicas`
+        workload = "nf" if world == 1 else "cfg4"
+        if world > 1:
+            a.synth_scaling = "strong"
     dflt = {"nf": (200, 20), "ml": (200, 20), "cfg5": (5, 1)}.get(workload, (20, 3))
     a.steps = dflt[0] if a.steps is None else a.steps
     a.warmup = dflt[1] if a.warmup is None else a.warmup
@@ -815,7 +875,7 @@ def main():
         name = "cfg4" if workload in ("synth", "cfg4") else workload
         if name not in SYNTH_CONFIGS:
             raise SystemExit("unknown --workload %s" % workload)
-        w = RowSharded(name, a.synth_scaling, a.synth_blocks, a.seed, device, rank, world, n_chunks=a.synth_chunks)
+        w = RowSharded(name, a.synth_scaling, a.synth_blocks, a.seed, device, rank, world, n_chunks=a.synth_chunks, exchange=a.synth_exchange)
         step, units = w.step, w.units_per_step              # global batch per step
 
     def barrier():
@@ -853,7 +913,8 @@ def main():
     line = {"metric": "bpr_train_edges_per_sec", "value": a.steps * units / dt, "unit": "edges/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "ms_per_step_hip_events": dt_events / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": w.config()}
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": w.config(),
+            "n_ranks_seen": n_ranks_seen, "n_devices_seen": n_devices_seen}
     if workload in ("nf", "ml"):
         gemm = getattr(w.fused, "gemm", "f32")
         line["arithmetic"] = ("fp32 storage and accumulation everywhere; the 8 projections and 4 weight-gradients multiply exact 3-term bf16 "
@@ -899,6 +960,7 @@ def main():
                         "hbm_gbs": k["gbs"], "frac_hbm": k["frac_hbm"]}
             line["roofline"] = roof(dom)
             line["roofline"]["second"] = roof(other)
+            line["roofline"]["step_kernel_time_by_class"] = kernel_time_shares()
             line["spmm_roofline"] = spmm_roofline_large(device, a.seed)
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline_nf(w)
@@ -925,6 +987,46 @@ def main():
             if world == 1 and not a.no_kernel_roofline:
                 line["spmm_in_situ"] = w.spmm_times_ms()
                 line["eval_sample"] = w.eval_sample()
+    if workload not in ("nf", "ml") and world > 1 and auto:
+        import gc
+        del w, step
+        gc.collect(); torch.cuda.empty_cache()
+        # (a) the same workload on ONE GPU, run by rank 0 alone inside this job (the others wait): the reference the strong-scaling
+        #     speed-up is quoted against, measured on the same box in the same run
+        ref = None
+        if not a.no_single_gpu_reference:
+            if rank == 0:
+                try:
+                    ref = row_sharded_measure("cfg4", "strong", a.seed, device, 0, 1, 8, lambda: None, exchange=a.synth_exchange, single=True)
+                except Exception as e:                        # pragma: no cover
+                    ref = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            barrier()
+        # (b) BASELINE.json's Netflix workload as batch-sharded replicas (llmrec_amd/dp.py): the global batch N x 1024 over the ranks
+        rep = None
+        try:
+            from llmrec_amd import dist as ldist
+            wn = NetflixShaped("nf", a.seed, device, rank, world, ldist.Comm())
+            for _ in range(20):
+                wn.step()
+            wn.fused.flush(); barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                wn.step()
+            wn.fused.flush(); torch.cuda.synchronize(); barrier()
+            dtn = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+            import torch.distributed as dist
+            dist.all_reduce(dtn, op=dist.ReduceOp.MAX)
+            rep = {"metric": "bpr_train_edges_per_sec", "value": 200 * wn.units_per_step * world / float(dtn.item()), "unit": "edges/s",
+                   "ms_per_step": float(dtn.item()) / 200 * 1e3, "steps": 200, "scaling": "weak", "config": wn.config()}
+            del wn
+        except Exception as e:                                # pragma: no cover - the main line must still be printed
+            rep = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        if rank == 0:
+            line["netflix_replicas"] = rep
+            if ref is not None:
+                line["single_gpu_reference"] = ref
+                if "value" in ref:
+                    line["speedup_vs_single_gpu"] = line["value"] / ref["value"]
     if rank == 0:
         print(json.dumps(line), flush=True)
     if use_pg:

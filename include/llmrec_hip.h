@@ -345,6 +345,9 @@ int llmrec_axpy_f32(int64_t rows, int32_t d, float alpha, const float* alpha_dev
 #define LLMREC_ZERO_MAX_TENSORS 8
 typedef struct { float* p; int64_t n; } llmrec_zero_tensor_t;
 int llmrec_zero_multi_f32(int32_t n_tensors, const llmrec_zero_tensor_t* tensors_host, llmrec_stream_t stream);
+/* dst[ids[j]][0..d) = 0 for j < n (ids[j] < 0 skipped): row-wise clean-up of a scatter target whose other rows are already zero
+ * (the row-sharded step scatters B gradient rows into 10^7-row tables; replaces a dense aten::zero_ per step) */
+int llmrec_zero_rows_f32(int64_t n, const int64_t* ids, int32_t d, float* dst, int64_t ldd, llmrec_stream_t stream);
 
 /* Loss assembly of reference main.py:273 / :280-283 on the device, one single-wave launch (replaces the
  * aten mul / sum / add / copy launches that assembled the logged scalars):

@@ -389,6 +389,18 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(int64_t rows, int d, co
     }
 }
 
+// dst[ids[j]][0..d) = 0 for j < n (ids[j] < 0 skipped): the row-wise clean-up of a scatter target whose other rows are
+// known to be zero already (row-sharded step: B of 10^7 rows), instead of a dense memset of the whole table
+__global__ __launch_bounds__(256) void zero_rows_kernel(int64_t n, const int64_t* __restrict__ ids, int d, float* __restrict__ dst, int64_t ldd) {
+    const int gl = threadIdx.x & 15;
+    const int64_t j = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (j >= n) return;
+    const int64_t row = ids[j];
+    if (row < 0) return;
+    float* p = dst + row * ldd;
+    for (int c = gl; c < d; c += 16) p[c] = 0.f;
+}
+
 struct GatherTerms { const float* t[LLMREC_MAX_TERMS]; int64_t ld[LLMREC_MAX_TERMS]; int n; };
 
 __global__ __launch_bounds__(256) void gather_mean_kernel(int64_t n, const int64_t* __restrict__ idx, int d, float scale, GatherTerms g,
@@ -648,6 +660,15 @@ int llmrec_gather_mean_f32(int64_t n, const int64_t* idx, int32_t d, float scale
         g.t[t] = terms[t]; g.ld[t] = term_ld[t];
     }
     gather_mean_kernel<<<(unsigned)ceil_div(n, 16), 256, 0, (hipStream_t)stream_>>>(n, idx, d, scale, g, out, ldo);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_zero_rows_f32(int64_t n, const int64_t* ids, int32_t d, float* dst, int64_t ldd, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n >= 0 && d > 0, "zero_rows: bad sizes");
+    if (n == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(ids && dst && ldd >= d, "zero_rows: null pointer or ld < d");
+    zero_rows_kernel<<<(unsigned)ceil_div(n, 16), 256, 0, (hipStream_t)stream_>>>(n, ids, d, dst, ldd);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

@@ -29,9 +29,10 @@ import torch.nn as nn
 class Comm:
     """Thin view of torch.distributed (identity when the world has one rank)."""
 
-    def __init__(self):
+    def __init__(self, single: bool = False):
+        """single: a communicator of this rank alone even when a process group exists (a 1-GPU reference run inside an N-GPU job)."""
         import torch.distributed as dist
-        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.dist = dist if (dist.is_available() and dist.is_initialized() and not single) else None
         self.rank = self.dist.get_rank() if self.dist else 0
         self.world = self.dist.get_world_size() if self.dist else 1
         import os
@@ -159,6 +160,11 @@ class HipBackend:
         for i, t in enumerate(tensors):
             arr[i].p, arr[i].n = t.data_ptr(), t.numel()
         o._lib.call("llmrec_zero_multi_f32", len(tensors), arr, o._stream())
+
+    def zero_rows(self, ids, dst):
+        """dst[ids] = 0 (ids < 0 skipped): row-wise clean-up of a scatter target (llmrec_zero_rows_f32)."""
+        o = self.ops
+        o._lib.call("llmrec_zero_rows_f32", ids.numel(), o._p(ids), dst.shape[1], o._p(dst), o._ld(dst), o._stream())
 
     def bpr_bwd_rows(self, Eu, Ei, u, p, n, decay, bsz, saved, grads2, rows3):
         o = self.ops

@@ -19,6 +19,16 @@ exchanges are organised for xGMI:
     norms / mf share: one all-reduce of 4 floats.
 The item table's gradient is complete on every rank after the layer all-reduces, so its AdamW update is replicated.
 
+``exchange="rs_ag"`` replaces each chunk's all-reduce by the DIRECT form of SURVEY.md 8(e) for a fully connected xGMI
+mesh: a reduce-scatter (every rank sends 1/world of the chunk to each peer over its own link and reduces the piece it
+owns), the row-local epilogue (the last layer's softmax) on the OWNED piece only, and an all-gather of the finished
+pieces - 2 (world - 1) / world of the chunk per link and direction instead of a ring's per-link bound, and the softmax
+is computed once per row instead of once per rank. Replicas stay bit-identical (every row is reduced at exactly one
+rank and broadcast). No multi-GPU box has been available to time either form; ``all_reduce`` stays the default.
+
+Scatter targets (dE_u, dE_i) are kept ALL-ZERO between steps: the step scatters B gradient rows into them and clears
+exactly those rows after their last reader (llmrec_zero_rows_f32) - no dense memset of the [U, d] table per step.
+
 The local kernels come from a ``backend`` (llmrec_amd.dist.HipBackend = the C-ABI HIP library; tests inject the
 torch-CPU stand-in to run this file under gloo with two ranks against the single-process oracle).
 """
@@ -34,6 +44,45 @@ from .dist import Comm, ShardedGraph
 
 class _Done:
     def wait(self):
+        return True
+
+
+class _ShardedExchange:
+    """reduce-scatter -> (row-local op on the owned piece) -> all-gather of one item-row chunk; see the module docstring.
+    start() queues the reduce-scatter behind the kernel that produced the chunk; finish_local() orders the current stream
+    after it, runs the epilogue on the owned rows and queues the all-gather; wait() orders the current stream after that."""
+
+    def __init__(self, comm: Comm, view: torch.Tensor, shard: torch.Tensor, after):
+        self.comm, self.view, self.shard, self.after = comm, view, shard, after
+        self.h = None
+        d = comm.dist
+        if comm._host_staged():                            # gloo stand-in (CPU tests / two processes on one GPU): reduce each piece at its owner
+            host = view.detach().cpu().reshape(comm.world, -1)
+            for r in range(comm.world):
+                part = host[r].clone()
+                d.reduce(part, dst=r)
+                if r == comm.rank:
+                    shard.copy_(part.reshape(shard.shape))
+        else:
+            self.h = d.reduce_scatter_tensor(shard.view(-1), view.reshape(-1), async_op=True)
+
+    def finish_local(self):
+        if self.h is not None:
+            self.h.wait()
+        if self.after is not None:
+            self.after(self.shard)
+        d, comm = self.comm.dist, self.comm
+        if comm._host_staged():
+            parts = [torch.empty(self.shard.numel(), dtype=self.shard.dtype) for _ in range(comm.world)]
+            d.all_gather(parts, self.shard.detach().cpu().reshape(-1))
+            self.view.copy_(torch.cat(parts).reshape(self.view.shape))
+            self.h = None
+        else:
+            self.h = d.all_gather_into_tensor(self.view.reshape(-1), self.shard.view(-1), async_op=True)
+
+    def wait(self):
+        if self.h is not None:
+            self.h.wait()
         return True
 
 
@@ -54,11 +103,18 @@ class ShardedFusedID:
 
     def __init__(self, graph: ShardedGraph, comm: Comm, backend, d: int, n_layers: int, n_users_global: int, seed: int,
                  lr: float, batch_local: int, drop_rate: float, decay: float, n_chunks: Optional[int] = None,
-                 user_init: Optional[torch.Tensor] = None, item_init: Optional[torch.Tensor] = None):
+                 user_init: Optional[torch.Tensor] = None, item_init: Optional[torch.Tensor] = None,
+                 batch_size_flag: Optional[float] = None, exchange: str = "all_reduce"):
+        """batch_size_flag: the divisor of the BPR regulariser - the reference divides by the --batch_size FLAG, not by the
+        number of triples in the batch (main.py:340: augmented triples do not change it); default = batch_local * world.
+        exchange: "all_reduce" | "rs_ag" (module docstring)."""
         self.g, self.comm, self.be = graph, comm, backend
         self.d, self.L, self.B = d, n_layers, batch_local
         self.remember, self.decay = 1.0 - drop_rate, decay
-        self.bsz_flag = float(batch_local * comm.world)
+        self.bsz_flag = float(batch_local * comm.world) if batch_size_flag is None else float(batch_size_flag)
+        if exchange not in ("all_reduce", "rs_ag"):
+            raise ValueError("ShardedFusedID: exchange must be all_reduce or rs_ag")
+        self.exchange = exchange
         dev = graph.s_i.device
         U, I = graph.n_users_local, graph.n_items
         self.U, self.I = U, I
@@ -84,7 +140,8 @@ class ShardedFusedID:
         # (llmrec_gather_mean_f32)
         self.Ul = [f(U, d) for _ in range(n_layers)]
         self.Il = [f(I, d) for _ in range(n_layers)]
-        self.dE_u, self.dE_i = f(U, d), f(I, d)
+        self.dE_u, self.dE_i = torch.zeros(U, d, dtype=torch.float32, device=dev), torch.zeros(I, d, dtype=torch.float32, device=dev)
+        self._scatter_dirty = False                           # True while rows of dE_u / dE_i may be non-zero (an aborted step)
         self.hU = f(U, d)
         self.E_u, self.E_i = self.hU, f(I, d)
         self.bufI, self.tmpI = f(I, d), f(I, d)
@@ -105,7 +162,12 @@ class ShardedFusedID:
             n_chunks = 1 if (comm.world == 1 and not comm.force) else max(1, min(8, (4 * I * d) // (32 << 20)))
         n_chunks = max(1, min(n_chunks, I))
         per = (I + n_chunks - 1) // n_chunks
+        if exchange == "rs_ag":                               # every chunk but possibly the last splits evenly over the ranks
+            per = (per + comm.world - 1) // comm.world * comm.world
         self.chunks = [(r0, min(r0 + per, I)) for r0 in range(0, I, per)]
+        # rs_ag: one staging piece per chunk (the rows this rank reduces and owns between the two halves of the exchange)
+        self.shards = [f((r1 - r0) // comm.world, d) if (exchange == "rs_ag" and (r1 - r0) % comm.world == 0) else None
+                       for r0, r1 in self.chunks]
         self.iu_fwd_chunks = [backend.row_chunk(graph.iu_fwd, r0, r1) for r0, r1 in self.chunks]
         self.ui_bwd_chunks = [backend.row_chunk(backend.with_scales(graph.ui_bwd, None, None), r0, r1) for r0, r1 in self.chunks]   # R^T pattern
         deg = backend.degrees(graph.by_user)
@@ -119,18 +181,30 @@ class ShardedFusedID:
 
     # -- the chunked, overlapped all-reduce ----------------------------------------------------------
     def _reduced_spmm(self, chunk_ops, X, out, epilogue_for=None, after=None):
-        """out[rows_c] = sum over ranks of chunk_ops[c] @ X, chunk by chunk: the all-reduce of chunk c is in flight
-        while chunk c + 1 is computed. after(c, view): optional row-local op on the reduced chunk (the softmax)."""
-        pending = []
+        """out[rows_c] = sum over ranks of chunk_ops[c] @ X, chunk by chunk: the exchange of chunk c is in flight
+        while chunk c + 1 is computed. after(view): optional row-local op on reduced rows (the softmax) - on the whole
+        chunk after an all-reduce, on the owned piece between the reduce-scatter and the all-gather of "rs_ag"."""
+        comm = self.comm
+        collective = comm.dist is not None and (comm.world > 1 or comm.force)
+        pending, started = [], []
         for c, (r0, r1) in enumerate(self.chunks):
             view = out[r0:r1]
             self.be.spmm(chunk_ops[c], X, out=view, epilogue=epilogue_for(r0, r1) if epilogue_for else None)
-            pending.append((all_reduce_start(self.comm, view), view))
             self.allreduce_bytes += view.numel() * 4
-        for c, (h, view) in enumerate(pending):
+            if collective and self.exchange == "rs_ag" and self.shards[c] is not None:
+                ex = _ShardedExchange(comm, view, self.shards[c], after)
+                if started:                                   # one chunk of lag: its reduce-scatter ran beside this chunk's SpMM
+                    started.pop().finish_local()
+                started.append(ex)
+                pending.append((ex, view, False))
+            else:
+                pending.append((all_reduce_start(comm, view), view, True))
+        while started:
+            started.pop().finish_local()
+        for h, view, whole in pending:
             h.wait()
-            if after is not None:
-                after(c, view)
+            if whole and after is not None:
+                after(view)
 
     # -- forward ---------------------------------------------------------------------------------------
     def forward(self, dense_users: bool = True):
@@ -141,7 +215,7 @@ class ShardedFusedID:
             last = l == L - 1
             be.spmm(self.g.ui_fwd, i_prev, out=self.Ul[l], epilogue={"op": "softmax"} if last else None)      # local users
             self._reduced_spmm(self.iu_fwd_chunks, self.Ul[l], self.Il[l],
-                               after=(lambda c, view: be.softmax_rows_into(view, view)) if last else None)
+                               after=(lambda view: be.softmax_rows_into(view, view)) if last else None)
             i_prev = self.Il[l]
         if dense_users:
             be.layer_mean_into([self.user_tab.detach()] + self.Ul, self.E_u)
@@ -176,7 +250,9 @@ class ShardedFusedID:
         # backward: compact gradient rows; users scatter locally, item rows are exchanged (all-gather of 2 B rows)
         ones = torch.ones(2, dtype=torch.float32, device=out.device)
         be.bpr_bwd_rows(self.Eu_rows, self.E_i, ar, p, n, self.decay, self.bsz_flag, saved, ones, self.rows3)
-        be.zero_([self.dE_u, self.dE_i])
+        if self._scatter_dirty:                               # only after a step that did not reach its clean-up
+            be.zero_([self.dE_u, self.dE_i])
+        self._scatter_dirty = True
         be.scatter_rows(u, self.rows3[0], self.dE_u, 1.0)
         self.my_ids[0].copy_(p); self.my_ids[1].copy_(n)
         comm.all_gather_into(self.gat_rows.view(-1), self.rows3[1:3].reshape(-1))
@@ -209,6 +285,10 @@ class ShardedFusedID:
             be.axpy_into(inv, self.dE_i, self.item_tab.grad)
         # user_tab.grad = inv * dE_u (U^0 only enters the mean): the factor rides in AdamW instead of a pass over the table
         be.optimizer_step(self.opt, {self.user_tab: inv})
+        # last readers done (the l = 0 message read dE_i, AdamW read dE_u as the user table's gradient): clear the touched rows
+        be.zero_rows(u, self.dE_u)
+        be.zero_rows(self.gat_ids.view(-1), self.dE_i)
+        self._scatter_dirty = False
         return (mf + emb).reshape(()), torch.cat([mf, emb])
 
     # -- evaluation ------------------------------------------------------------------------------------------
@@ -222,5 +302,5 @@ class ShardedFusedID:
 
     # -- accounting for bench.py -------------------------------------------------------------------------
     def message_bytes_per_step(self) -> dict:
-        return {"allreduce_I_x_d_bytes": 4 * self.I * self.d * 2 * self.L, "allreduce_messages": 2 * self.L * len(self.chunks),
+        return {"exchange": self.exchange, "allreduce_I_x_d_bytes": 4 * self.I * self.d * 2 * self.L, "allreduce_messages": 2 * self.L * len(self.chunks),
                 "bpr_rows_allgather_bytes_per_rank": 2 * self.B * (4 * self.d + 8), "prune_allgather_bytes_per_rank": 4 * self.B}

@@ -101,31 +101,55 @@ def bipartite_edges_device(n_users: int, n_items: int, n_edges: int, seed: int, 
                            item_alpha: float = 0.8, max_deg: int = 10_000):
     """Device generator for the large synthetic configs (cfg 4/5).
 
-    Returns (rows, cols) int64 device tensors with about ``n_edges`` distinct pairs (duplicates
-    are removed rather than topped up, so the count can fall short by a fraction of a percent;
-    the caller reads the exact count from the result)."""
+    Returns (rows, cols) int64 device tensors, sorted by (row, col), with EXACTLY ``n_edges`` distinct pairs (SURVEY.md
+    8(d): "no duplicate (u, i); E exact"): the first draw loses a few per cent to duplicates (hub users x popular items);
+    the deficit is topped up with fresh draws - users taken in proportion to their degree (a random existing edge's user),
+    items from the same popularity law - until the count is exact."""
     import torch
 
     g = torch.Generator(device=device)
     g.manual_seed(seed)
+    if n_edges > n_users * n_items:
+        raise ValueError("bipartite_edges_device: %d distinct pairs do not fit %d x %d" % (n_edges, n_users, n_items))
     # degrees: Pareto-ish via inverse CDF, clipped, scaled to the target sum
     u = torch.rand(n_users, generator=g, device=device, dtype=torch.float64)
     raw = torch.clamp((1.0 - u) ** (-1.0 / 0.8), 1.0, float(min(max_deg, n_items)))
     deg = torch.clamp((raw * (n_edges / raw.sum())).floor(), min=1.0).to(torch.int64)
     rows = torch.repeat_interleave(torch.arange(n_users, device=device, dtype=torch.int64), deg)
-    # popularity ~ rank^-alpha by inverse CDF of the continuous approximation
-    r = torch.rand(rows.numel(), generator=g, device=device, dtype=torch.float64)
-    a = 1.0 - item_alpha
-    rank = ((r * ((n_items + 1.0) ** a - 1.0) + 1.0) ** (1.0 / a) - 1.0).floor().to(torch.int64)
-    rank.clamp_(0, n_items - 1)
-    del r
+    del u, raw, deg
     # spread ranks over ids with a multiplicative hash so hot items are not adjacent rows
     mult = 2654435761 % n_items
     while np.gcd(mult, n_items) != 1:
         mult += 1
-    cols = (rank * mult) % n_items
-    del rank
-    key = torch.unique(rows * n_items + cols)       # sorted, distinct
+    a = 1.0 - item_alpha
+
+    def draw_items(n):
+        # popularity ~ rank^-alpha by inverse CDF of the continuous approximation
+        r = torch.rand(n, generator=g, device=device, dtype=torch.float64)
+        rank = ((r * ((n_items + 1.0) ** a - 1.0) + 1.0) ** (1.0 / a) - 1.0).floor().to(torch.int64)
+        rank.clamp_(0, n_items - 1)
+        return (rank * mult) % n_items
+
+    key = torch.unique(rows * n_items + draw_items(rows.numel()))       # sorted, distinct
+    del rows
+    for _ in range(64):
+        need = n_edges - key.numel()
+        if need <= 0:
+            break
+        m = int(need * 1.25) + 1024
+        pick = torch.randint(0, key.numel(), (m,), generator=g, device=device)
+        new = torch.unique(torch.div(key[pick], n_items, rounding_mode="floor") * n_items + draw_items(m))
+        pos = torch.searchsorted(key, new).clamp_(max=key.numel() - 1)
+        new = new[key[pos] != new]                                       # not present yet
+        if new.numel() > need:                                           # an unbiased subset, not the lowest keys
+            new = new[torch.randperm(new.numel(), generator=g, device=device)[:need]]
+        key = torch.sort(torch.cat([key, new])).values
+        del pick, new, pos
+    if key.numel() > n_edges:                                            # the first draw can overshoot by the floor()s' slack: drop at random
+        keep = torch.randperm(key.numel(), generator=g, device=device)[:n_edges]
+        key = key[torch.sort(keep).values]
+    if key.numel() != n_edges:
+        raise RuntimeError("bipartite_edges_device: %d of %d edges after the top-up rounds" % (key.numel(), n_edges))
     rows = torch.div(key, n_items, rounding_mode="floor")
     cols = key - rows * n_items
     return rows, cols

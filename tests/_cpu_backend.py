@@ -75,6 +75,9 @@ class CpuBackend:
         for t in tensors:
             t.zero_()
 
+    def zero_rows(self, ids, dst):
+        dst[ids[ids >= 0]] = 0.0
+
     def bpr_bwd_rows(self, Eu, Ei, u, p, n, decay, bsz, saved, grads2, rows3):
         B = u.numel()
         ds = grads2[0] * saved[:B]

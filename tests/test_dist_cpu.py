@@ -33,9 +33,10 @@ def _problem():
     return rows, cols, u_tab, i_tab, batches
 
 
-def _oracle_run():
+def _oracle_run(n_aug=0):
     import scipy.sparse as sp
     rows, cols, u_tab, i_tab, batches = _problem()
+    batches = _with_aug(batches, n_aug)
     R = sp.csr_matrix((np.ones(rows.size, dtype=np.float32), (rows, cols)), shape=(U, I))
     a_ui, a_iu = O.normalized_graphs(R)
     pu = torch.tensor(u_tab, requires_grad=True); pi = torch.tensor(i_tab, requires_grad=True)
@@ -104,7 +105,7 @@ def test_two_rank_sharded_training_matches_single_process_oracle(tmp_path):
     assert np.abs(r0["items"] - ref_i).max() <= 1e-4 * np.abs(ref_i).max()
 
 
-def _fused_worker(rank, world, port, out_dir):
+def _fused_worker(rank, world, port, out_dir, exchange, n_aug):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -117,24 +118,42 @@ def _fused_worker(rank, world, port, out_dir):
     u0, u1 = ld.user_block(U, rank, world)
     sel = (rows >= u0) & (rows < u1)
     g = ld.ShardedGraph.build(torch.tensor(rows[sel] - u0), torch.tensor(cols[sel]), u1 - u0, I, u0, comm, be)
-    st = ShardedFusedID(g, comm, be, D, L, U, seed=1, lr=LR, batch_local=B_LOCAL, drop_rate=DROP, decay=DECAY, n_chunks=3,
-                        user_init=torch.tensor(u_tab[u0:u1]), item_init=torch.tensor(i_tab))
+    st = ShardedFusedID(g, comm, be, D, L, U, seed=1, lr=LR, batch_local=B_LOCAL + n_aug, drop_rate=DROP, decay=DECAY, n_chunks=3,
+                        user_init=torch.tensor(u_tab[u0:u1]), item_init=torch.tensor(i_tab),
+                        batch_size_flag=float(world * B_LOCAL), exchange=exchange)
     assert len(st.chunks) == 3
+    if exchange == "rs_ag":                                    # 45 items: chunks of 16 rows split over the two ranks, the last (13 rows) does not
+        assert [s_ is not None for s_ in st.shards] == [True, True, False]
     losses = []
-    for per_rank in batches:
+    for per_rank in _with_aug(batches, n_aug):
         us, ps, ns = per_rank[rank]
         loss, _ = st.step((torch.tensor(us - u0), torch.tensor(ps), torch.tensor(ns)))
         losses.append(float(loss))
+        assert float(st.dE_u.abs().max()) == 0.0 and float(st.dE_i.abs().max()) == 0.0    # scatter targets are clean between steps
     np.savez(os.path.join(out_dir, "f%d.npz" % rank), users=st.user_tab.detach().numpy(), items=st.item_tab.detach().numpy(),
              losses=np.array(losses), msg=np.array([st.allreduce_bytes]))
     dist.destroy_process_group()
 
 
-def test_two_rank_fused_sharded_step_matches_single_process_oracle(tmp_path):
-    """llmrec_amd/dist_fused.py (hand-written backward, chunked all-reduces, BPR gradient rows exchanged by all-gather +
-    deterministic scatter) on two gloo ranks vs the single-process oracle after 3 optimiser steps."""
-    ref_u, ref_i, ref_losses = _oracle_run()
-    mp.spawn(_fused_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+def _with_aug(batches, n_aug):
+    """The reference's LLM-augmented triples (main.py:216-224): extra (user, pos, neg) triples for users of the batch, appended."""
+    if not n_aug:
+        return batches
+    rng = np.random.default_rng(77)
+    out = []
+    for per_rank in batches:
+        out.append([(np.concatenate([us, us[:n_aug]]), np.concatenate([ps, rng.integers(0, I, size=n_aug)]),
+                     np.concatenate([ns, rng.integers(0, I, size=n_aug)])) for us, ps, ns in per_rank])
+    return out
+
+
+@pytest.mark.parametrize("exchange,n_aug", [("all_reduce", 0), ("rs_ag", 0), ("rs_ag", 3)])
+def test_two_rank_fused_sharded_step_matches_single_process_oracle(tmp_path, exchange, n_aug):
+    """llmrec_amd/dist_fused.py (hand-written backward, chunked exchanges - all-reduce or reduce-scatter + all-gather -, BPR
+    gradient rows exchanged by all-gather + deterministic scatter) on two gloo ranks vs the single-process oracle after 3
+    optimiser steps; with augmented triples the regulariser's divisor stays the batch-size flag (main.py:340)."""
+    ref_u, ref_i, ref_losses = _oracle_run(n_aug)
+    mp.spawn(_fused_worker, args=(2, _free_port(), str(tmp_path), exchange, n_aug), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "f0.npz"), np.load(tmp_path / "f1.npz")
     got_u = np.concatenate([r0["users"], r1["users"]])
     assert np.array_equal(r0["items"], r1["items"])                            # replicas stay bit-identical

@@ -16,11 +16,14 @@ pytestmark = pytest.mark.gpu
 
 from oracle import oracle as O
 
-U, I, D, L, B_LOCAL, STEPS = 900, 700, 64, 2, 128, 3
+U, I, L, B_LOCAL, STEPS = 900, 700, 2, 128, 3
 DROP, DECAY, LR = 0.71, 1e-5, 1e-3
+# (d, augmented triples per rank): cfg-4-like (d = 64) and cfg-5-like (BASELINE.json configs[4]: d = 128, 5 % pseudo-augmented
+# triples appended to the batch - reference main.py:216-224 -, prune loss on)
+CASES = [(64, 0), (128, 6)]
 
 
-def _problem(world):
+def _problem(world, D, n_aug):
     rng = np.random.default_rng(4)
     deg = rng.integers(1, 30, size=U); deg[7] = 600; deg[U - 3] = 200                     # hubs in both halves
     rows = np.repeat(np.arange(U), deg)
@@ -36,14 +39,17 @@ def _problem(world):
         for r in range(world):
             u0, u1 = r * per, min((r + 1) * per, U)
             pos = rng.integers(0, I, size=B_LOCAL); pos[:40] = 5                           # duplicate gradient rows (>= 3 per id)
-            per_rank.append((rng.integers(u0, u1, size=B_LOCAL), pos, rng.integers(0, I, size=B_LOCAL)))
+            us, ns = rng.integers(u0, u1, size=B_LOCAL), rng.integers(0, I, size=B_LOCAL)
+            if n_aug:                                                                      # extra triples for users of the batch
+                us, pos, ns = np.concatenate([us, us[:n_aug]]), np.concatenate([pos, rng.integers(0, I, size=n_aug)]), np.concatenate([ns, rng.integers(0, I, size=n_aug)])
+            per_rank.append((us, pos, ns))
         batches.append(per_rank)
     return rows, cols, u_tab, i_tab, batches
 
 
-def _oracle_run(world):
+def _oracle_run(world, D, n_aug):
     import scipy.sparse as sp
-    rows, cols, u_tab, i_tab, batches = _problem(world)
+    rows, cols, u_tab, i_tab, batches = _problem(world, D, n_aug)
     R = sp.csr_matrix((np.ones(rows.size, dtype=np.float32), (rows, cols)), shape=(U, I))
     a_ui, a_iu = O.normalized_graphs(R)
     pu = torch.tensor(u_tab, requires_grad=True); pi = torch.tensor(i_tab, requires_grad=True)
@@ -67,43 +73,47 @@ def _oracle_run(world):
     return pu.detach().numpy(), pi.detach().numpy(), losses
 
 
-def _run_rank(rank, world, n_chunks):
+def _run_rank(rank, world, n_chunks, D, n_aug, exchange="all_reduce"):
     from llmrec_amd import dist as ld
     from llmrec_amd.dist_fused import ShardedFusedID
-    rows, cols, u_tab, i_tab, batches = _problem(world)
+    rows, cols, u_tab, i_tab, batches = _problem(world, D, n_aug)
     comm, be = ld.Comm(), ld.HipBackend()
     u0, u1 = ld.user_block(U, rank, world)
     sel = (rows >= u0) & (rows < u1)
     g = ld.ShardedGraph.build(torch.tensor(rows[sel] - u0).cuda(), torch.tensor(cols[sel]).cuda(), u1 - u0, I, u0, comm, be)
-    st = ShardedFusedID(g, comm, be, D, L, U, seed=1, lr=LR, batch_local=B_LOCAL, drop_rate=DROP, decay=DECAY, n_chunks=n_chunks,
-                        user_init=torch.tensor(u_tab[u0:u1]), item_init=torch.tensor(i_tab))
+    st = ShardedFusedID(g, comm, be, D, L, U, seed=1, lr=LR, batch_local=B_LOCAL + n_aug, drop_rate=DROP, decay=DECAY, n_chunks=n_chunks,
+                        user_init=torch.tensor(u_tab[u0:u1]), item_init=torch.tensor(i_tab),
+                        batch_size_flag=float(world * B_LOCAL), exchange=exchange)       # the divisor is the FLAG (main.py:340), not B + aug
     losses = []
     for per_rank in batches:
         us, ps, ns = per_rank[rank]
         loss, _ = st.step((torch.tensor(us - u0).cuda(), torch.tensor(ps).cuda(), torch.tensor(ns).cuda()))
         losses.append(float(loss))
+        assert float(st.dE_u.abs().max()) == 0.0 and float(st.dE_i.abs().max()) == 0.0    # row-wise clean-up left the scatter targets zero
     return st, losses
 
 
+@pytest.mark.parametrize("D,n_aug", CASES)
 @pytest.mark.parametrize("n_chunks", [1, 5])
-def test_fused_sharded_step_single_rank_matches_oracle(n_chunks):
-    ref_u, ref_i, ref_losses = _oracle_run(1)
-    st, losses = _run_rank(0, 1, n_chunks)
+def test_fused_sharded_step_single_rank_matches_oracle(n_chunks, D, n_aug):
+    ref_u, ref_i, ref_losses = _oracle_run(1, D, n_aug)
+    st, losses = _run_rank(0, 1, n_chunks, D, n_aug)
     assert len(st.chunks) == n_chunks
     assert np.allclose(losses, ref_losses, rtol=2e-5), (losses, ref_losses)
     got_u, got_i = st.user_tab.detach().cpu().numpy(), st.item_tab.detach().cpu().numpy()
     assert np.abs(got_u - ref_u).max() <= 1e-4 * np.abs(ref_u).max()
     assert np.abs(got_i - ref_i).max() <= 1e-4 * np.abs(ref_i).max()
-    loss, _ = st.step()                                            # the device sampler path
-    assert np.isfinite(float(loss))
+    if n_aug == 0:
+        loss, _ = st.step()                                        # the device sampler path
+        assert np.isfinite(float(loss))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, D, n_aug, exchange):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    st, losses = _run_rank(rank, world, 3)
+    st, losses = _run_rank(rank, world, 3, D, n_aug, exchange)
     np.savez(os.path.join(out_dir, "g%d.npz" % rank), users=st.user_tab.detach().cpu().numpy(), items=st.item_tab.detach().cpu().numpy(),
              losses=np.array(losses))
     dist.barrier()
@@ -116,16 +126,27 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_fused_sharded_step_two_processes_one_gpu_match_oracle(tmp_path):
+@pytest.mark.parametrize("D,n_aug,exchange", [(64, 0, "all_reduce"), (128, 6, "all_reduce"), (128, 6, "rs_ag")])
+def test_fused_sharded_step_two_processes_one_gpu_match_oracle(tmp_path, D, n_aug, exchange):
     world = 2
-    ref_u, ref_i, ref_losses = _oracle_run(world)
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref_u, ref_i, ref_losses = _oracle_run(world, D, n_aug)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), D, n_aug, exchange), nprocs=world, join=True)
     r = [np.load(tmp_path / ("g%d.npz" % k)) for k in range(world)]
     assert np.array_equal(r[0]["items"], r[1]["items"])                                   # replicas bit-identical (deterministic scatter)
     assert np.allclose(r[0]["losses"], ref_losses, rtol=2e-5) and np.allclose(r[1]["losses"], ref_losses, rtol=2e-5)
     got_u = np.concatenate([r[0]["users"], r[1]["users"]])
     assert np.abs(got_u - ref_u).max() <= 1e-4 * np.abs(ref_u).max()
     assert np.abs(r[0]["items"] - ref_i).max() <= 1e-4 * np.abs(ref_i).max()
+
+
+def test_zero_rows_clears_exactly_the_listed_rows():
+    from llmrec_amd import dist as ld
+    be = ld.HipBackend()
+    big = torch.ones(500, 3 * 128, device="cuda")
+    ids = torch.tensor([3, 499, -1, 3, 77], device="cuda")
+    be.zero_rows(ids, big[:, 128:256])                                                    # a column slice (ld = 384)
+    want = torch.ones(500, 3 * 128); want[[3, 499, 77], 128:256] = 0.0
+    assert torch.equal(big.cpu(), want)
 
 
 def test_scatter_rows_is_deterministic_and_matches_index_add():

@@ -132,3 +132,20 @@ def test_synth_generator_exact_and_duplicate_free():
     r, c = bipartite_edges(300, 200, 2500, seed=1, max_deg=150)
     assert r.size == 2500 and np.unique(r * 200 + c).size == 2500
     assert np.bincount(r, minlength=300).min() >= 1
+
+
+def test_device_generator_gives_exactly_the_requested_distinct_edges():
+    """"no duplicate (u, i); E exact" - the cfg 4 / cfg 5 generator (run here on the CPU device)."""
+    import torch
+    from llmrec_amd import synth
+    for U, I, E, seed in ((20000, 5000, 400000, 1), (3000, 500, 200000, 2), (64, 4096, 70000, 3)):
+        r, c = synth.bipartite_edges_device(U, I, E, seed, "cpu")
+        key = r * I + c
+        assert r.numel() == E and bool((key[1:] > key[:-1]).all())          # exact count, sorted, distinct
+        assert int(r.min()) >= 0 and int(r.max()) < U and int(c.min()) >= 0 and int(c.max()) < I
+        pop = torch.bincount(c, minlength=I).double()
+        if seed == 1:                                                         # (the denser cases saturate the popular items)
+            assert float(pop.max()) > 8 * float(pop.mean())                   # the popularity skew survives the top-up
+    r2, c2 = synth.bipartite_edges_device(20000, 5000, 400000, 1, "cpu")
+    r1, c1 = synth.bipartite_edges_device(20000, 5000, 400000, 1, "cpu")
+    assert torch.equal(r1, r2) and torch.equal(c1, c2)                        # a function of the seed
