@@ -64,6 +64,8 @@ class FusedStep:
         # (llmrec_bpr_multi_zero_rows_f32); the fusion backward writes d*_cat = source + its own term
         # (llmrec_fuse_bwd_src_f32). No dense memset of the six gradient buffers (70 MB per step at the Netflix shape).
         self.sparse_zero = os.environ.get("LLMREC_SPARSE_ZERO", "1") == "1"
+        # LLMREC_CHECK_ZERO=1 (debug; synchronises, so not under capture): assert that invariant before every scatter
+        self.check_zero = os.environ.get("LLMREC_CHECK_ZERO", "0") == "1"
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         self.dE_u, self.dE_i = z(U, d), z(I, d)
         if self.sparse_zero:
@@ -360,6 +362,11 @@ class FusedStep:
         if not self._zeroed and not self.sparse_zero:
             self._zero_accumulators()
         self._zeroed = False
+        if self.sparse_zero and self.check_zero and not torch.cuda.is_current_stream_capturing():
+            dirty = [n for n, t in (("dE_u", self.dE_u), ("dE_i", self.dE_i), ("sc_U", self.sc_U), ("sc_I", self.sc_I), ("sc_prof", self.sc_prof))
+                     if float(t.abs().max()) != 0.0]
+            if dirty:
+                raise RuntimeError("FusedStep: scatter targets not all-zero before the loss backward: %s (an aborted step? call reset_scatter_targets())" % dirty)
         _call("llmrec_bpr_multi_bwd_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), float(hp.decay),
               float(hp.batch_size), _p(self.saved))
         if after_first is not None:
@@ -507,15 +514,29 @@ class FusedStep:
             self._zero_in_forward = False
         self._zeroed = True
 
+    def reset_scatter_targets(self):
+        """Dense clear of the buffers the sparse-zero scheme keeps all-zero between steps (set-up, (re)capture, and after a
+        step that raised between the loss backward's scatter and its row-wise clean-up)."""
+        for t in (self.dE_u, self.dE_i) + ((self.sc_U, self.sc_I, self.sc_prof) if self.sparse_zero else ()):
+            t.zero_()
+
     def step_eager(self, users, pos, neg, n_valid=None, sampler=None):
         """sampler: optional callable that fills (users, pos, neg, n_valid) on the current stream first (inside the same
         graph when captured; running it on a side stream beside the forward measured no faster)."""
         side = os.environ.get("LLMREC_SAMPLER_SIDE", "1") == "1" and self.multi_stream
-        if sampler is not None and not side:
-            sampler()
-        self._train_forward(sampler if side else None)
-        self.loss_backward(users, pos, neg, n_valid)
-        self.opt.step(advanced=True)
+        try:
+            if sampler is not None and not side:
+                sampler()
+            self._train_forward(sampler if side else None)
+            self.loss_backward(users, pos, neg, n_valid)
+            self.opt.step(advanced=True)
+        except Exception:
+            if not torch.cuda.is_current_stream_capturing():   # the invariant of LLMREC_SPARSE_ZERO may be broken: restore it
+                try:
+                    self.reset_scatter_targets()
+                except Exception:
+                    pass
+            raise
         return self.scal[1], self.scal[2], self.scal[3]
 
     def flush(self):
@@ -556,6 +577,11 @@ class FusedStep:
         ev[0].replay()
         return ev[1], ev[2]
 
+    def drop_eval_graph(self, query_users: torch.Tensor):
+        """Release every captured evaluation (graph, result lists, top-K workspace) of this query tensor."""
+        for key in [k for k in self._eval_graphs if k[0] == query_users.data_ptr() and k[1] == query_users.numel()]:
+            del self._eval_graphs[key]
+
     # -- HIP graph --------------------------------------------------------------------------------
     def _make_static(self):
         dev = self.E_u.device
@@ -578,6 +604,7 @@ class FusedStep:
         def one_step():
             fill = (lambda: batcher.fill(st["users"], st["pos"], st["neg"], st["n_valid"])) if batcher is not None else None
             self.step_eager(st["users"], st["pos"], st["neg"], st["n_valid"], sampler=fill)
+        self.reset_scatter_targets()                           # (re)capture starts from the invariant, whatever ran before
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):                             # warm-up on a side stream (allocations, plan caches)

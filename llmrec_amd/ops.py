@@ -121,13 +121,16 @@ class SpmmPlan:
         return c
 
     def scratch(self, d: int, device) -> Optional[torch.Tensor]:
-        """The plan's own partial-sum scratch for width d: for callers that run their SpMMs on ONE stream."""
+        """The plan's own partial-sum scratch for width d, one per (d, current stream): plans are shared by the operands over
+        one rowptr (ui.fwd / iu.bwd, iu.fwd / ui.bwd), and two SpMMs over such operands issued on different streams must
+        not share the partial sums of their split rows."""
         if not self.n_seg:
             return None
         cache = self.__dict__.setdefault("_scratch", {})
-        if d not in cache:
-            cache[d] = torch.empty(self.n_seg * d, dtype=torch.float32, device=device)
-        return cache[d]
+        key = (d, torch.cuda.current_stream().cuda_stream)
+        if key not in cache:
+            cache[key] = torch.empty(self.n_seg * d, dtype=torch.float32, device=device)
+        return cache[key]
 
     @staticmethod
     def build(rowptr: torch.Tensor, t_wave: int = 128, t_block: int = 2048, segment: int = 2048) -> "SpmmPlan":
@@ -174,6 +177,10 @@ class Csr:
         sw, key = spmm_shape(d, self.nnz, whole_row)
         pl = self.plans.get(key)
         if pl is None:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                # building a plan synchronises (llmrec_spmm_plan_count returns counts to the host) - illegal under capture
+                raise RuntimeError("Csr.plan_for: no row plan for (d = %d, whole_row = %s) yet and the stream is being captured; "
+                                   "run the same product once eagerly (a warm-up step) before capturing" % (d, whole_row))
             pl = self.plans[key] = SpmmPlan.build(self.rowptr, *key)
         return sw, pl
 

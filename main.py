@@ -37,7 +37,9 @@ from llmrec_amd import engine, ops
 
 args = parse_args()
 if torch.cuda.is_available():                              # --gpu_id (reference parser.py:22) selects the device
-    torch.cuda.set_device(args.gpu_id if 0 <= args.gpu_id < torch.cuda.device_count() else 0)
+    if not 0 <= args.gpu_id < torch.cuda.device_count():   # a mistyped id must not land (and contend) on GPU 0 silently
+        raise SystemExit("--gpu_id %d: this process sees %d GPU(s)" % (args.gpu_id, torch.cuda.device_count()))
+    torch.cuda.set_device(args.gpu_id)
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 ATTRIBUTE_KEYS = {                                         # reference main.py:69-72
@@ -171,8 +173,9 @@ class Trainer(object):
                 if cache is None:
                     cache = self._eval_queries = {}
                 if users_key not in cache:
-                    if len(cache) >= 4:                        # bound the number of live evaluation graphs
-                        cache.pop(next(iter(cache)))
+                    if len(cache) >= 4:                        # bound the number of live evaluation graphs: drop the oldest query
+                        old_q = cache.pop(next(iter(cache)))   # AND the graph / lists / workspace FusedStep keeps for it
+                        fused.drop_eval_graph(old_q)
                     cache[users_key] = torch.as_tensor(users_key, dtype=torch.int64, device=device)
                 q = cache[users_key]
                 st = data_generator.device_state(device)
