@@ -12,7 +12,8 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "llmrec_hip.h")
-LIB_PATH = os.path.join(HERE, "lib", "libllmrec_hip.so")
+# LLMREC_LIB: tools/ load the instrumented build (python -m llmrec_amd.build --tools) through the same binding
+LIB_PATH = os.environ.get("LLMREC_LIB") or os.path.join(HERE, "lib", "libllmrec_hip.so")
 
 _SCALARS = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,

@@ -34,15 +34,19 @@ def _deps_mtime() -> float:
     return max(os.path.getmtime(f) for f in files)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():
-        return LIB
+def build(force: bool = False, verbose: bool = True, tools: bool = False) -> str:
+    """tools=True: the instrumented variant for tools/ (-DLLMREC_TOOLS_BUILD: cycle buckets, ablation launches) as
+    lib/libllmrec_hip_tools.so; LLMREC_LIB=<path> makes llmrec_amd._lib load it instead of the product library."""
+    lib = LIB.replace(".so", "_tools.so") if tools else LIB
+    objdir = OBJDIR + ("_tools" if tools else "")
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _deps_mtime():
+        return lib
     hipcc = _hipcc()
-    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
 
     def compile_one(src):
-        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + (["-DLLMREC_TOOLS_BUILD"] if tools else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr))
@@ -52,15 +56,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    tmp = LIB + ".tmp"
+    tmp = lib + ".tmp"
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)
-    os.replace(tmp, LIB)
+    os.replace(tmp, lib)
     if verbose:
-        print("[llmrec_amd.build] built", LIB)
-    return LIB
+        print("[llmrec_amd.build] built", lib)
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, tools="--tools" in sys.argv)
