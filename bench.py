@@ -177,6 +177,9 @@ class NetflixShaped:
                 "embed_size": self.args.embed_size, "prop_layers": len(eval(self.args.weight_size)),
                 "batch_size": self.hp.batch_size, "aug_sample_rate": self.hp.aug_sample_rate,
                 "prune_loss_drop_rate": self.hp.prune_loss_drop_rate, "side_features": "image512+text768+llm1536x(1+5)",
+                "item_side_operands": ("pre-propagated once at set-up: the step projects A_ui F_k [U x K] (llmrec_amd/fused.py; the features and the graph are "
+                                       "constants of a run, A (F W^T + 1 b^T) = (A F) W^T + (A 1) b^T), every W-dependent product runs every step"
+                                       if getattr(self.fused, "preprop", False) else "projected, then propagated (the reference's order of operations)"),
                 "sampler": "device, inside the step graph (llmrec_sample_batch: BPR triples + LLM-augmented triples, device step counter)", "global_batch": self.hp.batch_size * self.world,
                 "parallelism": "single GPU" if not hasattr(self.fused, "gsz") else
                 ("dp%d: batch-sharded replicas (llmrec_amd/dp.py), graph + tables replicated, prune over the global batch "
@@ -193,18 +196,20 @@ class NetflixShaped:
         ops, d, m_ = self.ops, self.args.embed_size, self.model
         pr = self.fused.gemm
         f = self.fused
-        item_pairs = [(dYi[:, (2 + k) * d:(3 + k) * d], m_.item_feats[key]) for k, key in enumerate(self.keys)]
+        # the item-side operands of the step: the pre-propagated A_ui F_k (rows = users) by default, else the features themselves
+        Fi = f.AX if f.preprop else [m_.image_feats, m_.text_feats] + [m_.item_feats[key] for key in self.keys]
+        item_pairs = [(dYi[:, (2 + k) * d:(3 + k) * d], Fi[2 + k]) for k in range(len(self.keys))]
         jobs = {
             "item_trans_x5": (lambda: ops.linear_wgrad_grouped(item_pairs, m_.item_trans.weight.grad, m_.item_trans.bias.grad, False, ws, precision=pr)),
             "user_trans": (lambda: ops.linear_wgrad_grouped([(dYu, m_.user_feats)], m_.user_trans.weight.grad, m_.user_trans.bias.grad, False, f.ws_wgrad_b, precision=pr)),
-            "text_trans": (lambda: ops.linear_wgrad_grouped([(dYi[:, d:2 * d], m_.text_feats)], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False, f.ws_wgrad_c, precision=pr)),
-            "image_trans": (lambda: ops.linear_wgrad_grouped([(dYi[:, 0:d], m_.image_feats)], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False, f.ws_wgrad_d, precision=pr)),
+            "text_trans": (lambda: ops.linear_wgrad_grouped([(dYi[:, d:2 * d], Fi[1])], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False, f.ws_wgrad_c, precision=pr)),
+            "image_trans": (lambda: ops.linear_wgrad_grouped([(dYi[:, 0:d], Fi[0])], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False, f.ws_wgrad_d, precision=pr)),
         }
-        multi = getattr(f, "wgrad_multi", False)
+        multi = f.gemm == "bf16x3"
         if multi:                                             # item_trans', text's and image's gradients are ONE launch in the step
             targets = [(item_pairs, m_.item_trans.weight.grad, m_.item_trans.bias.grad, False),
-                       ([(dYi[:, d:2 * d], m_.text_feats)], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False),
-                       ([(dYi[:, 0:d], m_.image_feats)], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False)]
+                       ([(dYi[:, d:2 * d], Fi[1])], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False),
+                       ([(dYi[:, 0:d], Fi[0])], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False)]
             ws_multi = torch.empty(max(ops.linear_wgrad_multi_workspace(targets), 16), dtype=torch.uint8, device=dYi.device)
             jobs = {"item+text+image_trans (one launch)": (lambda: ops.linear_wgrad_multi(targets, ws_multi)), "user_trans": jobs["user_trans"]}
         # as the step launches them (llmrec_amd/fused.py _backward): user_trans' on its own stream (in the step it runs beside
@@ -213,10 +218,8 @@ class NetflixShaped:
         main_s, side_s = torch.cuda.Stream(), torch.cuda.Stream()
         if multi:
             order = {k: (side_s if k == "user_trans" else main_s) for k in jobs}
-        elif f.wgrad_serial:
-            order = {"item_trans_x5": main_s, "text_trans": main_s, "image_trans": main_s, "user_trans": side_s}
         else:
-            order = {"item_trans_x5": main_s, "text_trans": torch.cuda.Stream(), "image_trans": torch.cuda.Stream(), "user_trans": side_s}
+            order = {"item_trans_x5": main_s, "text_trans": main_s, "image_trans": main_s, "user_trans": side_s}
         acc = {k: 0.0 for k in jobs}
         wall = 0.0
         for it in range(iters + 3):
@@ -246,7 +249,8 @@ class NetflixShaped:
         out = []
         W = self.model.item_trans.weight.detach(); b = self.model.item_trans.bias.detach()
         X = self.feats["attr/" + self.keys[0]]
-        feats = [self.feats["image"], self.feats["text"], self.feats["user"]] + [self.feats["attr/" + k] for k in self.keys]
+        # the operands the step's GEMM launches actually stream (pre-propagated item side: A_ui F_k with U rows instead of F_k with I rows)
+        feats = [j[0] for j in self.fused.projection_jobs()]
         flop_all = sum(2.0 * x.shape[0] * x.shape[1] * d for x in feats)
         byts_all = sum(4.0 * (x.shape[0] * x.shape[1] + d * x.shape[1] + x.shape[0] * d) for x in feats)
         ms = event_time_ms(self.fused._project_all, 20)
@@ -264,17 +268,19 @@ class NetflixShaped:
         byts = 4.0 * (sh.n_items * sh.llm_dim + d * sh.llm_dim + sh.n_items * d)
         # the step's weight gradients: item_trans (5 attribute streams grouped), user, text, image - four single-target launches here
         # (the isolated serial figure), the step's own layout (multi-target launch + user_trans') in _wgrad_in_situ_ms below
-        dYi = torch.randn(sh.n_items, 7 * d, device=self.device); dYu = torch.randn(sh.n_users, d, device=self.device)
+        dYi = torch.randn(sh.n_users if self.fused.preprop else sh.n_items, 7 * d, device=self.device); dYu = torch.randn(sh.n_users, d, device=self.device)
         m_ = self.model
         ws = self.fused.ws_wgrad
 
+        Fi = self.fused.AX if self.fused.preprop else [m_.image_feats, m_.text_feats] + [m_.item_feats[key] for key in self.keys]
+
         def wgrad_all():
             pr = self.fused.gemm
-            ops.linear_wgrad_grouped([(dYi[:, (2 + k) * d:(3 + k) * d], m_.item_feats[key]) for k, key in enumerate(self.keys)],
+            ops.linear_wgrad_grouped([(dYi[:, (2 + k) * d:(3 + k) * d], Fi[2 + k]) for k in range(len(self.keys))],
                                      m_.item_trans.weight.grad, m_.item_trans.bias.grad, False, ws, precision=pr)
             ops.linear_wgrad_grouped([(dYu, m_.user_feats)], m_.user_trans.weight.grad, m_.user_trans.bias.grad, False, ws, precision=pr)
-            ops.linear_wgrad_grouped([(dYi[:, d:2 * d], m_.text_feats)], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False, ws, precision=pr)
-            ops.linear_wgrad_grouped([(dYi[:, 0:d], m_.image_feats)], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False, ws, precision=pr)
+            ops.linear_wgrad_grouped([(dYi[:, d:2 * d], Fi[1])], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False, ws, precision=pr)
+            ops.linear_wgrad_grouped([(dYi[:, 0:d], Fi[0])], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False, ws, precision=pr)
         ms_serial = event_time_ms(wgrad_all, 20)
         # IN SITU: the launches as the step issues them (the multi-target launch on one stream, user_trans' on a second one);
         # each launch's own duration is what a rocprofv3 kernel trace of the step reports as the kernel's average
@@ -283,12 +289,12 @@ class NetflixShaped:
         ms = sum(per_launch.values())
         n_l = len(per_launch)
         multi = n_l == 2
-        out.append({"kernel": (("linear_wgrad_bf16x3_multi_kernel + reduce_chunks_multi_kernel (item_trans x5 + text + image in one launch) and "
-                                "linear_wgrad_bf16x3_kernel + reduce_chunks_kernel (user_trans)") if multi else
+        out.append({"kernel": (("linear_wgrad_bf16x3_v2_multi_kernel + reduce_chunks_multi_kernel: item_trans x5 + text + image in one launch, and "
+                                "user_trans in a second one") if multi else
                                (("linear_wgrad_bf16x3_kernel" if bf else "linear_wgrad_kernel<true>") +
                                 " + reduce_chunks_kernel (the step's 4 launches: item_trans x5 grouped, user, text, image")) +
                               ("; 3-term bf16 split: HBM-bound on the X stream, tflops are fp32-EQUIVALENT" if bf else "") + (")" if not multi else ""),
-                    "pmc": ([("linear_wgrad_bf16x3_multi_kernel", 1), ("reduce_chunks_multi_kernel", 1), ("linear_wgrad_bf16x3_kernel", 1), ("reduce_chunks_kernel", 1)]
+                    "pmc": ([("linear_wgrad_bf16x3_v2_multi_kernel", 2), ("reduce_chunks_multi_kernel", 2)]
                             if multi else [("linear_wgrad_bf16x3_kernel" if bf else "linear_wgrad_kernel", 4), ("reduce_chunks_kernel", 4)]),
                     "launches": n_l, "avg_launch_ms": ms / n_l, "per_launch_ms_in_situ": per_launch, "ms_wall_group": wall,
                     "ms_serial_isolated": ms_serial,

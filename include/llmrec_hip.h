@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LLMREC_ABI_VERSION 2
+#define LLMREC_ABI_VERSION 3
 
 enum {
     LLMREC_OK = 0,
@@ -146,13 +146,19 @@ typedef struct {
     const float* X; int64_t ldx; int64_t M; int32_t K;
     const float* W; int64_t ldw; const float* bias;
     float* Y; int64_t ldy;
+    const float* bias_scale;   /* [M] or NULL (= all ones): Y[r] = X[r] W^T + bias_scale[r] * bias. With X = A F (a constant feature
+                                  matrix propagated once through a constant adjacency) and bias_scale = the row sums of A this is
+                                  A (F W^T + 1 b^T), i.e. projection + propagation (reference Models.py:145-157) as ONE product */
 } llmrec_linear_problem_t;
 int llmrec_linear_fwd_grouped_f32(int32_t n_problems, const llmrec_linear_problem_t* problems_host, int32_t N,
                                   llmrec_stream_t stream);
 /* Weight gradient of one Linear fed by several (dY_p, X_p) pairs - the reference's shared
  * item_trans receives 5 per step (Models.py:150): dW (+)= sum_p dY_p^T X_p, db (+)= sum_p colsum(dY_p).
  * Workspace: llmrec_linear_wgrad_workspace_bytes(sum_p M_p, N, K). */
-typedef struct { const float* dY; int64_t lddy; const float* X; int64_t ldx; int64_t M; } llmrec_wgrad_problem_t;
+typedef struct { const float* dY; int64_t lddy; const float* X; int64_t ldx; int64_t M;
+                 const float* db_row_weight;   /* [M] or NULL (= ones): db (+)= sum_r db_row_weight[r] dY[r] - the bias gradient of a projection
+                                                  with llmrec_linear_problem_t.bias_scale (bf16x3, N = 64, K % 128 == 0 only) */
+} llmrec_wgrad_problem_t;
 int llmrec_linear_wgrad_grouped_f32(int32_t n_problems, const llmrec_wgrad_problem_t* problems_host, int32_t N, int32_t K,
                                     float* dW, int64_t lddw, float* db, int32_t accumulate,
                                     void* workspace, int64_t workspace_bytes, llmrec_stream_t stream);
@@ -225,6 +231,25 @@ int llmrec_fuse_bwd_src_f32(int64_t rows, int32_t d, const float* dOut, int64_t 
                             const float* rates_host, float* const* d_terms_host, const int64_t* d_ld_host,
                             const float* const* src_terms_host, const int64_t* src_ld_host,
                             int32_t n_reg_terms, float reg_two_coef, llmrec_stream_t stream);
+/* The user-side and the item-side fusion (or fusion backward, llmrec_fuse_bwd_src_f32 semantics) of one step as ONE launch
+ * (n_problems <= 2; the two row ranges are independent): on two streams each launch paid a cross-queue fork and join for
+ * 15 - 26 us of work (reference Models.py:188-197 for users and items). */
+typedef struct {
+    int64_t rows; float mean_scale;
+    int32_t n_mean; const float* const* mean_terms; const int64_t* mean_ld;
+    int32_t n_norm; const float* const* norm_terms; const int64_t* norm_ld; const float* rates;
+    float* out; int64_t ldo;
+} llmrec_fuse_fwd_problem_t;
+int llmrec_fuse_fwd_multi_f32(int32_t n_problems, const llmrec_fuse_fwd_problem_t* problems_host, int32_t d, llmrec_stream_t stream);
+typedef struct {
+    int64_t rows; const float* dOut; int64_t lddo;
+    int32_t n_norm; const float* const* norm_terms; const int64_t* norm_ld; const float* rates;
+    float* const* d_terms; const int64_t* d_ld;
+    const float* const* src_terms; const int64_t* src_ld;      /* src_terms[t] may be NULL (= 0) */
+    int32_t n_reg_terms; float reg_two_coef;
+} llmrec_fuse_bwd_problem_t;
+int llmrec_fuse_bwd_src_multi_f32(int32_t n_problems, const llmrec_fuse_bwd_problem_t* problems_host, int32_t d, llmrec_stream_t stream);
+
 /* n_reg_terms / reg_two_coef: the first n_reg_terms terms additionally receive reg_two_coef * x - the gradient of a
  * sum-of-squares regulariser coef * sum x^2 on them (reference main.py:151-156 on the image / text streams), folded in
  * because the kernel has x in registers anyway; pass 0, 0 for the plain backward. */
@@ -339,6 +364,16 @@ int llmrec_sumsq_f32(int64_t rows, int32_t d, const float* X, int64_t ldx, float
 /* Y (+)= alpha_dev[0] * alpha * X   (gradient of the regulariser; alpha_dev may be NULL = 1) */
 int llmrec_axpy_f32(int64_t rows, int32_t d, float alpha, const float* alpha_dev, const float* X, int64_t ldx,
                     float* Y, int64_t ldy, int32_t accumulate, llmrec_stream_t stream);
+
+/* out_g[j] (+)= sum_r w[r] * X[r][group_width g + j] for the n_groups column groups of X (w NULL = ones); groups that name the same
+ * destination are summed in group order; two-level, fixed order (deterministic). The bias gradient of projections whose operand was
+ * propagated beforehand (llmrec_linear_problem_t.bias_scale): db = sum_r bias_scale[r] dY[r]; one call serves every Linear of the
+ * [rows, 7 d] gradient buffer (reference: the autograd bias gradients of Models.py:145-150). group_width <= 64, n_groups <= MAX_GROUPS. */
+#define LLMREC_COLSUM_MAX_GROUPS 8
+int64_t llmrec_weighted_colsum_workspace_bytes(int32_t n_columns);
+int llmrec_weighted_colsum_f32(int64_t rows, int32_t n_groups, int32_t group_width, const float* X, int64_t ldx, const float* w,
+                               float* const* group_out_host, int32_t accumulate,
+                               void* workspace, int64_t workspace_bytes, llmrec_stream_t stream);
 
 /* Clear up to LLMREC_ZERO_MAX_TENSORS fp32 buffers in ONE launch (the backward's scatter targets; replaces
  * one aten::zero_ per tensor inside the captured step). */

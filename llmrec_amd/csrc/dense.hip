@@ -183,6 +183,7 @@ struct LinearGroup {
     const float* X[LLMREC_LINEAR_MAX_PROBLEMS];
     const float* W[LLMREC_LINEAR_MAX_PROBLEMS];
     const float* bias[LLMREC_LINEAR_MAX_PROBLEMS];
+    const float* bias_scale[LLMREC_LINEAR_MAX_PROBLEMS];   // [M] or null: Y[r] = X[r] W^T + bias_scale[r] * bias (a pre-propagated operand: (A X) W^T + (A 1) b^T)
     float* Y[LLMREC_LINEAR_MAX_PROBLEMS];
     int64_t ldx[LLMREC_LINEAR_MAX_PROBLEMS];
     int64_t ldw[LLMREC_LINEAR_MAX_PROBLEMS];
@@ -301,6 +302,15 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup 
     float* __restrict__ Y = g.Y[prob];
     const int64_t ldy = g.ldy[prob];
     const float* bias = g.bias[prob];
+    const float* bscale = g.bias_scale[prob];
+    float rs[RT][4];                                                       // the bias weight of this lane's rows (1 unless a scale is given)
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + t * 16 + lq * 4 + r;
+            rs[t][r] = (bscale && row < M) ? bscale[row] : 1.f;
+        }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int c = n * 16 + li;
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(256, 3) void linear_fwd_grouped_kernel(LinearGroup 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = row0 + t * 16 + lq * 4 + r;
-                if (row < M) Y[row * ldy + c] = acc[t][n][r] + b;
+                if (row < M) Y[row * ldy + c] = fmaf(rs[t][r], b, acc[t][n][r]);
             }
     }
 }
@@ -397,22 +407,6 @@ __device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-#ifdef LLMREC_FWD_PROFILE
-__device__ unsigned long long g_fwd_prof[8];
-#define FP_DECL() long long fp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long fp_t = clock64()
-#define FP_MARK(slot) do { const long long n_ = clock64(); fp_acc[slot] += n_ - fp_t; fp_t = n_; } while (0)
-#define FP_TOUCH(x) asm volatile("" :: "v"(x))
-#define FP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define FP_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define FP_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_fwd_prof[i_], (unsigned long long)fp_acc[i_]); } while (0)
-#else
-#define FP_DECL() do {} while (0)
-#define FP_MARK(slot) do {} while (0)
-#define FP_TOUCH(x) do {} while (0)
-#define FP_WAIT_VM(n) do {} while (0)
-#define FP_WAIT_LGKM() do {} while (0)
-#define FP_FLUSH() do {} while (0)
-#endif
 
 constexpr int GB_WS = 40;              // LDS row stride of one bf16 W tile in 2-byte units (32 k + 8 pad = 80 B)
 
@@ -544,13 +538,9 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
     store_w(0, w0);
     __syncthreads();
     int cur = 0;
-    FP_DECL();
     auto kstep = [&](int kb, const float4 (&xc)[RT][2], float4 (&xl)[RT][2], const float4 (&ws)[WLOADS], float4 (&wl)[WLOADS]) {
         load_w(kb + 2 * GF_BK, wl);                                        // zeros beyond K (guarded)
         load_x(kb + 2 * GF_BK, xl);
-        FP_MARK(0);                                                        // issuing the loads of step k + 2
-        FP_WAIT_VM(12);                                                    // (profile build, RT = 2, NT = 4: the 12 younger loads may stay in flight)
-        FP_MARK(1);                                                        // waiting for this step's X rows
         uint4 ah[RT], am[RT], al[RT];
         if (XPOSE) {
             float4* xw = x_lds[XPOSE ? wave : 0];
@@ -567,7 +557,6 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
 #pragma unroll
             for (int t = 0; t < RT; ++t) split8(xc[t][0], xc[t][1], ah[t], am[t], al[t]);
         }
-        FP_TOUCH(al[RT - 1].w); FP_MARK(2);                                // the X split (VALU)
         uint4 bh[NT], bm[NT], bl[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -576,7 +565,6 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
             bm[n] = *reinterpret_cast<const uint4*>(&w_lds[cur][1][off]);
             bl[n] = *reinterpret_cast<const uint4*>(&w_lds[cur][2][off]);
         }
-        FP_WAIT_LGKM(); FP_MARK(3);                                        // the W fragments from LDS
         // smallest terms first; consecutive MFMAs hit different accumulators
 #pragma unroll
         for (int t = 0; t < RT; ++t)
@@ -602,11 +590,8 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[t][n] = mfma_bf16(ah[t], bh[n], acc[t][n]);
-        FP_TOUCH(acc[RT - 1][NT - 1][0]); FP_MARK(4);                      // the 6 x RT x NT MFMAs
         store_w(cur ^ 1, ws);
-        FP_WAIT_LGKM(); FP_MARK(5);                                        // waiting for W of step k + 1, its split, the LDS stores
         __syncthreads();
-        FP_MARK(6);                                                        // the block barrier
         cur ^= 1;
     };
     for (int kb = 0; kb < K; kb += 3 * GF_BK) {                          // steps past K multiply zeros
@@ -614,10 +599,18 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
         kstep(kb + GF_BK, x1, x0, w2, w0);
         kstep(kb + 2 * GF_BK, x2, x1, w0, w1);
     }
-    FP_MARK(7); FP_FLUSH();
     float* __restrict__ Y = g.Y[prob];
     const int64_t ldy = g.ldy[prob];
     const float* bias = g.bias[prob];
+    const float* bscale = g.bias_scale[prob];
+    float rs[RT][4];                                                       // the bias weight of this lane's rows (1 unless a scale is given)
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + t * 16 + lq * 4 + r;
+            rs[t][r] = (bscale && row < M) ? bscale[row] : 1.f;
+        }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int c = n * 16 + li;
@@ -628,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_grouped_bf16x3_kernel(Linea
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = row0 + t * 16 + lq * 4 + r;
-                if (row < M) Y[row * ldy + c] = acc[t][n][r] + b;
+                if (row < M) Y[row * ldy + c] = fmaf(rs[t][r], b, acc[t][n][r]);
             }
     }
 }
@@ -654,6 +647,7 @@ struct WgradGroup {
     int64_t lddy[LLMREC_LINEAR_MAX_PROBLEMS];
     int64_t ldx[LLMREC_LINEAR_MAX_PROBLEMS];
     int64_t M[LLMREC_LINEAR_MAX_PROBLEMS];
+    const float* db_w[LLMREC_LINEAR_MAX_PROBLEMS];         // [M] or null: the bias gradient is sum_r db_w[r] dY[r] (v2 body only)
     int32_t vec_ok[LLMREC_LINEAR_MAX_PROBLEMS];
     int32_t chunk_begin[LLMREC_LINEAR_MAX_PROBLEMS + 1];   // first partial slab of each problem
     int32_t n_problems;
@@ -663,7 +657,7 @@ struct WgradGroup {
 // Three register stages rotate STATICALLY (the loop is unrolled by 3), so a tile's loads have two
 // full MFMA stages (2 x 2048 cycles) to land before they are consumed.
 template <bool FAST>
-__global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(WgradGroup g, int N, int K, float* __restrict__ partial,
+__global__ __launch_bounds__(256, FAST ? 2 : 1) void linear_wgrad_kernel(WgradGroup g, int N, int K, float* __restrict__ partial,
                                                            float* __restrict__ partial_db, int64_t MC, int n_kslab, int n_slabs) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -968,7 +962,7 @@ __global__ __launch_bounds__(256, 1) void linear_wgrad_bf16x3_multi_kernel(Wgrad
 //   * D tile (t, c): column = lane & 31 -> k = k0 + 4 (lane & 31) + c, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> n = 2 row + t;
 //   * the four waves of a block (four consecutive row slabs of one k slab) are summed through LDS by ALL four waves
 //     (each adds its quarter of the tile in wave order: deterministic) before one partial slab is written.
-// STAGES register stages rotate statically (the loop is unrolled by STAGES).
+// Measured against five other organisations (producer / consumer pairs, loader waves, two waves per SIMD, ...): profiles/experiments/r03_wgrad.md.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -1005,19 +999,14 @@ __device__ __forceinline__ void split16(const float2 (&v)[8], uint4 (&H)[2], uin
 }
 
 #ifdef LLMREC_TOOLS_BUILD
-__device__ unsigned long long g_w3prof[24];   // [0..7] producer buckets, [8..15] consumer buckets, [16..23] SIMD id of waves 0..7 of block 0
-#define W3P_DECL() long long w3p_t = clock64(); long long w3p_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define W3P_MARK(slot) do { const long long n_ = clock64(); w3p_acc[slot] += n_ - w3p_t; w3p_t = n_; } while (0)
-#define W3P_FLUSH(base) do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_w3prof[(base) + i_], (unsigned long long)w3p_acc[i_]); } while (0)
-#else
-#define W3P_DECL() do {} while (0)
-#define W3P_MARK(slot) do {} while (0)
-#define W3P_FLUSH(base) do {} while (0)
+// instrumented build (python -m llmrec_amd.build --tools): every wave adds the span of its main loop in shader cycles and in ticks of
+// the constant 100 MHz counter -> the EFFECTIVE shader clock of the launch (tools/wgrad_probe.py; profiles/experiments/r03_wgrad.md)
+__device__ unsigned long long g_wgrad_clock[3];
 #endif
+
 constexpr int W2_KW = 128;                                  // k columns per wave
 constexpr int W2_RED_FLOATS = 4 * 128 * 64 + 4 * 64;        // LDS of the block's final reduction (129 KB)
 
-template <int STAGES, int ABL = 0>   // ABL: ablation builds of tools/wgrad_probe.py only (1 no MFMA, 2 no split, 4 no loads in the loop)
 __device__ __forceinline__ void wgrad_bf16x3_v2_body(const WgradGroup& g, int N, int K, float* __restrict__ partial,
                                                      float* __restrict__ partial_db, int64_t MC, int n_kslab, int n_slabs, int lb, float* red) {
     const int lane = threadIdx.x & 63;
@@ -1030,8 +1019,6 @@ __device__ __forceinline__ void wgrad_bf16x3_v2_body(const WgradGroup& g, int N,
     const int slab = active ? slab_raw : n_slabs - 1;             // idle waves of the last group recompute a slab and drop it
     int prob = 0;
     while (prob + 1 < g.n_problems && slab >= g.chunk_begin[prob + 1]) ++prob;
-    const float* __restrict__ dY = g.dY[prob];
-    const float* __restrict__ X = g.X[prob];
     const int64_t lddy = g.lddy[prob], ldx = g.ldx[prob], M = g.M[prob];
     const int nblk = blockIdx.y;
     const int64_t m_begin = (int64_t)(slab - g.chunk_begin[prob]) * MC;
@@ -1058,10 +1045,9 @@ __device__ __forceinline__ void wgrad_bf16x3_v2_body(const WgradGroup& g, int N,
         offa[j] = (uint32_t)(8 * h + j) * la + 4u * (uint32_t)n_base;
         offb[j] = (uint32_t)(8 * h + j) * lbx + 4u * (uint32_t)k_base;
     }
-    const char* dYb = reinterpret_cast<const char*>(uniform_u64(dY));
-    const char* Xb = reinterpret_cast<const char*>(uniform_u64(X));
+    const char* dYb = reinterpret_cast<const char*>(uniform_u64(g.dY[prob]));
+    const char* Xb = reinterpret_cast<const char*>(uniform_u64(g.X[prob]));
     auto load_tile = [&](int64_t m0, float2 (&aa)[8], float4 (&bb)[8]) {
-        if constexpr ((ABL & 4) != 0) { if (m0 != m_begin) return; }
         const int64_t mc = m0 < m_end ? m0 : m_end;              // wave-uniform; at m_end the buffers are empty: zeros
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(dYb + (uint64_t)mc * la), 0, (int)((uint32_t)(m_end - mc) * la), 0x00020000);
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (uint64_t)mc * lbx), 0, (int)((uint32_t)(m_end - mc) * lbx), 0x00020000);
@@ -1073,29 +1059,26 @@ __device__ __forceinline__ void wgrad_bf16x3_v2_body(const WgradGroup& g, int N,
             bb[j] = make_float4(__uint_as_float(vb.x), __uint_as_float(vb.y), __uint_as_float(vb.z), __uint_as_float(vb.w));
         }
     };
-    auto mma_tile = [&](const float2 (&aa)[8], const float4 (&bb)[8]) {
+    // bias gradient: column sums of dY, optionally weighted per row (a pre-propagated operand: db = sum_r (A 1)[r] dY[r]); only the
+    // k-slab-0 waves' sums are written, so only they fetch the weights (16 scalar loads per tile, rows clamped into the problem)
+    const float* dbw = (kslab == 0 && partial_db) ? g.db_w[prob] : nullptr;
+    auto mma_tile = [&](int64_t m0, const float2 (&aa)[8], const float4 (&bb)[8]) {
+        if (dbw) {                                                   // wave-uniform
+            const int64_t last = M - 1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const f32x2 v = {aa[j].x, aa[j].y}; dbs2 += v; }
-        uint4 bh[4], bm[4], bl[4], ah[2], am[2], al[2];
-        if constexpr ((ABL & 2) != 0) {                             // no split: the raw words stand in for the fragments
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { bh[c] = __builtin_bit_cast(uint4, bb[2 * c]); bm[c] = __builtin_bit_cast(uint4, bb[2 * c + 1]); bl[c] = bh[c]; }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { ah[t] = make_uint4(__float_as_uint(aa[4 * t].x), __float_as_uint(aa[4 * t].y), __float_as_uint(aa[4 * t + 1].x), __float_as_uint(aa[4 * t + 1].y));
-                                          am[t] = make_uint4(__float_as_uint(aa[4 * t + 2].x), __float_as_uint(aa[4 * t + 2].y), __float_as_uint(aa[4 * t + 3].x), __float_as_uint(aa[4 * t + 3].y)); al[t] = ah[t]; }
+            for (int j = 0; j < 8; ++j) {
+                const int64_t r0 = m0 + j < last ? m0 + j : last, r1 = m0 + 8 + j < last ? m0 + 8 + j : last;
+                const float w0 = dbw[r0], w1 = dbw[r1];              // uniform addresses: scalar loads
+                const float wj = h ? w1 : w0;
+                dbs2.x = fmaf(wj, aa[j].x, dbs2.x); dbs2.y = fmaf(wj, aa[j].y, dbs2.y);
+            }
         } else {
-            split32(bb, bh, bm, bl);
-            split16(aa, ah, am, al);
-        }
-        if constexpr ((ABL & 1) != 0) {                             // no MFMA: the fragments are folded into one accumulator register
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { const uint4 x = make_uint4(bh[c].x ^ bm[c].x ^ bl[c].x, bh[c].y ^ bm[c].y ^ bl[c].y, bh[c].z ^ bm[c].z ^ bl[c].z, bh[c].w ^ bm[c].w ^ bl[c].w);
-                                          acc[0][c][0] += __uint_as_float((x.x ^ x.y ^ x.z ^ x.w) & 0x3fffffffu); }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { const uint4 x = make_uint4(ah[t].x ^ am[t].x ^ al[t].x, ah[t].y ^ am[t].y ^ al[t].y, ah[t].z ^ am[t].z ^ al[t].z, ah[t].w ^ am[t].w ^ al[t].w);
-                                          acc[1][t][0] += __uint_as_float((x.x ^ x.y ^ x.z ^ x.w) & 0x3fffffffu); }
-            return;
+            for (int j = 0; j < 8; ++j) { const f32x2 v = {aa[j].x, aa[j].y}; dbs2 += v; }
         }
+        uint4 bh[4], bm[4], bl[4], ah[2], am[2], al[2];
+        split32(bb, bh, bm, bl);
+        split16(aa, ah, am, al);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             // smallest terms first (as in the forward)
@@ -1113,56 +1096,30 @@ __device__ __forceinline__ void wgrad_bf16x3_v2_body(const WgradGroup& g, int N,
             for (int c = 0; c < 4; ++c) acc[t][c] = mfma32_bf16(ah[t], bh[c], acc[t][c]);
         }
     };
-    // the loop body is straight-line (whole groups of STAGES tiles); the left-over full tiles and the ragged tail follow it
-    const int n_tiles = (int)((m_end - m_begin) / 16);           // full 16-row tiles of this slab
-    float2 a0[8], a1[8], a2[STAGES == 3 ? 8 : 1];
-    float4 b0[8], b1[8], b2[STAGES == 3 ? 8 : 1];
+    // two register stages rotate statically; the loop body is straight-line (pairs of tiles), an odd last tile follows it
+    const int n_tiles = (int)((m_end - m_begin + 15) / 16);      // the last tile may be ragged: its missing rows read as zero
+    float2 a0[8], a1[8];
+    float4 b0[8], b1[8];
     int64_t m0 = m_begin;
     load_tile(m0, a0, b0);
 #ifdef LLMREC_TOOLS_BUILD
-    const long long w2_c0 = clock64(), w2_r0 = wall_clock64();
+    const long long clk0 = clock64(), ref0 = wall_clock64();
 #endif
-    if constexpr (STAGES == 2) {
-        for (int g2 = n_tiles >> 1; g2 > 0; --g2) {
-            load_tile(m0 + 16, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_tile(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_tile(m0 + 32, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_tile(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            m0 += 32;
-        }
-#ifdef LLMREC_TOOLS_BUILD
-        if (lane == 0) { atomicAdd(&g_w3prof[12], (unsigned long long)(clock64() - w2_c0)); atomicAdd(&g_w3prof[13], (unsigned long long)(wall_clock64() - w2_r0)); atomicAdd(&g_w3prof[14], 1ull); }
-#endif
-        if (n_tiles & 1) { mma_tile(a0, b0); m0 += 16; }
-    } else {
+    for (int g2 = n_tiles >> 1; g2 > 0; --g2) {
         load_tile(m0 + 16, a1, b1);
-        for (int g3 = n_tiles / 3; g3 > 0; --g3) {
-            load_tile(m0 + 32, a2, b2);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_tile(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_tile(m0 + 48, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_tile(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            load_tile(m0 + 64, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_tile(a2, b2);
-            __builtin_amdgcn_sched_barrier(0);
-            m0 += 48;
-        }
-        const int left = n_tiles % 3;
-        if (left >= 1) { mma_tile(a0, b0); m0 += 16; }
-        if (left >= 2) { mma_tile(a1, b1); m0 += 16; }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(m0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(m0 + 32, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(m0 + 16, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        m0 += 32;
     }
-    if (m0 < m_end) {                                            // the ragged tail (at most once per problem): rows past the end read as zero
-        load_tile(m0, a0, b0);
-        mma_tile(a0, b0);
-    }
+#ifdef LLMREC_TOOLS_BUILD
+    if (lane == 0) { atomicAdd(&g_wgrad_clock[0], (unsigned long long)(clock64() - clk0)); atomicAdd(&g_wgrad_clock[1], (unsigned long long)(wall_clock64() - ref0)); atomicAdd(&g_wgrad_clock[2], 1ull); }
+#endif
+    if (n_tiles & 1) mma_tile(m0, a0, b0);
     float2 dbs = make_float2(dbs2.x, dbs2.y);
     dbs.x += __shfl_xor(dbs.x, 32, 64); dbs.y += __shfl_xor(dbs.y, 32, 64);
     // element (t, c, r) of lane l at [wave][((t * 4 + c) * 16 + r) * 64 + l]: conflict-free
@@ -1200,862 +1157,12 @@ __device__ __forceinline__ void wgrad_bf16x3_v2_body(const WgradGroup& g, int N,
     }
 }
 
-template <int STAGES, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void linear_wgrad_bf16x3_v2_multi_kernel(WgradMulti m, int N) {
     __shared__ __attribute__((aligned(16))) float red[W2_RED_FLOATS];
     const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
     int t = 0;
     while (t + 1 < m.n_targets && lb >= m.block_begin[t + 1]) ++t;
-    wgrad_bf16x3_v2_body<STAGES, ABL>(m.g[t], N, m.K[t], m.partial[t], m.partial_db[t], m.MC, m.n_kslab[t], m.n_slabs[t], lb - m.block_begin[t], red);
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Weight gradient, third organisation (round 3): PRODUCER / CONSUMER wave pairs.
-// Measured on the v2 body (tools/wgrad_probe.py ablations, profiles/experiments/r03_wgrad.md): loads alone 75 us, loads + split
-// 132 us, loads + MFMAs 138 us, everything 180 us - the three phases of a single wave per SIMD ADD UP (an in-order wave
-// splits, then multiplies, and the 32x32x16 MFMA does not co-execute with register loads, profiles/r02_coexec_mfma_valu.txt).
-// Here a block is 8 waves = 4 pairs, waves w and w + 4 on one SIMD:
-//   producer (w < 4): streams its X / dY tiles into an LDS ring by LDS-DMA (buffer_load ... lds: no VGPR landing, co-executes with
-//       the partner's MFMAs; rows past the slab end are out of the descriptor's range and land as zeros), reads a landed tile back
-//       (lane-linear: every lane gets the 16 bytes it addressed), splits it into the three bf16 planes and stores them in
-//       FRAGMENT order (lane l's 16 bytes of fragment f at f * 1 KB + 16 l);
-//   consumer (w >= 4): ds_read_b128 of the 18 fragments + the 48 v_mfma_f32_32x32x16_bf16 of the tile, nothing else.
-// The VALU of the split runs under the partner's MFMAs (8 of 32 cycles held), the memory stream under both.
-// Hand-off per pair through two LDS counters (ready / consumed), spin bounded (a broken hand-off poisons the output instead
-// of hanging the GPU). Same work decomposition as v2: pair q = (row slab 4 g + q, k slab), 64 n x 128 k tile, 16-row steps,
-// the four tiles summed through LDS at the end.
-// ---------------------------------------------------------------------------------------------
-constexpr int W3_RAWX = 8192;                              // one X tile as loaded: 8 instructions x 1 KB
-constexpr int W3_RAWY = 4096;                              // one dY tile: 4 instructions x 1 KB
-constexpr int W3_PLANES = 18 * 1024;                       // X: 4 tiles x 3 planes, dY: 2 tiles x 3 planes, 1 KB each
-constexpr int W3_PAIR = 2 * W3_RAWX + W3_RAWY + W3_PLANES; // 38 KB per pair
-constexpr int W3_FLAGS = 4 * W3_PAIR;                      // ready[4], consumed[4]
-constexpr int W3_LDS = W3_FLAGS + 64;
-static_assert(W3_LDS >= (int)sizeof(float) * W2_RED_FLOATS, "the final reduction reuses the ring");
-constexpr uint32_t W3_SPIN_LIMIT = 1u << 22;               // ~ seconds; a healthy wait is a few hundred polls at most
-
-// one LDS-DMA piece: 64 lanes x 16 bytes from (descriptor, per-lane byte offset) to LDS [lds_addr, + 1 KB), lane-linear
-__device__ __forceinline__ void dma_piece(uint32_t lds_addr, const u32x4& rsrc, uint32_t voff) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
-}
-__device__ __forceinline__ u32x4 make_rsrc(uint64_t base, uint32_t bytes) {
-    u32x4 r;
-    r.x = __builtin_amdgcn_readfirstlane((uint32_t)base);
-    r.y = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32) & 0xffffu);
-    r.z = __builtin_amdgcn_readfirstlane(bytes);
-    r.w = 0x00020000u;
-    return r;
-}
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// the hand-off counters live in LDS and are accessed as LDS (ds_read_b32 / ds_write_b32): through a generic pointer they would be
-// FLAT accesses, whose s_waitcnt vmcnt(0) drains the producer's DMA queue at every poll
-typedef volatile uint32_t __attribute__((address_space(3))) * lds_flag_t;
-// spin until *flag >= want (another wave of this block writes it); false after W3_SPIN_LIMIT polls
-__device__ __forceinline__ bool spin_until(lds_flag_t flag, uint32_t want) {
-    for (uint32_t n = 0; n < W3_SPIN_LIMIT; ++n) {
-        if (*flag >= want) return true;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
-}
-
-__global__ __launch_bounds__(512, 2) void linear_wgrad_bf16x3_v3_multi_kernel(WgradMulti mm, int N) {
-    __shared__ __attribute__((aligned(1024))) char lds[W3_LDS];
-    const int lb_all = xcd_logical_block(blockIdx.x, gridDim.x);
-    int tg = 0;
-    while (tg + 1 < mm.n_targets && lb_all >= mm.block_begin[tg + 1]) ++tg;
-    const WgradGroup& g = mm.g[tg];
-    const int K = mm.K[tg], n_kslab = mm.n_kslab[tg], n_slabs = mm.n_slabs[tg];
-    const int64_t MC = mm.MC;
-    float* __restrict__ partial = mm.partial[tg];
-    float* __restrict__ partial_db = mm.partial_db[tg];
-    const int lb = lb_all - mm.block_begin[tg];
-
-    const int lane = threadIdx.x & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q = wave8 & 3;                                      // pair
-    const bool producer = wave8 < 4;
-    const int i = lane & 31, h = lane >> 5;
-    const int kslab = lb % n_kslab;
-    const int group = lb / n_kslab;
-    const int slab_raw = group * 4 + q;
-    const bool active = slab_raw < n_slabs;
-    const int slab = active ? slab_raw : n_slabs - 1;
-    int prob = 0;
-    while (prob + 1 < g.n_problems && slab >= g.chunk_begin[prob + 1]) ++prob;
-    const int64_t lddy = g.lddy[prob], ldx = g.ldx[prob], M = g.M[prob];
-    const int nblk = blockIdx.y;
-    const int64_t m_begin = (int64_t)(slab - g.chunk_begin[prob]) * MC;
-    const int64_t m_end = (m_begin + MC < M) ? m_begin + MC : M;
-    const int T = active ? (int)((m_end - m_begin + 15) / 16) : 0;  // 16-row tiles of this pair (the last one may be ragged)
-
-    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;               // LDS byte address of the ring (the low half of the flat address)
-    const uint32_t pair0 = lds0 + (uint32_t)q * W3_PAIR;
-    char* pair_p = lds + q * W3_PAIR;
-    char* planes_p = pair_p + 2 * W3_RAWX + W3_RAWY;
-    const lds_flag_t flags = (lds_flag_t)(lds + W3_FLAGS);
-    const lds_flag_t ready = flags + q, consumed = flags + 4 + q;
-    if (threadIdx.x < 8) flags[threadIdx.x] = 0u;
-#ifdef LLMREC_TOOLS_BUILD
-    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) g_w3prof[16 + wave8] = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);   // HW_ID.simd_id
-#endif
-    __syncthreads();
-    bool ok = true;
-    f32x2 dbs2 = {0.f, 0.f};
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
-
-    if (producer) {
-        const uint32_t la = 4u * (uint32_t)lddy, lbx = 4u * (uint32_t)ldx;        // row strides in bytes
-        // X piece j: lane (i, h) addresses row 8 h + j, columns k0 + 4 i ..; dY piece p: lane l addresses row 4 p + (l >> 4), columns 4 (l & 15) ..
-        uint32_t offx[8], offy[4];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) offx[j] = (uint32_t)(8 * h + j) * lbx + 4u * (uint32_t)(kslab * W2_KW + 4 * i);
-#pragma unroll
-        for (int p4 = 0; p4 < 4; ++p4) offy[p4] = (uint32_t)(4 * p4 + (lane >> 4)) * la + 4u * (uint32_t)(nblk * 64 + 4 * (lane & 15));
-        const uint64_t Xb = uniform_u64(g.X[prob]), Yb = uniform_u64(g.dY[prob]);
-        auto dma_x = [&](int u) {                                 // tile u -> ring slot u & 1 (nothing when u >= T)
-            if (u >= T) return;
-            const int64_t m0 = m_begin + 16 * (int64_t)u;
-            const u32x4 r = make_rsrc(Xb + (uint64_t)m0 * lbx, (uint32_t)(m_end - m0) * lbx);
-            const uint32_t dst = pair0 + (uint32_t)(u & 1) * W3_RAWX;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dma_piece(dst + 1024u * j, r, offx[j]);
-        };
-        auto dma_y = [&](int u) {
-            if (u >= T) return;
-            const int64_t m0 = m_begin + 16 * (int64_t)u;
-            const u32x4 r = make_rsrc(Yb + (uint64_t)m0 * la, (uint32_t)(m_end - m0) * la);
-            const uint32_t dst = pair0 + 2u * W3_RAWX;
-#pragma unroll
-            for (int p4 = 0; p4 < 4; ++p4) dma_piece(dst + 1024u * p4, r, offy[p4]);
-        };
-        // queue order: X(0) | Y(0) X(1) | Y(1) X(2) | ... : when tile u is needed, only X(u + 1) (8 pieces) may still be in flight
-        dma_x(0); dma_y(0); dma_x(1);
-        W3P_DECL();
-        for (int u = 0; u < T; ++u) {
-            if (u + 1 < T) wait_vmcnt<8>(); else wait_vmcnt<0>();
-            W3P_MARK(0);                                           // waiting for the tile's DMA
-            float4 bb[8]; float2 aa[8];
-            const char* rx = pair_p + (u & 1) * W3_RAWX;
-            const char* ry = pair_p + 2 * W3_RAWX;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bb[j] = *reinterpret_cast<const float4*>(rx + 1024 * j + 16 * lane);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {                          // row 8 h + j, columns 2 i, 2 i + 1 of the dY tile
-                const int r = 8 * h + j;
-                aa[j] = *reinterpret_cast<const float2*>(ry + 1024 * (r >> 2) + 256 * (r & 3) + 8 * i);
-            }
-            wait_lgkm0();                                          // both raw slots are in registers: refill them
-            W3P_MARK(1);                                           // reading the raw tile back
-            dma_y(u + 1); dma_x(u + 2);
-            W3P_MARK(2);                                           // issuing 12 DMA pieces
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const f32x2 v = {aa[j].x, aa[j].y}; dbs2 += v; }
-            uint4 bh[4], bm[4], bl[4], ah[2], am[2], al[2];
-            split32(bb, bh, bm, bl);
-            split16(aa, ah, am, al);
-#ifdef LLMREC_TOOLS_BUILD
-            asm volatile("" :: "v"(al[1].w), "v"(bl[3].w));
-#endif
-            W3P_MARK(3);                                           // the split
-            ok = ok && spin_until(consumed, (uint32_t)u);          // the consumer has taken the previous tile's fragments
-            W3P_MARK(4);                                           // waiting for the consumer
-            uint4* pl = reinterpret_cast<uint4*>(planes_p) + lane;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { pl[(3 * c + 0) * 64] = bh[c]; pl[(3 * c + 1) * 64] = bm[c]; pl[(3 * c + 2) * 64] = bl[c]; }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { pl[(12 + 3 * t + 0) * 64] = ah[t]; pl[(12 + 3 * t + 1) * 64] = am[t]; pl[(12 + 3 * t + 2) * 64] = al[t]; }
-            wait_lgkm0();
-            *ready = (uint32_t)(u + 1);
-            W3P_MARK(5);                                           // storing the 18 fragments
-        }
-        W3P_FLUSH(0);
-    } else {
-        W3P_DECL();
-        for (int u = 0; u < T; ++u) {
-            ok = ok && spin_until(ready, (uint32_t)(u + 1));
-            W3P_MARK(0);                                           // waiting for the producer
-            const uint4* pl = reinterpret_cast<const uint4*>(planes_p) + lane;
-            uint4 bh[4], bm[4], bl[4], ah[2], am[2], al[2];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { bh[c] = pl[(3 * c + 0) * 64]; bm[c] = pl[(3 * c + 1) * 64]; bl[c] = pl[(3 * c + 2) * 64]; }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { ah[t] = pl[(12 + 3 * t + 0) * 64]; am[t] = pl[(12 + 3 * t + 1) * 64]; al[t] = pl[(12 + 3 * t + 2) * 64]; }
-            wait_lgkm0();
-            *consumed = (uint32_t)(u + 1);
-            W3P_MARK(1);                                           // reading the fragments
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[t][c] = mfma32_bf16(al[t], bh[c], acc[t][c]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[t][c] = mfma32_bf16(ah[t], bl[c], acc[t][c]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[t][c] = mfma32_bf16(am[t], bm[c], acc[t][c]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[t][c] = mfma32_bf16(am[t], bh[c], acc[t][c]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[t][c] = mfma32_bf16(ah[t], bm[c], acc[t][c]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[t][c] = mfma32_bf16(ah[t], bh[c], acc[t][c]);
-            }
-#ifdef LLMREC_TOOLS_BUILD
-            asm volatile("" :: "v"(acc[1][3][15]), "v"(acc[0][0][0]));
-#endif
-            W3P_MARK(2);                                           // the 48 MFMAs
-        }
-        W3P_FLUSH(8);
-    }
-    wait_vmcnt<0>();
-    __syncthreads();                                              // every pair is done: the ring becomes the reduction scratch
-    float* red = reinterpret_cast<float*>(lds);
-    const float poison = ok ? 0.f : __builtin_nanf("");           // a hand-off that timed out must not pass for a result
-    if (!producer) {
-        float* rw = red + q * (128 * 64);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rw[((t * 4 + c) * 16 + r) * 64 + lane] = acc[t][c][r] + poison;
-    } else {
-        float2 dbs = make_float2(dbs2.x, dbs2.y);
-        dbs.x += __shfl_xor(dbs.x, 32, 64); dbs.y += __shfl_xor(dbs.y, 32, 64);
-        if (h == 0) {
-            red[4 * 128 * 64 + q * 64 + 2 * i + 0] = dbs.x + poison;
-            red[4 * 128 * 64 + q * 64 + 2 * i + 1] = dbs.y + poison;
-        }
-    }
-    __syncthreads();
-    // wave w (of 8) adds tile rows t = w >> 2, reg r in [4 (w & 3), +4) of the four pairs' tiles, in pair order (slab 4 g, +1, +2, +3)
-    float* pw = partial + (int64_t)group * N * K;
-    const int t_out = wave8 >> 2;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int r = 4 * (wave8 & 3) + rr;
-        float v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int e = ((t_out * 4 + c) * 16 + r) * 64 + lane;
-            v[c] = ((red[e] + red[128 * 64 + e]) + red[2 * 128 * 64 + e]) + red[3 * 128 * 64 + e];
-        }
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int n = nblk * 64 + 2 * row + t_out;
-        *reinterpret_cast<float4*>(pw + (int64_t)n * K + kslab * W2_KW + 4 * i) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    if (kslab == 0 && partial_db && wave8 == 0) {
-        const float* rd = red + 4 * 128 * 64;
-        partial_db[(int64_t)group * N + nblk * 64 + lane] = ((rd[lane] + rd[64 + lane]) + rd[128 + lane]) + rd[192 + lane];
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Weight gradient, v2 with the NEXT tile's 16 loads spread over the current tile's instruction stream.
-// Cycle buckets of the v2 body (tools/wgrad_probe.py, instrumented build): 50 % of a wave's time is spent ISSUING its 16 loads,
-// 1 % waiting for them, 49 % in split + MFMAs: a CU cannot hold a whole tile round (40 KB) in flight, so a burst of loads blocks at
-// issue for as long as the memory system takes to deliver it and the transfer never overlaps the arithmetic. Here one load is
-// issued after every ~150 cycles of split / MFMA work, so the memory pipe runs beside the arithmetic.
-// ---------------------------------------------------------------------------------------------
-template <int UNUSED = 0>
-__device__ __forceinline__ void wgrad_bf16x3_v5_body(const WgradGroup& g, int N, int K, float* __restrict__ partial,
-                                                     float* __restrict__ partial_db, int64_t MC, int n_kslab, int n_slabs, int lb, float* red) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i = lane & 31, h = lane >> 5;
-    const int kslab = lb % n_kslab;
-    const int group = lb / n_kslab;
-    const int slab_raw = group * 4 + wave;
-    const bool active = slab_raw < n_slabs;
-    const int slab = active ? slab_raw : n_slabs - 1;             // idle waves of the last group recompute a slab and drop it
-    int prob = 0;
-    while (prob + 1 < g.n_problems && slab >= g.chunk_begin[prob + 1]) ++prob;
-    const int64_t lddy = g.lddy[prob], ldx = g.ldx[prob], M = g.M[prob];
-    const int nblk = blockIdx.y;
-    const int64_t m_begin = (int64_t)(slab - g.chunk_begin[prob]) * MC;
-    const int64_t m_end = (m_begin + MC < M) ? m_begin + MC : M;
-    const int n_base = nblk * 64 + 2 * i;
-    const int k_base = kslab * W2_KW + 4 * i;
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
-    f32x2 dbs2 = {0.f, 0.f};
-    const uint32_t la = 4u * (uint32_t)lddy, lbx = 4u * (uint32_t)ldx;
-    uint32_t offa[8], offb[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        offa[j] = (uint32_t)(8 * h + j) * la + 4u * (uint32_t)n_base;
-        offb[j] = (uint32_t)(8 * h + j) * lbx + 4u * (uint32_t)k_base;
-    }
-    const char* dYb = reinterpret_cast<const char*>(uniform_u64(g.dY[prob]));
-    const char* Xb = reinterpret_cast<const char*>(uniform_u64(g.X[prob]));
-    // one tile: split + 48 MFMAs of (ca, cb) while the 16 loads of the tile at m_next go out one at a time into (na, nb)
-    auto tile = [&](const float2 (&ca)[8], const float4 (&cb)[8], float2 (&na)[8], float4 (&nb)[8], int64_t m_next) {
-        const int64_t mc = m_next < m_end ? m_next : m_end;      // wave-uniform; at m_end the buffers are empty: zeros
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(dYb + (uint64_t)mc * la), 0, (int)((uint32_t)(m_end - mc) * la), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (uint64_t)mc * lbx), 0, (int)((uint32_t)(m_end - mc) * lbx), 0x00020000);
-        auto issue = [&](int k) {                                  // load k of the next tile: X rows first (HBM), then dY (L2)
-            __builtin_amdgcn_sched_barrier(0);
-            if (k < 8) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb, offb[k & 7], 0, 0);
-                nb[k & 7] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-            } else {
-                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(ra, offa[k & 7], 0, 0);
-                na[k & 7] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        // phase A: residual arithmetic row by row (X: 12, dY: 6 instructions), one load after every second row
-        uint32_t xh[8][4], xm[8][4], xl[8][4], yh[8][2], ym[8][2], yl[8][2];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const f32x2 xy = {cb[j].x, cb[j].y}, zw = {cb[j].z, cb[j].w}, ab = {ca[j].x, ca[j].y};
-            dbs2 += ab;
-            xh[j][0] = __float_as_uint(xy.x) & 0xffff0000u; xh[j][1] = __float_as_uint(xy.y) & 0xffff0000u;
-            xh[j][2] = __float_as_uint(zw.x) & 0xffff0000u; xh[j][3] = __float_as_uint(zw.y) & 0xffff0000u;
-            yh[j][0] = __float_as_uint(ab.x) & 0xffff0000u; yh[j][1] = __float_as_uint(ab.y) & 0xffff0000u;
-            const f32x2 hxy = {__uint_as_float(xh[j][0]), __uint_as_float(xh[j][1])}, hzw = {__uint_as_float(xh[j][2]), __uint_as_float(xh[j][3])};
-            const f32x2 hab = {__uint_as_float(yh[j][0]), __uint_as_float(yh[j][1])};
-            const f32x2 r1xy = xy - hxy, r1zw = zw - hzw, r1ab = ab - hab;                      // exact
-            xm[j][0] = __float_as_uint(r1xy.x) & 0xffff0000u; xm[j][1] = __float_as_uint(r1xy.y) & 0xffff0000u;
-            xm[j][2] = __float_as_uint(r1zw.x) & 0xffff0000u; xm[j][3] = __float_as_uint(r1zw.y) & 0xffff0000u;
-            ym[j][0] = __float_as_uint(r1ab.x) & 0xffff0000u; ym[j][1] = __float_as_uint(r1ab.y) & 0xffff0000u;
-            const f32x2 mxy = {__uint_as_float(xm[j][0]), __uint_as_float(xm[j][1])}, mzw = {__uint_as_float(xm[j][2]), __uint_as_float(xm[j][3])};
-            const f32x2 mab = {__uint_as_float(ym[j][0]), __uint_as_float(ym[j][1])};
-            const f32x2 r2xy = r1xy - mxy, r2zw = r1zw - mzw, r2ab = r1ab - mab;                // exact, <= 8 significant bits
-            xl[j][0] = __float_as_uint(r2xy.x); xl[j][1] = __float_as_uint(r2xy.y);
-            xl[j][2] = __float_as_uint(r2zw.x); xl[j][3] = __float_as_uint(r2zw.y);
-            yl[j][0] = __float_as_uint(r2ab.x); yl[j][1] = __float_as_uint(r2ab.y);
-            if (j & 1) issue(j >> 1);                               // loads 0..3
-        }
-        // phase B: the packs (72 v_perm_b32), one load after every second X tile
-        uint4 bh[4], bm[4], bl[4], ah[2], am[2], al[2];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            bh[c] = make_uint4(pack_hi16(xh[0][c], xh[1][c]), pack_hi16(xh[2][c], xh[3][c]), pack_hi16(xh[4][c], xh[5][c]), pack_hi16(xh[6][c], xh[7][c]));
-            bm[c] = make_uint4(pack_hi16(xm[0][c], xm[1][c]), pack_hi16(xm[2][c], xm[3][c]), pack_hi16(xm[4][c], xm[5][c]), pack_hi16(xm[6][c], xm[7][c]));
-            bl[c] = make_uint4(pack_hi16(xl[0][c], xl[1][c]), pack_hi16(xl[2][c], xl[3][c]), pack_hi16(xl[4][c], xl[5][c]), pack_hi16(xl[6][c], xl[7][c]));
-            if (c & 1) issue(4 + (c >> 1));                         // loads 4, 5
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            ah[t] = make_uint4(pack_hi16(yh[0][t], yh[1][t]), pack_hi16(yh[2][t], yh[3][t]), pack_hi16(yh[4][t], yh[5][t]), pack_hi16(yh[6][t], yh[7][t]));
-            am[t] = make_uint4(pack_hi16(ym[0][t], ym[1][t]), pack_hi16(ym[2][t], ym[3][t]), pack_hi16(ym[4][t], ym[5][t]), pack_hi16(ym[6][t], ym[7][t]));
-            al[t] = make_uint4(pack_hi16(yl[0][t], yl[1][t]), pack_hi16(yl[2][t], yl[3][t]), pack_hi16(yl[4][t], yl[5][t]), pack_hi16(yl[6][t], yl[7][t]));
-        }
-        // the 48 MFMAs in 12 groups of four (smallest terms first), one load after each of the first ten groups (loads 6..15)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[t][c] = mfma32_bf16(al[t], bh[c], acc[t][c]);
-            issue(6 + 6 * t);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[t][c] = mfma32_bf16(ah[t], bl[c], acc[t][c]);
-            issue(7 + 6 * t);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[t][c] = mfma32_bf16(am[t], bm[c], acc[t][c]);
-            issue(8 + 6 * t);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[t][c] = mfma32_bf16(am[t], bh[c], acc[t][c]);
-            issue(9 + 6 * t);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[t][c] = mfma32_bf16(ah[t], bm[c], acc[t][c]);
-            if (t == 0) issue(10);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[t][c] = mfma32_bf16(ah[t], bh[c], acc[t][c]);
-            if (t == 0) issue(11);
-        }
-    };
-    float2 a0[8], a1[8];
-    float4 b0[8], b1[8];
-    const int n_tiles = (int)((m_end - m_begin + 15) / 16);      // the last tile may be ragged: its missing rows read as zero
-    {   // prologue: the first tile as one burst
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(dYb + (uint64_t)m_begin * la), 0, (int)((uint32_t)(m_end - m_begin) * la), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (uint64_t)m_begin * lbx), 0, (int)((uint32_t)(m_end - m_begin) * lbx), 0x00020000);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const u32x2 va = __builtin_amdgcn_raw_buffer_load_b64(ra, offa[j], 0, 0);
-            const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rb, offb[j], 0, 0);
-            a0[j] = make_float2(__uint_as_float(va.x), __uint_as_float(va.y));
-            b0[j] = make_float4(__uint_as_float(vb.x), __uint_as_float(vb.y), __uint_as_float(vb.z), __uint_as_float(vb.w));
-        }
-    }
-    int64_t m0 = m_begin;
-    for (int g2 = n_tiles >> 1; g2 > 0; --g2) {
-        tile(a0, b0, a1, b1, m0 + 16);
-        tile(a1, b1, a0, b0, m0 + 32);
-        m0 += 32;
-    }
-    if (n_tiles & 1) tile(a0, b0, a1, b1, m_end);                 // (its prefetch reads an empty buffer)
-    float2 dbs = make_float2(dbs2.x, dbs2.y);
-    dbs.x += __shfl_xor(dbs.x, 32, 64); dbs.y += __shfl_xor(dbs.y, 32, 64);
-    float* rw = red + wave * (128 * 64);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rw[((t * 4 + c) * 16 + r) * 64 + lane] = active ? acc[t][c][r] : 0.f;
-    if (h == 0) {
-        red[4 * 128 * 64 + wave * 64 + 2 * i + 0] = active ? dbs.x : 0.f;
-        red[4 * 128 * 64 + wave * 64 + 2 * i + 1] = active ? dbs.y : 0.f;
-    }
-    __syncthreads();
-    float* pw = partial + (int64_t)group * N * K;
-    const int t_out = wave >> 1;
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const int r = 8 * (wave & 1) + rr;
-        float v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int e = ((t_out * 4 + c) * 16 + r) * 64 + lane;
-            v[c] = ((red[e] + red[128 * 64 + e]) + red[2 * 128 * 64 + e]) + red[3 * 128 * 64 + e];
-        }
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int n = nblk * 64 + 2 * row + t_out;
-        *reinterpret_cast<float4*>(pw + (int64_t)n * K + kslab * W2_KW + 4 * i) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    if (kslab == 0 && partial_db && wave == 0) {
-        const float* rd = red + 4 * 128 * 64;
-        partial_db[(int64_t)group * N + nblk * 64 + lane] = ((rd[lane] + rd[64 + lane]) + rd[128 + lane]) + rd[192 + lane];
-    }
-}
-
-__global__ __launch_bounds__(256, 1) void linear_wgrad_bf16x3_v5_multi_kernel(WgradMulti m, int N) {
-    __shared__ __attribute__((aligned(16))) float red[W2_RED_FLOATS];
-    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
-    int t = 0;
-    while (t + 1 < m.n_targets && lb >= m.block_begin[t + 1]) ++t;
-    wgrad_bf16x3_v5_body<0>(m.g[t], N, m.K[t], m.partial[t], m.partial_db[t], m.MC, m.n_kslab[t], m.n_slabs[t], lb - m.block_begin[t], red);
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Weight gradient, LOADER / COMPUTE wave pairs (round 3, the organisation the measurements below lead to).
-// tools/wgrad_probe.py on the single-wave bodies above (profiles/experiments/r03_wgrad.md): a wave spends half of its time
-// ISSUING its 16 loads per tile (~170 cycles per VMEM instruction: the CU's one address / L1 path serves the four waves' instructions
-// one after the other, and an in-order wave waits at issue), 1 % waiting for data, the rest in split + MFMAs; spreading the loads
-// over the instruction stream changes nothing, and handing FRAGMENTS from a splitting wave to a multiplying wave through LDS is
-// bound by the LDS store path (18 KB of ds_write_b128 per tile). So: the wave that multiplies also splits, but never touches VMEM -
-//   loader (w < 4): LDS-DMA of its partner's X / dY tiles into an R-slot LDS ring (12 pieces of 1 KB per 16-row tile, rows past
-//       the slab's end land as zeros), counted vmcnt -> `ready`; it runs R - 1 tiles ahead, blocked at issue as long as it likes;
-//   compute (w >= 4, same SIMD as w - 4): waits for `ready` (LDS poll), reads the raw tile back 8 bytes per lane at a time, splits
-//       (dY, then X in two halves so that acc 128 + fragments + raw stay under the 256 registers two waves per SIMD allow) and
-//       issues the 48 MFMAs; `consumed` frees the slot.
-// Same work decomposition, summation order and results as the v2 body (bit for bit).
-// ---------------------------------------------------------------------------------------------
-constexpr int W6_TILE = W3_RAWX + W3_RAWY;                 // 12 KB: one raw tile (X 8 KB as loaded, dY 4 KB)
-template <int R> struct W6 {
-    static constexpr int PAIR = R * W6_TILE;
-    static constexpr int FLAGS = 4 * PAIR;
-    static constexpr int LDS = (FLAGS + 64 > (int)sizeof(float) * W2_RED_FLOATS) ? FLAGS + 64 : (int)sizeof(float) * W2_RED_FLOATS;
-};
-
-template <int R>
-__global__ __launch_bounds__(512, 2) void linear_wgrad_bf16x3_v6_multi_kernel(WgradMulti mm, int N) {
-    __shared__ __attribute__((aligned(1024))) char lds[W6<R>::LDS];
-    const int lb_all = xcd_logical_block(blockIdx.x, gridDim.x);
-    int tg = 0;
-    while (tg + 1 < mm.n_targets && lb_all >= mm.block_begin[tg + 1]) ++tg;
-    const WgradGroup& g = mm.g[tg];
-    const int K = mm.K[tg], n_kslab = mm.n_kslab[tg], n_slabs = mm.n_slabs[tg];
-    const int64_t MC = mm.MC;
-    float* __restrict__ partial = mm.partial[tg];
-    float* __restrict__ partial_db = mm.partial_db[tg];
-    const int lb = lb_all - mm.block_begin[tg];
-
-    const int lane = threadIdx.x & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q = wave8 & 3;                                      // pair
-    const bool loader = wave8 < 4;
-    const int i = lane & 31, h = lane >> 5;
-    const int kslab = lb % n_kslab;
-    const int group = lb / n_kslab;
-    const int slab_raw = group * 4 + q;
-    const bool active = slab_raw < n_slabs;
-    const int slab = active ? slab_raw : n_slabs - 1;
-    int prob = 0;
-    while (prob + 1 < g.n_problems && slab >= g.chunk_begin[prob + 1]) ++prob;
-    const int64_t lddy = g.lddy[prob], ldx = g.ldx[prob], M = g.M[prob];
-    const int nblk = blockIdx.y;
-    const int64_t m_begin = (int64_t)(slab - g.chunk_begin[prob]) * MC;
-    const int64_t m_end = (m_begin + MC < M) ? m_begin + MC : M;
-    const int T = active ? (int)((m_end - m_begin + 15) / 16) : 0;  // 16-row tiles of this pair (the last one may be ragged)
-
-    const uint32_t pair0 = (uint32_t)(uintptr_t)lds + (uint32_t)q * W6<R>::PAIR;   // LDS byte address of the pair's ring
-    const char* pair_p = lds + q * W6<R>::PAIR;
-    const lds_flag_t flags = (lds_flag_t)(lds + W6<R>::FLAGS);
-    const lds_flag_t ready = flags + q, consumed = flags + 4 + q;
-    if (threadIdx.x < 8) flags[threadIdx.x] = 0u;
-#ifdef LLMREC_TOOLS_BUILD
-    const long long w6_c0 = clock64(), w6_r0 = wall_clock64();     // shader cycles vs the constant 100 MHz counter: the effective clock
-#endif
-    __syncthreads();
-    bool ok = true;
-    f32x2 dbs2 = {0.f, 0.f};
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
-
-    if (loader) {
-        const uint32_t la = 4u * (uint32_t)lddy, lbx = 4u * (uint32_t)ldx;        // row strides in bytes
-        // X piece j: lane (i, h) addresses row 8 h + j, columns k0 + 4 i ..; dY piece p: lane l addresses row 4 p + (l >> 4), columns 4 (l & 15) ..
-        uint32_t offx[8], offy[4];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) offx[j] = (uint32_t)(8 * h + j) * lbx + 4u * (uint32_t)(kslab * W2_KW + 4 * i);
-#pragma unroll
-        for (int p4 = 0; p4 < 4; ++p4) offy[p4] = (uint32_t)(4 * p4 + (lane >> 4)) * la + 4u * (uint32_t)(nblk * 64 + 4 * (lane & 15));
-        const uint64_t Xb = uniform_u64(g.X[prob]), Yb = uniform_u64(g.dY[prob]);
-        auto dma_tile = [&](int u) {                              // tile u -> ring slot u % R: 12 pieces
-            const int64_t m0 = m_begin + 16 * (int64_t)u;
-            const u32x4 rx = make_rsrc(Xb + (uint64_t)m0 * lbx, (uint32_t)(m_end - m0) * lbx);
-            const u32x4 ry = make_rsrc(Yb + (uint64_t)m0 * la, (uint32_t)(m_end - m0) * la);
-            const uint32_t dst = pair0 + (uint32_t)(u % R) * W6_TILE;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dma_piece(dst + 1024u * j, rx, offx[j]);
-#pragma unroll
-            for (int p4 = 0; p4 < 4; ++p4) dma_piece(dst + W3_RAWX + 1024u * p4, ry, offy[p4]);
-        };
-        // tiles 0 .. R - 2 go out at once; in iteration u tile u + R - 1 follows as soon as the compute wave has left its slot
-        // (the one tile u - 1 used), then tile u is awaited: at most R - 1 younger tiles (12 pieces each) may still be in flight
-        for (int u = 0; u < R - 1 && u < T; ++u) dma_tile(u);
-        W3P_DECL();
-        for (int u = 0; u < T; ++u) {
-            if (u + R - 1 < T) {
-                ok = ok && spin_until(consumed, (uint32_t)u);
-                W3P_MARK(0);                                       // waiting for a free slot
-                dma_tile(u + R - 1);
-                W3P_MARK(1);                                       // issuing 12 pieces
-                wait_vmcnt<12 * (R - 1)>();
-            } else {
-                wait_vmcnt<0>();                                   // the last R - 1 tiles: nothing follows them
-            }
-            W3P_MARK(2);                                           // waiting for tile u to land
-            *ready = (uint32_t)(u + 1);
-        }
-        W3P_FLUSH(0);
-    } else {
-        W3P_DECL();
-        for (int u = 0; u < T; ++u) {
-            ok = ok && spin_until(ready, (uint32_t)(u + 1));
-            W3P_MARK(0);                                           // waiting for the loader
-            const char* rx = pair_p + (u % R) * W6_TILE;
-            const char* ry = rx + W3_RAWX;
-            float2 ya[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {                          // row 8 h + j, columns 2 i, 2 i + 1 of the dY tile
-                const int r = 8 * h + j;
-                ya[j] = *reinterpret_cast<const float2*>(ry + 1024 * (r >> 2) + 256 * (r & 3) + 8 * i);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const f32x2 v = {ya[j].x, ya[j].y}; dbs2 += v; }
-            uint4 ah[2], am[2], al[2];
-            split16(ya, ah, am, al);
-#ifdef LLMREC_TOOLS_BUILD
-            asm volatile("" :: "v"(al[1].w), "v"(ah[0].x));
-#endif
-            W3P_MARK(1);                                           // dY: read + split
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {                 // X tiles c = 2 half, 2 half + 1: the (x, y) / (z, w) halves of the loaded float4s
-                float2 xr[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xr[j] = *reinterpret_cast<const float2*>(rx + 1024 * j + 16 * lane + 8 * half);
-                if (half == 1) { wait_lgkm0(); *consumed = (uint32_t)(u + 1); }    // the slot is in registers: the loader may refill it
-                uint4 bh[2], bm[2], bl[2];
-                split16(xr, bh, bm, bl);
-                __builtin_amdgcn_sched_barrier(0);                 // (the second half's split must not move above the first half's MFMAs: 256 registers)
-#ifdef LLMREC_TOOLS_BUILD
-                asm volatile("" :: "v"(bl[1].w), "v"(bh[0].x));
-#endif
-                W3P_MARK(2);                                       // X half: read + split
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    // smallest terms first (as everywhere)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[t][2 * half + c] = mfma32_bf16(al[t], bh[c], acc[t][2 * half + c]);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[t][2 * half + c] = mfma32_bf16(ah[t], bl[c], acc[t][2 * half + c]);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[t][2 * half + c] = mfma32_bf16(am[t], bm[c], acc[t][2 * half + c]);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[t][2 * half + c] = mfma32_bf16(am[t], bh[c], acc[t][2 * half + c]);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[t][2 * half + c] = mfma32_bf16(ah[t], bm[c], acc[t][2 * half + c]);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[t][2 * half + c] = mfma32_bf16(ah[t], bh[c], acc[t][2 * half + c]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#ifdef LLMREC_TOOLS_BUILD
-                asm volatile("" :: "v"(acc[1][2 * half + 1][15]), "v"(acc[0][2 * half][0]));
-#endif
-                W3P_MARK(3);                                       // 24 MFMAs
-            }
-        }
-        W3P_FLUSH(8);
-    }
-    wait_vmcnt<0>();
-#ifdef LLMREC_TOOLS_BUILD
-    if (lane == 0 && wave8 == 4) { atomicAdd(&g_w3prof[12], (unsigned long long)(clock64() - w6_c0)); atomicAdd(&g_w3prof[13], (unsigned long long)(wall_clock64() - w6_r0)); }
-#endif
-    __syncthreads();                                              // every pair is done: the ring becomes the reduction scratch
-    float* red = reinterpret_cast<float*>(lds);
-    const float poison = ok ? 0.f : __builtin_nanf("");           // a hand-off that timed out must not pass for a result
-    if (!loader) {
-        float* rw = red + q * (128 * 64);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rw[((t * 4 + c) * 16 + r) * 64 + lane] = acc[t][c][r] + poison;
-        float2 dbs = make_float2(dbs2.x, dbs2.y);
-        dbs.x += __shfl_xor(dbs.x, 32, 64); dbs.y += __shfl_xor(dbs.y, 32, 64);
-        if (h == 0) {
-            red[4 * 128 * 64 + q * 64 + 2 * i + 0] = dbs.x;
-            red[4 * 128 * 64 + q * 64 + 2 * i + 1] = dbs.y;
-        }
-    } else if (!ok) {
-        red[4 * 128 * 64 + 256 + q] = poison;                     // (read below)
-    }
-    __syncthreads();
-    // wave w (of 8) adds tile rows t = w >> 2, reg r in [4 (w & 3), +4) of the four pairs' tiles, in pair order (slab 4 g, +1, +2, +3)
-    float* pw = partial + (int64_t)group * N * K;
-    const int t_out = wave8 >> 2;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int r = 4 * (wave8 & 3) + rr;
-        float v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int e = ((t_out * 4 + c) * 16 + r) * 64 + lane;
-            v[c] = ((red[e] + red[128 * 64 + e]) + red[2 * 128 * 64 + e]) + red[3 * 128 * 64 + e] + poison;
-        }
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int n = nblk * 64 + 2 * row + t_out;
-        *reinterpret_cast<float4*>(pw + (int64_t)n * K + kslab * W2_KW + 4 * i) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    if (kslab == 0 && partial_db && wave8 == 0) {
-        const float* rd = red + 4 * 128 * 64;
-        partial_db[(int64_t)group * N + nblk * 64 + lane] = ((rd[lane] + rd[64 + lane]) + rd[128 + lane]) + rd[192 + lane] + poison;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Weight gradient, TWO self-sufficient waves per SIMD (round 3). What the measurements on the bodies above say
-// (profiles/experiments/r03_wgrad.md): the kernel is bound by INSTRUCTION ISSUE - per 16-row tile ~224 VALU instructions of operand
-// split (~6.5 cycles each), 48 MFMAs (32-42 cycles each) and 12-16 memory instructions (66-170 cycles of issue each) - and a
-// single in-order wave per SIMD runs them one after the other: loads alone 75 us, loads + split 132, loads + MFMAs 138, all 180.
-// Moving the loads to a partner wave (v6) or the split to a partner wave (v3) leaves the other two in series. Here each SIMD
-// holds two waves that each do everything for every other tile of one (row slab, k slab): while one splits or sits at DMA issue,
-// the other's MFMAs run (the 32x32x16 MFMA holds the VALU for 8 of its 32 cycles and co-executes with LDS-DMA / ds_read).
-//   * 256 registers per wave: 128 accumulators + dY fragments + ONE half of the X tile at a time (raw 16, fragments 24);
-//   * operands arrive by LDS-DMA (no VGPR landing, nothing for the MFMA to collide with): per wave an X ring of two 8 KB slots and
-//     one 4 KB dY slot = 20 KB, 160 KB per block; rows past the slab's end are outside the descriptor and land as zeros;
-//   * the two accumulators of a pair and then the four pairs are summed through LDS in a fixed order before one partial slab is written.
-// ---------------------------------------------------------------------------------------------
-constexpr int W7_WAVE = 2 * W3_RAWX + W3_RAWY;             // 20 KB per wave
-constexpr int W7_LDS = 8 * W7_WAVE;                        // 160 KB
-static_assert(W7_LDS >= (int)sizeof(float) * W2_RED_FLOATS && W7_LDS <= 163840, "LDS budget");
-
-__global__ __launch_bounds__(512, 2) void linear_wgrad_bf16x3_v7_multi_kernel(WgradMulti mm, int N) {
-    __shared__ __attribute__((aligned(1024))) char lds[W7_LDS];
-    const int lb_all = xcd_logical_block(blockIdx.x, gridDim.x);
-    int tg = 0;
-    while (tg + 1 < mm.n_targets && lb_all >= mm.block_begin[tg + 1]) ++tg;
-    const WgradGroup& g = mm.g[tg];
-    const int K = mm.K[tg], n_kslab = mm.n_kslab[tg], n_slabs = mm.n_slabs[tg];
-    const int64_t MC = mm.MC;
-    float* __restrict__ partial = mm.partial[tg];
-    float* __restrict__ partial_db = mm.partial_db[tg];
-    const int lb = lb_all - mm.block_begin[tg];
-
-    const int lane = threadIdx.x & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q = wave8 & 3;                                      // pair = row slab 4 g + q; waves q and q + 4 share a SIMD
-    const int par = wave8 >> 2;                                   // this wave takes the pair's tiles par, par + 2, ...
-    const int i = lane & 31, h = lane >> 5;
-    const int kslab = lb % n_kslab;
-    const int group = lb / n_kslab;
-    const int slab_raw = group * 4 + q;
-    const bool active = slab_raw < n_slabs;
-    const int slab = active ? slab_raw : n_slabs - 1;
-    int prob = 0;
-    while (prob + 1 < g.n_problems && slab >= g.chunk_begin[prob + 1]) ++prob;
-    const int64_t lddy = g.lddy[prob], ldx = g.ldx[prob], M = g.M[prob];
-    const int nblk = blockIdx.y;
-    const int64_t m_begin = (int64_t)(slab - g.chunk_begin[prob]) * MC;
-    const int64_t m_end = (m_begin + MC < M) ? m_begin + MC : M;
-    const int T = active ? (int)((m_end - m_begin + 15) / 16) : 0;  // 16-row tiles of the pair (the last one may be ragged)
-    const int Tw = (T - par + 1) >> 1;                            // ... of this wave
-
-    const uint32_t ring0 = (uint32_t)(uintptr_t)lds + (uint32_t)wave8 * W7_WAVE;   // LDS byte address of this wave's ring
-    const char* ring_p = lds + wave8 * W7_WAVE;
-#ifdef LLMREC_TOOLS_BUILD
-    const long long w7_c0 = clock64(), w7_r0 = wall_clock64();     // shader cycles vs the constant 100 MHz counter: the effective clock
-#endif
-    f32x2 dbs2 = {0.f, 0.f};
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
-    {
-        const uint32_t la = 4u * (uint32_t)lddy, lbx = 4u * (uint32_t)ldx;        // row strides in bytes
-        // X piece j: lane (i, h) addresses row 8 h + j, columns k0 + 4 i ..; dY piece p: lane l addresses row 4 p + (l >> 4), columns 4 (l & 15) ..
-        uint32_t offx[8], offy[4];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) offx[j] = (uint32_t)(8 * h + j) * lbx + 4u * (uint32_t)(kslab * W2_KW + 4 * i);
-#pragma unroll
-        for (int p4 = 0; p4 < 4; ++p4) offy[p4] = (uint32_t)(4 * p4 + (lane >> 4)) * la + 4u * (uint32_t)(nblk * 64 + 4 * (lane & 15));
-        const uint64_t Xb = uniform_u64(g.X[prob]), Yb = uniform_u64(g.dY[prob]);
-        auto dma_x = [&](int v) {                                 // this wave's tile v -> X slot v & 1 (nothing past the end)
-            if (v >= Tw) return;
-            const int64_t m0 = m_begin + 16 * (int64_t)(2 * v + par);
-            const u32x4 r = make_rsrc(Xb + (uint64_t)m0 * lbx, (uint32_t)(m_end - m0) * lbx);
-            const uint32_t dst = ring0 + (uint32_t)(v & 1) * W3_RAWX;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dma_piece(dst + 1024u * j, r, offx[j]);
-        };
-        auto dma_y = [&](int v) {
-            if (v >= Tw) return;
-            const int64_t m0 = m_begin + 16 * (int64_t)(2 * v + par);
-            const u32x4 r = make_rsrc(Yb + (uint64_t)m0 * la, (uint32_t)(m_end - m0) * la);
-            const uint32_t dst = ring0 + 2u * W3_RAWX;
-#pragma unroll
-            for (int p4 = 0; p4 < 4; ++p4) dma_piece(dst + 1024u * p4, r, offy[p4]);
-        };
-        // queue order: X(0) | dY(0) X(1) | dY(1) X(2) | ...: when tile v is needed only X(v + 1) (8 pieces) may still be in flight
-        dma_x(0); dma_y(0); dma_x(1);
-        for (int v = 0; v < Tw; ++v) {
-            if (v + 1 < Tw) wait_vmcnt<8>(); else wait_vmcnt<0>();
-            const char* rx = ring_p + (v & 1) * W3_RAWX;
-            const char* ry = ring_p + 2 * W3_RAWX;
-            float2 ya[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {                          // row 8 h + j, columns 2 i, 2 i + 1 of the dY tile
-                const int r = 8 * h + j;
-                ya[j] = *reinterpret_cast<const float2*>(ry + 1024 * (r >> 2) + 256 * (r & 3) + 8 * i);
-            }
-            wait_lgkm0();                                          // the dY slot is in registers: refill it
-            dma_y(v + 1);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const f32x2 yv = {ya[j].x, ya[j].y}; dbs2 += yv; }
-            uint4 ah[2], am[2], al[2];
-            split16(ya, ah, am, al);
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {                 // X tiles c = 2 half, 2 half + 1: the (x, y) / (z, w) halves of the loaded float4s
-                float2 xr[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xr[j] = *reinterpret_cast<const float2*>(rx + 1024 * j + 16 * lane + 8 * half);
-                if (half == 1) { wait_lgkm0(); dma_x(v + 2); }     // the X slot is in registers: refill it with the tile after the next
-                uint4 bh[2], bm[2], bl[2];
-                split16(xr, bh, bm, bl);
-                __builtin_amdgcn_sched_barrier(0);                 // (the second half's split must not move above the first half's MFMAs: 256 registers)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    // smallest terms first (as everywhere)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[t][2 * half + c] = mfma32_bf16(al[t], bh[c], acc[t][2 * half + c]);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[t][2 * half + c] = mfma32_bf16(ah[t], bl[c], acc[t][2 * half + c]);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[t][2 * half + c] = mfma32_bf16(am[t], bm[c], acc[t][2 * half + c]);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[t][2 * half + c] = mfma32_bf16(am[t], bh[c], acc[t][2 * half + c]);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[t][2 * half + c] = mfma32_bf16(ah[t], bm[c], acc[t][2 * half + c]);
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[t][2 * half + c] = mfma32_bf16(ah[t], bh[c], acc[t][2 * half + c]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-    wait_vmcnt<0>();
-#ifdef LLMREC_TOOLS_BUILD
-    if (lane == 0) { atomicAdd(&g_w3prof[12], (unsigned long long)(clock64() - w7_c0)); atomicAdd(&g_w3prof[13], (unsigned long long)(wall_clock64() - w7_r0)); atomicAdd(&g_w3prof[14], 1ull); }
-#endif
-    __syncthreads();                                              // every wave is done: the rings become the reduction scratch
-    float* red = reinterpret_cast<float*>(lds);
-    float2 dbs = make_float2(dbs2.x, dbs2.y);
-    dbs.x += __shfl_xor(dbs.x, 32, 64); dbs.y += __shfl_xor(dbs.y, 32, 64);
-    // step 1: the odd-tile wave of each pair hands its tile (and bias sums) to the even-tile wave
-    if (par == 1) {
-        float* rw = red + q * (128 * 64);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rw[((t * 4 + c) * 16 + r) * 64 + lane] = acc[t][c][r];
-        if (h == 0) { red[4 * 128 * 64 + q * 64 + 2 * i + 0] = dbs.x; red[4 * 128 * 64 + q * 64 + 2 * i + 1] = dbs.y; }
-    }
-    __syncthreads();
-    if (par == 0) {
-        const float* rr_ = red + q * (128 * 64);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][c][r] += rr_[((t * 4 + c) * 16 + r) * 64 + lane];
-        if (h == 0) { dbs.x += red[4 * 128 * 64 + q * 64 + 2 * i + 0]; dbs.y += red[4 * 128 * 64 + q * 64 + 2 * i + 1]; }
-    }
-    __syncthreads();
-    // step 2: the four pairs (slab 4 g, +1, +2, +3), as in the v2 body
-    if (par == 0) {
-        float* rw = red + q * (128 * 64);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rw[((t * 4 + c) * 16 + r) * 64 + lane] = acc[t][c][r];
-        if (h == 0) { red[4 * 128 * 64 + q * 64 + 2 * i + 0] = dbs.x; red[4 * 128 * 64 + q * 64 + 2 * i + 1] = dbs.y; }
-    }
-    __syncthreads();
-    float* pw = partial + (int64_t)group * N * K;
-    const int t_out = wave8 >> 2;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int r = 4 * (wave8 & 3) + rr;
-        float v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int e = ((t_out * 4 + c) * 16 + r) * 64 + lane;
-            v[c] = ((red[e] + red[128 * 64 + e]) + red[2 * 128 * 64 + e]) + red[3 * 128 * 64 + e];
-        }
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int n = nblk * 64 + 2 * row + t_out;
-        *reinterpret_cast<float4*>(pw + (int64_t)n * K + kslab * W2_KW + 4 * i) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    if (kslab == 0 && partial_db && wave8 == 0) {
-        const float* rd = red + 4 * 128 * 64;
-        partial_db[(int64_t)group * N + nblk * 64 + lane] = ((rd[lane] + rd[64 + lane]) + rd[128 + lane]) + rd[192 + lane];
-    }
+    wgrad_bf16x3_v2_body(m.g[t], N, m.K[t], m.partial[t], m.partial_db[t], m.MC, m.n_kslab[t], m.n_slabs[t], lb - m.block_begin[t], red);
 }
 
 struct ReduceMulti {
@@ -2209,7 +1316,7 @@ static int linear_fwd_grouped_impl(int32_t n_problems, const llmrec_linear_probl
         LLMREC_CHECK_ARG(p[i].M >= 0 && p[i].K > 0, "linear_fwd_grouped: problem %d has bad sizes", i);
         LLMREC_CHECK_ARG(p[i].M == 0 || (p[i].X && p[i].W && p[i].Y && p[i].ldx >= p[i].K && p[i].ldw >= p[i].K && p[i].ldy >= N),
                          "linear_fwd_grouped: problem %d has a null pointer or a small ld", i);
-        g.X[i] = p[i].X; g.W[i] = p[i].W; g.bias[i] = p[i].bias; g.Y[i] = p[i].Y;
+        g.X[i] = p[i].X; g.W[i] = p[i].W; g.bias[i] = p[i].bias; g.bias_scale[i] = p[i].bias ? p[i].bias_scale : nullptr; g.Y[i] = p[i].Y;
         g.ldx[i] = p[i].ldx; g.ldw[i] = p[i].ldw; g.ldy[i] = p[i].ldy; g.M[i] = p[i].M; g.K[i] = p[i].K;
         g.vec_ok[i] = (p[i].ldx % 4 == 0) && (p[i].ldw % 4 == 0) && (((uintptr_t)p[i].X | (uintptr_t)p[i].W) % 16 == 0);
     }
@@ -2324,8 +1431,7 @@ static int linear_wgrad_grouped_impl(int32_t n_problems, const llmrec_wgrad_prob
         // entry point's bound, checked there)
         bool nonempty = true;
         for (int i = 0; i < n_problems; ++i) nonempty = nonempty && p[i].M > 0;
-        static const bool v1 = [] { const char* e = getenv("LLMREC_WGRAD_KERNEL"); return e && atoi(e) == 1; }();
-        if (nonempty && !v1) {
+        if (nonempty) {
             llmrec_wgrad_target_t one = {n_problems, p, K, dW, lddw, db, accumulate};
             return llmrec_linear_wgrad_multi_bf16x3(1, &one, N, workspace, workspace_bytes, stream_);
         }
@@ -2336,6 +1442,7 @@ static int linear_wgrad_grouped_impl(int32_t n_problems, const llmrec_wgrad_prob
     int n_slabs = 0;
     for (int i = 0; i < n_problems; ++i) {
         g.dY[i] = p[i].dY; g.X[i] = p[i].X; g.lddy[i] = p[i].lddy; g.ldx[i] = p[i].ldx; g.M[i] = p[i].M;
+        if (p[i].db_row_weight) { set_error("linear_wgrad: db_row_weight is served by the 128-wide-k-slab bf16x3 organisation only (N = 64, K %% 128 == 0)"); return LLMREC_EUNSUPPORTED; }
         g.vec_ok[i] = (p[i].lddy % 4 == 0) && (p[i].ldx % 4 == 0) && (((uintptr_t)p[i].dY | (uintptr_t)p[i].X) % 16 == 0);
         g.chunk_begin[i] = n_slabs;
         n_slabs += (int)ceil_div(p[i].M, MC);
@@ -2368,13 +1475,11 @@ static int linear_wgrad_grouped_impl(int32_t n_problems, const llmrec_wgrad_prob
     return LLMREC_OK;
 }
 
-// which organisation a multi-target launch runs: 2 = wgrad_bf16x3_v2_body (128-wide k slabs, every K % 128 == 0), 1 = wgrad_bf16x3_body
+// which organisation a multi-target launch runs: 2 = wgrad_bf16x3_v2_body (128-wide k slabs: every K % 128 == 0), 1 = wgrad_bf16x3_body
 static int wgrad_multi_version(int32_t n_targets, const llmrec_wgrad_target_t* t) {
-    static const int forced = [] { const char* e = getenv("LLMREC_WGRAD_KERNEL"); return e ? atoi(e) : 0; }();   // A/B runs: 1, 2 (2 stages), 3 (3 stages)
-    if (forced == 1) return 1;
     for (int i = 0; i < n_targets; ++i)
         if (t[i].K % W2_KW) return 1;
-    return forced >= 3 && forced <= 8 ? forced : 2;
+    return 2;
 }
 // one slab length for every target of a multi-target launch: the launch is ceil(blocks / 256) rounds of (mc + a fixed cost)
 static int64_t wgrad_multi_slab_rows(int32_t n_targets, const llmrec_wgrad_target_t* t) {
@@ -2448,7 +1553,8 @@ int llmrec_linear_wgrad_multi_bf16x3(int32_t n_targets, const llmrec_wgrad_targe
         int n_slabs = 0;
         for (int j = 0; j < t[i].n_problems; ++j) {
             const llmrec_wgrad_problem_t& q = t[i].problems[j];
-            g.dY[j] = q.dY; g.X[j] = q.X; g.lddy[j] = q.lddy; g.ldx[j] = q.ldx; g.M[j] = q.M; g.vec_ok[j] = 1;
+            g.dY[j] = q.dY; g.X[j] = q.X; g.lddy[j] = q.lddy; g.ldx[j] = q.ldx; g.M[j] = q.M; g.vec_ok[j] = 1; g.db_w[j] = q.db_row_weight;
+            if (q.db_row_weight && version == 1) { set_error("linear_wgrad_multi: db_row_weight needs every K %% %d == 0", W2_KW); return LLMREC_EUNSUPPORTED; }
             g.chunk_begin[j] = n_slabs;
             n_slabs += (int)ceil_div(q.M, m.MC);
         }
@@ -2467,26 +1573,8 @@ int llmrec_linear_wgrad_multi_bf16x3(int32_t n_targets, const llmrec_wgrad_targe
     }
     for (int i = n_targets; i <= LLMREC_WGRAD_MAX_TARGETS; ++i) { m.block_begin[i] = blocks; r.block_begin[i] = rblocks; }
     const dim3 grid((unsigned)blocks, (unsigned)(N / 64));
-    static const int abl = [] { const char* e = getenv("LLMREC_WGRAD_ABL"); return e ? atoi(e) : 0; }();   // tools/wgrad_probe.py only
-    if (version != 1 && abl) {
-        switch (abl) {
-            case 1: linear_wgrad_bf16x3_v2_multi_kernel<2, 1><<<grid, 256, 0, stream>>>(m, N); break;
-            case 2: linear_wgrad_bf16x3_v2_multi_kernel<2, 2><<<grid, 256, 0, stream>>>(m, N); break;
-            case 3: linear_wgrad_bf16x3_v2_multi_kernel<2, 3><<<grid, 256, 0, stream>>>(m, N); break;
-            case 4: linear_wgrad_bf16x3_v2_multi_kernel<2, 4><<<grid, 256, 0, stream>>>(m, N); break;
-            case 5: linear_wgrad_bf16x3_v2_multi_kernel<2, 5><<<grid, 256, 0, stream>>>(m, N); break;
-            case 6: linear_wgrad_bf16x3_v2_multi_kernel<2, 6><<<grid, 256, 0, stream>>>(m, N); break;
-            default: linear_wgrad_bf16x3_v2_multi_kernel<3, 3><<<grid, 256, 0, stream>>>(m, N); break;   // 7: loads only, three stages
-        }
-    }
-    else if (version == 4) linear_wgrad_bf16x3_v3_multi_kernel<<<grid, 512, 0, stream>>>(m, N);
-    else if (version == 5) linear_wgrad_bf16x3_v5_multi_kernel<<<grid, 256, 0, stream>>>(m, N);
-    else if (version == 6) linear_wgrad_bf16x3_v6_multi_kernel<3><<<grid, 512, 0, stream>>>(m, N);
-    else if (version == 7) linear_wgrad_bf16x3_v6_multi_kernel<2><<<grid, 512, 0, stream>>>(m, N);
-    else if (version == 8) linear_wgrad_bf16x3_v7_multi_kernel<<<grid, 512, 0, stream>>>(m, N);
-    else if (version == 1) linear_wgrad_bf16x3_multi_kernel<<<grid, 256, 0, stream>>>(m, N);
-    else if (version == 3) linear_wgrad_bf16x3_v2_multi_kernel<3><<<grid, 256, 0, stream>>>(m, N);
-    else linear_wgrad_bf16x3_v2_multi_kernel<2><<<grid, 256, 0, stream>>>(m, N);
+    if (version == 1) linear_wgrad_bf16x3_multi_kernel<<<grid, 256, 0, stream>>>(m, N);
+    else linear_wgrad_bf16x3_v2_multi_kernel<<<grid, 256, 0, stream>>>(m, N);
     LLMREC_LAUNCH_CHECK();
     reduce_chunks_multi_kernel<<<rblocks, 256, 0, stream>>>(r);
     LLMREC_LAUNCH_CHECK();
@@ -2494,11 +1582,11 @@ int llmrec_linear_wgrad_multi_bf16x3(int32_t n_targets, const llmrec_wgrad_targe
 }
 
 #ifdef LLMREC_TOOLS_BUILD
-// tools only: the producer / consumer cycle buckets of linear_wgrad_bf16x3_v3_multi_kernel since the last call (then cleared)
-int llmrec_tools_wgrad_prof(unsigned long long* out24_host) {
-    if (hipMemcpyFromSymbol(out24_host, HIP_SYMBOL(g_w3prof), sizeof(unsigned long long) * 24) != hipSuccess) return LLMREC_EHIP;
-    unsigned long long zero[24] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_w3prof), zero, sizeof(zero)) != hipSuccess) return LLMREC_EHIP;
+// tools only: {shader cycles, 100 MHz ticks, waves} summed over the main loops of the v2 weight-gradient waves since the last call (then cleared)
+int llmrec_tools_wgrad_clock(unsigned long long* out3_host) {
+    if (hipMemcpyFromSymbol(out3_host, HIP_SYMBOL(g_wgrad_clock), sizeof(unsigned long long) * 3) != hipSuccess) return LLMREC_EHIP;
+    unsigned long long zero[3] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_clock), zero, sizeof(zero)) != hipSuccess) return LLMREC_EHIP;
     return LLMREC_OK;
 }
 #endif
@@ -2508,7 +1596,7 @@ int llmrec_linear_wgrad_f32(int64_t M, int32_t N, int32_t K, const float* dY, in
                             int32_t accumulate, void* workspace, int64_t workspace_bytes,
                             llmrec_stream_t stream_) {
     LLMREC_CHECK_ARG(M >= 0, "linear_wgrad: bad sizes");
-    llmrec_wgrad_problem_t one = {dY, lddy, X, ldx, M};
+    llmrec_wgrad_problem_t one = {dY, lddy, X, ldx, M, nullptr};
     return llmrec_linear_wgrad_grouped_f32(1, &one, N, K, dW, lddw, db, accumulate, workspace, workspace_bytes, stream_);
 }
 

@@ -197,6 +197,94 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(int64_t rows, int d, Fuse
     }
 }
 
+// The user-side and the item-side fusion (or its backward) as ONE launch: the two row ranges are independent, on two streams each
+// launch paid a cross-queue fork and join (~10 us each way in a replayed graph) for 15 - 26 us of work. Blocks
+// [0, block_begin) sweep problem 0, the rest problem 1.
+constexpr int FUSE_MAX_PROBLEMS = 2;
+struct FuseMulti {
+    FuseArgs a[FUSE_MAX_PROBLEMS];
+    int64_t rows[FUSE_MAX_PROBLEMS];
+    float* out[FUSE_MAX_PROBLEMS]; int64_t ldo[FUSE_MAX_PROBLEMS];            // forward
+    const float* dOut[FUSE_MAX_PROBLEMS]; int64_t lddo[FUSE_MAX_PROBLEMS];    // backward
+    int block_begin;                                                          // first block of problem 1
+};
+#define ROW_LOOP_MULTI(m)                                                                          \
+    const int prob = (int)blockIdx.x >= (m).block_begin ? 1 : 0;                                   \
+    const FuseArgs& a = (m).a[prob];                                                               \
+    const int64_t rows = (m).rows[prob];                                                           \
+    const int gl = threadIdx.x & (RL - 1);                                                         \
+    const int blk = (int)blockIdx.x - (prob ? (m).block_begin : 0);                                \
+    const int nblk = prob ? (int)gridDim.x - (m).block_begin : (m).block_begin;                    \
+    const int64_t row_stride = (int64_t)nblk * ROWS_PER_BLOCK;                                     \
+    for (int64_t row = (int64_t)blk * ROWS_PER_BLOCK + threadIdx.x / RL; row < rows; row += row_stride)
+
+template <int VEC, int NCHUNK>
+__global__ __launch_bounds__(256) void fuse_fwd_multi_kernel(int d, FuseMulti m) {
+    ROW_LOOP_MULTI(m) {
+        RowReg<VEC, NCHUNK> acc, t;
+        acc.fill(0.f);
+        for (int i = 0; i < a.n_mean; ++i) {
+            t.load(a.mean_terms[i] + row * a.mean_ld[i], gl, d);
+#pragma unroll
+            for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc.x[k][q] += t.x[k][q];
+        }
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc.x[k][q] *= a.mean_scale;
+        for (int i = 0; i < a.n_norm; ++i) {
+            t.load(a.norm_terms[i] + row * a.norm_ld[i], gl, d);
+            const float nrm = fmaxf(sqrtf(t.dot(t)), 1e-12f);           // F.normalize eps
+            const float w = a.rates[i] / nrm;
+#pragma unroll
+            for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc.x[k][q] = fmaf(w, t.x[k][q], acc.x[k][q]);
+        }
+        acc.store(m.out[prob] + row * m.ldo[prob], gl, d);
+    }
+}
+
+// (accumulate == 2 semantics of fuse_bwd_kernel: d_terms[t] = s_terms[t] (or 0) + the term's gradient)
+template <int VEC, int NCHUNK>
+__global__ __launch_bounds__(256) void fuse_bwd_src_multi_kernel(int d, FuseMulti m) {
+    ROW_LOOP_MULTI(m) {
+        RowReg<VEC, NCHUNK> g, t, o;
+        g.load(m.dOut[prob] + row * m.lddo[prob], gl, d);
+        for (int i = 0; i < a.n_norm; ++i) {
+            t.load(a.norm_terms[i] + row * a.norm_ld[i], gl, d);
+            const float nn = sqrtf(t.dot(t));
+            float* dst = a.d_terms[i] + row * a.d_ld[i];
+            if (a.s_terms[i]) o.load(a.s_terms[i] + row * a.s_ld[i], gl, d);
+            else o.fill(0.f);
+            if (nn >= 1e-12f) {
+                const float inv = 1.0f / nn;
+                const float proj = t.dot(g) * inv * inv;                 // <n, g> / ||x||
+                const float w = a.rates[i] * inv;
+#pragma unroll
+                for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) o.x[k][q] += w * (g.x[k][q] - t.x[k][q] * proj);
+            } else {                                                     // clamp active: x / eps
+                const float w = a.rates[i] * 1e12f;
+#pragma unroll
+                for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) o.x[k][q] += w * g.x[k][q];
+            }
+            if (i < a.n_reg) {
+#pragma unroll
+                for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) o.x[k][q] = fmaf(a.reg2, t.x[k][q], o.x[k][q]);
+            }
+            o.store(dst, gl, d);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // sum of squares (two-level, fixed order), axpy
 // ---------------------------------------------------------------------------------------------
@@ -401,6 +489,56 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(int64_t n, const int64_t
     for (int c = gl; c < d; c += 16) p[c] = 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// weighted column sums in 64-column groups: out_g[j] (+)= sum_r w[r] * X[r][64 g + j]. The bias gradient of a projection whose
+// operand was propagated beforehand (Y = (A F) W^T + (A 1) b^T: db = sum_r (A 1)[r] dY[r]). Two levels, fixed order.
+// ---------------------------------------------------------------------------------------------
+constexpr int COLSUM_BLOCKS = 128;
+constexpr int COLSUM_MAX_D = 64 * LLMREC_COLSUM_MAX_GROUPS;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(int64_t rows, int d, const float* __restrict__ X, int64_t ldx,
+                                                             const float* __restrict__ w, float* __restrict__ partial) {
+    float acc[COLSUM_MAX_D / 256] = {};
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float wr = w ? w[r] : 1.f;
+        const float* row = X + r * ldx;
+#pragma unroll
+        for (int k = 0; k < COLSUM_MAX_D / 256; ++k) {
+            const int c = k * 256 + threadIdx.x;
+            if (c < d) acc[k] = fmaf(wr, row[c], acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < COLSUM_MAX_D / 256; ++k) {
+        const int c = k * 256 + threadIdx.x;
+        if (c < d) partial[(int64_t)blockIdx.x * d + c] = acc[k];
+    }
+}
+struct ColsumGroups { float* out[LLMREC_COLSUM_MAX_GROUPS]; int n_groups; };
+// one block, one thread per column: the partials of a column are added in four interleaved chains (fixed order; consecutive threads
+// read consecutive addresses), then thread j < gw adds the groups that share a destination, in group order
+__global__ __launch_bounds__(COLSUM_MAX_D) void colsum_final_kernel(int n_partial, int d, int gw, const float* __restrict__ partial, ColsumGroups g, int accumulate) {
+    __shared__ float col[COLSUM_MAX_D];
+    const int c = threadIdx.x;
+    if (c < d) {
+        const float* p = partial + c;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = 0;
+        for (; b + 4 <= n_partial; b += 4) {
+            s0 += p[(int64_t)b * d]; s1 += p[(int64_t)(b + 1) * d]; s2 += p[(int64_t)(b + 2) * d]; s3 += p[(int64_t)(b + 3) * d];
+        }
+        for (; b < n_partial; ++b) s0 += p[(int64_t)b * d];
+        col[c] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (c >= gw) return;
+    for (int q = 0; q < g.n_groups; ++q) {
+        bool first = true;                                       // the first group writing this destination decides overwrite / accumulate
+        for (int e = 0; e < q; ++e) first = first && g.out[e] != g.out[q];
+        float* o = g.out[q] + c;
+        *o = (first && !accumulate) ? col[gw * q + c] : *o + col[gw * q + c];
+    }
+}
+
 struct GatherTerms { const float* t[LLMREC_MAX_TERMS]; int64_t ld[LLMREC_MAX_TERMS]; int n; };
 
 __global__ __launch_bounds__(256) void gather_mean_kernel(int64_t n, const int64_t* __restrict__ idx, int d, float scale, GatherTerms g,
@@ -531,6 +669,82 @@ static int fuse_bwd_impl(int64_t rows, int32_t d, const float* dOut, int64_t ldd
     int rc = dispatch_rows(d, vec4,
         [&](auto nc) { fuse_bwd_kernel<4, decltype(nc)::value><<<grid, 256, 0, stream>>>(rows, d, a, dOut, lddo, accumulate); return 0; },
         [&](auto nc) { fuse_bwd_kernel<1, decltype(nc)::value><<<grid, 256, 0, stream>>>(rows, d, a, dOut, lddo, accumulate); return 0; });
+    if (rc) return rc;
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_fuse_fwd_multi_f32(int32_t n_problems, const llmrec_fuse_fwd_problem_t* p, int32_t d, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= FUSE_MAX_PROBLEMS && p && d > 0, "fuse_fwd_multi: 1..%d problems", FUSE_MAX_PROBLEMS);
+    FuseMulti m = {};
+    bool vec4 = d % 4 == 0;
+    int blocks[FUSE_MAX_PROBLEMS] = {0, 0};
+    for (int k = 0; k < n_problems; ++k) {
+        const llmrec_fuse_fwd_problem_t& q = p[k];
+        LLMREC_CHECK_ARG(q.rows >= 0 && q.n_mean >= 0 && q.n_norm >= 0 && q.n_mean <= LLMREC_MAX_TERMS && q.n_norm <= LLMREC_MAX_TERMS,
+                         "fuse_fwd_multi: problem %d has bad sizes", k);
+        LLMREC_CHECK_ARG(q.rows == 0 || (q.out && q.ldo >= d), "fuse_fwd_multi: problem %d: null out or ld < d", k);
+        FuseArgs& a = m.a[k];
+        a.n_mean = q.n_mean; a.n_norm = q.n_norm; a.mean_scale = q.mean_scale;
+        vec4 = vec4 && q.ldo % 4 == 0 && aligned16(q.out);
+        for (int i = 0; i < q.n_mean; ++i) {
+            LLMREC_CHECK_ARG(q.mean_terms[i] && q.mean_ld[i] >= d, "fuse_fwd_multi: problem %d: bad mean term %d", k, i);
+            a.mean_terms[i] = q.mean_terms[i]; a.mean_ld[i] = q.mean_ld[i];
+            vec4 = vec4 && q.mean_ld[i] % 4 == 0 && aligned16(q.mean_terms[i]);
+        }
+        for (int i = 0; i < q.n_norm; ++i) {
+            LLMREC_CHECK_ARG(q.norm_terms[i] && q.norm_ld[i] >= d, "fuse_fwd_multi: problem %d: bad norm term %d", k, i);
+            a.norm_terms[i] = q.norm_terms[i]; a.norm_ld[i] = q.norm_ld[i]; a.rates[i] = q.rates[i];
+            vec4 = vec4 && q.norm_ld[i] % 4 == 0 && aligned16(q.norm_terms[i]);
+        }
+        m.rows[k] = q.rows; m.out[k] = q.out; m.ldo[k] = q.ldo;
+        blocks[k] = q.rows > 0 ? grid_for(q.rows, ROWS_PER_BLOCK) : 0;
+    }
+    m.block_begin = blocks[0];
+    const int grid = blocks[0] + blocks[1];
+    if (grid == 0) return LLMREC_OK;
+    int rc = dispatch_rows(d, vec4,
+        [&](auto nc) { fuse_fwd_multi_kernel<4, decltype(nc)::value><<<grid, 256, 0, stream>>>(d, m); return 0; },
+        [&](auto nc) { fuse_fwd_multi_kernel<1, decltype(nc)::value><<<grid, 256, 0, stream>>>(d, m); return 0; });
+    if (rc) return rc;
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_fuse_bwd_src_multi_f32(int32_t n_problems, const llmrec_fuse_bwd_problem_t* p, int32_t d, llmrec_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= FUSE_MAX_PROBLEMS && p && d > 0, "fuse_bwd_src_multi: 1..%d problems", FUSE_MAX_PROBLEMS);
+    FuseMulti m = {};
+    bool vec4 = d % 4 == 0;
+    int blocks[FUSE_MAX_PROBLEMS] = {0, 0};
+    for (int k = 0; k < n_problems; ++k) {
+        const llmrec_fuse_bwd_problem_t& q = p[k];
+        LLMREC_CHECK_ARG(q.rows >= 0 && q.n_norm >= 0 && q.n_norm <= LLMREC_MAX_TERMS && q.n_reg_terms >= 0 && q.n_reg_terms <= q.n_norm,
+                         "fuse_bwd_src_multi: problem %d has bad sizes", k);
+        if (q.rows == 0 || q.n_norm == 0) continue;
+        LLMREC_CHECK_ARG(q.dOut && q.lddo >= d && q.src_terms && q.src_ld, "fuse_bwd_src_multi: problem %d: null pointer or ld < d", k);
+        FuseArgs& a = m.a[k];
+        a.n_norm = q.n_norm; a.n_reg = q.n_reg_terms; a.reg2 = q.reg_two_coef;
+        vec4 = vec4 && q.lddo % 4 == 0 && aligned16(q.dOut);
+        for (int i = 0; i < q.n_norm; ++i) {
+            LLMREC_CHECK_ARG(q.norm_terms[i] && q.d_terms[i] && q.norm_ld[i] >= d && q.d_ld[i] >= d, "fuse_bwd_src_multi: problem %d: bad term %d", k, i);
+            a.norm_terms[i] = q.norm_terms[i]; a.norm_ld[i] = q.norm_ld[i]; a.rates[i] = q.rates[i];
+            a.d_terms[i] = q.d_terms[i]; a.d_ld[i] = q.d_ld[i];
+            a.s_terms[i] = q.src_terms[i]; a.s_ld[i] = q.src_terms[i] ? q.src_ld[i] : 0;
+            LLMREC_CHECK_ARG(!a.s_terms[i] || a.s_ld[i] >= d, "fuse_bwd_src_multi: problem %d: source term %d has ld < d", k, i);
+            vec4 = vec4 && q.norm_ld[i] % 4 == 0 && q.d_ld[i] % 4 == 0 && aligned16(q.norm_terms[i]) && aligned16(q.d_terms[i]) &&
+                   (!a.s_terms[i] || (a.s_ld[i] % 4 == 0 && aligned16(a.s_terms[i])));
+        }
+        m.rows[k] = q.rows; m.dOut[k] = q.dOut; m.lddo[k] = q.lddo;
+        blocks[k] = grid_for(q.rows, ROWS_PER_BLOCK);
+    }
+    m.block_begin = blocks[0];
+    const int grid = blocks[0] + blocks[1];
+    if (grid == 0) return LLMREC_OK;
+    int rc = dispatch_rows(d, vec4,
+        [&](auto nc) { fuse_bwd_src_multi_kernel<4, decltype(nc)::value><<<grid, 256, 0, stream>>>(d, m); return 0; },
+        [&](auto nc) { fuse_bwd_src_multi_kernel<1, decltype(nc)::value><<<grid, 256, 0, stream>>>(d, m); return 0; });
     if (rc) return rc;
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
@@ -669,6 +883,38 @@ int llmrec_zero_rows_f32(int64_t n, const int64_t* ids, int32_t d, float* dst, i
     if (n == 0) return LLMREC_OK;
     LLMREC_CHECK_ARG(ids && dst && ldd >= d, "zero_rows: null pointer or ld < d");
     zero_rows_kernel<<<(unsigned)ceil_div(n, 16), 256, 0, (hipStream_t)stream_>>>(n, ids, d, dst, ldd);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int64_t llmrec_weighted_colsum_workspace_bytes(int32_t d) {
+    if (d <= 0 || d > COLSUM_MAX_D) return -1;
+    return (int64_t)sizeof(float) * COLSUM_BLOCKS * d;
+}
+
+int llmrec_weighted_colsum_f32(int64_t rows, int32_t n_groups, int32_t group_width, const float* X, int64_t ldx, const float* w,
+                               float* const* group_out_host, int32_t accumulate,
+                               void* workspace, int64_t workspace_bytes, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(rows >= 0 && n_groups >= 1 && n_groups <= LLMREC_COLSUM_MAX_GROUPS && group_width >= 1 && group_width <= 64,
+                     "weighted_colsum: 1..%d groups of 1..64 columns", LLMREC_COLSUM_MAX_GROUPS);
+    const int32_t d = n_groups * group_width;
+    LLMREC_CHECK_ARG(group_out_host && (rows == 0 || (X && ldx >= d)), "weighted_colsum: null pointer or ld < d");
+    if (!workspace || workspace_bytes < llmrec_weighted_colsum_workspace_bytes(d)) {
+        set_error("weighted_colsum: workspace %lld < %lld", (long long)workspace_bytes, (long long)llmrec_weighted_colsum_workspace_bytes(d));
+        return LLMREC_EWORKSPACE;
+    }
+    ColsumGroups g = {};
+    g.n_groups = n_groups;
+    for (int q = 0; q < g.n_groups; ++q) {
+        LLMREC_CHECK_ARG(group_out_host[q], "weighted_colsum: group %d has no destination", q);
+        g.out[q] = group_out_host[q];
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    float* partial = (float*)workspace;
+    const int blocks = (int)(rows < COLSUM_BLOCKS ? (rows > 0 ? rows : 1) : COLSUM_BLOCKS);
+    colsum_partial_kernel<<<blocks, 256, 0, stream>>>(rows, d, X, ldx, w, partial);
+    LLMREC_LAUNCH_CHECK();
+    colsum_final_kernel<<<1, COLSUM_MAX_D, 0, stream>>>(blocks, d, group_width, partial, g, accumulate);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

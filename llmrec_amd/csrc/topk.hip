@@ -145,25 +145,8 @@ __device__ __forceinline__ void sort64(float (&s)[NV], int (&i)[NV], int lane) {
     bitonic_net<32, NV>(s, i, lane, 0);
 }
 
-// cycle accounting for tools/topk_prof.hip (compiled out of the library). The TK_ABL_* switches (also tools-only) take one part of
-// the sweep away at a time: TK_ABL_THR = a filter that is final from the first round on (1000.0f: nothing ever passes),
-// TK_ABL_NOMFMA = the tile is consumed by plain adds, TK_ABL_NOLOAD = the same tile is reused.
-#ifdef LLMREC_TOPK_PROFILE
-__device__ unsigned long long g_topk_prof[10];   // [8] sweep in 100 MHz wall-clock ticks, [9] longest sweep
-__device__ unsigned long long g_topk_place[4096][4];   // per block: HW_ID, XCC_ID, start, end (100 MHz wall clock)
-#define TK_NOW() clock64()
-#define TK_ADD(slot, since) do { tk_acc[slot] += clock64() - (since); } while (0)
-#define TK_DECL() long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long tk_wall0 = wall_clock64()
-#define TK_FLUSH() do { if (lane == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_topk_prof[i_], (unsigned long long)tk_acc[i_]); \
-        atomicAdd(&g_topk_prof[8], wall_clock64() - tk_wall0); atomicMax(&g_topk_prof[9], (unsigned long long)tk_acc[0]); \
-        if (w == 0 && blockIdx.x < 4096) { g_topk_place[blockIdx.x][0] = __builtin_amdgcn_s_getreg(63492); g_topk_place[blockIdx.x][1] = __builtin_amdgcn_s_getreg(63508); \
-            g_topk_place[blockIdx.x][2] = tk_wall0; g_topk_place[blockIdx.x][3] = wall_clock64(); } } } while (0)
-#else
-#define TK_DECL() do {} while (0)
-#define TK_FLUSH() do {} while (0)
-#define TK_NOW() 0ll
-#define TK_ADD(slot, since) do { (void)(since); } while (0)
-#endif
+// (The cycle accounting and the one-part-removed ablation builds of round 2 - profiles/r02_topk_ablation.txt - were tools-only
+// variants of this kernel; they are no longer part of the source.)
 
 constexpr int TK_TILE = 32;   // items per wave per round
 constexpr int TK_CAP = 64;    // buffer slots per (wave, user): drained before a round could overflow it
@@ -228,11 +211,7 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     }
     const int q0 = tile * 16;
     if (q0 >= a.n_query) return;                               // block-uniform
-#if defined(TK_ABL_THR)
-    if (threadIdx.x < 16) thr_s[threadIdx.x] = TK_ABL_THR;
-#else
     if (threadIdx.x < 16) thr_s[threadIdx.x] = -INFINITY;
-#endif
     if (threadIdx.x < 2) flag_s[threadIdx.x] = 0;             // [0] drain requested, [1] waves that finished their quarter
     __syncthreads();
 
@@ -298,8 +277,6 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
         row0 += tile_stride; row1 += tile_stride;
     };
     if (my_rounds > 0) load_tile(t_begin);
-    TK_DECL();
-    const long long tk_start = TK_NOW();
     int64_t round = 0;
     bool counted = false;
     for (;;) {
@@ -311,11 +288,9 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
         //  wait, which would also wait for the prefetched tile)
         if (!drain) drain = __hip_atomic_load(&flag_s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
         if (drain) {                                           // wave-uniform; every wave of the block gets here
-            const long long tk_d0 = TK_NOW();
             if (fin && !counted) { counted = true; if (lane == 0) atomicAdd(&flag_s[1], 1); }
             if (!fin && lane == 0) __hip_atomic_store(&flag_s[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __syncthreads();
-            TK_ADD(3, tk_d0);                                  // waiting for the other waves at the rendezvous
             if (li == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cnt_s[w][lq * 4 + r] = cntr[r];
@@ -325,7 +300,6 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
             // happened before the first barrier and the next cycle's cannot happen before the last one - reading it after
             // the last barrier would race with a faster wave that has already finished its final round
             const int done_quarters = flag_s[1];
-            const long long tk_d1 = TK_NOW();
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int u = 4 * w + rr;
@@ -349,25 +323,13 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
 #pragma unroll
             for (int r = 0; r < 4; ++r) cntr[r] = 0;
             if (threadIdx.x == 0) flag_s[0] = 0;
-            TK_ADD(4, tk_d1);                                  // sort + merge
             __syncthreads();
-            TK_ADD(2, tk_d0);                                  // whole drain
             if (done_quarters == 4) break;    // all four quarters swept and drained
             continue;
         }
         const int64_t base = (t_begin + round) * TK_TILE;
-        const long long tk_r0 = TK_NOW();
-#ifdef LLMREC_TOPK_PROFILE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        TK_ADD(5, tk_r0);                                      // waiting for the prefetched tile
-        const long long tk_r1 = TK_NOW();
-#endif
         f32x4 acc[2];
         acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
-#if defined(TK_ABL_NOMFMA)
-#pragma unroll
-        for (int c = 0; c < DK; ++c) { acc[0][0] += b[0][c].x + b[0][c].y + b[0][c].z + b[0][c].w; acc[1][0] += b[1][c].x + b[1][c].y + b[1][c].z + b[1][c].w; }
-#else
 #pragma unroll
         for (int c = 0; c < DK; ++c)
 #pragma unroll
@@ -375,20 +337,10 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(cmp4(ua[c], s), cmp4(b[n][c], s), acc[n], 0, 0, 0);
-#endif
         // the next tile's operands go into the registers the MFMAs have just read: the loads fly during the selection
         __builtin_amdgcn_sched_barrier(0);
-#if defined(TK_ABL_NOLOAD)
-        if (round + 1 < my_rounds) { asm volatile("" : "+v"(b[0][0].x), "+v"(b[1][0].x)); }
-#else
         if (round + 1 < my_rounds) load_tile(t_begin + round + 1);
-#endif
         __builtin_amdgcn_sched_barrier(0);
-#ifdef LLMREC_TOPK_PROFILE
-        { const float touch = acc[0][0] + acc[1][0]; asm volatile("" :: "v"(touch)); }   // MFMA results have landed
-        TK_ADD(6, tk_r1);
-        const long long tk_r2 = TK_NOW();
-#endif
 
         // 32-bit mask of this tile's train items and the current filter, by the row-owner lanes
         uint32_t m = 0;
@@ -423,14 +375,8 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
                 cntr[r] += __popc(sub);
             }
         }
-#ifdef LLMREC_TOPK_PROFILE
-        TK_ADD(7, tk_r2);                                      // train mask + selection
-#endif
-        TK_ADD(1, tk_r0);                                      // whole round
         ++round;
     }
-    TK_ADD(0, tk_start);
-    TK_FLUSH();
     if (n_parts > 1) {                                         // a part's lists: all 64 slots, merged by topk_merge_kernel
         const int64_t base = ((int64_t)(tile - a.split_from) * n_parts + part) * 16;
 #pragma unroll

@@ -78,6 +78,8 @@ class DataParallelStep(FusedStep):
         self._pending_update = False
 
     # -- the three compute phases -----------------------------------------------------------------
+    INLINE_ADAMW = False        # the gradients are all-reduced over the replicas first (exchange_grads), then phase_c updates
+
     def _bpr_phase(self, phase, users, pos, neg, n_valid):
         hp = self.hp
         _call("llmrec_bpr_multi_fwd_sharded_f32", self.n_prob, self._problems(), self.d, _p(users), _p(pos), _p(neg), users.numel(),

@@ -53,24 +53,22 @@ class FusedStep:
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         U, I = self.U, self.I
         # forward buffers
-        self.P_cat, self.U_cat, self.I_cat = f(I, S * d), f(U, S * d), f(I, S * d)
+        self.U_cat, self.I_cat = f(U, S * d), f(I, S * d)
         self.P_usr, self.prof_i, self.prof_u = f(U, d), f(I, d), f(U, d)
         self.Ul = [f(U, d) for _ in range(self.L)]
         self.Il = [f(I, d) for _ in range(self.L)]
         self.E_u, self.E_i = f(U, d), f(I, d)
         # backward buffers
-        # LLMREC_SPARSE_ZERO=1 (default): the loss backward scatters into buffers that are all-zero between steps - dE_u / dE_i and
-        # the sc_* sources of the fusion backward - and clears exactly the rows it touched afterwards
-        # (llmrec_bpr_multi_zero_rows_f32); the fusion backward writes d*_cat = source + its own term
-        # (llmrec_fuse_bwd_src_f32). No dense memset of the six gradient buffers (70 MB per step at the Netflix shape).
-        self.sparse_zero = os.environ.get("LLMREC_SPARSE_ZERO", "1") == "1"
+        # The loss backward scatters into buffers that are all-zero between steps - dE_u / dE_i and the sc_* sources of the fusion
+        # backward - and clears exactly the rows it touched afterwards (llmrec_bpr_multi_zero_rows_f32); the fusion backward
+        # writes d*_cat = source + its own term (llmrec_fuse_bwd_src_f32). No dense memset of the six gradient buffers (70 MB
+        # per step at the Netflix shape; measured -2.2 % of the step in round 2).
         # LLMREC_CHECK_ZERO=1 (debug; synchronises, so not under capture): assert that invariant before every scatter
         self.check_zero = os.environ.get("LLMREC_CHECK_ZERO", "0") == "1"
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         self.dE_u, self.dE_i = z(U, d), z(I, d)
-        if self.sparse_zero:
-            self.sc_U, self.sc_I, self.sc_prof = z(U, 2 * d), z(I, S * d), z(U, d)
-        self.dU_cat, self.dI_cat, self.dP_cat = f(U, S * d), f(I, S * d), f(I, S * d)
+        self.sc_U, self.sc_I, self.sc_prof = z(U, 2 * d), z(I, S * d), z(U, d)
+        self.dU_cat, self.dI_cat = f(U, S * d), f(I, S * d)
         self.dprof_u, self.dprof_i, self.dP_usr = f(U, d), f(I, d), f(U, d)
         self.bufU, self.bufI, self.tmpU, self.tmpI = f(U, d), f(I, d), f(U, d), f(I, d)
         self.out = f(8, 2)
@@ -86,11 +84,10 @@ class FusedStep:
         self.ws_wgrad_b, self.ws_wgrad_c, self.ws_wgrad_d = wsq(model.user_feats), wsq(model.text_feats), wsq(model.image_feats)
         self.ws_wgrad_multi = None                           # sized at the first backward (needs the gradient tensors)
         self._partials = {}
-        # Three independent chains (7-stream side features / LLM profile / ID embeddings) run on three
-        # HIP streams in forward and in backward; under capture the fork/join becomes graph edges, so
-        # the latency-bound Netflix-scale SpMMs and the weight-gradient GEMMs overlap.
-        import os as _os
-        self.multi_stream = _os.environ.get("LLMREC_STREAMS", "1") == "1"
+        # Independent chains (7-stream side features / LLM profile / ID embeddings / the two fusion halves / the logged scalars)
+        # run on five HIP streams in forward and in backward; under capture the fork / join become graph edges, so the
+        # latency-bound Netflix-scale SpMMs overlap the GEMMs. LLMREC_STREAMS=0 keeps everything on one stream (debugging).
+        self.multi_stream = os.environ.get("LLMREC_STREAMS", "1") == "1"
         self.s1, self.s2, self.s3, self.s4 = (torch.cuda.Stream(device=dev) for _ in range(4))
         for p in model.parameters():
             if p.requires_grad and p.grad is None and p is not model.batch_norm.weight and p is not model.batch_norm.bias:
@@ -105,27 +102,49 @@ class FusedStep:
         self.graph_exec = None
         self.static = None
         self._eval_graphs = {}
-        self._bwd_accumulators = (self.dE_u, self.dE_i, self.dU_cat, self.dI_cat, self.dprof_u, self.dprof_i)
-        self._zeroed = False
-        self._zero_in_forward = False                         # set by step_eager: forward() alone (evaluation) must not pay for it
         # projection / weight-gradient arithmetic: "bf16x3" (default) = exact 3-term bf16 split of both operands, six bf16
-        # MFMAs, fp32-roundoff-class error (2e-6 measured), HBM-bound; "f32" = the exact fp32 MFMA fma chain
-
+        # MFMAs, fp32-roundoff-class error (2e-6 measured); "f32" = the exact fp32 MFMA fma chain
         self.gemm = os.environ.get("LLMREC_GEMM", "bf16x3")
-        self.wgrad_serial = os.environ.get("LLMREC_WGRAD_SERIAL", "1") == "1"
-        # LLMREC_WGRAD_MULTI=1 (default): item_trans', text's and image's weight gradients as ONE launch (bf16x3 only)
-        self.wgrad_multi = os.environ.get("LLMREC_WGRAD_MULTI", "1") == "1" and self.gemm == "bf16x3"
-        self.id_chain_late = os.environ.get("LLMREC_ID_CHAIN_LATE", "0") == "1"
-        # Launch (= capture) order at the fork points. Where a bit is set, the critical path's next launch is issued BEFORE the
-        # side stream's work and the side stream waits for an event recorded at the fork point; the order decides which branch
-        # the graph runs behind its parent without a cross-queue hand-off. Bits: 1 projection before the ID chain / sampler,
-        # 2 the forward's side-feature SpMMs before the profile chain, 4 fuse(user) before fuse(item), 8 the BPR backward
-        # before the feature regulariser / loss assembly, 16 fuse_bwd(item) before fuse_bwd(user), 32 the backward's side
-        # chain before the profile / ID chains. Measured one at a time and interleaved with the baseline on one box
-        # (0.6552-0.6576 ms per step): 2 -> 0.6435, 8 -> 0.6471, 2 + 8 -> 0.6297-0.6344; 1 and 32 lose 2-7 %, 4 and 16 are neutral.
-        self.critical_first = int(os.environ.get("LLMREC_CRITICAL_FIRST", "10"))
+        # PRE-PROPAGATED item-side operands (LLMREC_PREPROPAGATE=0 restores the reference's order of operations). The features F_k
+        # and the adjacency are constants of a run, and projection followed by propagation is one product:
+        #     A_ui (F_k W^T + 1 b^T) = (A_ui F_k) W^T + (A_ui 1) b^T            (Models.py:145-157: image / text / the 5 attributes)
+        # so A_ui F_k [U, K] is formed ONCE here, the step projects IT (llmrec_linear_problem_t.bias_scale = the row sums of A_ui) straight
+        # into U_cat, and the backward takes dW = dU_cat^T (A_ui F_k), db = sum_u (A_ui 1)[u] dU_cat[u]. Per step this removes the two
+        # [.., 7 d] SpMMs through A_ui (forward and transposed) from the critical path and shrinks both GEMMs from I = 17 366 to
+        # U = 13 187 rows; every parameter-dependent product is still computed every step, only the order of the (associative)
+        # products changes: results agree with the other order to fp32 rounding (tests/test_gpu_step.py, the bench's parity gate).
+        self.preprop = os.environ.get("LLMREC_PREPROPAGATE", "1") == "1" and d <= 64
+        if not self.preprop:
+            self.P_cat, self.dP_cat = f(I, S * d), f(I, S * d)        # the projected features and their gradient (reference order)
+        if self.preprop:
+            item_feats = [model.image_feats, model.text_feats] + [model.item_feats[k] for k in self.keys]
+            self.AX = [self._propagate_constant(self.ui.fwd, x) for x in item_feats]
+            self.a_rowsum = ops.spmm_raw(self.ui.fwd, torch.ones(I, 4, dtype=torch.float32, device=dev))[:, 0].contiguous()   # A_ui 1
+            self.ws_colsum = torch.empty(_lib.query("llmrec_weighted_colsum_workspace_bytes", S * d), dtype=torch.uint8, device=dev)
+        # AdamW inside the step, in two launches: the embedding tables as soon as the ID chain's backward has produced their
+        # gradients (beside the weight-gradient GEMM), the four Linears right after the slab reduction of that GEMM - the
+        # step's tail is then one small launch instead of reduction -> cross-stream join -> a 1.96 M-parameter update.
+        # (Batch-sharded replicas all-reduce the gradients first and update afterwards: llmrec_amd/dp.py sets this to False.)
+        self.inline_adamw = getattr(type(self), "INLINE_ADAMW", True)
+        self._zero_in_forward = False                         # set by step_eager: forward() alone (evaluation) must not advance AdamW
+        self._emb_params = [model.user_id_embedding.weight, model.item_id_embedding.weight]
+        self._lin_params = [p for p in optimizer.params if p.grad is not None and all(p is not e for e in self._emb_params)]
+        # Launch (= capture) order at the fork points decides which branch the graph runs behind its parent without a cross-queue
+        # hand-off (~10 us). Measured one at a time in round 2 (profiles/README.md): the forward's side-feature SpMMs are
+        # captured before the profile chain, the BPR backward before the regulariser / loss assembly (-3.6 % together); the
+        # other fork points are neutral or lose.
 
     # -- raw kernel helpers -----------------------------------------------------------------------
+    @staticmethod
+    def _propagate_constant(a: ops.Csr, X: torch.Tensor) -> torch.Tensor:
+        """A X for a constant feature matrix, 64 columns at a time (set-up only)."""
+        X = X.detach()
+        out = torch.empty(a.n_rows, X.shape[1], dtype=torch.float32, device=X.device)
+        step = 64 if X.shape[1] % 64 == 0 else X.shape[1]
+        for c0 in range(0, X.shape[1], step):
+            ops.spmm_raw(a, X[:, c0:c0 + step], out=out[:, c0:c0 + step])
+        return out
+
     def _fork(self, *streams):
         if self.multi_stream:
             cur = torch.cuda.current_stream()
@@ -175,23 +194,35 @@ class FusedStep:
         _call("llmrec_linear_fwd_f32", X.shape[0], self.d, X.shape[1], _p(X), _ld(X), _p(lin.weight), _ld(lin.weight), _p(lin.bias),
               _p(out), _ld(out))
 
-    def _project_all(self):
-        """All 8 projections of Models.py:145-150 in one grouped launch (d <= 64), else one by one."""
+    def projection_jobs(self):
+        """(X, Linear, out, bias_scale) of the step's 8 projections (Models.py:145-150), longest K first: the launch's tail then
+        consists of the short (512 / 768-wide) work units. Pre-propagated: the item-side operands are A_ui F_k and land in U_cat."""
         m = self.m
-        # longest K first: the launch's tail then consists of the short (512/768-wide) work units
-        jobs = [(m.item_feats[key], m.item_trans, self._side(self.P_cat, 2 + k)) for k, key in enumerate(self.keys)]
-        jobs.append((m.user_feats, m.user_trans, self.P_usr))
-        jobs += [(m.text_feats, m.text_trans, self._side(self.P_cat, 1)), (m.image_feats, m.image_trans, self._side(self.P_cat, 0))]
+        if self.preprop:
+            lins = [m.image_trans, m.text_trans] + [m.item_trans] * len(self.keys)
+            jobs = [(self.AX[s_], lins[s_], self._side(self.U_cat, s_), self.a_rowsum) for s_ in range(self.S)]
+        else:
+            jobs = [(m.item_feats[key], m.item_trans, self._side(self.P_cat, 2 + k), None) for k, key in enumerate(self.keys)]
+            jobs += [(m.text_feats, m.text_trans, self._side(self.P_cat, 1), None), (m.image_feats, m.image_trans, self._side(self.P_cat, 0), None)]
+        jobs.append((m.user_feats, m.user_trans, self.P_usr, None))
         jobs.sort(key=lambda j: -j[0].shape[1])
+        return jobs
+
+    def _project_all(self):
+        """All 8 projections in one grouped launch (d <= 64), else one by one."""
+        jobs = self.projection_jobs()
         if self.d > 64 or len(jobs) > _lib.CONST["LLMREC_LINEAR_MAX_PROBLEMS"]:
-            for X, lin, out in jobs:
+            if self.preprop:
+                raise RuntimeError("FusedStep: the pre-propagated projection needs the grouped launch (d <= 64); set LLMREC_PREPROPAGATE=0")
+            for X, lin, out, _ in jobs:
                 self._linear(X, lin, out)
             return
         arr = (ops.LinearProblem * len(jobs))()
-        for i, (X, lin, out) in enumerate(jobs):
+        for i, (X, lin, out, bscale) in enumerate(jobs):
             arr[i].X, arr[i].ldx, arr[i].M, arr[i].K = X.data_ptr(), _ld(X), X.shape[0], X.shape[1]
             arr[i].W, arr[i].ldw, arr[i].bias = lin.weight.data_ptr(), _ld(lin.weight), lin.bias.data_ptr()
             arr[i].Y, arr[i].ldy = out.data_ptr(), _ld(out)
+            arr[i].bias_scale = bscale.data_ptr() if bscale is not None else None
         _call("llmrec_linear_fwd_grouped_bf16x3" if self.gemm == "bf16x3" else "llmrec_linear_fwd_grouped_f32", len(jobs), arr, self.d)
 
     def _wgrad(self, dY, X, lin, accumulate, ws=None):
@@ -227,21 +258,12 @@ class FusedStep:
     # -- forward ----------------------------------------------------------------------------------
     def forward(self, sampler=None):
         m, d = self.m, self.d
-        order = self.critical_first                                      # capture order at the fork points (see __init__)
-        proj_first, side_first, fuse_user_first = order & 1, order & 2, order & 4
-        if proj_first:
-            ev0 = self._mark()
-            self._project_all()
-            self._fork_from(ev0, self.s2)
-        else:
-            self._fork(self.s2)
+        self._fork(self.s2)
         with self._on(self.s2):                                          # ID chain: needs no projection
             if sampler is not None and self.multi_stream:                # the batch is first read by the losses, after the join below:
                 sampler()                                                # sampling rides beside the projection instead of ahead of it
-            if self._zero_in_forward:                                    # the backward's scatter targets, off the critical path
-                if not self.sparse_zero:
-                    self._zero_accumulators()
-                self.opt.advance()                                       # AdamW's step counter / bias corrections, likewise
+            if self._zero_in_forward:
+                self.opt.advance()                                       # AdamW's step counter / bias corrections, off the critical path
             i_prev = m.item_id_embedding.weight
             for l in range(self.L):
                 last = l == self.L - 1
@@ -253,41 +275,34 @@ class FusedStep:
                     self._spmm(self.ui.fwd, i_prev, self.Ul[l], tag=2)
                     self._spmm(self.iu.fwd, self.Ul[l], self.Il[l], tag=2)
                 i_prev = self.Il[l]
-        if not proj_first:
-            self._project_all()
-        if not side_first:
-            self._fork(self.s1)
-        else:
-            ev1 = self._mark()
-            self._spmm(self.ui.fwd, self.P_cat, self.U_cat)
-            self._spmm(self.iu.fwd, self.U_cat, self.I_cat)
-            self._fork_from(ev1, self.s1)
+        self._project_all()
+        ev1 = self._mark()
+        if not self.preprop:
+            self._spmm(self.ui.fwd, self.P_cat, self.U_cat)              # 7 streams, one adjacency pass
+        self._spmm(self.iu.fwd, self.U_cat, self.I_cat)
+        self._fork_from(ev1, self.s1)
         with self._on(self.s1):                                          # profile stream: items first
             self._spmm(self.iu.fwd, self.P_usr, self.prof_i, tag=1)
             self._spmm(self.ui.fwd, self.prof_i, self.prof_u, tag=1)
-        if not side_first:
-            self._spmm(self.ui.fwd, self.P_cat, self.U_cat)              # 7 streams, one adjacency pass
-            self._spmm(self.iu.fwd, self.U_cat, self.I_cat)
         self._join(self.s1, self.s2)
 
-        def fuse(out, base, layers, cat, prof):
-            means = [base] + layers
-            norms = self._norm_terms(cat, prof)
+        # E_u and E_i (Models.py:185-197) in ONE launch: llmrec_fuse_fwd_multi_f32 (two independent row ranges)
+        keep = []
+
+        def problem(pr, out, base, layers, cat, prof):
+            means, norms = [base] + layers, self._norm_terms(cat, prof)
             mp, ml = self._tables(means)
             npt, nl = self._tables(norms)
-            _call("llmrec_fuse_fwd_f32", out.shape[0], d, 1.0 / len(means), len(means), mp, ml, len(norms), npt, nl, self._rates(),
-                  _p(out), _ld(out))
-        if fuse_user_first:
-            ev2 = self._mark()
-            fuse(self.E_u, m.user_id_embedding.weight, self.Ul, self.U_cat, self.prof_u)
-            self._fork_from(ev2, self.s3)
-        else:
-            self._fork(self.s3)
-        with self._on(self.s3):                                          # the item table beside the user table
-            fuse(self.E_i, m.item_id_embedding.weight, self.Il, self.I_cat, self.prof_i)
-        if not fuse_user_first:
-            fuse(self.E_u, m.user_id_embedding.weight, self.Ul, self.U_cat, self.prof_u)
-        self._join(self.s3)
+            rates = self._rates()
+            keep.extend((mp, ml, npt, nl, rates))
+            pr.rows, pr.mean_scale, pr.n_mean, pr.n_norm = out.shape[0], 1.0 / len(means), len(means), len(norms)
+            pr.mean_terms, pr.mean_ld = _c.cast(mp, _c.c_void_p), _c.cast(ml, _c.c_void_p)
+            pr.norm_terms, pr.norm_ld, pr.rates = _c.cast(npt, _c.c_void_p), _c.cast(nl, _c.c_void_p), _c.cast(rates, _c.c_void_p)
+            pr.out, pr.ldo = out.data_ptr(), _ld(out)
+        arr = (ops.FuseFwdProblem * 2)()
+        problem(arr[0], self.E_i, m.item_id_embedding.weight, self.Il, self.I_cat, self.prof_i)
+        problem(arr[1], self.E_u, m.user_id_embedding.weight, self.Ul, self.U_cat, self.prof_u)
+        _call("llmrec_fuse_fwd_multi_f32", 2, arr, d)
 
     def outputs(self):
         """The reference's 14-tuple as views of the forward buffers (Models.py:199)."""
@@ -300,7 +315,7 @@ class FusedStep:
     def _problems(self):
         arr = (ops.BprProblem * self.n_prob)()
         tabs = [(self.E_u, self.E_i, self.dE_u, self.dE_i)]
-        tU, tI, tP = (self.sc_U, self.sc_I, self.sc_prof) if self.sparse_zero else (self.dU_cat, self.dI_cat, self.dprof_u)
+        tU, tI, tP = self.sc_U, self.sc_I, self.sc_prof
         for s in range(2):
             tabs.append((self._side(self.U_cat, s), self._side(self.I_cat, s), self._side(tU, s), self._side(tI, s)))
         for k in range(len(self.keys)):
@@ -324,21 +339,9 @@ class FusedStep:
             with self._on(self.s3):
                 self._feat_reg()
                 self._assemble_loss(0)
-        if self.critical_first & 8:
-            ev = self._mark()
-            self._backward(probs, users, pos, neg, n_valid, after_first=lambda: (self._fork_from(ev, self.s3), side()))
-        else:
-            self._fork(self.s3)
-            side()
-            self._backward(probs, users, pos, neg, n_valid)
+        ev = self._mark()                                                # the BPR backward is captured before the side work
+        self._backward(probs, users, pos, neg, n_valid, after_first=lambda: (self._fork_from(ev, self.s3), side()))
         self._join(self.s3)
-
-    def _zero_accumulators(self):
-        """The six scatter targets of the backward, cleared by ONE launch (llmrec_zero_multi_f32)."""
-        arr = (ops.ZeroTensor * len(self._bwd_accumulators))()
-        for i, t in enumerate(self._bwd_accumulators):
-            arr[i].p, arr[i].n = t.data_ptr(), t.numel()
-        _call("llmrec_zero_multi_f32", len(self._bwd_accumulators), arr)
 
     def _assemble_loss(self, mode: int, tail=None, inv_world: float = 1.0):
         """Logged scalars (main.py:273,280-283) from the 8 BPR results + the regulariser: one single-wave launch."""
@@ -353,16 +356,13 @@ class FusedStep:
                   self.ws_sumsq.numel())
 
     def _backward(self, probs, users, pos, neg, n_valid, replicated_scale: float = 1.0, after_first=None):
-        """Hand-written backward from the saved BPR state to the parameter gradients. replicated_scale
-        weights the batch-independent loss terms (1 / world on batch-sharded replicas, whose
+        """Hand-written backward from the saved BPR state to the parameter gradients (and, with inline_adamw, the update).
+        replicated_scale weights the batch-independent loss terms (1 / world on batch-sharded replicas, whose
         gradients are summed over ranks afterwards)."""
         hp, d, L, S = self.hp, self.d, self.L, self.S
         B = users.numel()
         coef = hp.feat_reg_decay * 0.5 / self.I * replicated_scale
-        if not self._zeroed and not self.sparse_zero:
-            self._zero_accumulators()
-        self._zeroed = False
-        if self.sparse_zero and self.check_zero and not torch.cuda.is_current_stream_capturing():
+        if self.check_zero and not torch.cuda.is_current_stream_capturing():
             dirty = [n for n, t in (("dE_u", self.dE_u), ("dE_i", self.dE_i), ("sc_U", self.sc_U), ("sc_I", self.sc_I), ("sc_prof", self.sc_prof))
                      if float(t.abs().max()) != 0.0]
             if dirty:
@@ -371,48 +371,34 @@ class FusedStep:
               float(hp.batch_size), _p(self.saved))
         if after_first is not None:
             after_first()
-        fuse_item_first, side_chain_first = self.critical_first & 16, self.critical_first & 32
-        def fuse_bwd(dout, cat, prof, dcat, dprof):
+
+        # the backward of both fusions in ONE launch (llmrec_fuse_bwd_src_multi_f32)
+        keep = []
+
+        def problem(pr, dout, cat, prof, dcat, dprof, srcs):
             norms, dnorms = self._norm_terms(cat, prof), self._norm_terms(dcat, dprof)
             npt, nl = self._tables(norms)
             dp, dl = self._tables(dnorms)
+            # sources = what the loss backward scattered for this side (terms in _norm_terms order: image, text, profile, attributes);
             # the feature regulariser's gradient on the image / text streams (terms 0, 1) rides along: 2 coef x
-            if not self.sparse_zero:
-                _call("llmrec_fuse_bwd_f32", dout.shape[0], d, _p(dout), _ld(dout), len(norms), npt, nl, self._rates(), dp, dl, 1,
-                      2, float(2.0 * coef))
-                return
-            # sources = what the loss backward scattered for this side (terms in _norm_terms order: image, text, profile, attributes)
-            if dcat is self.dI_cat:
-                srcs = [self._side(self.sc_I, 0), self._side(self.sc_I, 1), None] + [self._side(self.sc_I, 2 + k) for k in range(len(self.keys))]
-            else:
-                srcs = [self._side(self.sc_U, 0), self._side(self.sc_U, 1), self.sc_prof] + [None] * len(self.keys)
             sp = (_c.c_void_p * len(srcs))(*[t.data_ptr() if t is not None else None for t in srcs])
             sl = (_c.c_int64 * len(srcs))(*[_ld(t) if t is not None else 0 for t in srcs])
-            _call("llmrec_fuse_bwd_src_f32", dout.shape[0], d, _p(dout), _ld(dout), len(norms), npt, nl, self._rates(), dp, dl, sp, sl,
-                  2, float(2.0 * coef))
-        if fuse_item_first:                                              # the item side feeds the side chain = the critical path
-            ev4 = self._mark()
-            fuse_bwd(self.dE_i, self.I_cat, self.prof_i, self.dI_cat, self.dprof_i)
-            self._fork_from(ev4, self.s4)
-            with self._on(self.s4):
-                fuse_bwd(self.dE_u, self.U_cat, self.prof_u, self.dU_cat, self.dprof_u)
-        else:
-            self._fork(self.s4)
-            with self._on(self.s4):                                      # item side beside the user side
-                fuse_bwd(self.dE_i, self.I_cat, self.prof_i, self.dI_cat, self.dprof_i)
-            fuse_bwd(self.dE_u, self.U_cat, self.prof_u, self.dU_cat, self.dprof_u)
-        self._join(self.s4)
+            rates = self._rates()
+            keep.extend((npt, nl, dp, dl, sp, sl, rates))
+            pr.rows, pr.dOut, pr.lddo, pr.n_norm = dout.shape[0], dout.data_ptr(), _ld(dout), len(norms)
+            pr.norm_terms, pr.norm_ld, pr.rates = _c.cast(npt, _c.c_void_p), _c.cast(nl, _c.c_void_p), _c.cast(rates, _c.c_void_p)
+            pr.d_terms, pr.d_ld = _c.cast(dp, _c.c_void_p), _c.cast(dl, _c.c_void_p)
+            pr.src_terms, pr.src_ld = _c.cast(sp, _c.c_void_p), _c.cast(sl, _c.c_void_p)
+            pr.n_reg_terms, pr.reg_two_coef = 2, float(2.0 * coef)
+        arr = (ops.FuseBwdProblem * 2)()
+        problem(arr[0], self.dE_i, self.I_cat, self.prof_i, self.dI_cat, self.dprof_i,
+                [self._side(self.sc_I, 0), self._side(self.sc_I, 1), None] + [self._side(self.sc_I, 2 + k) for k in range(len(self.keys))])
+        problem(arr[1], self.dE_u, self.U_cat, self.prof_u, self.dU_cat, self.dprof_u,
+                [self._side(self.sc_U, 0), self._side(self.sc_U, 1), self.sc_prof] + [None] * len(self.keys))
+        _call("llmrec_fuse_bwd_src_multi_f32", 2, arr, d)
         m = self.m
         inv = 1.0 / (L + 1)
-        side_done = False
-        if side_chain_first:                                             # the side chain's two products first, then the side streams
-            ev5 = self._mark()
-            self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
-            self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
-            side_done = True
-            self._fork_from(ev5, self.s1)
-        else:
-            self._fork(self.s1)
+        self._fork(self.s1)
         with self._on(self.s1):
             # profile chain: prof_u = ui(prof_i), prof_i = iu(P_usr); then user_trans' weight gradient
             self._spmm(self.ui.bwd, self.dprof_u, self.dprof_i, accumulate=True, tag=1)
@@ -444,92 +430,80 @@ class FusedStep:
             if L == 0:
                 self._axpy(inv, self.dE_i, m.item_id_embedding.weight.grad, False)
             self._axpy(inv, self.dE_u, m.user_id_embedding.weight.grad, False)    # U^0 only enters the mean
-            if self.sparse_zero:                                                  # last reader of dE_u / dE_i: clear the touched rows
-                _call("llmrec_bpr_multi_zero_rows_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid))
+            # last reader of dE_u / dE_i: clear the touched rows
+            _call("llmrec_bpr_multi_zero_rows_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid))
+            if self.inline_adamw:                                                 # both tables' gradients are final: update them here,
+                self.opt.step_params(self._emb_params)                            # beside the weight-gradient GEMM
 
-        if not self.id_chain_late:
-            if side_chain_first:
-                self._fork_from(ev5, self.s2)
-            else:
-                self._fork(self.s2)
-            with self._on(self.s2):
-                id_chain()
-        # side chain: I_cat = iu(U_cat), U_cat = ui(P_cat); then the item-side weight gradients
-        if not side_done:
-            self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
+        self._fork(self.s2)
+        with self._on(self.s2):
+            id_chain()
+        # side chain: I_cat = iu(U_cat), U_cat = ui(P_cat) (or the pre-propagated projection); then the item-side weight gradients
+        self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
+        if self.preprop:
+            dY_cat, feats, roww = self.dU_cat, self.AX, self.a_rowsum     # dW = dU_cat^T (A_ui F), db = sum_u (A_ui 1)[u] dU_cat[u]: no product through A_ui^T
+        else:
             self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
-        if self.id_chain_late:
-            # LLMREC_ID_CHAIN_LATE=1: the ID chain's six small launches only have to be done before AdamW; started here they
-            # run beside the weight gradients (346 of a SIMD's 512 registers: an SpMM wave fits next to a weight-gradient
-            # wave) instead of competing with the side chain's two products. Worth 1-2 % with three weight-gradient
-            # launches back to back; with the single multi-target launch the chain then ends AFTER it (its SpMMs stretch
-            # to 50-70 us beside the gradient) and the step time is the same either way, so the default starts it early.
-            self._fork(self.s2)
-            with self._on(self.s2):
-                id_chain()
-        item_pairs = [(self._side(self.dP_cat, 2 + k), m.item_feats[key]) for k, key in enumerate(self.keys)]
-        if self.wgrad_multi:
-            # One launch for the three item-side Linears: equal slabs over all of them, so the launch is whole rounds of
-            # equal blocks and the two short gradients pay no ramp-up / ragged last round of their own (same box: three launches
-            # back to back 0.661 ms per step, one launch 0.637 ms; folding user_trans' in as well - it then no longer runs
-            # beside the side chain's SpMMs - is 1 % slower).
+            dY_cat, feats, roww = self.dP_cat, [m.image_feats, m.text_feats] + [m.item_feats[key] for key in self.keys], None
+        item_pairs = [(self._side(dY_cat, 2 + k), feats[2 + k], roww) for k in range(len(self.keys))]
+        text_pairs, image_pairs = [(self._side(dY_cat, 1), feats[1], roww)], [(self._side(dY_cat, 0), feats[0], roww)]
+        done = False
+        if self.gemm == "bf16x3":
+            # One launch for the three item-side Linears: equal slabs over all of them, so the launch is whole rounds of equal
+            # blocks and the two short gradients pay no ramp-up / ragged last round of their own (round 2, same box: three launches
+            # back to back 0.661 ms per step, one launch 0.637 ms; folding user_trans' in as well - it then no longer runs beside
+            # the side chain's SpMMs - is 1 % slower). The bias gradients (row-weighted when pre-propagated) come out of the same launch.
             targets = [(item_pairs, m.item_trans.weight.grad, m.item_trans.bias.grad, False),
-                       ([(self._side(self.dP_cat, 1), m.text_feats)], m.text_trans.weight.grad, m.text_trans.bias.grad, False),
-                       ([(self._side(self.dP_cat, 0), m.image_feats)], m.image_trans.weight.grad, m.image_trans.bias.grad, False)]
+                       (text_pairs, m.text_trans.weight.grad, m.text_trans.bias.grad, False),
+                       (image_pairs, m.image_trans.weight.grad, m.image_trans.bias.grad, False)]
             if self.ws_wgrad_multi is None:
                 need = ops.linear_wgrad_multi_workspace(targets)
-                self.ws_wgrad_multi = torch.empty(max(need, 0), dtype=torch.uint8, device=self.dP_cat.device) if need >= 0 else False
+                self.ws_wgrad_multi = torch.empty(max(need, 0), dtype=torch.uint8, device=dY_cat.device) if need >= 0 else False
             if self.ws_wgrad_multi is not False:
                 ops.linear_wgrad_multi(targets, self.ws_wgrad_multi)
-                self._join(self.s1, self.s2)
-                return
-        if self.wgrad_serial:
-            # Default (LLMREC_WGRAD_SERIAL=1): item_trans', text's and image's weight gradients back to back on this stream. Each
-            # fills the chip (one wave per SIMD, HBM-bound); side by side (LLMREC_WGRAD_SERIAL=0, below) they interleave their
-            # blocks: every launch then lasts 2-3x longer (47 / 125 / 141 us against 17 / 19 / 130 us) while the step gains
-            # 2.7 % (0.652 vs 0.670 ms) from the short launches' ramp-up and tail hiding under the long one. The serial form
-            # stays the default so that a launch's duration - what the bench's roofline and a rocprof summary report - is the
-            # kernel's own.
-            ops.linear_wgrad_grouped(item_pairs, m.item_trans.weight.grad, m.item_trans.bias.grad, False, self.ws_wgrad, precision=self.gemm)
-            self._wgrad(self._side(self.dP_cat, 1), m.text_feats, m.text_trans, False, ws=self.ws_wgrad_c)
-            self._wgrad(self._side(self.dP_cat, 0), m.image_feats, m.image_trans, False, ws=self.ws_wgrad_d)
-            self._join(self.s1, self.s2)
-            return
-        # text / image weight gradients (and their partial-slab reductions) run beside item_trans' on their own streams
-        self._fork(self.s3, self.s4)
-        with self._on(self.s3):
-            self._wgrad(self._side(self.dP_cat, 1), m.text_feats, m.text_trans, False, ws=self.ws_wgrad_c)
-        with self._on(self.s4):
-            self._wgrad(self._side(self.dP_cat, 0), m.image_feats, m.image_trans, False, ws=self.ws_wgrad_d)
-        # the shared item_trans receives all attribute streams in one grouped launch (features are constants: no dX)
-        ops.linear_wgrad_grouped(item_pairs, m.item_trans.weight.grad, m.item_trans.bias.grad, False, self.ws_wgrad, precision=self.gemm)
-        self._join(self.s1, self.s2, self.s3, self.s4)
+                done = True
+        if not done:
+            # exact-fp32 GEMMs, or shapes outside the multi-target fast path (N != 64, K % 128 != 0): one launch per Linear; their
+            # kernels sum dY unweighted, so a pre-propagated step takes its bias gradients from llmrec_weighted_colsum_f32
+            strip = lambda pairs: [p_[:2] for p_ in pairs]
+            bias = (lambda lin: None) if self.preprop else (lambda lin: lin.bias.grad)
+            if self.preprop:
+                outs = [m.image_trans.bias.grad, m.text_trans.bias.grad] + [m.item_trans.bias.grad] * len(self.keys)
+                gp = (_c.c_void_p * S)(*[t.data_ptr() for t in outs])
+                _call("llmrec_weighted_colsum_f32", self.U, S, d, _p(dY_cat), _ld(dY_cat), _p(self.a_rowsum), gp, 0, _p(self.ws_colsum), self.ws_colsum.numel())
+            ops.linear_wgrad_grouped(strip(item_pairs), m.item_trans.weight.grad, bias(m.item_trans), False, self.ws_wgrad, precision=self.gemm)
+            ops.linear_wgrad_grouped(strip(text_pairs), m.text_trans.weight.grad, bias(m.text_trans), False, self.ws_wgrad_c, precision=self.gemm)
+            ops.linear_wgrad_grouped(strip(image_pairs), m.image_trans.weight.grad, bias(m.image_trans), False, self.ws_wgrad_d, precision=self.gemm)
+        self._join(self.s1)                                              # user_trans' gradient
+        if self.inline_adamw:
+            self.opt.step_params(self._lin_params)                       # the four Linears: 0.3 M parameters, one short launch
+        self._join(self.s2)
 
     def _train_forward(self, sampler=None):
-        """forward() of a training step: also clears the backward's scatter targets (and samples the batch) on a side stream."""
+        """forward() of a training step: also advances AdamW's counters (and samples the batch) on a side stream."""
         self._zero_in_forward = True
         try:
             self.forward(sampler)
         finally:
             self._zero_in_forward = False
-        self._zeroed = True
 
     def reset_scatter_targets(self):
         """Dense clear of the buffers the sparse-zero scheme keeps all-zero between steps (set-up, (re)capture, and after a
         step that raised between the loss backward's scatter and its row-wise clean-up)."""
-        for t in (self.dE_u, self.dE_i) + ((self.sc_U, self.sc_I, self.sc_prof) if self.sparse_zero else ()):
+        for t in (self.dE_u, self.dE_i, self.sc_U, self.sc_I, self.sc_prof):
             t.zero_()
 
     def step_eager(self, users, pos, neg, n_valid=None, sampler=None):
         """sampler: optional callable that fills (users, pos, neg, n_valid) on the current stream first (inside the same
         graph when captured; running it on a side stream beside the forward measured no faster)."""
-        side = os.environ.get("LLMREC_SAMPLER_SIDE", "1") == "1" and self.multi_stream
+        side = self.multi_stream                                 # the sampler rides beside the projection (forward())
         try:
             if sampler is not None and not side:
                 sampler()
             self._train_forward(sampler if side else None)
             self.loss_backward(users, pos, neg, n_valid)
-            self.opt.step(advanced=True)
+            if not self.inline_adamw:
+                self.opt.step(advanced=True)
         except Exception:
             if not torch.cuda.is_current_stream_capturing():   # the invariant of LLMREC_SPARSE_ZERO may be broken: restore it
                 try:

@@ -506,7 +506,8 @@ class BprProblem(_c.Structure):
 class LinearProblem(_c.Structure):
     """llmrec_linear_problem_t"""
     _fields_ = [("X", _c.c_void_p), ("ldx", _c.c_int64), ("M", _c.c_int64), ("K", _c.c_int32),
-                ("W", _c.c_void_p), ("ldw", _c.c_int64), ("bias", _c.c_void_p), ("Y", _c.c_void_p), ("ldy", _c.c_int64)]
+                ("W", _c.c_void_p), ("ldw", _c.c_int64), ("bias", _c.c_void_p), ("Y", _c.c_void_p), ("ldy", _c.c_int64),
+                ("bias_scale", _c.c_void_p)]
 
 
 class ZeroTensor(_c.Structure):
@@ -514,9 +515,24 @@ class ZeroTensor(_c.Structure):
     _fields_ = [("p", _c.c_void_p), ("n", _c.c_int64)]
 
 
+class FuseFwdProblem(_c.Structure):
+    """llmrec_fuse_fwd_problem_t"""
+    _fields_ = [("rows", _c.c_int64), ("mean_scale", _c.c_float), ("n_mean", _c.c_int32), ("mean_terms", _c.c_void_p), ("mean_ld", _c.c_void_p),
+                ("n_norm", _c.c_int32), ("norm_terms", _c.c_void_p), ("norm_ld", _c.c_void_p), ("rates", _c.c_void_p),
+                ("out", _c.c_void_p), ("ldo", _c.c_int64)]
+
+
+class FuseBwdProblem(_c.Structure):
+    """llmrec_fuse_bwd_problem_t"""
+    _fields_ = [("rows", _c.c_int64), ("dOut", _c.c_void_p), ("lddo", _c.c_int64), ("n_norm", _c.c_int32), ("norm_terms", _c.c_void_p),
+                ("norm_ld", _c.c_void_p), ("rates", _c.c_void_p), ("d_terms", _c.c_void_p), ("d_ld", _c.c_void_p),
+                ("src_terms", _c.c_void_p), ("src_ld", _c.c_void_p), ("n_reg_terms", _c.c_int32), ("reg_two_coef", _c.c_float)]
+
+
 class WgradProblem(_c.Structure):
     """llmrec_wgrad_problem_t"""
-    _fields_ = [("dY", _c.c_void_p), ("lddy", _c.c_int64), ("X", _c.c_void_p), ("ldx", _c.c_int64), ("M", _c.c_int64)]
+    _fields_ = [("dY", _c.c_void_p), ("lddy", _c.c_int64), ("X", _c.c_void_p), ("ldx", _c.c_int64), ("M", _c.c_int64),
+                ("db_row_weight", _c.c_void_p)]
 
 
 class WgradTarget(_c.Structure):
@@ -532,9 +548,11 @@ def _wgrad_targets(targets):
     N = targets[0][1].shape[0]
     for i, (pairs, dW, db, accumulate) in enumerate(targets):
         probs = (WgradProblem * len(pairs))()
-        for j, (dY, X) in enumerate(pairs):
+        for j, pair in enumerate(pairs):                       # (dY, X) or (dY, X, db_row_weight)
+            dY, X = pair[:2]
             _need_gpu(dY, X)
             probs[j].dY, probs[j].lddy, probs[j].X, probs[j].ldx, probs[j].M = dY.data_ptr(), _ld(dY), X.data_ptr(), _ld(X), X.shape[0]
+            probs[j].db_row_weight = pair[2].data_ptr() if len(pair) > 2 and pair[2] is not None else None
         keep.append(probs)
         arr[i].n_problems, arr[i].problems, arr[i].K = len(pairs), _c.cast(probs, _c.c_void_p), dW.shape[1]
         arr[i].dW, arr[i].lddw, arr[i].db, arr[i].accumulate = dW.data_ptr(), _ld(dW), (db.data_ptr() if db is not None else None), 1 if accumulate else 0
@@ -564,9 +582,11 @@ def linear_wgrad_grouped(pairs, dW, db, accumulate: bool, ws: Optional[torch.Ten
     precision "bf16x3": llmrec_linear_wgrad_grouped_bf16x3 (three-term bf16 split, fp32-class error)."""
     arr = (WgradProblem * len(pairs))()
     M_total = 0
-    for i, (dY, X) in enumerate(pairs):
+    for i, pair in enumerate(pairs):                           # (dY, X) or (dY, X, db_row_weight)
+        dY, X = pair[:2]
         _need_gpu(dY, X)
         arr[i].dY, arr[i].lddy, arr[i].X, arr[i].ldx, arr[i].M = dY.data_ptr(), _ld(dY), X.data_ptr(), _ld(X), X.shape[0]
+        arr[i].db_row_weight = pair[2].data_ptr() if len(pair) > 2 and pair[2] is not None else None
         M_total += X.shape[0]
     N, K = dW.shape
     need = _lib.query("llmrec_linear_wgrad_workspace_bytes", M_total, N, K)
@@ -577,12 +597,14 @@ def linear_wgrad_grouped(pairs, dW, db, accumulate: bool, ws: Optional[torch.Ten
 
 
 def linear_fwd_grouped(jobs, N: int, precision: str = "f32"):
-    """jobs: list of (X, W, bias, out) - one launch. precision "f32": exact fp32 MFMA
+    """jobs: list of (X, W, bias, out) or (X, W, bias, out, bias_scale) - one launch. precision "f32": exact fp32 MFMA
     (llmrec_linear_fwd_grouped_f32); "bf16x3": three-term bf16 split, six bf16 MFMAs, fp32-class
-    error (llmrec_linear_fwd_grouped_bf16x3)."""
+    error (llmrec_linear_fwd_grouped_bf16x3). bias_scale [M]: out[r] = X[r] W^T + bias_scale[r] * bias."""
     arr = (LinearProblem * len(jobs))()
-    for i, (X, W, b, out) in enumerate(jobs):
+    for i, job in enumerate(jobs):
+        X, W, b, out = job[:4]
         _need_gpu(X, W, b, out)
+        arr[i].bias_scale = job[4].data_ptr() if len(job) > 4 and job[4] is not None else None
         arr[i].X, arr[i].ldx, arr[i].M, arr[i].K = X.data_ptr(), _ld(X), X.shape[0], X.shape[1]
         arr[i].W, arr[i].ldw, arr[i].bias = W.data_ptr(), _ld(W), (b.data_ptr() if b is not None else None)
         arr[i].Y, arr[i].ldy = out.data_ptr(), _ld(out)
@@ -697,13 +719,24 @@ class FusedAdamW:
         _lib.call("llmrec_adamw_advance", _p(self.dev_state), self.lr, self.betas[0], self.betas[1], _stream())
 
     @torch.no_grad()
+    def step_params(self, params):
+        """The update of a SUBSET of the parameters (their gradients are final), the step counter having been advanced already
+        (advance()): a fused step updates its embedding tables while the weight-gradient GEMM of the Linears is still running."""
+        self._update([p for p in params if p.grad is not None])
+
+    @torch.no_grad()
     def step(self, advanced: bool = False):
         live = [p for p in self.params if p.grad is not None]
         if not live:
             return
-        _need_gpu(*live)
         if not advanced:
             self.advance()
+        self._update(live)
+
+    def _update(self, live):
+        if not live:
+            return
+        _need_gpu(*live)
         cap = CONST["LLMREC_ADAMW_MAX_TENSORS"]
         for lo in range(0, len(live), cap):
             group = live[lo:lo + cap]

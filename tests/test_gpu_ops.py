@@ -685,3 +685,131 @@ def test_fuse_bwd_source_mode_and_zero_rows(ops):
         want_u = torch.ones(U, d, device=DEV); want_u[users[:nv]] = 0
         want_i = torch.ones(I, 2 * d, device=DEV); want_i[pos[:nv], d:] = 0; want_i[neg[:nv], d:] = 0
         assert torch.equal(dEu[i], want_u) and torch.equal(dEi[i], want_i)
+
+
+def test_fuse_pair_launches_equal_the_single_launches(ops):
+    """llmrec_fuse_fwd_multi_f32 / llmrec_fuse_bwd_src_multi_f32 (user side + item side in one launch) against the
+    per-side entry points, bit for bit; different row counts and term counts per side, a NULL source term."""
+    import ctypes as C
+    from llmrec_amd import _lib
+    from llmrec_amd.ops import _p, _ld, FuseFwdProblem, FuseBwdProblem
+    g = torch.Generator(device=DEV); g.manual_seed(15)
+    rn = lambda *s: torch.randn(*s, generator=g, device=DEV)
+    d = 64
+    tab = lambda ts: ((C.c_void_p * len(ts))(*[t.data_ptr() if t is not None else None for t in ts]),
+                      (C.c_int64 * len(ts))(*[_ld(t) if t is not None else 0 for t in ts]))
+    sides = []
+    for rows, n_mean, n_norm in ((777, 3, 8), (4101, 4, 5)):
+        cat = rn(rows, n_norm * d); cat[3] = 0.0
+        sides.append({"rows": rows, "means": [rn(rows, d) for _ in range(n_mean)], "norms": [cat[:, k * d:(k + 1) * d] for k in range(n_norm)],
+                      "rates": (C.c_float * n_norm)(*[0.1 * (k + 1) for k in range(n_norm)]), "dout": rn(rows, d),
+                      "srcs": [rn(rows, d) if k % 3 else None for k in range(n_norm)]})
+    keep = []
+    # forward
+    fwd = (FuseFwdProblem * 2)(); outs_multi, outs_single = [], []
+    for pr, sd in zip(fwd, sides):
+        mp, ml = tab(sd["means"]); npt, nl = tab(sd["norms"]); keep += [mp, ml, npt, nl]
+        out = torch.empty(sd["rows"], d, device=DEV); ref = torch.empty(sd["rows"], d, device=DEV)
+        outs_multi.append(out); outs_single.append(ref)
+        pr.rows, pr.mean_scale, pr.n_mean, pr.n_norm = sd["rows"], 1.0 / len(sd["means"]), len(sd["means"]), len(sd["norms"])
+        pr.mean_terms, pr.mean_ld = C.cast(mp, C.c_void_p), C.cast(ml, C.c_void_p)
+        pr.norm_terms, pr.norm_ld, pr.rates = C.cast(npt, C.c_void_p), C.cast(nl, C.c_void_p), C.cast(sd["rates"], C.c_void_p)
+        pr.out, pr.ldo = out.data_ptr(), d
+        _lib.call("llmrec_fuse_fwd_f32", sd["rows"], d, 1.0 / len(sd["means"]), len(sd["means"]), mp, ml, len(sd["norms"]), npt, nl, sd["rates"], _p(ref), d, None)
+    _lib.call("llmrec_fuse_fwd_multi_f32", 2, fwd, d, None)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(outs_multi, outs_single))
+    # backward (source mode)
+    bwd = (FuseBwdProblem * 2)(); d_multi, d_single = [], []
+    for pr, sd in zip(bwd, sides):
+        n = len(sd["norms"])
+        dm = [torch.full((sd["rows"], d), 7.0, device=DEV) for _ in range(n)]; ds = [torch.full((sd["rows"], d), 7.0, device=DEV) for _ in range(n)]
+        d_multi.append(dm); d_single.append(ds)
+        npt, nl = tab(sd["norms"]); dp, dl = tab(dm); dps, dls = tab(ds); sp, sl = tab(sd["srcs"]); keep += [npt, nl, dp, dl, dps, dls, sp, sl]
+        pr.rows, pr.dOut, pr.lddo, pr.n_norm = sd["rows"], sd["dout"].data_ptr(), d, n
+        pr.norm_terms, pr.norm_ld, pr.rates = C.cast(npt, C.c_void_p), C.cast(nl, C.c_void_p), C.cast(sd["rates"], C.c_void_p)
+        pr.d_terms, pr.d_ld, pr.src_terms, pr.src_ld = C.cast(dp, C.c_void_p), C.cast(dl, C.c_void_p), C.cast(sp, C.c_void_p), C.cast(sl, C.c_void_p)
+        pr.n_reg_terms, pr.reg_two_coef = 2, 0.01
+        _lib.call("llmrec_fuse_bwd_src_f32", sd["rows"], d, _p(sd["dout"]), d, n, npt, nl, sd["rates"], dps, dls, sp, sl, 2, 0.01, None)
+    _lib.call("llmrec_fuse_bwd_src_multi_f32", 2, bwd, d, None)
+    torch.cuda.synchronize()
+    for dm, ds in zip(d_multi, d_single):
+        assert all(torch.equal(a, b) for a, b in zip(dm, ds))
+
+
+def test_weighted_column_sums_in_groups(ops):
+    """llmrec_weighted_colsum_f32: out_g[j] (+)= sum_r w[r] X[r][gw g + j]; groups sharing a destination are summed; deterministic."""
+    import ctypes as C
+    from llmrec_amd import _lib
+    from llmrec_amd.ops import _p, _ld
+    g = torch.Generator(device=DEV); g.manual_seed(21)
+    for rows, n_groups, gw in ((13187, 7, 64), (301, 3, 16), (5, 8, 64), (0, 2, 64)):
+        big = torch.randn(max(rows, 1), n_groups * gw + 8, generator=g, device=DEV)[:rows]
+        X = big[:, 4:4 + n_groups * gw]                                      # a column slice (ld > d, 16-byte misaligned)
+        w = torch.rand(rows, generator=g, device=DEV)
+        shared = torch.full((gw,), 3.0, device=DEV)                          # groups 1.. share one destination (the 5 attribute streams)
+        first = torch.full((gw,), 5.0, device=DEV)
+        outs = [first] + [shared] * (n_groups - 1)
+        gp = (C.c_void_p * n_groups)(*[t.data_ptr() for t in outs])
+        ws = torch.empty(_lib.query("llmrec_weighted_colsum_workspace_bytes", n_groups * gw), dtype=torch.uint8, device=DEV)
+        _lib.call("llmrec_weighted_colsum_f32", rows, n_groups, gw, _p(X), _ld(X), _p(w), gp, 0, _p(ws), ws.numel(), None)
+        want = (w.double()[:, None] * X.double()).sum(0).reshape(n_groups, gw)
+        assert torch.allclose(first.double(), want[0], rtol=0, atol=2e-6 * max(1.0, float(want.abs().max())))
+        assert torch.allclose(shared.double(), want[1:].sum(0), rtol=0, atol=2e-6 * max(1.0, float(want.abs().max())))
+        a = shared.clone()
+        first.fill_(5.0); shared.fill_(3.0)
+        _lib.call("llmrec_weighted_colsum_f32", rows, n_groups, gw, _p(X), _ld(X), _p(w), gp, 0, _p(ws), ws.numel(), None)
+        assert torch.equal(a, shared)                                        # run-to-run identical
+        _lib.call("llmrec_weighted_colsum_f32", rows, n_groups, gw, _p(X), _ld(X), None, gp, 1, _p(ws), ws.numel(), None)   # accumulate, w = ones
+        assert torch.allclose(first.double(), want[0] + X.double().sum(0).reshape(n_groups, gw)[0], rtol=0, atol=4e-6 * max(1.0, float(want.abs().max())))
+
+
+def test_projection_of_a_pre_propagated_operand(ops):
+    """llmrec_linear_problem_t.bias_scale: (A F) W^T + (A 1) b^T equals A (F W^T + 1 b^T) - the identity the fused step's
+    pre-propagated item-side operands rest on (reference Models.py:145-157)."""
+    g = torch.Generator(device=DEV); g.manual_seed(31)
+    U_, I_, K, d = 700, 900, 256, 64
+    rows = torch.randint(0, U_, (6000,), generator=g, device=DEV); cols = torch.randint(0, I_, (6000,), generator=g, device=DEV)
+    key = torch.unique(rows * I_ + cols); rows, cols = key // I_, key % I_
+    gr = ops.BipartiteGraph.from_edges(rows, cols, U_, I_)
+    F_ = torch.randn(I_, K, generator=g, device=DEV); W = torch.randn(d, K, generator=g, device=DEV) / 16; b = torch.randn(d, generator=g, device=DEV)
+    AF = torch.empty(U_, K, device=DEV)
+    for c0 in range(0, K, 64):
+        ops.spmm_raw(gr.ui.fwd, F_[:, c0:c0 + 64], out=AF[:, c0:c0 + 64])
+    c_u = ops.spmm_raw(gr.ui.fwd, torch.ones(I_, 4, device=DEV))[:, 0].contiguous()
+    for precision in ("bf16x3", "f32"):
+        out = torch.empty(U_, d, device=DEV)
+        ops.linear_fwd_grouped([(AF, W, b, out, c_u)], d, precision=precision)
+        P = F_.double() @ W.double().t() + b.double()
+        A = torch.zeros(U_, I_, dtype=torch.float64, device=DEV); A[rows, cols] = 1.0
+        want = gr.s_u.double()[:, None] * (A @ P)
+        assert float((out.double() - want).abs().max() / want.abs().max()) < 3e-6, precision
+
+
+def test_weight_gradient_with_row_weighted_bias_gradient(ops):
+    """llmrec_wgrad_problem_t.db_row_weight: dW as ever, db = sum_r w[r] dY[r] (the bias gradient of a projection with bias_scale),
+    several problems per target with different weights, ragged M; and the refusal where the organisation does not serve it."""
+    g = torch.Generator(device=DEV); g.manual_seed(41)
+    rn = lambda *s: torch.randn(*s, generator=g, device=DEV)
+    relmax = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    d, K = 64, 256
+    Ms = [1301, 517, 64]
+    dY = rn(sum(Ms), 3 * d)
+    pairs, want_w, want_b = [], torch.zeros(d, K, dtype=torch.float64, device=DEV), torch.zeros(d, dtype=torch.float64, device=DEV)
+    r0 = 0
+    for j, M in enumerate(Ms):
+        X = rn(M, K); w = torch.rand(M, generator=g, device=DEV) if j != 1 else None
+        dy = dY[r0:r0 + M, d:2 * d]; r0 += M                                       # a column slice, ld = 3 d
+        pairs.append((dy, X, w))
+        want_w += dy.double().t() @ X.double()
+        want_b += (dy.double() * (w.double()[:, None] if w is not None else 1.0)).sum(0)
+    dW = torch.empty(d, K, device=DEV); db = torch.empty(d, device=DEV)
+    ops.linear_wgrad_multi([(pairs, dW, db, False)])
+    assert relmax(dW, want_w) < 3e-6 and relmax(db, want_b) < 3e-6
+    a = db.clone()
+    ops.linear_wgrad_multi([(pairs, dW, db, False)])
+    assert torch.equal(a, db)
+    ops.linear_wgrad_grouped(pairs, dW, db, False, precision="bf16x3")                 # the single-target entry routes to the same launch
+    assert relmax(db, want_b) < 3e-6
+    with pytest.raises(RuntimeError):                                                  # the exact-fp32 kernels sum dY unweighted: refused
+        ops.linear_wgrad_grouped(pairs, dW, db, False, precision="f32")

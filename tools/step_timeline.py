@@ -1,5 +1,5 @@
 """One steady-state training step as a kernel timeline (from a rocprofv3 rocpd database of bench.py).
-python tools/step_timeline.py <results.db> <out.txt>  - picks the last complete step (delimited by adamw_multi_kernel)."""
+python tools/step_timeline.py <results.db> <out.txt>  - picks a steady-state step (delimited by the in-graph sampler launch)."""
 import sqlite3, sys
 db, out = sys.argv[1], sys.argv[2]
 c = sqlite3.connect(db)
@@ -8,11 +8,11 @@ name = "name" if "name" in cols else "kernel_name"
 qcol = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
 sel = f"select {name}, start, end" + (f", {qcol}" if qcol else ", 0") + " from kernels order by start"
 rows = c.execute(sel).fetchall()
-ends = [i for i, r in enumerate(rows) if "adamw_multi_kernel" in r[0]]
-# steady-state: take the step between the 3rd-last and 2nd-last optimizer launches that are ~one step apart
-cand = [(ends[i - 1], ends[i]) for i in range(1, len(ends))]
-lo, hi = cand[len(cand) // 2]
-step = rows[lo + 1: hi + 1]
+# a step = the launches from one in-graph sampler launch (the step's first kernel) up to the next one
+starts = [i for i, r in enumerate(rows) if "sample_batch_kernel" in r[0]]
+cand = [(starts[i - 1], starts[i]) for i in range(1, len(starts))]
+lo, hi = cand[len(cand) // 2]                                  # a steady-state step from the middle of the run
+step = rows[lo: hi]
 t0 = step[0][1]
 with open(out, "w") as f:
     f.write("# start_us  dur_us  gap_since_prev_end_us  stream  kernel\n")
@@ -20,5 +20,6 @@ with open(out, "w") as f:
     for n, s, e, q in step:
         f.write("%9.2f %8.2f %8.2f  %s  %s\n" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, q, n.split("(")[0][-70:]))
         prev_end = max(prev_end, e)
-    f.write("# step span %.2f us, kernel time sum %.2f us, %d kernels\n" % ((step[-1][2] - t0) / 1e3, sum(e - s for _, s, e, _ in step) / 1e3, len(step)))
+    f.write("# step span %.2f us (first launch to the last end), %.2f us to the next step's first launch, kernel time sum %.2f us, %d kernels\n" % (
+        (max(e for _, s, e, _ in step) - t0) / 1e3, (rows[hi][1] - t0) / 1e3, sum(e - s for _, s, e, _ in step) / 1e3, len(step)))
 print(open(out).read()[-200:])

@@ -1,5 +1,7 @@
 """GPU probe of the weight-gradient launches at the Netflix shape: the multi-target launch (item_trans x5 + text + image) and
-user_trans', timed with HIP events, checked against fp64. LLMREC_WGRAD_KERNEL=1|2|3 selects the organisation (read once per process).
+user_trans', timed with HIP events, checked against fp64. With LLMREC_LIB=<instrumented build> (python -m llmrec_amd.build --tools)
+also the effective shader clock of the launch. (The LLMREC_WGRAD_KERNEL / LLMREC_WGRAD_ABL variants of round 3 are in
+profiles/experiments/r03_dense_with_wgrad_variants.hip.txt.)
 Usage: python tools/wgrad_probe.py [iters]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -48,19 +50,19 @@ det = bool(torch.equal(a, dW["item"]))
 ms_m, ms_s = timeit(multi), timeit(single)
 bytes_m = 4.0 * (5 * I * 1536 + I * 768 + I * 512 + 7 * I * d + d * (1536 + 768 + 512))
 bytes_s = 4.0 * (U * 1536 + U * d + d * 1536)
-print("WGRAD_KERNEL=%s ABL=%s multi %.4f ms (%.0f GB/s, %.3f of 8 TB/s)  user %.4f ms (%.0f GB/s)  max rel err vs fp64 %s  deterministic %s" % (
-    os.environ.get("LLMREC_WGRAD_KERNEL", "default"), os.environ.get("LLMREC_WGRAD_ABL", "-"), ms_m, bytes_m / ms_m / 1e6, bytes_m / ms_m / 1e6 / 8000, ms_s, bytes_s / ms_s / 1e6,
+print("multi %.4f ms (%.0f GB/s, %.3f of 8 TB/s)  user %.4f ms (%.0f GB/s)  max rel err vs fp64 %s  deterministic %s" % (
+    ms_m, bytes_m / ms_m / 1e6, bytes_m / ms_m / 1e6 / 8000, ms_s, bytes_s / ms_s / 1e6,
     {k: "%.1e" % v for k, v in errs.items()}, det))
-assert os.environ.get('LLMREC_WGRAD_ABL') or (max(errs.values()) < 3e-6 and det)
+assert max(errs.values()) < 3e-6 and det
 
-if os.environ.get("LLMREC_LIB"):                              # instrumented build: loop span in shader cycles and by the 100 MHz counter
+if os.environ.get("LLMREC_LIB"):                              # instrumented build: the effective shader clock of the launch
     import ctypes
     lib = ops._lib.load()
-    buf = (ctypes.c_ulonglong * 24)()
-    lib.llmrec_tools_wgrad_prof(buf)
+    buf = (ctypes.c_ulonglong * 3)()
+    lib.llmrec_tools_wgrad_clock(buf)
     multi(); torch.cuda.synchronize()
-    lib.llmrec_tools_wgrad_prof(buf)
+    lib.llmrec_tools_wgrad_clock(buf)
     v = list(buf)
-    if v[14]:
+    if v[2]:
         print("main loop per wave: %.0f k shader cycles, %.1f us by the 100 MHz counter -> %.2f GHz effective (%d waves)" % (
-            v[12] / v[14] / 1e3, v[13] / v[14] / 100.0, v[12] / max(v[13], 1) / 10.0, v[14]))
+            v[0] / v[2] / 1e3, v[1] / v[2] / 100.0, v[0] / max(v[1], 1) / 10.0, v[2]))
