@@ -189,58 +189,25 @@ class NetflixShaped:
                         + (" + HIP graph replay" if self.use_graph else "")}
 
 
-    def _wgrad_in_situ_ms(self, dYi, dYu, ws, iters: int = 20):
-        """Durations of the step's weight-gradient launches (each = the GEMM + its slab reduction; two with the multi-target launch, four without), launched as the
-        step launches them, HIP events on each launch's own stream; and the wall time of the group."""
+    def _wgrad_launch_ms(self, dY_cat, dYu, iters: int = 20):
+        """Duration of the step's weight-gradient launch (the GEMM over all four Linears + its slab reduction), HIP events on the
+        stream it is launched on (a side stream, as llmrec_amd/fused.py launches it), the launch built exactly as the step builds it."""
         import torch
-        ops, d, m_ = self.ops, self.args.embed_size, self.model
-        pr = self.fused.gemm
-        f = self.fused
-        # the item-side operands of the step: the pre-propagated A_ui F_k (rows = users) by default, else the features themselves
-        Fi = f.AX if f.preprop else [m_.image_feats, m_.text_feats] + [m_.item_feats[key] for key in self.keys]
-        item_pairs = [(dYi[:, (2 + k) * d:(3 + k) * d], Fi[2 + k]) for k in range(len(self.keys))]
-        jobs = {
-            "item_trans_x5": (lambda: ops.linear_wgrad_grouped(item_pairs, m_.item_trans.weight.grad, m_.item_trans.bias.grad, False, ws, precision=pr)),
-            "user_trans": (lambda: ops.linear_wgrad_grouped([(dYu, m_.user_feats)], m_.user_trans.weight.grad, m_.user_trans.bias.grad, False, f.ws_wgrad_b, precision=pr)),
-            "text_trans": (lambda: ops.linear_wgrad_grouped([(dYi[:, d:2 * d], Fi[1])], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False, f.ws_wgrad_c, precision=pr)),
-            "image_trans": (lambda: ops.linear_wgrad_grouped([(dYi[:, 0:d], Fi[0])], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False, f.ws_wgrad_d, precision=pr)),
-        }
-        multi = f.gemm == "bf16x3"
-        if multi:                                             # item_trans', text's and image's gradients are ONE launch in the step
-            targets = [(item_pairs, m_.item_trans.weight.grad, m_.item_trans.bias.grad, False),
-                       ([(dYi[:, d:2 * d], Fi[1])], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False),
-                       ([(dYi[:, 0:d], Fi[0])], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False)]
-            ws_multi = torch.empty(max(ops.linear_wgrad_multi_workspace(targets), 16), dtype=torch.uint8, device=dYi.device)
-            jobs = {"item+text+image_trans (one launch)": (lambda: ops.linear_wgrad_multi(targets, ws_multi)), "user_trans": jobs["user_trans"]}
-        # as the step launches them (llmrec_amd/fused.py _backward): user_trans' on its own stream (in the step it runs beside
-        # the SpMM chains); the item-side gradients as one multi-target launch (default), or with LLMREC_WGRAD_MULTI=0 as three
-        # launches back to back on one stream (LLMREC_WGRAD_SERIAL=1) / side by side on three
-        main_s, side_s = torch.cuda.Stream(), torch.cuda.Stream()
-        if multi:
-            order = {k: (side_s if k == "user_trans" else main_s) for k in jobs}
-        else:
-            order = {"item_trans_x5": main_s, "text_trans": main_s, "image_trans": main_s, "user_trans": side_s}
-        acc = {k: 0.0 for k in jobs}
-        wall = 0.0
+        ops, f = self.ops, self.fused
+        targets = f.wgrad_targets(dY_cat, dYu)
+        ws = torch.empty(max(ops.linear_wgrad_multi_workspace(targets), 16), dtype=torch.uint8, device=dY_cat.device)
+        st = torch.cuda.Stream()
+        acc = 0.0
         for it in range(iters + 3):
-            cur = torch.cuda.current_stream()
-            ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in jobs}
-            w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            w0.record()
-            for st in set(order.values()):
-                st.wait_stream(cur)
-            for k in sorted(jobs, key=lambda k: k != "user_trans"):        # user_trans' first, as in the step
-                with torch.cuda.stream(order[k]):
-                    ev[k][0].record(); jobs[k](); ev[k][1].record()
-            for st in set(order.values()):
-                cur.wait_stream(st)
-            w1.record()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                e0.record(); ops.linear_wgrad_multi(targets, ws); e1.record()
+            torch.cuda.current_stream().wait_stream(st)
             torch.cuda.synchronize()
             if it >= 3:
-                for k in jobs:
-                    acc[k] += ev[k][0].elapsed_time(ev[k][1])
-                wall += w0.elapsed_time(w1)
-        return {k: v / iters for k, v in acc.items()}, wall / iters
+                acc += e0.elapsed_time(e1)
+        return acc / iters
 
     # ---- per-kernel roofline (dominant kernels of this workload, timed in isolation) -------------
     def kernel_rooflines(self):
@@ -264,46 +231,25 @@ class NetflixShaped:
                     "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
                     "algorithmic_flop_per_launch": flop_all, "algorithmic_bytes_per_launch": byts_all,
                     "algorithmic_flop_per_step": flop_all, "algorithmic_bytes_per_step": byts_all, "launches": 1})
-        flop = 2.0 * sh.n_items * sh.llm_dim * d
-        byts = 4.0 * (sh.n_items * sh.llm_dim + d * sh.llm_dim + sh.n_items * d)
-        # the step's weight gradients: item_trans (5 attribute streams grouped), user, text, image - four single-target launches here
-        # (the isolated serial figure), the step's own layout (multi-target launch + user_trans') in _wgrad_in_situ_ms below
-        dYi = torch.randn(sh.n_users if self.fused.preprop else sh.n_items, 7 * d, device=self.device); dYu = torch.randn(sh.n_users, d, device=self.device)
-        m_ = self.model
-        ws = self.fused.ws_wgrad
-
-        Fi = self.fused.AX if self.fused.preprop else [m_.image_feats, m_.text_feats] + [m_.item_feats[key] for key in self.keys]
-
-        def wgrad_all():
-            pr = self.fused.gemm
-            ops.linear_wgrad_grouped([(dYi[:, (2 + k) * d:(3 + k) * d], Fi[2 + k]) for k in range(len(self.keys))],
-                                     m_.item_trans.weight.grad, m_.item_trans.bias.grad, False, ws, precision=pr)
-            ops.linear_wgrad_grouped([(dYu, m_.user_feats)], m_.user_trans.weight.grad, m_.user_trans.bias.grad, False, ws, precision=pr)
-            ops.linear_wgrad_grouped([(dYi[:, d:2 * d], Fi[1])], m_.text_trans.weight.grad, m_.text_trans.bias.grad, False, ws, precision=pr)
-            ops.linear_wgrad_grouped([(dYi[:, 0:d], Fi[0])], m_.image_trans.weight.grad, m_.image_trans.bias.grad, False, ws, precision=pr)
-        ms_serial = event_time_ms(wgrad_all, 20)
-        # IN SITU: the launches as the step issues them (the multi-target launch on one stream, user_trans' on a second one);
-        # each launch's own duration is what a rocprofv3 kernel trace of the step reports as the kernel's average
-        # duration (profiles/r02_bench_nf_kernel_stats_*.csv), and it is the denominator of the roofline figure below.
-        per_launch, wall = self._wgrad_in_situ_ms(dYi, dYu, ws)
-        ms = sum(per_launch.values())
-        n_l = len(per_launch)
-        multi = n_l == 2
-        out.append({"kernel": (("linear_wgrad_bf16x3_v2_multi_kernel + reduce_chunks_multi_kernel: item_trans x5 + text + image in one launch, and "
-                                "user_trans in a second one") if multi else
-                               (("linear_wgrad_bf16x3_kernel" if bf else "linear_wgrad_kernel<true>") +
-                                " + reduce_chunks_kernel (the step's 4 launches: item_trans x5 grouped, user, text, image")) +
-                              ("; 3-term bf16 split: HBM-bound on the X stream, tflops are fp32-EQUIVALENT" if bf else "") + (")" if not multi else ""),
-                    "pmc": ([("linear_wgrad_bf16x3_v2_multi_kernel", 2), ("reduce_chunks_multi_kernel", 2)]
-                            if multi else [("linear_wgrad_bf16x3_kernel" if bf else "linear_wgrad_kernel", 4), ("reduce_chunks_kernel", 4)]),
-                    "launches": n_l, "avg_launch_ms": ms / n_l, "per_launch_ms_in_situ": per_launch, "ms_wall_group": wall,
-                    "ms_serial_isolated": ms_serial,
-                    "timing": "HIP events on each launch's own stream, launched as in the step (item_trans' + text's + image's as one multi-target launch unless LLMREC_WGRAD_MULTI=0, user_trans' on a second stream); ms = the sum of the launches' durations",
-                    "bound": "hbm" if bf else "mfma", "calls_per_step": 1, "ms": ms, "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
-                    "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
-                    "gbs_wall_group": byts_all / wall / 1e6,
-                    "algorithmic_flop_per_launch": flop_all / n_l, "algorithmic_bytes_per_launch": byts_all / n_l,
-                    "algorithmic_flop_per_step": flop_all, "algorithmic_bytes_per_step": byts_all})
+        # the step's weight gradients: ONE multi-target launch (item_trans x5, user_trans, text_trans, image_trans) + its slab reduction
+        bf_ok = bf and d == 64
+        # operands = the gradient buffers the last training step left (the chip is power-bound in this kernel and its clock depends
+        # on the data: N(0, 1) stand-ins for the ~1e-5-sized gradients make the same launch ~30 % slower than it is in the step)
+        dY_cat = self.fused.dU_cat if self.fused.preprop else self.fused.dP_cat
+        dYu = self.fused.dP_usr
+        if bf_ok:
+            ms = self._wgrad_launch_ms(dY_cat, dYu)
+            out.append({"kernel": "linear_wgrad_bf16x3_v2_multi_kernel + reduce_chunks_multi_kernel: the weight gradients of all four Linears "
+                                  "(item_trans x5, user_trans, text_trans, image_trans) in one launch; 3-term bf16 split: tflops are fp32-EQUIVALENT",
+                        "pmc": [("linear_wgrad_bf16x3_v2_multi_kernel", 1), ("reduce_chunks_multi_kernel", 1)],
+                        "launches": 1, "avg_launch_ms": ms,
+                        "timing": "HIP events around the launch on the side stream it is issued on, built as the step builds it (llmrec_amd/fused.py wgrad_targets)",
+                        "bound": "hbm", "calls_per_step": 1, "ms": ms, "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                        "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
+                        "note": "power-bound, not bandwidth-bound: the shader clock averages 1.37 GHz in this kernel (2.33 GHz for its load stream alone, "
+                                "1.88 GHz for its MFMAs alone; profiles/experiments/r03_wgrad.md)",
+                        "algorithmic_flop_per_launch": flop_all, "algorithmic_bytes_per_launch": byts_all,
+                        "algorithmic_flop_per_step": flop_all, "algorithmic_bytes_per_step": byts_all})
         Xi = torch.randn(sh.n_items, d, device=self.device)
         a = self.graph.ui.fwd
         ms = event_time_ms(lambda: ops.spmm_raw(a, Xi), 50)
@@ -948,8 +894,9 @@ def main():
             line["kernels"] = ks
             # dominant kernel = the largest share of the step's GPU time: the weight-gradient launches (rocprofv3 round 1:
             # 25 % of the step) ahead of the single grouped-projection launch; both are reported, the dominant one first
-            dom = max(ks[:2], key=lambda k: k["ms"])
-            other = min(ks[:2], key=lambda k: k["ms"])
+            gemms = [k for k in ks if "algorithmic_bytes_per_launch" in k]
+            dom = max(gemms, key=lambda k: k["ms"])
+            other = min(gemms, key=lambda k: k["ms"])
 
             def roof(k):
                 hbm = k.get("bound") == "hbm"
@@ -965,7 +912,8 @@ def main():
                         "timing": k.get("timing", "HIP events around the launch on its stream, in isolation"),
                         "hbm_gbs": k["gbs"], "frac_hbm": k["frac_hbm"]}
             line["roofline"] = roof(dom)
-            line["roofline"]["second"] = roof(other)
+            if other is not dom:
+                line["roofline"]["second"] = roof(other)
             line["roofline"]["step_kernel_time_by_class"] = kernel_time_shares()
             line["spmm_roofline"] = spmm_roofline_large(device, a.seed)
         if not a.no_cpu_baseline and world == 1:

@@ -92,8 +92,9 @@ class DataParallelStep(FusedStep):
             raise RuntimeError("DataParallelStep: every rank passes exactly b_max = %d slots (n_valid marks the used ones)" % self.b_max)
         if sampler is not None:
             sampler()
-        self._train_forward()
+        self._train_forward()                                            # (also starts the feature regulariser's value on s3)
         self._bpr_phase(1, users, pos, neg, n_valid)
+        self._join(self.s3)
 
     def phase_b(self, users, pos, neg, n_valid=None):
         """selection against the gathered global batch + backward into the gradient bucket."""
@@ -101,7 +102,6 @@ class DataParallelStep(FusedStep):
         P = self.n_prob
         self._fork(self.s3)
         with self._on(self.s3):                                          # loss scalars for the bucket's tail, off the critical path
-            self._feat_reg()
             # tail[:P] = this rank's shares of the mf values; tail[P] = (emb + feat_reg) / world (identical on all ranks)
             self._assemble_loss(1, self.tail, 1.0 / self.world)
         self._backward(self._problems(), users, pos, neg, n_valid, replicated_scale=1.0 / self.world)

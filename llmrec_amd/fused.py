@@ -208,6 +208,21 @@ class FusedStep:
         jobs.sort(key=lambda j: -j[0].shape[1])
         return jobs
 
+    def wgrad_targets(self, dY_cat, dP_usr):
+        """The step's weight gradients as llmrec_linear_wgrad_multi targets [(pairs, dW, db, accumulate)]: item_trans (5 attribute
+        streams), user_trans, text_trans, image_trans. dY_cat = the [rows, 7 d] gradient of the projections' outputs (dU_cat when
+        the operands are pre-propagated - its pairs carry the row weights of the bias gradient - else dP_cat)."""
+        m = self.m
+        if self.preprop:
+            feats, roww = self.AX, self.a_rowsum
+        else:
+            feats, roww = [m.image_feats, m.text_feats] + [m.item_feats[key] for key in self.keys], None
+        item_pairs = [(self._side(dY_cat, 2 + k), feats[2 + k], roww) for k in range(len(self.keys))]
+        return [(item_pairs, m.item_trans.weight.grad, m.item_trans.bias.grad, False),
+                ([(dP_usr, m.user_feats)], m.user_trans.weight.grad, m.user_trans.bias.grad, False),
+                ([(self._side(dY_cat, 1), feats[1], roww)], m.text_trans.weight.grad, m.text_trans.bias.grad, False),
+                ([(self._side(dY_cat, 0), feats[0], roww)], m.image_trans.weight.grad, m.image_trans.bias.grad, False)]
+
     def _project_all(self):
         """All 8 projections in one grouped launch (d <= 64), else one by one."""
         jobs = self.projection_jobs()
@@ -284,6 +299,10 @@ class FusedStep:
         with self._on(self.s1):                                          # profile stream: items first
             self._spmm(self.iu.fwd, self.P_usr, self.prof_i, tag=1)
             self._spmm(self.ui.fwd, self.prof_i, self.prof_u, tag=1)
+        if self._zero_in_forward:                                        # training: the feature regulariser's value needs only U_cat / I_cat -
+            self._fork(self.s3)                                          # captured HERE it runs beside the fusion and the BPR launches (captured
+            with self._on(self.s3):                                      # after the BPR backward, round 2, the graph ran it last: the step's tail)
+                self._feat_reg()
         self._join(self.s1, self.s2)
 
         # E_u and E_i (Models.py:185-197) in ONE launch: llmrec_fuse_fwd_multi_f32 (two independent row ranges)
@@ -334,10 +353,10 @@ class FusedStep:
         hp = self.hp
         _call("llmrec_bpr_multi_fwd_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid),
               float(1 - hp.prune_loss_drop_rate), float(hp.decay), float(hp.batch_size), _p(self.out), _p(self.saved))
-        # feature regulariser value + loss values for logging, off the critical path: loss = sum_p w_mf[p] * mf_p + emb_0 + feat_reg
+        # loss values for logging, off the critical path: loss = sum_p w_mf[p] * mf_p + emb_0 + feat_reg (the regulariser's value
+        # was computed on s3 during the forward)
         def side():
             with self._on(self.s3):
-                self._feat_reg()
                 self._assemble_loss(0)
         ev = self._mark()                                                # the BPR backward is captured before the side work
         self._backward(probs, users, pos, neg, n_valid, after_first=lambda: (self._fork_from(ev, self.s3), side()))
@@ -400,10 +419,11 @@ class FusedStep:
         inv = 1.0 / (L + 1)
         self._fork(self.s1)
         with self._on(self.s1):
-            # profile chain: prof_u = ui(prof_i), prof_i = iu(P_usr); then user_trans' weight gradient
+            # profile chain: prof_u = ui(prof_i), prof_i = iu(P_usr); user_trans' weight gradient joins the item-side ones below
             self._spmm(self.ui.bwd, self.dprof_u, self.dprof_i, accumulate=True, tag=1)
             self._spmm(self.iu.bwd, self.dprof_i, self.dP_usr, tag=1)
-            self._wgrad(self.dP_usr, m.user_feats, m.user_trans, False, ws=self.ws_wgrad_b)
+            if self.gemm != "bf16x3":
+                self._wgrad(self.dP_usr, m.user_feats, m.user_trans, False, ws=self.ws_wgrad_b)
 
         def id_chain():
             # ID chain (items of layer l+1 from the new users; softmax on the last layer)
@@ -440,28 +460,27 @@ class FusedStep:
             id_chain()
         # side chain: I_cat = iu(U_cat), U_cat = ui(P_cat) (or the pre-propagated projection); then the item-side weight gradients
         self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
-        if self.preprop:
-            dY_cat, feats, roww = self.dU_cat, self.AX, self.a_rowsum     # dW = dU_cat^T (A_ui F), db = sum_u (A_ui 1)[u] dU_cat[u]: no product through A_ui^T
-        else:
+        if not self.preprop:
             self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
-            dY_cat, feats, roww = self.dP_cat, [m.image_feats, m.text_feats] + [m.item_feats[key] for key in self.keys], None
-        item_pairs = [(self._side(dY_cat, 2 + k), feats[2 + k], roww) for k in range(len(self.keys))]
-        text_pairs, image_pairs = [(self._side(dY_cat, 1), feats[1], roww)], [(self._side(dY_cat, 0), feats[0], roww)]
+        dY_cat = self.dU_cat if self.preprop else self.dP_cat
+        targets = self.wgrad_targets(dY_cat, self.dP_usr)
+        item_pairs, text_pairs, image_pairs = targets[0][0], targets[2][0], targets[3][0]
         done = False
         if self.gemm == "bf16x3":
-            # One launch for the three item-side Linears: equal slabs over all of them, so the launch is whole rounds of equal
-            # blocks and the two short gradients pay no ramp-up / ragged last round of their own (round 2, same box: three launches
-            # back to back 0.661 ms per step, one launch 0.637 ms; folding user_trans' in as well - it then no longer runs beside
-            # the side chain's SpMMs - is 1 % slower). The bias gradients (row-weighted when pre-propagated) come out of the same launch.
-            targets = [(item_pairs, m.item_trans.weight.grad, m.item_trans.bias.grad, False),
-                       (text_pairs, m.text_trans.weight.grad, m.text_trans.bias.grad, False),
-                       (image_pairs, m.image_trans.weight.grad, m.image_trans.bias.grad, False)]
+            # ONE launch for all four Linears: equal slabs over all of them, so the launch is whole rounds of equal blocks and the
+            # short gradients pay no ramp-up / ragged last round of their own (round 2, same box: three launches back to back 0.661 ms
+            # per step, one launch 0.637 ms). user_trans' gradient is in the same launch since round 3: with the pre-propagated
+            # operands nothing separates the two launches in time any more, and side by side each ran at half speed (the chip is
+            # power-bound here: profiles/experiments/r03_wgrad.md). The bias gradients (row-weighted when pre-propagated) come out of it too.
+            self._join(self.s1)                                          # dP_usr (the profile chain is long done by now)
             if self.ws_wgrad_multi is None:
                 need = ops.linear_wgrad_multi_workspace(targets)
                 self.ws_wgrad_multi = torch.empty(max(need, 0), dtype=torch.uint8, device=dY_cat.device) if need >= 0 else False
             if self.ws_wgrad_multi is not False:
                 ops.linear_wgrad_multi(targets, self.ws_wgrad_multi)
                 done = True
+            else:                                                        # outside the multi-target fast path: user_trans' on its own
+                self._wgrad(self.dP_usr, m.user_feats, m.user_trans, False, ws=self.ws_wgrad_b)
         if not done:
             # exact-fp32 GEMMs, or shapes outside the multi-target fast path (N != 64, K % 128 != 0): one launch per Linear; their
             # kernels sum dY unweighted, so a pre-propagated step takes its bias gradients from llmrec_weighted_colsum_f32
