@@ -318,8 +318,15 @@ def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumu
         if epilogue is not None:
             raise RuntimeError("spmm: accumulate and an explicit epilogue are exclusive (pass Z = Y, alpha = 1)")
         epilogue = spmm_epilogue(EPI_NONE, 1.0, Y)
+    col_scale = a.col_scale
+    if col_scale is not None and a.val is None and a.nnz >= SPMM_LATENCY_NNZ:
+        # HBM-bound graphs: A diag(c) X = A (c . X) - one dense pass over X (8 d bytes per row) instead of a second random 4-byte
+        # gather per EDGE (PMC, 36.6 M edges: 9.9 GB of memory traffic per launch with the per-edge scale, 6.9 GB without)
+        Xs = torch.empty(X.shape, dtype=torch.float32, device=X.device)
+        _lib.call("llmrec_scale_rows_f32", X.shape[0], d, _p(col_scale), _p(X), _ld(X), _p(Xs), _ld(Xs), _stream())
+        X, col_scale = Xs, None
     _lib.call("llmrec_spmm_f32", a.n_rows, a.n_cols, _p(a.rowptr), _p(a.colidx), _p(a.val), _p(a.row_scale),
-              _p(a.col_scale), _p(X), _ld(X), _p(Y), _ld(Y), d, sw, _c.byref(pl.c_struct()), _p(partials),
+              _p(col_scale), _p(X), _ld(X), _p(Y), _ld(Y), d, sw, _c.byref(pl.c_struct()), _p(partials),
               _c.byref(epilogue) if epilogue is not None else None, _stream())
     return Y
 
