@@ -976,6 +976,10 @@ def main():
         except Exception as e:                                # pragma: no cover - the main line must still be printed
             rep = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if rank == 0:
+            line["scaling_note"] = ("N > 1 measures BASELINE.json configs[3] (north_star's multi-GPU split: user-row-sharded ID path, one I x d exchange per layer "
+                                    "and direction, the same 10 M x 1 M x 200 M graph over the ranks = STRONG scaling); the N = 1 line is configs[1] (Netflix shape). "
+                                    "Scaling is value / single_gpu_reference.value (the same workload on one GPU, measured by rank 0 inside this run), "
+                                    "not value / the N = 1 line's value; the Netflix workload as batch-sharded replicas is netflix_replicas")
             line["netflix_replicas"] = rep
             if ref is not None:
                 line["single_gpu_reference"] = ref
