@@ -436,11 +436,13 @@ int llmrec_score_topk_f32(int32_t n_query, const int64_t* query_users,
                           const int32_t* train_rowptr, const int32_t* train_colidx,
                           int32_t K, int32_t* out_idx /* n_query x K */, float* out_score /* n_query x K */,
                           llmrec_stream_t stream);
-/* The same with a workspace of llmrec_score_topk_workspace_bytes(n_query, n_items) bytes (16-byte aligned; 0 = none needed):
- * the user tiles left over after the last full round of one 16-user tile per compute unit are each swept by several
- * blocks (parts of the item range) whose 64-slot lists are merged by a second launch - the same lists, bit for bit, with
- * the left-over blocks spread over the device. workspace == NULL behaves like llmrec_score_topk_f32. */
-int64_t llmrec_score_topk_workspace_bytes(int32_t n_query, int64_t n_items);
+/* The same with a workspace of llmrec_score_topk_workspace_bytes(n_query, n_items, d) bytes (16-byte aligned):
+ *   - the item table is first re-laid in MFMA fragment order (one pass over Ei, written into the workspace), so that every load of
+ *     the sweep is one contiguous KB instead of 64 row pieces;
+ *   - the user tiles left over after the last full round of one 16-user tile per compute unit are each swept by several
+ *     blocks (parts of the item range) whose 64-slot lists are merged by a second launch, spreading the left-over blocks over the device.
+ * The lists and scores are the same, bit for bit. workspace == NULL behaves like llmrec_score_topk_f32. */
+int64_t llmrec_score_topk_workspace_bytes(int32_t n_query, int64_t n_items, int32_t d);
 int llmrec_score_topk_ws_f32(int32_t n_query, const int64_t* query_users,
                              const float* Eu, int64_t ldu, const float* Ei, int64_t ldi,
                              int64_t n_items, int32_t d,

@@ -58,6 +58,9 @@ struct TopkArgs {
     // 64-slot lists go to ws_idx / ws_score [(tile - split_from) * n_parts + part][16][64] and are merged by topk_merge_kernel
     int split_from, n_parts;
     int32_t* ws_idx; float* ws_score;
+    // the item table re-laid in FRAGMENT order by topk_pack_items_kernel (null: the sweep loads Ei itself):
+    // packed[((tile * 2 + n) * DK + c) * 64 + lane] = the float4 lane `lane` feeds to column tile n, k chunk c of item tile `tile`
+    const float4* packed;
 };
 
 template <int DK>
@@ -190,9 +193,26 @@ __global__ __launch_bounds__(256) void scores_kernel(TopkArgs a) {
     }
 }
 
+// The sweep's B fragments are 16 rows x 64 bytes per load instruction when taken from the row-major table: 64 different cache lines per
+// wave instruction, served one lane at a time by the CU's address path (round 2's ablation: 31 % of the sweep is fragment-load issue, and
+// the exact-fp32 MFMA hides none of it). One pass over the (L2-resident) item table per call re-lays it in fragment order, so that every
+// load of the sweep is 64 lanes x 16 contiguous bytes. Same values, same MFMA order: the scores do not change by a bit.
+__global__ __launch_bounds__(256) void topk_pack_items_kernel(TopkArgs a, int DK, float4* __restrict__ packed, int64_t n_vec) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;     // ((tile * 2 + n) * DK + c) * 64 + lane
+    if (v >= n_vec) return;
+    const int lane = (int)(v & 63), li = lane & 15, lq = lane >> 4;
+    const int64_t f = v >> 6;
+    const int c = (int)(f % DK);
+    const int64_t tn = f / DK;                                     // tile * 2 + n
+    int64_t item = tn * 16 + li;
+    if (item > a.n_items - 1) item = a.n_items - 1;                // the partial last tile repeats the last item (masked by the range check)
+    packed[v] = ld4g(a.Ei + item * a.ldi, 16 * c + 4 * lq, a.d, a.vec_ok);
+}
+
 // FAST: d == 16 DK and 16-byte aligned rows - plain float4 loads. (A branch around a global load makes
 // hipcc wait for each load before issuing the next: the guarded loader costs ~8 exposed L2 latencies per round.)
-template <int DK, bool FAST>
+// PACKED: the item tiles come from a.packed (fragment order, one contiguous KB per load instruction).
+template <int DK, bool FAST, bool PACKED>
 __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(TopkArgs a) {
     __shared__ float buf_s[4][16][TK_CAP];
     __shared__ int32_t buf_i[4][16][TK_CAP];
@@ -261,7 +281,14 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     const float* row0 = a.Ei + (t_begin * TK_TILE + li) * a.ldi;
     const float* row1 = row0 + 16 * a.ldi;
     const int64_t tile_stride = (int64_t)TK_TILE * a.ldi;
+    const float4* pk = PACKED ? a.packed + (t_begin * 2 * DK) * 64 + lane : nullptr;
     auto load_tile = [&](int64_t t) {
+        if (PACKED) {
+#pragma unroll
+            for (int c = 0; c < DK; ++c) { b[0][c] = pk[c * 64]; b[1][c] = pk[(DK + c) * 64]; }
+            pk += 2 * DK * 64;
+            return;
+        }
         const float* r0 = row0; const float* r1 = row1;
         if ((t + 1) * TK_TILE > a.n_items) {                   // wave-uniform
             int64_t i0 = t * TK_TILE + li, i1 = i0 + 16;
@@ -492,10 +519,16 @@ static int launch_topk(const TopkArgs& a, hipStream_t stream) {
     const int n_tiles = (int)ceil_div(a.n_query, 16);
     const int grid = a.split_from + (n_tiles - a.split_from) * a.n_parts;
     const bool fast = a.vec_ok && a.d == 16 * DK;
+    if (SELECT && a.packed) {
+        const int64_t n_vec = ceil_div(a.n_items, TK_TILE) * 2 * DK * 64;
+        topk_pack_items_kernel<<<(unsigned)ceil_div(n_vec, 256), 256, 0, stream>>>(a, DK, const_cast<float4*>(a.packed), n_vec);
+        LLMREC_LAUNCH_CHECK();
+    }
 #define LLMREC_TOPK_CASE(D) case D: \
         if (!SELECT) scores_kernel<D><<<grid, 256, 0, stream>>>(a); \
-        else if (fast) score_topk_kernel<D, true><<<grid, 256, 0, stream>>>(a); \
-        else score_topk_kernel<D, false><<<grid, 256, 0, stream>>>(a); \
+        else if (a.packed) score_topk_kernel<D, true, true><<<grid, 256, 0, stream>>>(a); \
+        else if (fast) score_topk_kernel<D, true, false><<<grid, 256, 0, stream>>>(a); \
+        else score_topk_kernel<D, false, false><<<grid, 256, 0, stream>>>(a); \
         break;
     switch (DK) {
         LLMREC_TOPK_CASE(1) LLMREC_TOPK_CASE(2) LLMREC_TOPK_CASE(3) LLMREC_TOPK_CASE(4)
@@ -517,12 +550,19 @@ using namespace llmrec;
 
 extern "C" {
 
-int64_t llmrec_score_topk_workspace_bytes(int32_t n_query, int64_t n_items) {
-    if (n_query < 0 || n_items <= 0) return -1;
+static int64_t topk_split_bytes(int32_t n_query, int64_t n_items) {
     int split_from = 0, n_parts = 1;
     plan_split(n_query, n_items, &split_from, &n_parts);
     if (n_parts == 1) return 0;
     return ((int64_t)ceil_div(n_query, 16) - split_from) * n_parts * 16 * 64 * 8;
+}
+static int64_t topk_packed_bytes(int64_t n_items, int32_t d) {
+    return ceil_div(n_items, TK_TILE) * 2 * ceil_div(d, 16) * 64 * 16;      // the item table in fragment order (rows padded to whole tiles, d to 16)
+}
+
+int64_t llmrec_score_topk_workspace_bytes(int32_t n_query, int64_t n_items, int32_t d) {
+    if (n_query < 0 || n_items <= 0 || d <= 0) return -1;
+    return align_up(topk_split_bytes(n_query, n_items), 256) + topk_packed_bytes(n_items, d);
 }
 
 int llmrec_score_topk_f32(int32_t n_query, const int64_t* query_users,
@@ -550,13 +590,16 @@ int llmrec_score_topk_ws_f32(int32_t n_query, const int64_t* query_users,
     a.n_items = n_items; a.d = d; a.train_rowptr = train_rowptr; a.train_colidx = train_colidx; a.K = K;
     a.out_idx = out_idx; a.out_score = out_score; a.S = nullptr; a.lds = 0;
     a.vec_ok = (ldu % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)Eu | (uintptr_t)Ei) % 16 == 0);
-    a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr;
-    const int64_t need = llmrec_score_topk_workspace_bytes(n_query, n_items);
-    if (workspace && need > 0) {                               // without a workspace every tile is swept by one block
+    a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
+    if (workspace) {                                           // without a workspace: one block per user tile, fragments straight from Ei
+        const int64_t need = llmrec_score_topk_workspace_bytes(n_query, n_items, d), split = topk_split_bytes(n_query, n_items);
         LLMREC_CHECK_ARG(workspace_bytes >= need && (uintptr_t)workspace % 16 == 0, "score_topk: workspace of %lld bytes needed (16-byte aligned)", (long long)need);
-        plan_split(n_query, n_items, &a.split_from, &a.n_parts);
-        a.ws_score = (float*)workspace;
-        a.ws_idx = (int32_t*)((char*)workspace + need / 2);
+        if (split > 0) {
+            plan_split(n_query, n_items, &a.split_from, &a.n_parts);
+            a.ws_score = (float*)workspace;
+            a.ws_idx = (int32_t*)((char*)workspace + split / 2);
+        }
+        a.packed = (const float4*)((char*)workspace + align_up(split, 256));
     }
     return launch_topk<true>(a, (hipStream_t)stream_);
 }
@@ -572,7 +615,7 @@ int llmrec_scores_f32(int32_t n_query, const int64_t* query_users,
     a.n_items = n_items; a.d = d; a.train_rowptr = nullptr; a.train_colidx = nullptr; a.K = 1;
     a.out_idx = nullptr; a.out_score = nullptr; a.S = S; a.lds = lds;
     a.vec_ok = (ldu % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)Eu | (uintptr_t)Ei) % 16 == 0);
-    a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr;
+    a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
     return launch_topk<false>(a, (hipStream_t)stream_);
 }
 

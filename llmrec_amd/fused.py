@@ -550,7 +550,7 @@ class FusedStep:
             n = q.numel()
             idx = torch.empty(n, K, dtype=torch.int32, device=q.device)
             sc = torch.empty(n, K, dtype=torch.float32, device=q.device)
-            ws = ops.topk_workspace(n, self.I, q.device)
+            ws = ops.topk_workspace(n, self.I, q.device, self.d)
 
             def run():
                 self.forward()

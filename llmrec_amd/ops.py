@@ -774,16 +774,16 @@ def score_topk(Eu, Ei, query_users: torch.Tensor, train: Optional[Csr], K: int):
     n = q.numel()
     idx = torch.empty(n, K, dtype=torch.int32, device=Eu.device)
     sc = torch.empty(n, K, dtype=torch.float32, device=Eu.device)
-    ws = topk_workspace(n, Ei.shape[0], Eu.device)
+    ws = topk_workspace(n, Ei.shape[0], Eu.device, Eu.shape[1])
     _lib.call("llmrec_score_topk_ws_f32", n, _p(q), _p(Eu), _ld(Eu), _p(Ei), _ld(Ei), Ei.shape[0], Eu.shape[1],
               _p(train.rowptr) if train is not None else None, _p(train.colidx) if train is not None else None,
               K, _p(idx), _p(sc), _p(ws), ws.numel() if ws is not None else 0, _stream())
     return idx, sc
 
 
-def topk_workspace(n_query: int, n_items: int, device) -> Optional[torch.Tensor]:
-    """Scratch for llmrec_score_topk_ws_f32 (the part lists of the left-over user tiles); None when no tile is split."""
-    nbytes = _lib.query("llmrec_score_topk_workspace_bytes", n_query, n_items)
+def topk_workspace(n_query: int, n_items: int, device, d: int = 64) -> Optional[torch.Tensor]:
+    """Scratch for llmrec_score_topk_ws_f32: the item table in fragment order + the part lists of the left-over user tiles."""
+    nbytes = _lib.query("llmrec_score_topk_workspace_bytes", n_query, n_items, d)
     return torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes > 0 else None
 
 

@@ -285,9 +285,10 @@ def test_spmm_at_10M_edges_sampled_rows_match_fp64(ops, d):
 
 @pytest.mark.parametrize("n_users", [U_NF, 300, 4096 + 16 * 57])
 def test_topk_split_left_over_tiles_equal_the_unsplit_sweep(ops, n_users):
-    """llmrec_score_topk_ws_f32 cuts the user tiles beyond the last full round of one tile per CU into item parts and
-    merges their lists: the result is the unsplit kernel's, bit for bit (ids and scores), including users whose train
-    rows leave fewer than K candidates in a part."""
+    """llmrec_score_topk_ws_f32 re-lays the item table in MFMA fragment order, cuts the user tiles beyond the last full round of one
+    tile per CU into item parts and merges their lists: the result is the workspace-free kernel's, bit for bit (ids and scores),
+    including users whose train rows leave fewer than K candidates in a part; I_NF = 17366 is not a multiple of the 32-item tile
+    (the packed table's padded last tile)."""
     from llmrec_amd import _lib
     from llmrec_amd.ops import _p, _ld
     g = torch.Generator(device=DEV); g.manual_seed(n_users)
@@ -308,8 +309,8 @@ def test_topk_split_left_over_tiles_equal_the_unsplit_sweep(ops, n_users):
             ci_h[rp_h[u]:rp_h[u + 1]] = np.sort(rng.choice(I_NF, size=int(deg_h[u]), replace=False))
     ci.copy_(torch.from_numpy(ci_h))
     rp32 = rp.to(torch.int32)
-    need = _lib.query("llmrec_score_topk_workspace_bytes", n_users, I_NF)
-    assert need > 0, "these shapes leave user tiles over"
+    need = _lib.query("llmrec_score_topk_workspace_bytes", n_users, I_NF, D)
+    assert need > -(-I_NF // 32) * 2 * (D // 16) * 64 * 16, "these shapes leave user tiles over (more than the packed item table)"
     out = []
     for ws in (None, torch.empty(need, dtype=torch.uint8, device=DEV)):
         idx = torch.empty(n_users, K, dtype=torch.int32, device=DEV)
