@@ -189,6 +189,42 @@ class NetflixShaped:
                         + (" + HIP graph replay" if self.use_graph else "")}
 
 
+    def insitu_gemm_ms(self, rounds: int = 20):
+        """Durations of the step's two GEMM launches INSIDE the step: HIP events recorded on the launching stream right before and after
+        each launch (llmrec_amd/fused.py `probe`) while the step runs with eager launches - the same kernels on the same five streams
+        as the replayed graph, which cannot carry timing events (ROCm refuses external event-record nodes in a captured graph); the
+        rocprofv3 averages of the graph-replayed run are the cross-check (profiles/). Returns {"projection": ms, "wgrad": ms}
+        (wgrad = the GEMM + its slab reduction / AdamW launch), medians over `rounds` steps, or None on batch-sharded replicas."""
+        import torch
+        f = self.fused
+        if hasattr(f, "gsz"):
+            return None
+        ev = {t: [torch.cuda.Event(enable_timing=True) for _ in range(2)] for t in ("projection", "wgrad")}
+        seen = set()
+
+        def probe(tag, edge):
+            ev[tag][edge].record()
+            seen.add((tag, edge))
+        out = None
+        try:
+            f.probe = probe
+            acc = {t: [] for t in ev}
+            for r in range(rounds + 3):
+                u, p, n, nv = self.batcher.next()
+                f.step_eager(u, p, n, nv)
+                torch.cuda.synchronize()
+                if r >= 3:
+                    for t in ev:
+                        if (t, 0) in seen and (t, 1) in seen:
+                            acc[t].append(ev[t][0].elapsed_time(ev[t][1]))
+            out = {t: sorted(v)[len(v) // 2] for t, v in acc.items() if v}
+            out["readings"] = rounds
+        except Exception as e:                                  # pragma: no cover - fall back to the isolated timings
+            out = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
+        finally:
+            f.probe = None
+        return out
+
     def _wgrad_launch_ms(self, dY_cat, dYu, iters: int = 20):
         """Duration of the step's weight-gradient launch (the GEMM over all four Linears + its slab reduction), HIP events on the
         stream it is launched on (a side stream, as llmrec_amd/fused.py launches it), the launch built exactly as the step builds it."""
@@ -220,13 +256,19 @@ class NetflixShaped:
         feats = [j[0] for j in self.fused.projection_jobs()]
         flop_all = sum(2.0 * x.shape[0] * x.shape[1] * d for x in feats)
         byts_all = sum(4.0 * (x.shape[0] * x.shape[1] + d * x.shape[1] + x.shape[0] * d) for x in feats)
-        ms = event_time_ms(self.fused._project_all, 20)
+        insitu = self.insitu_gemm_ms() or {}
+        ms_iso = event_time_ms(self.fused._project_all, 20)
+        ms = insitu.get("projection", ms_iso)
+        t_insitu = ("HIP events on the launching stream right before and after the launch while the whole step runs with eager launches (same kernels "
+                    "and streams as the replayed graph, which cannot carry timing events on ROCm; median of %d steps); ms_isolated = the same launch "
+                    "alone between events after a device synchronisation" % insitu.get("readings", 0))
         bf = self.fused.gemm == "bf16x3"
         out.append({"kernel": ("linear_fwd_grouped_bf16x3_kernel (all 8 projections, one launch; 3-term bf16 split, 6 bf16 MFMAs: "
                                "HBM-bound on the X stream - tflops/frac_mfma_f32 are fp32-EQUIVALENT figures)") if bf else
                               "linear_fwd_grouped_kernel (all 8 projections of one forward, one launch, exact fp32 MFMA)",
                     "pmc": [("linear_fwd_grouped_bf16x3_kernel" if bf else "linear_fwd_grouped_kernel", 1)],
-                    "bound": "hbm" if bf else "mfma", "calls_per_step": 1, "ms": ms,
+                    "bound": "hbm" if bf else "mfma", "calls_per_step": 1, "ms": ms, "ms_isolated": ms_iso,
+                    "timing": t_insitu if "projection" in insitu else "HIP events around the launch on its stream, in isolation",
                     "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                     "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
                     "algorithmic_flop_per_launch": flop_all, "algorithmic_bytes_per_launch": byts_all,
@@ -238,12 +280,13 @@ class NetflixShaped:
         dY_cat = self.fused.dU_cat if self.fused.preprop else self.fused.dP_cat
         dYu = self.fused.dP_usr
         if bf_ok:
-            ms = self._wgrad_launch_ms(dY_cat, dYu)
+            ms_iso = self._wgrad_launch_ms(dY_cat, dYu)
+            ms = insitu.get("wgrad", ms_iso)
             out.append({"kernel": "linear_wgrad_bf16x3_v2_multi_kernel + reduce_chunks_multi_kernel: the weight gradients of all four Linears "
                                   "(item_trans x5, user_trans, text_trans, image_trans) in one launch; 3-term bf16 split: tflops are fp32-EQUIVALENT",
                         "pmc": [("linear_wgrad_bf16x3_v2_multi_kernel", 1), ("reduce_chunks_multi_kernel", 1)],
-                        "launches": 1, "avg_launch_ms": ms,
-                        "timing": "HIP events around the launch on the side stream it is issued on, built as the step builds it (llmrec_amd/fused.py wgrad_targets)",
+                        "launches": 1, "avg_launch_ms": ms, "ms_isolated": ms_iso, "insitu_error": insitu.get("error"),
+                        "timing": t_insitu if "wgrad" in insitu else "HIP events around the launch on the side stream it is issued on, built as the step builds it (llmrec_amd/fused.py wgrad_targets)",
                         "bound": "hbm", "calls_per_step": 1, "ms": ms, "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                         "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
                         "note": "power-bound, not bandwidth-bound: the shader clock averages 1.37 GHz in this kernel (2.33 GHz for its load stream alone, "
@@ -434,7 +477,7 @@ def kernel_time_shares():
     kernel on the critical path. None when no summary is committed."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_nf_kernel_stats*.csv")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_nf_kernel_stats*.csv")))   # by name: the newest round's last
     if not files:
         return None
     path = files[-1]
@@ -768,6 +811,35 @@ def exact_f32_step_time(w: "NetflixShaped", steps: int):
             "unit": "edges/s", "steps": steps, "gemm": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32) in projections and weight-gradients"}
 
 
+def reference_order_step_time(w: "NetflixShaped", steps: int):
+    """The same step with the item-side features projected first and propagated afterwards, as the reference orders the two products
+    (LLMREC_PREPROPAGATE=0: no A_ui F_k operands formed at set-up): a second FusedStep over the same model / optimizer, graph-captured
+    like the timed one."""
+    import torch
+    from llmrec_amd.fused import FusedStep
+    a = w.args
+    old = os.environ.get("LLMREC_PREPROPAGATE")
+    os.environ["LLMREC_PREPROPAGATE"] = "0"
+    try:
+        f = FusedStep(w.model, w.graph, w.hp, (a.model_cat_rate, a.user_cat_rate, a.item_cat_rate), w.opt, w.hp.batch_size + w.batcher.n_aug)
+    finally:
+        if old is None:
+            del os.environ["LLMREC_PREPROPAGATE"]
+        else:
+            os.environ["LLMREC_PREPROPAGATE"] = old
+    f.capture(batcher=w.batcher)
+    for _ in range(5):
+        f.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        f.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"ms_per_step": dt / steps * 1e3, "value": steps * w.hp.batch_size / dt, "unit": "edges/s", "steps": steps,
+            "order": "project F_k [I x K], then propagate through A_ui and A_iu every step (Models.py:145-157 as written)"}
+
+
 def main():
     a = parse()
     import torch
@@ -889,6 +961,8 @@ def main():
                         "includes": "no-grad full-graph forward + fp32 MFMA scoring + masked top-50"}
         if world == 1 and not a.no_kernel_roofline and getattr(w.fused, "gemm", "f32") == "bf16x3" and os.environ.get("LLMREC_FORCE_DP", "0") != "1":
             line["exact_f32"] = exact_f32_step_time(w, min(a.steps, 100))
+            if getattr(w.fused, "preprop", False):
+                line["reference_order"] = reference_order_step_time(w, min(a.steps, 100))
         if not a.no_kernel_roofline:
             ks = w.kernel_rooflines()
             line["kernels"] = ks
@@ -906,7 +980,7 @@ def main():
                         "achieved": k["gbs"] if hbm else k["tflops"], "peak": HBM_PEAK_GBS if hbm else MFMA_F32_PEAK_TFLOPS,
                         "unit": "GB/s" if hbm else "TFLOP/s", "frac": k["frac_hbm"] if hbm else k["frac_mfma_f32"],
                         "traffic": None if traffic is None else traffic / n, "traffic_source": src,
-                        "launches_per_step": n, "ms_per_launch": k["ms"] / n, "ms_per_step": k["ms"],
+                        "launches_per_step": n, "ms_per_launch": k["ms"] / n, "ms_per_step": k["ms"], "ms_isolated": k.get("ms_isolated"),
                         "algorithmic_flop_per_launch": k["algorithmic_flop_per_launch"],
                         "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"],
                         "timing": k.get("timing", "HIP events around the launch on its stream, in isolation"),

@@ -180,6 +180,17 @@ typedef struct { int32_t n_problems; const llmrec_wgrad_problem_t* problems; int
 int64_t llmrec_linear_wgrad_multi_workspace_bytes(int32_t n_targets, const llmrec_wgrad_target_t* targets_host, int32_t N);
 int llmrec_linear_wgrad_multi_bf16x3(int32_t n_targets, const llmrec_wgrad_target_t* targets_host, int32_t N,
                                      void* workspace, int64_t workspace_bytes, llmrec_stream_t stream);
+/* llmrec_linear_wgrad_multi_bf16x3 with the AdamW update of every target's W and b inside the reduction launch (the arithmetic of
+ * llmrec_adamw_multi_f32, element by element, on the gradient that launch has just summed and stored: parameters, moments and
+ * gradients come out bit-identical to the two calls in sequence). A fused training step ends on this launch instead of
+ * reduction -> update. updates_host[t]: W / b (the parameters dW / db are the gradients of; b, m_b, v_b NULL when the target has no
+ * db), their moments, g_scale as in llmrec_adamw_tensor_t; W and dW contiguous (lddw == K); state3 = the device state of
+ * llmrec_adamw_advance. */
+typedef struct { float* W; float* m_W; float* v_W; float* b; float* m_b; float* v_b; float g_scale; } llmrec_wgrad_update_t;
+int llmrec_linear_wgrad_multi_adamw_bf16x3(int32_t n_targets, const llmrec_wgrad_target_t* targets_host, int32_t N,
+                                           void* workspace, int64_t workspace_bytes, const llmrec_wgrad_update_t* updates_host,
+                                           const float* state3, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                           llmrec_stream_t stream);
 /* Same contract, split precision: each fp32 operand = exact sum of three bf16 numbers, product by the
  * six bf16 MFMAs (v_mfma_f32_16x16x32_bf16, fp32 accumulate) whose terms are >= 2^-24 relative.
  * fp32-roundoff-class error (not the bit-identical fma chain); 3/8 of the fp32 matrix time, so the
@@ -203,6 +214,10 @@ int llmrec_softmax_rows_fwd_f32(int64_t rows, int32_t d, const float* Z, int64_t
 int llmrec_softmax_rows_bwd_f32(int64_t rows, int32_t d, const float* Y, int64_t ldy,
                                 const float* dY, int64_t lddy, float* dZ, int64_t lddz,
                                 llmrec_stream_t stream);
+/* dZ = softmax_bwd(Y, alpha * dY): the scaling of the incoming gradient (the "+ mean term" factor 1 / (L + 1) of the ID chain) in the
+ * same pass; alpha = 1 is llmrec_softmax_rows_bwd_f32 bit for bit. */
+int llmrec_softmax_rows_bwd_scaled_f32(int64_t rows, int32_t d, float alpha, const float* Y, int64_t ldy, const float* dY, int64_t lddy,
+                                       float* dZ, int64_t lddz, llmrec_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * R6  fusion  out = scale * sum_t mean_terms[t] + sum_t rates[t] * normalize(terms[t])
@@ -322,6 +337,25 @@ int llmrec_bpr_multi_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* pro
                              const int64_t* users, const int64_t* pos, const int64_t* neg,
                              int32_t B_max, const int32_t* n_valid_dev, float decay, float batch_size_flag,
                              const float* saved, llmrec_stream_t stream);
+/* The same step of one LOCAL batch (no gathered layout) with the selection and the backward in ONE launch - the fused training
+ * step's critical path is scores -> [rank + backward rows] instead of scores -> rank -> reduce -> backward:
+ *   llmrec_bpr_multi_scores_f32       launch 1: m_b, sigmoid(-x_b) and the per-sample squared norms into `saved`
+ *   llmrec_bpr_multi_select_bwd_f32   launch 2: every block re-sums the batch's squared norms (the summation tree of the loss launch
+ *                                     below, so the bits agree), ranks its 16 samples against the batch in LDS, writes the kept
+ *                                     coefficients / values into `saved` and scatter-adds the gradient rows (as llmrec_bpr_multi_bwd_f32)
+ *   llmrec_bpr_multi_losses_f32       any time after launch 2, on any stream: out[p] = {mf_p, emb_p} and the norm / k slots of `saved`
+ *                                     (only the logged loss values depend on it)
+ * Results: `out`, `saved` bit-identical to llmrec_bpr_multi_fwd_f32, gradient rows identical to llmrec_bpr_multi_bwd_f32 up to the
+ * order of the atomic adds on rows several samples share. */
+int llmrec_bpr_multi_scores_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
+                                const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                int32_t B_max, const int32_t* n_valid_dev, float* saved, llmrec_stream_t stream);
+int llmrec_bpr_multi_select_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
+                                    const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                    int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
+                                    float batch_size_flag, float* saved, llmrec_stream_t stream);
+int llmrec_bpr_multi_losses_f32(int32_t n_problems, int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
+                                float batch_size_flag, float* out, float* saved, llmrec_stream_t stream);
 /* Clears exactly the rows llmrec_bpr_multi_bwd_f32 added into (dEu[u_b], dEi[p_b], dEi[q_b] of every problem, b < n_valid),
  * so scatter targets that start all-zero are all-zero again. */
 int llmrec_bpr_multi_zero_rows_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,

@@ -250,6 +250,77 @@ __global__ __launch_bounds__(256) void bpr_bwd_multi_kernel(BprTables t, int d, 
     }
 }
 
+// selection + backward of a LOCAL batch in one launch (llmrec_bpr_multi_select_bwd_f32): grid = (ceil(B_max / 16), problems).
+// Every block (1) re-sums the batch's three squared-norm columns with the summation tree of bpr_reduce_kernel - thread t of that
+// 1024-thread launch is emulated by the four slots t, t + 256, ... of this block's threads, then the same pairwise tree over 1024 LDS
+// slots - so Su, Sp, Sq carry the bits the loss launch writes; (2) stages the batch's log-sigmoids in LDS and ranks its 16 samples as
+// bpr_rank_kernel does; (3) adds the gradient rows of its samples as bpr_bwd_multi_kernel does.
+__global__ __launch_bounds__(256) void bpr_select_bwd_multi_kernel(BprTables t, int d, const int64_t* __restrict__ users,
+                                                                   const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
+                                                                   int B_max, const int32_t* __restrict__ n_valid_dev, double remember_rate,
+                                                                   float decay, float bsz, float* __restrict__ saved_all, int saved_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* m_s = reinterpret_cast<float*>(smem);                      // [B]
+    __shared__ float red[3][BPR_THREADS];
+    const int B = bpr_batch(n_valid_dev, B_max);
+    const int prob = blockIdx.y;
+    float* saved = saved_all + (int64_t)prob * saved_stride;
+    float* sc = saved + B_max + 4;
+    for (int v = threadIdx.x; v < BPR_THREADS; v += 256) {            // the partial sums of bpr_reduce_kernel's thread v
+        float su = 0.f, sp = 0.f, sq = 0.f;
+        for (int b = v; b < B; b += BPR_THREADS) {
+            m_s[b] = sc[b];
+            su += sc[2 * B_max + b]; sp += sc[3 * B_max + b]; sq += sc[4 * B_max + b];
+        }
+        red[0][v] = su; red[1][v] = sp; red[2][v] = sq;
+    }
+    __syncthreads();
+    for (int off = BPR_THREADS / 2; off > 0; off >>= 1) {             // block_tree_sum's tree, three columns at once
+        for (int i = threadIdx.x; i < off; i += 256) {
+            red[0][i] += red[0][i + off]; red[1][i] += red[1][i + off]; red[2][i] += red[2][i + off];
+        }
+        __syncthreads();
+    }
+    const float Su = red[0][0], Sp = red[1][0], Sq = red[2][0];
+    const int k = (int)(remember_rate * (double)B);
+    const int gl = threadIdx.x & 15;
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (b >= B_max) return;
+    if (b >= B) { if (gl == 0) { saved[b] = 0.f; sc[B_max + b] = 0.f; } return; }
+    const float mb = m_s[b];
+    bool keep = true;
+    if (k < B) {
+        int rank = 0;
+        for (int j = gl; j < B; j += 16) {
+            const float mj = m_s[j];
+            rank += (mj < mb) || (mj == mb && j < b);
+        }
+        rank = (int)group_sum<16>((float)rank);                           // < 2^24: exact
+        keep = rank < k;
+    }
+    const float coef = keep ? (-1.0f / (float)k) * sc[B_max + b] : 0.f;   // every lane of the group reads slot 1 before lane 0 rewrites it
+    __builtin_amdgcn_wave_barrier();
+    if (gl == 0) { saved[b] = coef; sc[B_max + b] = keep ? mb : 0.f; }
+    const float g_mf = t.g_mf[prob], g_emb = t.g_emb[prob];
+    const float base = -4.0f * decay / bsz * g_emb;
+    const float du_ = 2.0f * Su + 1e-8f, dp_ = 2.0f * Sp + 1e-8f, dq_ = 2.0f * Sq + 1e-8f;
+    const float cu = base / (du_ * du_), cp = base / (dp_ * dp_), cq = base / (dq_ * dq_);
+    const int64_t ui = users[b], pi = pos[b], qi = neg[b];
+    const float ds = g_mf * coef;
+    const float* u = t.Eu[prob] + ui * t.ldu[prob];
+    const float* p = t.Ei[prob] + pi * t.ldi[prob];
+    const float* q = t.Ei[prob] + qi * t.ldi[prob];
+    float* du = t.dEu[prob] + ui * t.lddu[prob];
+    float* dpp = t.dEi[prob] + pi * t.lddi[prob];
+    float* dqq = t.dEi[prob] + qi * t.lddi[prob];
+    for (int c = gl; c < d; c += 16) {
+        const float uu = u[c], pp = p[c], qq = q[c];
+        atomicAdd(du + c, fmaf(ds, pp - qq, cu * uu));
+        atomicAdd(dpp + c, fmaf(ds, uu, cp * pp));
+        atomicAdd(dqq + c, fmaf(-ds, uu, cq * qq));
+    }
+}
+
 // the rows bpr_bwd_multi_kernel added into are cleared again (same grid): the scatter targets stay all-zero between steps
 // without a dense memset
 __global__ __launch_bounds__(256) void bpr_zero_rows_kernel(BprTables t, int d, const int64_t* __restrict__ users,
@@ -613,6 +684,45 @@ int llmrec_bpr_multi_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* pro
     dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_problems);
     bpr_bwd_multi_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(t, d, users, pos, neg, B_max, n_valid_dev, decay, batch_size_flag,
                                                                 saved, LLMREC_BPR_SAVED_FLOATS(B_max));
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_bpr_multi_scores_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
+                                const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                int32_t B_max, const int32_t* n_valid_dev, float* saved, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && problems_host && d > 0 && saved, "bpr_multi_scores: bad argument");
+    if (B_max > LLMREC_BPR_MAX_B) { set_error("bpr_multi_scores: B_max %d > %d", B_max, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
+    LLMREC_CHECK_ARG(B_max == 0 || (users && pos && neg), "bpr_multi_scores: null index pointer");
+    BprTables t = {};
+    LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, false), "bpr_multi_scores: bad problem table");
+    return launch_bpr_fwd(t, n_problems, d, users, pos, neg, B_max, n_valid_dev, 0.0, 0.f, 1.f, nullptr, saved, BprGather{}, true, false,
+                          nullptr, (hipStream_t)stream_);
+}
+
+int llmrec_bpr_multi_select_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
+                                    const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                    int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
+                                    float batch_size_flag, float* saved, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && problems_host && d > 0 && saved, "bpr_multi_select_bwd: bad argument");
+    if (B_max > LLMREC_BPR_MAX_B) { set_error("bpr_multi_select_bwd: B_max %d > %d", B_max, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
+    if (B_max == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(users && pos && neg, "bpr_multi_select_bwd: null index pointer");
+    BprTables t = {};
+    LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, true), "bpr_multi_select_bwd: bad problem table");
+    dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_problems);
+    bpr_select_bwd_multi_kernel<<<grid, 256, sizeof(float) * (size_t)B_max, (hipStream_t)stream_>>>(
+        t, d, users, pos, neg, B_max, n_valid_dev, remember_rate, decay, batch_size_flag, saved, LLMREC_BPR_SAVED_FLOATS(B_max));
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_bpr_multi_losses_f32(int32_t n_problems, int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
+                                float batch_size_flag, float* out, float* saved, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && B_max >= 0 && out && saved, "bpr_multi_losses: bad argument");
+    if (B_max > LLMREC_BPR_MAX_B) { set_error("bpr_multi_losses: B_max %d > %d", B_max, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
+    bpr_reduce_kernel<<<n_problems, BPR_THREADS, 0, (hipStream_t)stream_>>>(B_max, n_valid_dev, remember_rate, decay, batch_size_flag, out, saved,
+                                                                           LLMREC_BPR_SAVED_FLOATS(B_max), BprGather{});
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

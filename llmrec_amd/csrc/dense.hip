@@ -1173,8 +1173,17 @@ struct ReduceMulti {
     int32_t block_begin[LLMREC_WGRAD_MAX_TARGETS + 1];
     int32_t n_targets;
 };
+// the optional AdamW update riding in the reduction launch (llmrec_linear_wgrad_multi_adamw_bf16x3)
+struct ReduceUpdate {
+    float* p[LLMREC_WGRAD_MAX_TARGETS]; float* mo[LLMREC_WGRAD_MAX_TARGETS]; float* vo[LLMREC_WGRAD_MAX_TARGETS];
+    float* pb[LLMREC_WGRAD_MAX_TARGETS]; float* mb[LLMREC_WGRAD_MAX_TARGETS]; float* vb[LLMREC_WGRAD_MAX_TARGETS];
+    float gscale[LLMREC_WGRAD_MAX_TARGETS];
+    const float* state;
+    float decay_mul, b1, b2, eps;
+};
 // reduce_chunks_kernel for every target of a multi-target launch (same chunk order, same four-way summation)
-__global__ void reduce_chunks_multi_kernel(ReduceMulti m) {
+template <bool UPDATE>
+__global__ void reduce_chunks_multi_kernel(ReduceMulti m, ReduceUpdate u) {
     int t = 0;
     while (t + 1 < m.n_targets && (int)blockIdx.x >= m.block_begin[t + 1]) ++t;
     const int64_t e = (int64_t)(blockIdx.x - m.block_begin[t]) * blockDim.x + threadIdx.x;
@@ -1197,7 +1206,24 @@ __global__ void reduce_chunks_multi_kernel(ReduceMulti m) {
     float* o;
     if (second) o = m.out_b[t] + (e - n_elem);
     else { const int64_t r = e / m.row_len[t], col = e % m.row_len[t]; o = m.out[t] + r * m.ld_out[t] + col; }
-    *o = m.accumulate[t] ? (*o + s) : s;
+    const float g = m.accumulate[t] ? (*o + s) : s;
+    *o = g;
+    if (UPDATE) {                                                // adamw_multi_kernel's arithmetic (rowops.hip) on this element
+        const int64_t i = second ? e - n_elem : e;               // (W contiguous: ld_out == row_len)
+        float* __restrict__ p = (second ? u.pb[t] : u.p[t]) + i;
+        float* __restrict__ mo = (second ? u.mb[t] : u.mo[t]) + i;
+        float* __restrict__ vo = (second ? u.vb[t] : u.vo[t]) + i;
+        const float gs = u.gscale[t];
+        const float step_size = u.state[1], bc2s = u.state[2];
+        const float w1 = 1.0f - u.b1, w2 = 1.0f - u.b2;
+        const float gi = gs == 1.0f ? g : gs * g;
+        float pi = *p * u.decay_mul;
+        const float mi = *mo + w1 * (gi - *mo);
+        const float vi = fmaf(w2 * gi, gi, *vo * u.b2);
+        const float denom = sqrtf(vi) / bc2s + u.eps;
+        pi = pi - step_size * (mi / denom);
+        *p = pi; *mo = mi; *vo = vi;
+    }
 }
 
 // out[e] (+)= sum over chunks of partial[chunk][e], chunks in ascending order (deterministic); a second, short
@@ -1526,8 +1552,8 @@ int64_t llmrec_linear_wgrad_multi_workspace_bytes(int32_t n_targets, const llmre
     return bytes;
 }
 
-int llmrec_linear_wgrad_multi_bf16x3(int32_t n_targets, const llmrec_wgrad_target_t* t, int32_t N,
-                                     void* workspace, int64_t workspace_bytes, llmrec_stream_t stream_) {
+static int linear_wgrad_multi_impl(int32_t n_targets, const llmrec_wgrad_target_t* t, int32_t N, void* workspace, int64_t workspace_bytes,
+                                   const ReduceUpdate* upd, llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!wgrad_multi_ok(n_targets, t, N)) {
         set_error("linear_wgrad_multi: outside the fast path (1..%d targets, N %% 64 == 0, K %% 64 == 0, non-empty 16-byte aligned problems, 32-bit offsets)",
@@ -1576,9 +1602,33 @@ int llmrec_linear_wgrad_multi_bf16x3(int32_t n_targets, const llmrec_wgrad_targe
     if (version == 1) linear_wgrad_bf16x3_multi_kernel<<<grid, 256, 0, stream>>>(m, N);
     else linear_wgrad_bf16x3_v2_multi_kernel<<<grid, 256, 0, stream>>>(m, N);
     LLMREC_LAUNCH_CHECK();
-    reduce_chunks_multi_kernel<<<rblocks, 256, 0, stream>>>(r);
+    if (upd) reduce_chunks_multi_kernel<true><<<rblocks, 256, 0, stream>>>(r, *upd);
+    else reduce_chunks_multi_kernel<false><<<rblocks, 256, 0, stream>>>(r, ReduceUpdate{});
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
+}
+
+int llmrec_linear_wgrad_multi_bf16x3(int32_t n_targets, const llmrec_wgrad_target_t* t, int32_t N,
+                                     void* workspace, int64_t workspace_bytes, llmrec_stream_t stream_) {
+    return linear_wgrad_multi_impl(n_targets, t, N, workspace, workspace_bytes, nullptr, stream_);
+}
+
+int llmrec_linear_wgrad_multi_adamw_bf16x3(int32_t n_targets, const llmrec_wgrad_target_t* t, int32_t N,
+                                           void* workspace, int64_t workspace_bytes, const llmrec_wgrad_update_t* upd,
+                                           const float* state3, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                           llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(upd && state3 && n_targets >= 1 && n_targets <= LLMREC_WGRAD_MAX_TARGETS && t, "linear_wgrad_multi_adamw: bad argument");
+    ReduceUpdate u = {};
+    for (int i = 0; i < n_targets; ++i) {
+        LLMREC_CHECK_ARG(upd[i].W && upd[i].m_W && upd[i].v_W, "linear_wgrad_multi_adamw: target %d has a null parameter / moment pointer", i);
+        LLMREC_CHECK_ARG(!t[i].db || (upd[i].b && upd[i].m_b && upd[i].v_b), "linear_wgrad_multi_adamw: target %d has db but no bias parameter / moments", i);
+        LLMREC_CHECK_ARG(t[i].lddw == t[i].K, "linear_wgrad_multi_adamw: target %d: dW (and W) must be contiguous (lddw == K)", i);
+        LLMREC_CHECK_ARG(upd[i].g_scale != 0.0f, "linear_wgrad_multi_adamw: target %d has g_scale 0 (set 1 for a plain gradient)", i);
+        u.p[i] = upd[i].W; u.mo[i] = upd[i].m_W; u.vo[i] = upd[i].v_W; u.pb[i] = upd[i].b; u.mb[i] = upd[i].m_b; u.vb[i] = upd[i].v_b;
+        u.gscale[i] = upd[i].g_scale;
+    }
+    u.state = state3; u.decay_mul = (float)(1.0 - (double)lr * (double)weight_decay); u.b1 = beta1; u.b2 = beta2; u.eps = eps;
+    return linear_wgrad_multi_impl(n_targets, t, N, workspace, workspace_bytes, &u, stream_);
 }
 
 #ifdef LLMREC_TOOLS_BUILD

@@ -96,11 +96,15 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(int64_t rows, int d, c
 template <int VEC, int NCHUNK>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(int64_t rows, int d, const float* __restrict__ Y, int64_t ldy,
                                                           const float* __restrict__ dY, int64_t lddy,
-                                                          float* __restrict__ dZ, int64_t lddz) {
+                                                          float* __restrict__ dZ, int64_t lddz, float alpha) {
     ROW_LOOP_HEADER {
         RowReg<VEC, NCHUNK> y, g;
         y.load(Y + row * ldy, gl, d);
         g.load(dY + row * lddy, gl, d);
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k)                               // dY pre-scaled (alpha = 1: exact): the "+ mean term" axpy ahead of
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) g.x[k][q] *= alpha;          // the ID chain's first softmax backward rides here
         const float dot = y.dot(g);
 #pragma unroll
         for (int k = 0; k < NCHUNK; ++k)
@@ -572,8 +576,8 @@ int llmrec_softmax_rows_fwd_f32(int64_t rows, int32_t d, const float* Z, int64_t
     return LLMREC_OK;
 }
 
-int llmrec_softmax_rows_bwd_f32(int64_t rows, int32_t d, const float* Y, int64_t ldy, const float* dY, int64_t lddy,
-                                float* dZ, int64_t lddz, llmrec_stream_t stream_) {
+int llmrec_softmax_rows_bwd_scaled_f32(int64_t rows, int32_t d, float alpha, const float* Y, int64_t ldy, const float* dY, int64_t lddy,
+                                       float* dZ, int64_t lddz, llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LLMREC_CHECK_ARG(rows >= 0 && d > 0, "softmax_bwd: bad sizes");
     if (rows == 0) return LLMREC_OK;
@@ -581,11 +585,16 @@ int llmrec_softmax_rows_bwd_f32(int64_t rows, int32_t d, const float* Y, int64_t
     const bool vec4 = d % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && lddz % 4 == 0 && aligned16(Y) && aligned16(dY) && aligned16(dZ);
     const int grid = grid_for(rows, ROWS_PER_BLOCK);
     int rc = dispatch_rows(d, vec4,
-        [&](auto nc) { softmax_bwd_kernel<4, decltype(nc)::value><<<grid, 256, 0, stream>>>(rows, d, Y, ldy, dY, lddy, dZ, lddz); return 0; },
-        [&](auto nc) { softmax_bwd_kernel<1, decltype(nc)::value><<<grid, 256, 0, stream>>>(rows, d, Y, ldy, dY, lddy, dZ, lddz); return 0; });
+        [&](auto nc) { softmax_bwd_kernel<4, decltype(nc)::value><<<grid, 256, 0, stream>>>(rows, d, Y, ldy, dY, lddy, dZ, lddz, alpha); return 0; },
+        [&](auto nc) { softmax_bwd_kernel<1, decltype(nc)::value><<<grid, 256, 0, stream>>>(rows, d, Y, ldy, dY, lddy, dZ, lddz, alpha); return 0; });
     if (rc) return rc;
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
+}
+
+int llmrec_softmax_rows_bwd_f32(int64_t rows, int32_t d, const float* Y, int64_t ldy, const float* dY, int64_t lddy,
+                                float* dZ, int64_t lddz, llmrec_stream_t stream_) {
+    return llmrec_softmax_rows_bwd_scaled_f32(rows, d, 1.0f, Y, ldy, dY, lddy, dZ, lddz, stream_);
 }
 
 int llmrec_fuse_fwd_f32(int64_t rows, int32_t d, float mean_scale,

@@ -127,6 +127,9 @@ class FusedStep:
         # (Batch-sharded replicas all-reduce the gradients first and update afterwards: llmrec_amd/dp.py sets this to False.)
         self.inline_adamw = getattr(type(self), "INLINE_ADAMW", True)
         self._zero_in_forward = False                         # set by step_eager: forward() alone (evaluation) must not advance AdamW
+        # measurement hook (bench.py): probe(tag, edge) is called on the launching stream right before (edge 0) and after (edge 1) the two
+        # GEMM launches, so that a copy of the step graph can carry timing events around them; None on the product path
+        self.probe = None
         self._emb_params = [model.user_id_embedding.weight, model.item_id_embedding.weight]
         self._lin_params = [p for p in optimizer.params if p.grad is not None and all(p is not e for e in self._emb_params)]
         # Launch (= capture) order at the fork points decides which branch the graph runs behind its parent without a cross-queue
@@ -247,8 +250,8 @@ class FusedStep:
     def _softmax(self, Z, Y):
         _call("llmrec_softmax_rows_fwd_f32", Z.shape[0], self.d, _p(Z), _ld(Z), _p(Y), _ld(Y))
 
-    def _softmax_bwd(self, Y, dY, dZ):
-        _call("llmrec_softmax_rows_bwd_f32", Y.shape[0], self.d, _p(Y), _ld(Y), _p(dY), _ld(dY), _p(dZ), _ld(dZ))
+    def _softmax_bwd(self, Y, dY, dZ, alpha: float = 1.0):
+        _call("llmrec_softmax_rows_bwd_scaled_f32", Y.shape[0], self.d, float(alpha), _p(Y), _ld(Y), _p(dY), _ld(dY), _p(dZ), _ld(dZ))
 
     def _axpy(self, alpha, X, Y, accumulate, rows=None, cols=None):
         rows = X.shape[0] if rows is None else rows
@@ -290,7 +293,11 @@ class FusedStep:
                     self._spmm(self.ui.fwd, i_prev, self.Ul[l], tag=2)
                     self._spmm(self.iu.fwd, self.Ul[l], self.Il[l], tag=2)
                 i_prev = self.Il[l]
+        if self.probe is not None:
+            self.probe("projection", 0)
         self._project_all()
+        if self.probe is not None:
+            self.probe("projection", 1)
         ev1 = self._mark()
         if not self.preprop:
             self._spmm(self.ui.fwd, self.P_cat, self.U_cat)              # 7 streams, one adjacency pass
@@ -351,15 +358,20 @@ class FusedStep:
             raise RuntimeError("FusedStep: batch of %d exceeds b_max %d" % (B, self.b_max))
         probs = self._problems()
         hp = self.hp
-        _call("llmrec_bpr_multi_fwd_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid),
-              float(1 - hp.prune_loss_drop_rate), float(hp.decay), float(hp.batch_size), _p(self.out), _p(self.saved))
-        # loss values for logging, off the critical path: loss = sum_p w_mf[p] * mf_p + emb_0 + feat_reg (the regulariser's value
-        # was computed on s3 during the forward)
-        def side():
-            with self._on(self.s3):
-                self._assemble_loss(0)
-        ev = self._mark()                                                # the BPR backward is captured before the side work
-        self._backward(probs, users, pos, neg, n_valid, after_first=lambda: (self._fork_from(ev, self.s3), side()))
+        remember = float(1 - hp.prune_loss_drop_rate)
+        # critical path: scores -> [selection + gradient rows] (two launches); the loss VALUES (one more launch) and their assembly for
+        # the log line ride on the ID chain's stream (a branch of their own right behind the BPR launches: the graph ran it as the step's tail)
+        self._check_scatter_targets()
+        _call("llmrec_bpr_multi_scores_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), _p(self.saved))
+        _call("llmrec_bpr_multi_select_bwd_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), remember,
+              float(hp.decay), float(hp.batch_size), _p(self.saved))
+
+        def side():                              # (runs on the ID chain's stream, _backward places it)
+            _call("llmrec_bpr_multi_losses_f32", self.n_prob, B, _p(n_valid), remember, float(hp.decay), float(hp.batch_size),
+                  _p(self.out), _p(self.saved))
+            self._join(self.s3)                  # the regulariser's value (s3, during the forward)
+            self._assemble_loss(0)               # loss = sum_p w_mf[p] * mf_p + emb_0 + feat_reg
+        self._backward(probs, users, pos, neg, n_valid, side_work=side, bpr_bwd_done=True)
         self._join(self.s3)
 
     def _assemble_loss(self, mode: int, tail=None, inv_world: float = 1.0):
@@ -374,20 +386,27 @@ class FusedStep:
             _call("llmrec_sumsq_f32", blk.shape[0], 2 * self.d, _p(blk), _ld(blk), float(coef), k, _p(self.scal), _p(self.ws_sumsq),
                   self.ws_sumsq.numel())
 
-    def _backward(self, probs, users, pos, neg, n_valid, replicated_scale: float = 1.0, after_first=None):
-        """Hand-written backward from the saved BPR state to the parameter gradients (and, with inline_adamw, the update).
-        replicated_scale weights the batch-independent loss terms (1 / world on batch-sharded replicas, whose
-        gradients are summed over ranks afterwards)."""
-        hp, d, L, S = self.hp, self.d, self.L, self.S
-        B = users.numel()
-        coef = hp.feat_reg_decay * 0.5 / self.I * replicated_scale
+    def _check_scatter_targets(self):
         if self.check_zero and not torch.cuda.is_current_stream_capturing():
             dirty = [n for n, t in (("dE_u", self.dE_u), ("dE_i", self.dE_i), ("sc_U", self.sc_U), ("sc_I", self.sc_I), ("sc_prof", self.sc_prof))
                      if float(t.abs().max()) != 0.0]
             if dirty:
                 raise RuntimeError("FusedStep: scatter targets not all-zero before the loss backward: %s (an aborted step? call reset_scatter_targets())" % dirty)
-        _call("llmrec_bpr_multi_bwd_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), float(hp.decay),
-              float(hp.batch_size), _p(self.saved))
+
+    def _backward(self, probs, users, pos, neg, n_valid, replicated_scale: float = 1.0, after_first=None, bpr_bwd_done: bool = False,
+                  side_work=None):
+        """Hand-written backward from the saved BPR state to the parameter gradients (and, with inline_adamw, the update).
+        replicated_scale weights the batch-independent loss terms (1 / world on batch-sharded replicas, whose
+        gradients are summed over ranks afterwards). bpr_bwd_done: the loss launch already scattered the gradient rows.
+        after_first: side work captured right after the BPR backward; side_work: launches for the ID chain's stream, ahead of its last SpMM."""
+        hp, d, L, S = self.hp, self.d, self.L, self.S
+        B = users.numel()
+        coef = hp.feat_reg_decay * 0.5 / self.I * replicated_scale
+        if not bpr_bwd_done:
+            self._check_scatter_targets()
+            _call("llmrec_bpr_multi_bwd_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), float(hp.decay),
+                  float(hp.batch_size), _p(self.saved))
+        ev_rows = self._mark()                                           # dE_u / dE_i hold the scattered rows: all the ID chain needs
         if after_first is not None:
             after_first()
 
@@ -415,6 +434,7 @@ class FusedStep:
         problem(arr[1], self.dE_u, self.U_cat, self.prof_u, self.dU_cat, self.dprof_u,
                 [self._side(self.sc_U, 0), self._side(self.sc_U, 1), self.sc_prof] + [None] * len(self.keys))
         _call("llmrec_fuse_bwd_src_multi_f32", 2, arr, d)
+        ev_fuse = self._mark()                                           # the fusion backward has read dE_u / dE_i
         m = self.m
         inv = 1.0 / (L + 1)
         self._fork(self.s1)
@@ -431,10 +451,15 @@ class FusedStep:
             #   dI[L] = inv dE_i                      -> g = softmax_bwd(I_L, dI[L])            (one row kernel, no SpMM feeds it)
             #   dU[l+1] = inv dE_u + A_iu^T g         -> h = softmax_bwd(U_L, dU[l+1]) on the last layer
             #   dI[l]   = inv dE_i + A_ui^T h         -> (l > 0) feeds the next round as g; (l = 0) IS the item table's gradient
+            # U^0 only enters the mean: the user table's gradient needs nothing else. It and the logged loss values go first: whatever
+            # this stream still has queued when the weight-gradient GEMM takes every CU (about when the chain's last SpMM starts)
+            # waits for the GEMM's blocks to retire and becomes the step's tail.
+            self._axpy(inv, self.dE_u, m.user_id_embedding.weight.grad, False)
+            if side_work is not None:
+                side_work()
             g = self.bufI
-            if L >= 1:
-                self._axpy(inv, self.dE_i, self.bufI, False)                              # dI[L] = mean part
-                self._softmax_bwd(self.Il[L - 1], self.bufI, self.tmpI); g = self.tmpI
+            if L >= 1:                                                                    # dI[L] = inv dE_i (mean part), g = softmax_bwd(I_L, dI[L])
+                self._softmax_bwd(self.Il[L - 1], self.dE_i, self.tmpI, alpha=inv); g = self.tmpI
             for l in range(L - 1, -1, -1):
                 last = l == L - 1
                 if last:
@@ -449,13 +474,18 @@ class FusedStep:
                 g = self.bufI
             if L == 0:
                 self._axpy(inv, self.dE_i, m.item_id_embedding.weight.grad, False)
-            self._axpy(inv, self.dE_u, m.user_id_embedding.weight.grad, False)    # U^0 only enters the mean
-            # last reader of dE_u / dE_i: clear the touched rows
+            # after the last reader of dE_u / dE_i (this chain and the fusion backward): clear the touched rows
+            if ev_fuse is not None:
+                torch.cuda.current_stream().wait_event(ev_fuse)
             _call("llmrec_bpr_multi_zero_rows_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid))
             if self.inline_adamw:                                                 # both tables' gradients are final: update them here,
                 self.opt.step_params(self._emb_params)                            # beside the weight-gradient GEMM
 
-        self._fork(self.s2)
+        # the ID chain depends on the BPR rows only, not on the fusion backward: it starts beside it (captured after it, so that the
+        # fusion backward stays the graph's same-queue successor of the BPR launch) and has most of its SpMMs behind it when the
+        # weight-gradient GEMM takes every CU (one 512-register wave per SIMD leaves no room for a second kernel)
+        if ev_rows is not None:
+            self._fork_from(ev_rows, self.s2)
         with self._on(self.s2):
             id_chain()
         # side chain: I_cat = iu(U_cat), U_cat = ui(P_cat) (or the pre-propagated projection); then the item-side weight gradients
@@ -465,7 +495,7 @@ class FusedStep:
         dY_cat = self.dU_cat if self.preprop else self.dP_cat
         targets = self.wgrad_targets(dY_cat, self.dP_usr)
         item_pairs, text_pairs, image_pairs = targets[0][0], targets[2][0], targets[3][0]
-        done = False
+        done, updated = False, []
         if self.gemm == "bf16x3":
             # ONE launch for all four Linears: equal slabs over all of them, so the launch is whole rounds of equal blocks and the
             # short gradients pay no ramp-up / ragged last round of their own (round 2, same box: three launches back to back 0.661 ms
@@ -477,7 +507,16 @@ class FusedStep:
                 need = ops.linear_wgrad_multi_workspace(targets)
                 self.ws_wgrad_multi = torch.empty(max(need, 0), dtype=torch.uint8, device=dY_cat.device) if need >= 0 else False
             if self.ws_wgrad_multi is not False:
-                ops.linear_wgrad_multi(targets, self.ws_wgrad_multi)
+                if self.probe is not None:
+                    self.probe("wgrad", 0)
+                if self.inline_adamw:                                    # the four Linears' AdamW rides in the slab-reduction launch
+                    lins = (m.item_trans, m.user_trans, m.text_trans, m.image_trans)          # (wgrad_targets' order)
+                    ops.linear_wgrad_multi(targets, self.ws_wgrad_multi, update=(self.opt, [(l.weight, l.bias) for l in lins]))
+                    updated = [p_ for l in lins for p_ in (l.weight, l.bias)]
+                else:
+                    ops.linear_wgrad_multi(targets, self.ws_wgrad_multi)
+                if self.probe is not None:
+                    self.probe("wgrad", 1)
                 done = True
             else:                                                        # outside the multi-target fast path: user_trans' on its own
                 self._wgrad(self.dP_usr, m.user_feats, m.user_trans, False, ws=self.ws_wgrad_b)
@@ -494,8 +533,8 @@ class FusedStep:
             ops.linear_wgrad_grouped(strip(text_pairs), m.text_trans.weight.grad, bias(m.text_trans), False, self.ws_wgrad_c, precision=self.gemm)
             ops.linear_wgrad_grouped(strip(image_pairs), m.image_trans.weight.grad, bias(m.image_trans), False, self.ws_wgrad_d, precision=self.gemm)
         self._join(self.s1)                                              # user_trans' gradient
-        if self.inline_adamw:
-            self.opt.step_params(self._lin_params)                       # the four Linears: 0.3 M parameters, one short launch
+        if self.inline_adamw:                                            # whatever the reduction launch did not update (all four Linears on
+            self.opt.step_params([p_ for p_ in self._lin_params if all(p_ is not q for q in updated)])   # the per-target fallback paths)
         self._join(self.s2)
 
     def _train_forward(self, sampler=None):

@@ -548,6 +548,12 @@ class WgradTarget(_c.Structure):
                 ("db", _c.c_void_p), ("accumulate", _c.c_int32)]
 
 
+class WgradUpdate(_c.Structure):
+    """llmrec_wgrad_update_t"""
+    _fields_ = [("W", _c.c_void_p), ("m_W", _c.c_void_p), ("v_W", _c.c_void_p), ("b", _c.c_void_p), ("m_b", _c.c_void_p), ("v_b", _c.c_void_p),
+                ("g_scale", _c.c_float)]
+
+
 def _wgrad_targets(targets):
     """targets: [(pairs, dW, db, accumulate)] -> (ctypes array, keep-alive list, N)"""
     arr = (WgradTarget * len(targets))()
@@ -572,16 +578,34 @@ def linear_wgrad_multi_workspace(targets) -> int:
     return _lib.query("llmrec_linear_wgrad_multi_workspace_bytes", len(targets), arr, N)
 
 
-def linear_wgrad_multi(targets, ws: Optional[torch.Tensor] = None):
+def linear_wgrad_multi(targets, ws: Optional[torch.Tensor] = None, update=None):
     """The bf16x3 weight gradients of several Linears in one launch + one reduction launch (llmrec_linear_wgrad_multi_bf16x3).
-    targets: [(pairs, dW, db, accumulate)], pairs = [(dY, X)] as in linear_wgrad_grouped; all dW have N rows."""
+    targets: [(pairs, dW, db, accumulate)], pairs = [(dY, X)] as in linear_wgrad_grouped; all dW have N rows.
+    update = (FusedAdamW, [(W, b)] per target): the AdamW update of those parameters rides in the reduction launch
+    (llmrec_linear_wgrad_multi_adamw_bf16x3; the optimizer's step counter has been advanced already)."""
     arr, keep, N = _wgrad_targets(targets)
     need = _lib.query("llmrec_linear_wgrad_multi_workspace_bytes", len(targets), arr, N)
     if need < 0:
         raise RuntimeError("linear_wgrad_multi: shapes outside the fast path (use linear_wgrad_grouped per target)")
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=targets[0][1].device)
-    _lib.call("llmrec_linear_wgrad_multi_bf16x3", len(targets), arr, N, _p(ws), ws.numel(), _stream())
+    if update is None:
+        _lib.call("llmrec_linear_wgrad_multi_bf16x3", len(targets), arr, N, _p(ws), ws.numel(), _stream())
+        return
+    opt, params = update
+    upd = (WgradUpdate * len(targets))()
+    for i, (W, b) in enumerate(params):
+        stW = opt.moments(W)
+        upd[i].W, upd[i].m_W, upd[i].v_W = W.data_ptr(), stW[0].data_ptr(), stW[1].data_ptr()
+        if b is not None:
+            stb = opt.moments(b)
+            upd[i].b, upd[i].m_b, upd[i].v_b = b.data_ptr(), stb[0].data_ptr(), stb[1].data_ptr()
+        gs = float(opt.grad_scale.get(W, 1.0))
+        if b is not None and float(opt.grad_scale.get(b, 1.0)) != gs:
+            raise RuntimeError("linear_wgrad_multi: W and b of one target need the same grad_scale")
+        upd[i].g_scale = gs
+    _lib.call("llmrec_linear_wgrad_multi_adamw_bf16x3", len(targets), arr, N, _p(ws), ws.numel(), upd, _p(opt.dev_state), opt.lr, opt.betas[0],
+              opt.betas[1], opt.eps, opt.wd, _stream())
 
 
 def linear_wgrad_grouped(pairs, dW, db, accumulate: bool, ws: Optional[torch.Tensor] = None, precision: str = "f32"):
@@ -739,6 +763,15 @@ class FusedAdamW:
         if not advanced:
             self.advance()
         self._update(live)
+
+    def moments(self, p):
+        """(exp_avg, exp_avg_sq) of a parameter, created on first use."""
+        st = self.state.get(p)
+        if st is None:
+            if not p.is_contiguous():
+                raise RuntimeError("FusedAdamW: contiguous parameters expected")
+            st = self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
+        return st
 
     def _update(self, live):
         if not live:

@@ -456,6 +456,66 @@ def test_bpr_multi_sharded_matches_oracle_on_concatenated_batch(ops):
         assert rel_err(grads[i][1].cpu(), want[i][3]) < 2e-5
 
 
+@pytest.mark.parametrize("drop,cap,valid,d", [(0.71, 1126, 1126, 64), (0.0, 1024, 1000, 64), (0.5, 2048, 1500, 128), (0.71, 96, 0, 64), (0.999, 40, 40, 16)])
+def test_bpr_select_and_backward_in_one_launch(ops, drop, cap, valid, d):
+    """scores -> llmrec_bpr_multi_select_bwd_f32 -> llmrec_bpr_multi_losses_f32 (the fused step's loss path) against
+    llmrec_bpr_multi_fwd_f32 + llmrec_bpr_multi_bwd_f32: `saved` and `out` bit for bit (valid < capacity included, an empty
+    batch included), gradients to atomic-order rounding, and against the oracle's autograd."""
+    import ctypes
+    from llmrec_amd import _lib
+    rng = np.random.default_rng(5)
+    U, I, P = 300, 420, 3
+    tabs = [(torch.tensor((rng.standard_normal((U, d)) * 0.3).astype(np.float32)), torch.tensor((rng.standard_normal((I, d)) * 0.3).astype(np.float32)))
+            for _ in range(P)]
+    idx = [torch.tensor(rng.integers(0, n, size=cap)).to(DEV) for n in (U, I, I)]
+    nv = torch.tensor([valid], dtype=torch.int32, device=DEV)
+    dev_t = [(a.to(DEV), b.to(DEV)) for a, b in tabs]
+    w = [(1.0, 1.0), (0.7, 0.0), (0.02, 1.3)]
+    p_ = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(fused):
+        grads = [(torch.zeros(U, d, device=DEV), torch.zeros(I, d, device=DEV)) for _ in range(P)]
+        arr = (ops.BprProblem * P)()
+        for i in range(P):
+            arr[i].Eu, arr[i].ldu, arr[i].Ei, arr[i].ldi = dev_t[i][0].data_ptr(), d, dev_t[i][1].data_ptr(), d
+            arr[i].dEu, arr[i].lddu, arr[i].dEi, arr[i].lddi = grads[i][0].data_ptr(), d, grads[i][1].data_ptr(), d
+            arr[i].g_mf, arr[i].g_emb = w[i]
+        saved = torch.full((P * ops.bpr_saved_floats(cap),), 7.0, device=DEV)
+        out = torch.zeros(P, 2, device=DEV)
+        common = (P, arr, d, p_(idx[0]), p_(idx[1]), p_(idx[2]), cap, p_(nv))
+        if fused:
+            _lib.call("llmrec_bpr_multi_scores_f32", *common, p_(saved), st)
+            _lib.call("llmrec_bpr_multi_select_bwd_f32", *common, 1 - drop, 1e-5, 64.0, p_(saved), st)
+            _lib.call("llmrec_bpr_multi_losses_f32", P, cap, p_(nv), 1 - drop, 1e-5, 64.0, p_(out), p_(saved), st)
+        else:
+            _lib.call("llmrec_bpr_multi_fwd_f32", *common, 1 - drop, 1e-5, 64.0, p_(out), p_(saved), st)
+            _lib.call("llmrec_bpr_multi_bwd_f32", *common, 1e-5, 64.0, p_(saved), st)
+        torch.cuda.synchronize()
+        return saved.cpu(), out.cpu(), [(a.cpu(), b.cpu()) for a, b in grads]
+    s0, o0, g0 = run(False)
+    s1, o1, g1 = run(True)
+    stride = ops.bpr_saved_floats(cap)
+    for i in range(P):                                       # every slot the contract defines: coefficients, norm sums + k, kept values, norms
+        a, b = s0[i * stride:(i + 1) * stride], s1[i * stride:(i + 1) * stride]
+        assert torch.equal(a[:cap + 4].view(torch.int32), b[:cap + 4].view(torch.int32))
+        lo = cap + 4
+        for slot in (0, 1, 2, 3, 4):
+            assert torch.equal(a[lo + slot * cap:lo + slot * cap + valid].view(torch.int32), b[lo + slot * cap:lo + slot * cap + valid].view(torch.int32)), slot
+    assert torch.equal(o0.view(torch.int32), o1.view(torch.int32))
+    for i in range(P):
+        assert rel_err(g1[i][0], g0[i][0]) < 1e-6 and rel_err(g1[i][1], g0[i][1]) < 1e-6
+    if valid and int((1 - drop) * valid) > 0:
+        cfg = O.Config(batch_size=64, decay=1e-5, prune_loss_drop_rate=drop)
+        for i, (Eu, Ei) in enumerate(tabs):
+            a = Eu.clone().requires_grad_(True); b = Ei.clone().requires_grad_(True)
+            u, pp, q = (x[:valid].cpu() for x in idx)
+            mf, emb = O.bpr_loss(a[u], b[pp], b[q], cfg)
+            (w[i][0] * mf + w[i][1] * emb).backward()
+            assert abs(float(o1[i, 0]) - float(mf)) < 3e-6 * abs(float(mf))
+            assert rel_err(g1[i][0], a.grad) < 2e-5 and rel_err(g1[i][1], b.grad) < 2e-5
+
+
 # ------------------------------------------------------------------------------------------
 # R9/R10 scoring + top-K
 # ------------------------------------------------------------------------------------------
@@ -813,3 +873,52 @@ def test_weight_gradient_with_row_weighted_bias_gradient(ops):
     assert relmax(db, want_b) < 3e-6
     with pytest.raises(RuntimeError):                                                  # the exact-fp32 kernels sum dY unweighted: refused
         ops.linear_wgrad_grouped(pairs, dW, db, False, precision="f32")
+
+
+def test_weight_gradient_launch_with_the_adamw_update_inside(ops):
+    """llmrec_linear_wgrad_multi_adamw_bf16x3 = llmrec_linear_wgrad_multi_bf16x3 followed by llmrec_adamw_multi_f32 on (W, b) of every
+    target: gradients, parameters and both moments bit for bit, over two steps (non-zero moments in the second), one target without a
+    bias gradient, one with a row-weighted one."""
+    N = 64
+    shapes = [(3, 700, 256), (1, 900, 128), (1, 333, 384)]            # (pairs, M, K)
+    rngs = np.random.default_rng(22)
+    data = []
+    for n_pairs, M, K in shapes:
+        data.append([(torch.tensor((rngs.standard_normal((M, N)) * 1e-3).astype(np.float32), device=DEV),
+                      torch.tensor(rngs.standard_normal((M, K)).astype(np.float32), device=DEV),
+                      torch.tensor(rngs.random(M).astype(np.float32), device=DEV)) for _ in range(n_pairs)])
+
+    def run(fused):
+        torch.manual_seed(0)
+        rng2 = np.random.default_rng(23)
+        lin = []
+        for t, (n_pairs, M, K) in enumerate(shapes):
+            W = torch.tensor((rng2.standard_normal((N, K)) * 0.05).astype(np.float32), device=DEV)
+            b = None if t == 1 else torch.tensor((rng2.standard_normal(N) * 0.05).astype(np.float32), device=DEV)
+            W.grad = torch.zeros_like(W)
+            if b is not None:
+                b.grad = torch.zeros_like(b)
+            lin.append((W, b))
+        params = [p_ for W, b in lin for p_ in (W, b) if p_ is not None]
+        opt = ops.FusedAdamW(params, lr=1e-3)
+        for step in range(2):
+            targets = []
+            for t, (W, b) in enumerate(lin):
+                pairs = [(dY * (1.0 + step), X, w) if t == 2 else (dY * (1.0 + step), X) for dY, X, w in data[t]]
+                targets.append((pairs, W.grad, b.grad if b is not None else None, False))
+            opt.advance()
+            if fused:
+                ops.linear_wgrad_multi(targets, update=(opt, lin))
+            else:
+                ops.linear_wgrad_multi(targets)
+                opt.step_params(params)
+        torch.cuda.synchronize()
+        out = []
+        for p_ in params:
+            out += [p_.detach().cpu(), p_.grad.cpu(), opt.state[p_][0].cpu(), opt.state[p_][1].cpu()]
+        return out
+    a, b = run(False), run(True)
+    assert len(a) == len(b) == 4 * 5
+    for x, y in zip(a, b):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    assert float(a[2].abs().max()) > 0 and float(a[3].abs().max()) > 0   # (moments were written)
