@@ -189,61 +189,28 @@ class NetflixShaped:
                         + (" + HIP graph replay" if self.use_graph else "")}
 
 
-    def insitu_gemm_ms(self, rounds: int = 20):
-        """Durations of the step's two GEMM launches INSIDE the step: HIP events recorded on the launching stream right before and after
-        each launch (llmrec_amd/fused.py `probe`) while the step runs with eager launches - the same kernels on the same five streams
-        as the replayed graph, which cannot carry timing events (ROCm refuses external event-record nodes in a captured graph); the
-        rocprofv3 averages of the graph-replayed run are the cross-check (profiles/). Returns {"projection": ms, "wgrad": ms}
-        (wgrad = the GEMM + its slab reduction / AdamW launch), medians over `rounds` steps, or None on batch-sharded replicas."""
-        import torch
-        f = self.fused
-        if hasattr(f, "gsz"):
-            return None
-        ev = {t: [torch.cuda.Event(enable_timing=True) for _ in range(2)] for t in ("projection", "wgrad")}
-        seen = set()
-
-        def probe(tag, edge):
-            ev[tag][edge].record()
-            seen.add((tag, edge))
-        out = None
-        try:
-            f.probe = probe
-            acc = {t: [] for t in ev}
-            for r in range(rounds + 3):
-                u, p, n, nv = self.batcher.next()
-                f.step_eager(u, p, n, nv)
-                torch.cuda.synchronize()
-                if r >= 3:
-                    for t in ev:
-                        if (t, 0) in seen and (t, 1) in seen:
-                            acc[t].append(ev[t][0].elapsed_time(ev[t][1]))
-            out = {t: sorted(v)[len(v) // 2] for t, v in acc.items() if v}
-            out["readings"] = rounds
-        except Exception as e:                                  # pragma: no cover - fall back to the isolated timings
-            out = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
-        finally:
-            f.probe = None
-        return out
-
     def _wgrad_launch_ms(self, dY_cat, dYu, iters: int = 20):
-        """Duration of the step's weight-gradient launch (the GEMM over all four Linears + its slab reduction), HIP events on the
-        stream it is launched on (a side stream, as llmrec_amd/fused.py launches it), the launch built exactly as the step builds it."""
+        """Average duration of the step's weight-gradient launch (the GEMM over all four Linears + its slab-reduction launch), HIP events
+        on the stream it is launched on, `iters` launches back to back between the two events, the launch built exactly as the step builds
+        it (llmrec_amd/fused.py wgrad_targets; the AdamW update that rides in the step's reduction launch is left out: it would move the
+        parameters `iters` times)."""
         import torch
         ops, f = self.ops, self.fused
         targets = f.wgrad_targets(dY_cat, dYu)
         ws = torch.empty(max(ops.linear_wgrad_multi_workspace(targets), 16), dtype=torch.uint8, device=dY_cat.device)
         st = torch.cuda.Stream()
-        acc = 0.0
-        for it in range(iters + 3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            st.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(st):
-                e0.record(); ops.linear_wgrad_multi(targets, ws); e1.record()
-            torch.cuda.current_stream().wait_stream(st)
-            torch.cuda.synchronize()
-            if it >= 3:
-                acc += e0.elapsed_time(e1)
-        return acc / iters
+        st.wait_stream(torch.cuda.current_stream())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                ops.linear_wgrad_multi(targets, ws)
+            e0.record()
+            for _ in range(iters):
+                ops.linear_wgrad_multi(targets, ws)
+            e1.record()
+        torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
 
     # ---- per-kernel roofline (dominant kernels of this workload, timed in isolation) -------------
     def kernel_rooflines(self):
@@ -256,19 +223,16 @@ class NetflixShaped:
         feats = [j[0] for j in self.fused.projection_jobs()]
         flop_all = sum(2.0 * x.shape[0] * x.shape[1] * d for x in feats)
         byts_all = sum(4.0 * (x.shape[0] * x.shape[1] + d * x.shape[1] + x.shape[0] * d) for x in feats)
-        insitu = self.insitu_gemm_ms() or {}
-        ms_iso = event_time_ms(self.fused._project_all, 20)
-        ms = insitu.get("projection", ms_iso)
-        t_insitu = ("HIP events on the launching stream right before and after the launch while the whole step runs with eager launches (same kernels "
-                    "and streams as the replayed graph, which cannot carry timing events on ROCm; median of %d steps); ms_isolated = the same launch "
-                    "alone between events after a device synchronisation" % insitu.get("readings", 0))
+        ms = event_time_ms(self.fused._project_all, 20)
+        t_how = ("HIP events on the launch's stream around 20 launches back to back (the replayed step graph cannot carry timing events: ROCm refuses "
+                 "external event-record nodes in a captured graph); in_step_us_rocprof = the same kernel's average duration inside the replayed "
+                 "graph in the committed rocprofv3 --kernel-trace --stats summary of this command")
         bf = self.fused.gemm == "bf16x3"
         out.append({"kernel": ("linear_fwd_grouped_bf16x3_kernel (all 8 projections, one launch; 3-term bf16 split, 6 bf16 MFMAs: "
                                "HBM-bound on the X stream - tflops/frac_mfma_f32 are fp32-EQUIVALENT figures)") if bf else
                               "linear_fwd_grouped_kernel (all 8 projections of one forward, one launch, exact fp32 MFMA)",
                     "pmc": [("linear_fwd_grouped_bf16x3_kernel" if bf else "linear_fwd_grouped_kernel", 1)],
-                    "bound": "hbm" if bf else "mfma", "calls_per_step": 1, "ms": ms, "ms_isolated": ms_iso,
-                    "timing": t_insitu if "projection" in insitu else "HIP events around the launch on its stream, in isolation",
+                    "bound": "hbm" if bf else "mfma", "calls_per_step": 1, "ms": ms, "timing": t_how,
                     "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                     "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
                     "algorithmic_flop_per_launch": flop_all, "algorithmic_bytes_per_launch": byts_all,
@@ -280,13 +244,11 @@ class NetflixShaped:
         dY_cat = self.fused.dU_cat if self.fused.preprop else self.fused.dP_cat
         dYu = self.fused.dP_usr
         if bf_ok:
-            ms_iso = self._wgrad_launch_ms(dY_cat, dYu)
-            ms = insitu.get("wgrad", ms_iso)
+            ms = self._wgrad_launch_ms(dY_cat, dYu)
             out.append({"kernel": "linear_wgrad_bf16x3_v2_multi_kernel + reduce_chunks_multi_kernel: the weight gradients of all four Linears "
                                   "(item_trans x5, user_trans, text_trans, image_trans) in one launch; 3-term bf16 split: tflops are fp32-EQUIVALENT",
                         "pmc": [("linear_wgrad_bf16x3_v2_multi_kernel", 1), ("reduce_chunks_multi_kernel", 1)],
-                        "launches": 1, "avg_launch_ms": ms, "ms_isolated": ms_iso, "insitu_error": insitu.get("error"),
-                        "timing": t_insitu if "wgrad" in insitu else "HIP events around the launch on the side stream it is issued on, built as the step builds it (llmrec_amd/fused.py wgrad_targets)",
+                        "launches": 1, "avg_launch_ms": ms, "timing": t_how,
                         "bound": "hbm", "calls_per_step": 1, "ms": ms, "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                         "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
                         "note": "power-bound, not bandwidth-bound: the shader clock averages 1.37 GHz in this kernel (2.33 GHz for its load stream alone, "
@@ -501,6 +463,28 @@ def kernel_time_shares():
     return {"file": os.path.basename(path), "sum_of_kernel_time_per_step_us": total,
             "note": "summed launch durations per step; launches on the step's five streams overlap, so the sum exceeds the step time",
             "classes": {k: {"per_step_us": round(v["per_step_us"], 2), "share_of_kernel_time": round(v["per_step_us"] / total, 4)} for k, v in top}}
+
+
+def rocprof_avg_us(parts):
+    """Sum of the average durations (us) of the named kernels in the newest committed rocprofv3 --kernel-trace --stats summary of this
+    bench (profiles/r*_bench_nf_kernel_stats*.csv): the in-step cross-check of the roofline's own event timing. None if absent."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_nf_kernel_stats*.csv")))
+    if not files:
+        return None
+    total = 0.0
+    try:
+        with open(files[-1]) as f:
+            rows = [rec for rec in csv.reader(line for line in f if not line.startswith("#")) if rec and rec[0] != "name"]
+    except Exception:
+        return None
+    for key, launches in parts:
+        hit = [float(rec[3]) for rec in rows if key in rec[0]]
+        if not hit:
+            return None
+        total += launches * hit[0]
+    return {"file": os.path.basename(files[-1]), "avg_us": round(total, 2)}
 
 
 def pmc_traffic_bytes(parts):
@@ -980,7 +964,7 @@ def main():
                         "achieved": k["gbs"] if hbm else k["tflops"], "peak": HBM_PEAK_GBS if hbm else MFMA_F32_PEAK_TFLOPS,
                         "unit": "GB/s" if hbm else "TFLOP/s", "frac": k["frac_hbm"] if hbm else k["frac_mfma_f32"],
                         "traffic": None if traffic is None else traffic / n, "traffic_source": src,
-                        "launches_per_step": n, "ms_per_launch": k["ms"] / n, "ms_per_step": k["ms"], "ms_isolated": k.get("ms_isolated"),
+                        "launches_per_step": n, "ms_per_launch": k["ms"] / n, "ms_per_step": k["ms"], "in_step_us_rocprof": rocprof_avg_us(k["pmc"]),
                         "algorithmic_flop_per_launch": k["algorithmic_flop_per_launch"],
                         "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"],
                         "timing": k.get("timing", "HIP events around the launch on its stream, in isolation"),

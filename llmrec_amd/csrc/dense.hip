@@ -1362,18 +1362,14 @@ static int linear_fwd_grouped_impl(int32_t n_problems, const llmrec_linear_probl
     bool k32 = fast;                                   // scalar-k addressing of the bf16x3 kernel (MODE 2)
     for (int i = 0; i < n_problems; ++i)
         k32 = k32 && (g.K[i] % 32 == 0) && (p[i].M * p[i].ldx + g.K[i]) < (1ll << 30) && ((int64_t)N * p[i].ldw + g.K[i]) < (1ll << 30);
-    // LLMREC_FWD_XPOSE=0 keeps the fragment-shaped X loads of round 1 (MODE 2) for A/B runs
-    static const bool xpose = [] { const char* e = getenv("LLMREC_FWD_XPOSE"); return !(e && e[0] == '0'); }();
 #define GROUPED_LAUNCH(KERNEL, NT_)                                                         \
     do {                                                                                    \
         if (rows_per_unit == 128) {                                                         \
-            if (k32 && xpose) KERNEL<NT_, 2, K32MODE><<<units, 256, 0, stream>>>(g, N);      \
-            else if (k32) KERNEL<NT_, 2, 2><<<units, 256, 0, stream>>>(g, N);                \
+            if (k32) KERNEL<NT_, 2, K32MODE><<<units, 256, 0, stream>>>(g, N);               \
             else if (fast) KERNEL<NT_, 2, 1><<<units, 256, 0, stream>>>(g, N);               \
             else KERNEL<NT_, 2, 0><<<units, 256, 0, stream>>>(g, N);                         \
         } else {                                                                            \
-            if (k32 && xpose) KERNEL<NT_, 1, K32MODE><<<units, 256, 0, stream>>>(g, N);      \
-            else if (k32) KERNEL<NT_, 1, 2><<<units, 256, 0, stream>>>(g, N);                \
+            if (k32) KERNEL<NT_, 1, K32MODE><<<units, 256, 0, stream>>>(g, N);               \
             else if (fast) KERNEL<NT_, 1, 1><<<units, 256, 0, stream>>>(g, N);               \
             else KERNEL<NT_, 1, 0><<<units, 256, 0, stream>>>(g, N);                         \
         }                                                                                   \

@@ -127,9 +127,6 @@ class FusedStep:
         # (Batch-sharded replicas all-reduce the gradients first and update afterwards: llmrec_amd/dp.py sets this to False.)
         self.inline_adamw = getattr(type(self), "INLINE_ADAMW", True)
         self._zero_in_forward = False                         # set by step_eager: forward() alone (evaluation) must not advance AdamW
-        # measurement hook (bench.py): probe(tag, edge) is called on the launching stream right before (edge 0) and after (edge 1) the two
-        # GEMM launches, so that a copy of the step graph can carry timing events around them; None on the product path
-        self.probe = None
         self._emb_params = [model.user_id_embedding.weight, model.item_id_embedding.weight]
         self._lin_params = [p for p in optimizer.params if p.grad is not None and all(p is not e for e in self._emb_params)]
         # Launch (= capture) order at the fork points decides which branch the graph runs behind its parent without a cross-queue
@@ -293,11 +290,7 @@ class FusedStep:
                     self._spmm(self.ui.fwd, i_prev, self.Ul[l], tag=2)
                     self._spmm(self.iu.fwd, self.Ul[l], self.Il[l], tag=2)
                 i_prev = self.Il[l]
-        if self.probe is not None:
-            self.probe("projection", 0)
         self._project_all()
-        if self.probe is not None:
-            self.probe("projection", 1)
         ev1 = self._mark()
         if not self.preprop:
             self._spmm(self.ui.fwd, self.P_cat, self.U_cat)              # 7 streams, one adjacency pass
@@ -507,16 +500,12 @@ class FusedStep:
                 need = ops.linear_wgrad_multi_workspace(targets)
                 self.ws_wgrad_multi = torch.empty(max(need, 0), dtype=torch.uint8, device=dY_cat.device) if need >= 0 else False
             if self.ws_wgrad_multi is not False:
-                if self.probe is not None:
-                    self.probe("wgrad", 0)
                 if self.inline_adamw:                                    # the four Linears' AdamW rides in the slab-reduction launch
                     lins = (m.item_trans, m.user_trans, m.text_trans, m.image_trans)          # (wgrad_targets' order)
                     ops.linear_wgrad_multi(targets, self.ws_wgrad_multi, update=(self.opt, [(l.weight, l.bias) for l in lins]))
                     updated = [p_ for l in lins for p_ in (l.weight, l.bias)]
                 else:
                     ops.linear_wgrad_multi(targets, self.ws_wgrad_multi)
-                if self.probe is not None:
-                    self.probe("wgrad", 1)
                 done = True
             else:                                                        # outside the multi-target fast path: user_trans' on its own
                 self._wgrad(self.dP_usr, m.user_feats, m.user_trans, False, ws=self.ws_wgrad_b)
