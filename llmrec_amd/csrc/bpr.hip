@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256) void bpr_bwd_multi_kernel(BprTables t, int d, 
 __global__ __launch_bounds__(256) void bpr_select_bwd_multi_kernel(BprTables t, int d, const int64_t* __restrict__ users,
                                                                    const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
                                                                    int B_max, const int32_t* __restrict__ n_valid_dev, double remember_rate,
-                                                                   float decay, float bsz, float* __restrict__ saved_all, int saved_stride) {
+                                                                   float decay, float bsz, float* __restrict__ saved_all, int saved_stride,
+                                                                   uint8_t* __restrict__ flag_u, uint8_t* __restrict__ flag_i) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* m_s = reinterpret_cast<float*>(smem);                      // [B]
     __shared__ float red[3][BPR_THREADS];
@@ -306,6 +307,10 @@ __global__ __launch_bounds__(256) void bpr_select_bwd_multi_kernel(BprTables t, 
     const float du_ = 2.0f * Su + 1e-8f, dp_ = 2.0f * Sp + 1e-8f, dq_ = 2.0f * Sq + 1e-8f;
     const float cu = base / (du_ * du_), cp = base / (dp_ * dp_), cq = base / (dq_ * dq_);
     const int64_t ui = users[b], pi = pos[b], qi = neg[b];
+    if (prob == 0 && gl == 0) {                                       // rows this batch touches (same rows for every problem)
+        if (flag_u) flag_u[ui] = 1;
+        if (flag_i) { flag_i[pi] = 1; flag_i[qi] = 1; }
+    }
     const float ds = g_mf * coef;
     const float* u = t.Eu[prob] + ui * t.ldu[prob];
     const float* p = t.Ei[prob] + pi * t.ldi[prob];
@@ -325,12 +330,17 @@ __global__ __launch_bounds__(256) void bpr_select_bwd_multi_kernel(BprTables t, 
 // without a dense memset
 __global__ __launch_bounds__(256) void bpr_zero_rows_kernel(BprTables t, int d, const int64_t* __restrict__ users,
                                                             const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
-                                                            int B_max, const int32_t* __restrict__ n_valid_dev) {
+                                                            int B_max, const int32_t* __restrict__ n_valid_dev,
+                                                            uint8_t* __restrict__ flag_u, uint8_t* __restrict__ flag_i) {
     const int B = bpr_batch(n_valid_dev, B_max);
     const int prob = blockIdx.y;
     const int gl = threadIdx.x & 15;
     const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (b >= B) return;
+    if (prob == 0 && gl == 0) {
+        if (flag_u) flag_u[users[b]] = 0;
+        if (flag_i) { flag_i[pos[b]] = 0; flag_i[neg[b]] = 0; }
+    }
     float* du = t.dEu[prob] + users[b] * t.lddu[prob];
     float* dpp = t.dEi[prob] + pos[b] * t.lddi[prob];
     float* dqq = t.dEi[prob] + neg[b] * t.lddi[prob];
@@ -703,7 +713,8 @@ int llmrec_bpr_multi_scores_f32(int32_t n_problems, const llmrec_bpr_problem_t* 
 int llmrec_bpr_multi_select_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
                                     const int64_t* users, const int64_t* pos, const int64_t* neg,
                                     int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
-                                    float batch_size_flag, float* saved, llmrec_stream_t stream_) {
+                                    float batch_size_flag, float* saved, uint8_t* user_row_flags, uint8_t* item_row_flags,
+                                    llmrec_stream_t stream_) {
     LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && problems_host && d > 0 && saved, "bpr_multi_select_bwd: bad argument");
     if (B_max > LLMREC_BPR_MAX_B) { set_error("bpr_multi_select_bwd: B_max %d > %d", B_max, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
     if (B_max == 0) return LLMREC_OK;
@@ -712,7 +723,8 @@ int llmrec_bpr_multi_select_bwd_f32(int32_t n_problems, const llmrec_bpr_problem
     LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, true), "bpr_multi_select_bwd: bad problem table");
     dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_problems);
     bpr_select_bwd_multi_kernel<<<grid, 256, sizeof(float) * (size_t)B_max, (hipStream_t)stream_>>>(
-        t, d, users, pos, neg, B_max, n_valid_dev, remember_rate, decay, batch_size_flag, saved, LLMREC_BPR_SAVED_FLOATS(B_max));
+        t, d, users, pos, neg, B_max, n_valid_dev, remember_rate, decay, batch_size_flag, saved, LLMREC_BPR_SAVED_FLOATS(B_max), user_row_flags,
+        item_row_flags);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }
@@ -729,14 +741,15 @@ int llmrec_bpr_multi_losses_f32(int32_t n_problems, int32_t B_max, const int32_t
 
 int llmrec_bpr_multi_zero_rows_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
                                    const int64_t* users, const int64_t* pos, const int64_t* neg,
-                                   int32_t B_max, const int32_t* n_valid_dev, llmrec_stream_t stream_) {
+                                   int32_t B_max, const int32_t* n_valid_dev, uint8_t* user_row_flags, uint8_t* item_row_flags,
+                                   llmrec_stream_t stream_) {
     LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && problems_host && d > 0, "bpr_multi_zero_rows: bad argument");
     if (B_max == 0) return LLMREC_OK;
     LLMREC_CHECK_ARG(users && pos && neg, "bpr_multi_zero_rows: null index pointer");
     BprTables t = {};
     LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, true), "bpr_multi_zero_rows: bad problem table");
     dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_problems);
-    bpr_zero_rows_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(t, d, users, pos, neg, B_max, n_valid_dev);
+    bpr_zero_rows_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(t, d, users, pos, neg, B_max, n_valid_dev, user_row_flags, item_row_flags);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

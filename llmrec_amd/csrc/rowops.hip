@@ -210,6 +210,7 @@ struct FuseMulti {
     int64_t rows[FUSE_MAX_PROBLEMS];
     float* out[FUSE_MAX_PROBLEMS]; int64_t ldo[FUSE_MAX_PROBLEMS];            // forward
     const float* dOut[FUSE_MAX_PROBLEMS]; int64_t lddo[FUSE_MAX_PROBLEMS];    // backward
+    const uint8_t* row_flags[FUSE_MAX_PROBLEMS];                              // backward: 0 = dOut and the sources of this row are all-zero
     int block_begin;                                                          // first block of problem 1
 };
 #define ROW_LOOP_MULTI(m)                                                                          \
@@ -256,6 +257,22 @@ template <int VEC, int NCHUNK>
 __global__ __launch_bounds__(256) void fuse_bwd_src_multi_kernel(int d, FuseMulti m) {
     ROW_LOOP_MULTI(m) {
         RowReg<VEC, NCHUNK> g, t, o;
+        if (m.row_flags[prob] && !m.row_flags[prob][row]) {
+            // a row the batch did not touch: dOut = 0 and the sources are 0, so every stream's gradient is w (0 - x 0) = +0 and
+            // what is left is the regulariser's reg2 * x on the first n_reg streams - the same bits as the general path below
+            for (int i = 0; i < a.n_norm; ++i) {
+                o.fill(0.f);
+                if (i < a.n_reg) {
+                    t.load(a.norm_terms[i] + row * a.norm_ld[i], gl, d);
+#pragma unroll
+                    for (int k = 0; k < NCHUNK; ++k)
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) o.x[k][q] = fmaf(a.reg2, t.x[k][q], o.x[k][q]);
+                }
+                o.store(a.d_terms[i] + row * a.d_ld[i], gl, d);
+            }
+            continue;
+        }
         g.load(m.dOut[prob] + row * m.lddo[prob], gl, d);
         for (int i = 0; i < a.n_norm; ++i) {
             t.load(a.norm_terms[i] + row * a.norm_ld[i], gl, d);
@@ -745,7 +762,7 @@ int llmrec_fuse_bwd_src_multi_f32(int32_t n_problems, const llmrec_fuse_bwd_prob
             vec4 = vec4 && q.norm_ld[i] % 4 == 0 && q.d_ld[i] % 4 == 0 && aligned16(q.norm_terms[i]) && aligned16(q.d_terms[i]) &&
                    (!a.s_terms[i] || (a.s_ld[i] % 4 == 0 && aligned16(a.s_terms[i])));
         }
-        m.rows[k] = q.rows; m.dOut[k] = q.dOut; m.lddo[k] = q.lddo;
+        m.rows[k] = q.rows; m.dOut[k] = q.dOut; m.lddo[k] = q.lddo; m.row_flags[k] = q.row_flags;
         blocks[k] = grid_for(q.rows, ROWS_PER_BLOCK);
     }
     m.block_begin = blocks[0];

@@ -68,6 +68,10 @@ class FusedStep:
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         self.dE_u, self.dE_i = z(U, d), z(I, d)
         self.sc_U, self.sc_I, self.sc_prof = z(U, 2 * d), z(I, S * d), z(U, d)
+        # one byte per row, raised by the loss launch for the rows of the batch and lowered again with the row clean-up: the fusion
+        # backward writes the ~90 % of rows no sample touched (zero gradient, zero sources) without reading them
+        self.flag_u = torch.zeros(U, dtype=torch.uint8, device=dev)
+        self.flag_i = torch.zeros(I, dtype=torch.uint8, device=dev)
         self.dU_cat, self.dI_cat = f(U, S * d), f(I, S * d)
         self.dprof_u, self.dprof_i, self.dP_usr = f(U, d), f(I, d), f(U, d)
         self.bufU, self.bufI, self.tmpU, self.tmpI = f(U, d), f(I, d), f(U, d), f(I, d)
@@ -357,7 +361,7 @@ class FusedStep:
         self._check_scatter_targets()
         _call("llmrec_bpr_multi_scores_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), _p(self.saved))
         _call("llmrec_bpr_multi_select_bwd_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), remember,
-              float(hp.decay), float(hp.batch_size), _p(self.saved))
+              float(hp.decay), float(hp.batch_size), _p(self.saved), _p(self.flag_u), _p(self.flag_i))
 
         def side():                              # (runs on the ID chain's stream, _backward places it)
             _call("llmrec_bpr_multi_losses_f32", self.n_prob, B, _p(n_valid), remember, float(hp.decay), float(hp.batch_size),
@@ -381,8 +385,8 @@ class FusedStep:
 
     def _check_scatter_targets(self):
         if self.check_zero and not torch.cuda.is_current_stream_capturing():
-            dirty = [n for n, t in (("dE_u", self.dE_u), ("dE_i", self.dE_i), ("sc_U", self.sc_U), ("sc_I", self.sc_I), ("sc_prof", self.sc_prof))
-                     if float(t.abs().max()) != 0.0]
+            dirty = [n for n, t in (("dE_u", self.dE_u), ("dE_i", self.dE_i), ("sc_U", self.sc_U), ("sc_I", self.sc_I), ("sc_prof", self.sc_prof),
+                                    ("flag_u", self.flag_u), ("flag_i", self.flag_i)) if float(t.float().abs().max()) != 0.0]
             if dirty:
                 raise RuntimeError("FusedStep: scatter targets not all-zero before the loss backward: %s (an aborted step? call reset_scatter_targets())" % dirty)
 
@@ -406,7 +410,7 @@ class FusedStep:
         # the backward of both fusions in ONE launch (llmrec_fuse_bwd_src_multi_f32)
         keep = []
 
-        def problem(pr, dout, cat, prof, dcat, dprof, srcs):
+        def problem(pr, dout, cat, prof, dcat, dprof, srcs, flags):
             norms, dnorms = self._norm_terms(cat, prof), self._norm_terms(dcat, dprof)
             npt, nl = self._tables(norms)
             dp, dl = self._tables(dnorms)
@@ -421,11 +425,12 @@ class FusedStep:
             pr.d_terms, pr.d_ld = _c.cast(dp, _c.c_void_p), _c.cast(dl, _c.c_void_p)
             pr.src_terms, pr.src_ld = _c.cast(sp, _c.c_void_p), _c.cast(sl, _c.c_void_p)
             pr.n_reg_terms, pr.reg_two_coef = 2, float(2.0 * coef)
+            pr.row_flags = flags.data_ptr() if (flags is not None and bpr_bwd_done) else None     # (only the fused loss launch raises them)
         arr = (ops.FuseBwdProblem * 2)()
         problem(arr[0], self.dE_i, self.I_cat, self.prof_i, self.dI_cat, self.dprof_i,
-                [self._side(self.sc_I, 0), self._side(self.sc_I, 1), None] + [self._side(self.sc_I, 2 + k) for k in range(len(self.keys))])
+                [self._side(self.sc_I, 0), self._side(self.sc_I, 1), None] + [self._side(self.sc_I, 2 + k) for k in range(len(self.keys))], self.flag_i)
         problem(arr[1], self.dE_u, self.U_cat, self.prof_u, self.dU_cat, self.dprof_u,
-                [self._side(self.sc_U, 0), self._side(self.sc_U, 1), self.sc_prof] + [None] * len(self.keys))
+                [self._side(self.sc_U, 0), self._side(self.sc_U, 1), self.sc_prof] + [None] * len(self.keys), self.flag_u)
         _call("llmrec_fuse_bwd_src_multi_f32", 2, arr, d)
         ev_fuse = self._mark()                                           # the fusion backward has read dE_u / dE_i
         m = self.m
@@ -470,7 +475,8 @@ class FusedStep:
             # after the last reader of dE_u / dE_i (this chain and the fusion backward): clear the touched rows
             if ev_fuse is not None:
                 torch.cuda.current_stream().wait_event(ev_fuse)
-            _call("llmrec_bpr_multi_zero_rows_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid))
+            _call("llmrec_bpr_multi_zero_rows_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid),
+                  _p(self.flag_u) if bpr_bwd_done else None, _p(self.flag_i) if bpr_bwd_done else None)
             if self.inline_adamw:                                                 # both tables' gradients are final: update them here,
                 self.opt.step_params(self._emb_params)                            # beside the weight-gradient GEMM
 
@@ -537,7 +543,7 @@ class FusedStep:
     def reset_scatter_targets(self):
         """Dense clear of the buffers the sparse-zero scheme keeps all-zero between steps (set-up, (re)capture, and after a
         step that raised between the loss backward's scatter and its row-wise clean-up)."""
-        for t in (self.dE_u, self.dE_i, self.sc_U, self.sc_I, self.sc_prof):
+        for t in (self.dE_u, self.dE_i, self.sc_U, self.sc_I, self.sc_prof, self.flag_u, self.flag_i):
             t.zero_()
 
     def step_eager(self, users, pos, neg, n_valid=None, sampler=None):

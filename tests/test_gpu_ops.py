@@ -483,15 +483,26 @@ def test_bpr_select_and_backward_in_one_launch(ops, drop, cap, valid, d):
             arr[i].g_mf, arr[i].g_emb = w[i]
         saved = torch.full((P * ops.bpr_saved_floats(cap),), 7.0, device=DEV)
         out = torch.zeros(P, 2, device=DEV)
+        flag_u, flag_i = torch.zeros(U, dtype=torch.uint8, device=DEV), torch.zeros(I, dtype=torch.uint8, device=DEV)
         common = (P, arr, d, p_(idx[0]), p_(idx[1]), p_(idx[2]), cap, p_(nv))
         if fused:
             _lib.call("llmrec_bpr_multi_scores_f32", *common, p_(saved), st)
-            _lib.call("llmrec_bpr_multi_select_bwd_f32", *common, 1 - drop, 1e-5, 64.0, p_(saved), st)
+            _lib.call("llmrec_bpr_multi_select_bwd_f32", *common, 1 - drop, 1e-5, 64.0, p_(saved), p_(flag_u), p_(flag_i), st)
             _lib.call("llmrec_bpr_multi_losses_f32", P, cap, p_(nv), 1 - drop, 1e-5, 64.0, p_(out), p_(saved), st)
         else:
             _lib.call("llmrec_bpr_multi_fwd_f32", *common, 1 - drop, 1e-5, 64.0, p_(out), p_(saved), st)
             _lib.call("llmrec_bpr_multi_bwd_f32", *common, 1e-5, 64.0, p_(saved), st)
         torch.cuda.synchronize()
+        if fused:                                            # the rows of the valid samples are flagged, no other; the clean-up lowers them
+            want_u = torch.zeros(U, dtype=torch.uint8); want_u[idx[0][:valid].cpu()] = 1
+            want_i = torch.zeros(I, dtype=torch.uint8); want_i[idx[1][:valid].cpu()] = 1; want_i[idx[2][:valid].cpu()] = 1
+            assert torch.equal(flag_u.cpu(), want_u) and torch.equal(flag_i.cpu(), want_i)
+            keep = [(a.clone(), b.clone()) for a, b in grads]
+            _lib.call("llmrec_bpr_multi_zero_rows_f32", *common, p_(flag_u), p_(flag_i), st)
+            torch.cuda.synchronize()
+            assert int(flag_u.sum()) == 0 and int(flag_i.sum()) == 0
+            assert all(float(a.abs().max()) == 0.0 and float(b.abs().max()) == 0.0 for a, b in grads)
+            grads = keep
         return saved.cpu(), out.cpu(), [(a.cpu(), b.cpu()) for a, b in grads]
     s0, o0, g0 = run(False)
     s1, o1, g1 = run(True)
@@ -739,7 +750,7 @@ def test_fuse_bwd_source_mode_and_zero_rows(ops):
         tgt = dEi[i][:, d:2 * d]                                             # a column slice: ld = 2 d
         probs[i].dEu, probs[i].lddu, probs[i].dEi, probs[i].lddi = dEu[i].data_ptr(), d, tgt.data_ptr(), 2 * d
         probs[i].g_mf, probs[i].g_emb = 1.0, 1.0
-    _lib.call("llmrec_bpr_multi_zero_rows_f32", 2, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), None)
+    _lib.call("llmrec_bpr_multi_zero_rows_f32", 2, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), None, None, None)
     torch.cuda.synchronize()
     for i in range(2):
         want_u = torch.ones(U, d, device=DEV); want_u[users[:nv]] = 0
@@ -795,6 +806,29 @@ def test_fuse_pair_launches_equal_the_single_launches(ops):
     torch.cuda.synchronize()
     for dm, ds in zip(d_multi, d_single):
         assert all(torch.equal(a, b) for a, b in zip(dm, ds))
+    # row flags: rows whose flag is 0 have zero dOut and zero sources (as the loss backward leaves them) - the flagged launch
+    # skips their reads and must write the same bits (regulariser term on the first two streams, +0 elsewhere)
+    flags = []
+    for sd in sides:
+        touched = torch.rand(sd["rows"], generator=g, device=DEV) < 0.1
+        touched[3] = True                                                    # (the all-zero cat row stays on the general path once)
+        sd["dout"][~touched] = 0.0
+        for t in sd["srcs"]:
+            if t is not None:
+                t[~touched] = 0.0
+        flags.append(touched.to(torch.uint8).contiguous())
+    _lib.call("llmrec_fuse_bwd_src_multi_f32", 2, bwd, d, None)
+    torch.cuda.synchronize()
+    plain = [[t.clone() for t in dm] for dm in d_multi]
+    for dm in d_multi:
+        for t in dm:
+            t.fill_(7.0)
+    for pr, fl in zip(bwd, flags):
+        pr.row_flags = fl.data_ptr()
+    _lib.call("llmrec_fuse_bwd_src_multi_f32", 2, bwd, d, None)
+    torch.cuda.synchronize()
+    for dm, pm in zip(d_multi, plain):
+        assert all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(dm, pm))
 
 
 def test_weighted_column_sums_in_groups(ops):
