@@ -262,10 +262,11 @@ typedef struct {
     float* const* d_terms; const int64_t* d_ld;
     const float* const* src_terms; const int64_t* src_ld;      /* src_terms[t] may be NULL (= 0) */
     int32_t n_reg_terms; float reg_two_coef;
-    const uint8_t* row_flags;   /* [rows] or NULL. row_flags[r] == 0 PROMISES that dOut[r] and every source row r are all-zero (a row no
-                                   sample of the batch touched - llmrec_bpr_multi_select_bwd_f32 raises the flags): the kernel then writes the
-                                   regulariser's term for the first n_reg_terms streams and zeros for the others without reading anything
-                                   else - the same bits, ~half the traffic of the launch at 10 % touched rows */
+    const uint8_t* row_flags;   /* [rows] or NULL. A row whose flag is not ACTIVE (see LLMREC_ROW_STAMP below) PROMISES that dOut[r] and every
+                                   source row r are all-zero (a row no sample of the batch touched - llmrec_bpr_multi_select_bwd_f32 stamps the
+                                   rows it touches): the kernel then writes the regulariser's term for the first n_reg_terms streams and zeros
+                                   for the others without reading anything else - the same bits, ~half the traffic at 10 % touched rows */
+    const int32_t* row_stamp;   /* device counter that defines ACTIVE, or NULL (active = non-zero flag) */
 } llmrec_fuse_bwd_problem_t;
 int llmrec_fuse_bwd_src_multi_f32(int32_t n_problems, const llmrec_fuse_bwd_problem_t* problems_host, int32_t d, llmrec_stream_t stream);
 
@@ -351,14 +352,21 @@ int llmrec_bpr_multi_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* pro
  *                                     (only the logged loss values depend on it)
  * Results: `out`, `saved` bit-identical to llmrec_bpr_multi_fwd_f32, gradient rows identical to llmrec_bpr_multi_bwd_f32 up to the
  * order of the atomic adds on rows several samples share. */
+/* Row stamps: the rows a batch touches are marked in byte arrays with the value LLMREC_ROW_STAMP(counter) of a device counter that
+ * the scores launch advances once per step; consumers (llmrec_fuse_bwd_problem_t.row_flags) treat a
+ * row as touched iff its byte equals the current stamp. Nothing ever has to be cleared - a stale byte differs from the current stamp for
+ * the next 254 steps, and a false "touched" only costs the general path (same result). */
+#define LLMREC_ROW_STAMP(counter) ((uint8_t)((uint32_t)(counter) % 255u + 1u))
 int llmrec_bpr_multi_scores_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
                                 const int64_t* users, const int64_t* pos, const int64_t* neg,
-                                int32_t B_max, const int32_t* n_valid_dev, float* saved, llmrec_stream_t stream);
+                                int32_t B_max, const int32_t* n_valid_dev, float* saved,
+                                int32_t* row_stamp /* optional: device counter, += 1 by this launch */, llmrec_stream_t stream);
 int llmrec_bpr_multi_select_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
                                     const int64_t* users, const int64_t* pos, const int64_t* neg,
                                     int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
                                     float batch_size_flag, float* saved,
-                                    uint8_t* user_row_flags, uint8_t* item_row_flags,   /* optional: [u_b] / [p_b], [q_b] := 1 for b < n_valid */
+                                    uint8_t* user_row_flags, uint8_t* item_row_flags,   /* optional: [u_b] / [p_b], [q_b] := stamp for b < n_valid */
+                                    const int32_t* row_stamp,                           /* optional device counter (NULL: stamp = 1) */
                                     llmrec_stream_t stream);
 int llmrec_bpr_multi_losses_f32(int32_t n_problems, int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
                                 float batch_size_flag, float* out, float* saved, llmrec_stream_t stream);
@@ -366,9 +374,7 @@ int llmrec_bpr_multi_losses_f32(int32_t n_problems, int32_t B_max, const int32_t
  * so scatter targets that start all-zero are all-zero again. */
 int llmrec_bpr_multi_zero_rows_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
                                    const int64_t* users, const int64_t* pos, const int64_t* neg,
-                                   int32_t B_max, const int32_t* n_valid_dev,
-                                   uint8_t* user_row_flags, uint8_t* item_row_flags,    /* optional: the same rows' flags := 0 */
-                                   llmrec_stream_t stream);
+                                   int32_t B_max, const int32_t* n_valid_dev, llmrec_stream_t stream);
 /* dEu[u_b] += g_mf * ds_b * (Ei[p_b] - Ei[q_b]) + g_emb * c_u * Eu[u_b]   (atomic scatter-add)
  * dEi[p_b] += g_mf * ds_b * Eu[u_b] + g_emb * c_p * Ei[p_b] ; dEi[q_b] likewise with -ds_b, c_q
  * g_mf / g_emb are upstream gradients read from device memory (grads2[0], grads2[1]). */

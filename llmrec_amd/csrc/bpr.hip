@@ -48,11 +48,12 @@ __device__ __forceinline__ int bpr_batch(const int32_t* n_valid_dev, int B_max) 
 __global__ __launch_bounds__(256) void bpr_scores_kernel(BprTables t, int d, const int64_t* __restrict__ users,
                                                          const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
                                                          int B_max, const int32_t* __restrict__ n_valid_dev,
-                                                         float* __restrict__ saved_all, int saved_stride) {
+                                                         float* __restrict__ saved_all, int saved_stride, int32_t* __restrict__ row_stamp) {
     const int B = bpr_batch(n_valid_dev, B_max);
     const int prob = blockIdx.y;
     const int gl = threadIdx.x & 15;
     const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row_stamp && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) row_stamp[0] += 1;   // a new step: new stamp (see the header)
     if (b >= B) return;
     float* sc = saved_all + (int64_t)prob * saved_stride + B_max + 4;
     const float* u = t.Eu[prob] + users[b] * t.ldu[prob];
@@ -259,7 +260,8 @@ __global__ __launch_bounds__(256) void bpr_select_bwd_multi_kernel(BprTables t, 
                                                                    const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
                                                                    int B_max, const int32_t* __restrict__ n_valid_dev, double remember_rate,
                                                                    float decay, float bsz, float* __restrict__ saved_all, int saved_stride,
-                                                                   uint8_t* __restrict__ flag_u, uint8_t* __restrict__ flag_i) {
+                                                                   uint8_t* __restrict__ flag_u, uint8_t* __restrict__ flag_i,
+                                                                   const int32_t* __restrict__ row_stamp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* m_s = reinterpret_cast<float*>(smem);                      // [B]
     __shared__ float red[3][BPR_THREADS];
@@ -308,8 +310,9 @@ __global__ __launch_bounds__(256) void bpr_select_bwd_multi_kernel(BprTables t, 
     const float cu = base / (du_ * du_), cp = base / (dp_ * dp_), cq = base / (dq_ * dq_);
     const int64_t ui = users[b], pi = pos[b], qi = neg[b];
     if (prob == 0 && gl == 0) {                                       // rows this batch touches (same rows for every problem)
-        if (flag_u) flag_u[ui] = 1;
-        if (flag_i) { flag_i[pi] = 1; flag_i[qi] = 1; }
+        const uint8_t stamp = row_stamp ? LLMREC_ROW_STAMP(row_stamp[0]) : (uint8_t)1;
+        if (flag_u) flag_u[ui] = stamp;
+        if (flag_i) { flag_i[pi] = stamp; flag_i[qi] = stamp; }
     }
     const float ds = g_mf * coef;
     const float* u = t.Eu[prob] + ui * t.ldu[prob];
@@ -330,17 +333,12 @@ __global__ __launch_bounds__(256) void bpr_select_bwd_multi_kernel(BprTables t, 
 // without a dense memset
 __global__ __launch_bounds__(256) void bpr_zero_rows_kernel(BprTables t, int d, const int64_t* __restrict__ users,
                                                             const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
-                                                            int B_max, const int32_t* __restrict__ n_valid_dev,
-                                                            uint8_t* __restrict__ flag_u, uint8_t* __restrict__ flag_i) {
+                                                            int B_max, const int32_t* __restrict__ n_valid_dev) {
     const int B = bpr_batch(n_valid_dev, B_max);
     const int prob = blockIdx.y;
     const int gl = threadIdx.x & 15;
     const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (b >= B) return;
-    if (prob == 0 && gl == 0) {
-        if (flag_u) flag_u[users[b]] = 0;
-        if (flag_i) { flag_i[pos[b]] = 0; flag_i[neg[b]] = 0; }
-    }
     float* du = t.dEu[prob] + users[b] * t.lddu[prob];
     float* dpp = t.dEi[prob] + pos[b] * t.lddi[prob];
     float* dqq = t.dEi[prob] + neg[b] * t.lddi[prob];
@@ -567,12 +565,12 @@ extern "C" {
 static int launch_bpr_fwd(const BprTables& t, int n_prob, int d, const int64_t* users, const int64_t* pos, const int64_t* neg,
                           int B_max, const int32_t* n_valid_dev, double remember_rate, float decay, float bsz,
                           float* out, float* saved, const BprGather& ga, bool do_scores, bool do_select, float* pack_out,
-                          hipStream_t stream) {
+                          hipStream_t stream, int32_t* row_stamp = nullptr) {
     const int stride = LLMREC_BPR_SAVED_FLOATS(B_max);
     const BprGather none = {};
     if (do_scores && B_max > 0) {
         dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_prob);
-        bpr_scores_kernel<<<grid, 256, 0, stream>>>(t, d, users, pos, neg, B_max, n_valid_dev, saved, stride);
+        bpr_scores_kernel<<<grid, 256, 0, stream>>>(t, d, users, pos, neg, B_max, n_valid_dev, saved, stride, row_stamp);
         LLMREC_LAUNCH_CHECK();
     }
     if (pack_out) {                                                     // local norm sums, then this rank's gather block
@@ -700,21 +698,21 @@ int llmrec_bpr_multi_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* pro
 
 int llmrec_bpr_multi_scores_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
                                 const int64_t* users, const int64_t* pos, const int64_t* neg,
-                                int32_t B_max, const int32_t* n_valid_dev, float* saved, llmrec_stream_t stream_) {
+                                int32_t B_max, const int32_t* n_valid_dev, float* saved, int32_t* row_stamp, llmrec_stream_t stream_) {
     LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && problems_host && d > 0 && saved, "bpr_multi_scores: bad argument");
     if (B_max > LLMREC_BPR_MAX_B) { set_error("bpr_multi_scores: B_max %d > %d", B_max, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
     LLMREC_CHECK_ARG(B_max == 0 || (users && pos && neg), "bpr_multi_scores: null index pointer");
     BprTables t = {};
     LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, false), "bpr_multi_scores: bad problem table");
     return launch_bpr_fwd(t, n_problems, d, users, pos, neg, B_max, n_valid_dev, 0.0, 0.f, 1.f, nullptr, saved, BprGather{}, true, false,
-                          nullptr, (hipStream_t)stream_);
+                          nullptr, (hipStream_t)stream_, row_stamp);
 }
 
 int llmrec_bpr_multi_select_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
                                     const int64_t* users, const int64_t* pos, const int64_t* neg,
                                     int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
                                     float batch_size_flag, float* saved, uint8_t* user_row_flags, uint8_t* item_row_flags,
-                                    llmrec_stream_t stream_) {
+                                    const int32_t* row_stamp, llmrec_stream_t stream_) {
     LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && problems_host && d > 0 && saved, "bpr_multi_select_bwd: bad argument");
     if (B_max > LLMREC_BPR_MAX_B) { set_error("bpr_multi_select_bwd: B_max %d > %d", B_max, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
     if (B_max == 0) return LLMREC_OK;
@@ -724,7 +722,7 @@ int llmrec_bpr_multi_select_bwd_f32(int32_t n_problems, const llmrec_bpr_problem
     dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_problems);
     bpr_select_bwd_multi_kernel<<<grid, 256, sizeof(float) * (size_t)B_max, (hipStream_t)stream_>>>(
         t, d, users, pos, neg, B_max, n_valid_dev, remember_rate, decay, batch_size_flag, saved, LLMREC_BPR_SAVED_FLOATS(B_max), user_row_flags,
-        item_row_flags);
+        item_row_flags, row_stamp);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }
@@ -741,15 +739,14 @@ int llmrec_bpr_multi_losses_f32(int32_t n_problems, int32_t B_max, const int32_t
 
 int llmrec_bpr_multi_zero_rows_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
                                    const int64_t* users, const int64_t* pos, const int64_t* neg,
-                                   int32_t B_max, const int32_t* n_valid_dev, uint8_t* user_row_flags, uint8_t* item_row_flags,
-                                   llmrec_stream_t stream_) {
+                                   int32_t B_max, const int32_t* n_valid_dev, llmrec_stream_t stream_) {
     LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && problems_host && d > 0, "bpr_multi_zero_rows: bad argument");
     if (B_max == 0) return LLMREC_OK;
     LLMREC_CHECK_ARG(users && pos && neg, "bpr_multi_zero_rows: null index pointer");
     BprTables t = {};
     LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, true), "bpr_multi_zero_rows: bad problem table");
     dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_problems);
-    bpr_zero_rows_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(t, d, users, pos, neg, B_max, n_valid_dev, user_row_flags, item_row_flags);
+    bpr_zero_rows_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(t, d, users, pos, neg, B_max, n_valid_dev);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

@@ -210,7 +210,8 @@ struct FuseMulti {
     int64_t rows[FUSE_MAX_PROBLEMS];
     float* out[FUSE_MAX_PROBLEMS]; int64_t ldo[FUSE_MAX_PROBLEMS];            // forward
     const float* dOut[FUSE_MAX_PROBLEMS]; int64_t lddo[FUSE_MAX_PROBLEMS];    // backward
-    const uint8_t* row_flags[FUSE_MAX_PROBLEMS];                              // backward: 0 = dOut and the sources of this row are all-zero
+    const uint8_t* row_flags[FUSE_MAX_PROBLEMS];                              // backward: not active = dOut and the sources of this row are all-zero
+    const int32_t* row_stamp[FUSE_MAX_PROBLEMS];                              // device counter defining "active" (NULL: non-zero)
     int block_begin;                                                          // first block of problem 1
 };
 #define ROW_LOOP_MULTI(m)                                                                          \
@@ -257,7 +258,7 @@ template <int VEC, int NCHUNK>
 __global__ __launch_bounds__(256) void fuse_bwd_src_multi_kernel(int d, FuseMulti m) {
     ROW_LOOP_MULTI(m) {
         RowReg<VEC, NCHUNK> g, t, o;
-        if (m.row_flags[prob] && !m.row_flags[prob][row]) {
+        if (m.row_flags[prob] && !(m.row_stamp[prob] ? m.row_flags[prob][row] == LLMREC_ROW_STAMP(m.row_stamp[prob][0]) : m.row_flags[prob][row] != 0)) {
             // a row the batch did not touch: dOut = 0 and the sources are 0, so every stream's gradient is w (0 - x 0) = +0 and
             // what is left is the regulariser's reg2 * x on the first n_reg streams - the same bits as the general path below
             for (int i = 0; i < a.n_norm; ++i) {
@@ -762,7 +763,7 @@ int llmrec_fuse_bwd_src_multi_f32(int32_t n_problems, const llmrec_fuse_bwd_prob
             vec4 = vec4 && q.norm_ld[i] % 4 == 0 && q.d_ld[i] % 4 == 0 && aligned16(q.norm_terms[i]) && aligned16(q.d_terms[i]) &&
                    (!a.s_terms[i] || (a.s_ld[i] % 4 == 0 && aligned16(a.s_terms[i])));
         }
-        m.rows[k] = q.rows; m.dOut[k] = q.dOut; m.lddo[k] = q.lddo; m.row_flags[k] = q.row_flags;
+        m.rows[k] = q.rows; m.dOut[k] = q.dOut; m.lddo[k] = q.lddo; m.row_flags[k] = q.row_flags; m.row_stamp[k] = q.row_stamp;
         blocks[k] = grid_for(q.rows, ROWS_PER_BLOCK);
     }
     m.block_begin = blocks[0];

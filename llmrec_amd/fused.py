@@ -68,10 +68,13 @@ class FusedStep:
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         self.dE_u, self.dE_i = z(U, d), z(I, d)
         self.sc_U, self.sc_I, self.sc_prof = z(U, 2 * d), z(I, S * d), z(U, d)
-        # one byte per row, raised by the loss launch for the rows of the batch and lowered again with the row clean-up: the fusion
-        # backward writes the ~90 % of rows no sample touched (zero gradient, zero sources) without reading them
+        # one byte per row, stamped by the loss launch for the rows of the batch with the step's stamp (a device counter: nothing is ever
+        # cleared, no reader races a clean-up): the fusion backward writes the ~90 % of rows no sample touched (zero gradient, zero
+        # sources) without reading them. (The same stamps offered to the transposed side product as "rows whose attribute streams are
+        # all-zero" bought nothing: at 4 edges per row that SpMM is bound by its per-row latency chain, not by the gathers.)
         self.flag_u = torch.zeros(U, dtype=torch.uint8, device=dev)
         self.flag_i = torch.zeros(I, dtype=torch.uint8, device=dev)
+        self.row_stamp = torch.zeros(1, dtype=torch.int32, device=dev)     # advanced by the scores launch (LLMREC_ROW_STAMP)
         self.dU_cat, self.dI_cat = f(U, S * d), f(I, S * d)
         self.dprof_u, self.dprof_i, self.dP_usr = f(U, d), f(I, d), f(U, d)
         self.bufU, self.bufI, self.tmpU, self.tmpI = f(U, d), f(I, d), f(U, d), f(I, d)
@@ -359,9 +362,10 @@ class FusedStep:
         # critical path: scores -> [selection + gradient rows] (two launches); the loss VALUES (one more launch) and their assembly for
         # the log line ride on the ID chain's stream (a branch of their own right behind the BPR launches: the graph ran it as the step's tail)
         self._check_scatter_targets()
-        _call("llmrec_bpr_multi_scores_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), _p(self.saved))
+        _call("llmrec_bpr_multi_scores_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), _p(self.saved),
+              _p(self.row_stamp))
         _call("llmrec_bpr_multi_select_bwd_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), remember,
-              float(hp.decay), float(hp.batch_size), _p(self.saved), _p(self.flag_u), _p(self.flag_i))
+              float(hp.decay), float(hp.batch_size), _p(self.saved), _p(self.flag_u), _p(self.flag_i), _p(self.row_stamp))
 
         def side():                              # (runs on the ID chain's stream, _backward places it)
             _call("llmrec_bpr_multi_losses_f32", self.n_prob, B, _p(n_valid), remember, float(hp.decay), float(hp.batch_size),
@@ -385,8 +389,8 @@ class FusedStep:
 
     def _check_scatter_targets(self):
         if self.check_zero and not torch.cuda.is_current_stream_capturing():
-            dirty = [n for n, t in (("dE_u", self.dE_u), ("dE_i", self.dE_i), ("sc_U", self.sc_U), ("sc_I", self.sc_I), ("sc_prof", self.sc_prof),
-                                    ("flag_u", self.flag_u), ("flag_i", self.flag_i)) if float(t.float().abs().max()) != 0.0]
+            dirty = [n for n, t in (("dE_u", self.dE_u), ("dE_i", self.dE_i), ("sc_U", self.sc_U), ("sc_I", self.sc_I), ("sc_prof", self.sc_prof))
+                     if float(t.abs().max()) != 0.0]
             if dirty:
                 raise RuntimeError("FusedStep: scatter targets not all-zero before the loss backward: %s (an aborted step? call reset_scatter_targets())" % dirty)
 
@@ -425,7 +429,8 @@ class FusedStep:
             pr.d_terms, pr.d_ld = _c.cast(dp, _c.c_void_p), _c.cast(dl, _c.c_void_p)
             pr.src_terms, pr.src_ld = _c.cast(sp, _c.c_void_p), _c.cast(sl, _c.c_void_p)
             pr.n_reg_terms, pr.reg_two_coef = 2, float(2.0 * coef)
-            pr.row_flags = flags.data_ptr() if (flags is not None and bpr_bwd_done) else None     # (only the fused loss launch raises them)
+            if flags is not None and bpr_bwd_done:                      # (only the fused loss launch stamps the rows)
+                pr.row_flags, pr.row_stamp = flags.data_ptr(), self.row_stamp.data_ptr()
         arr = (ops.FuseBwdProblem * 2)()
         problem(arr[0], self.dE_i, self.I_cat, self.prof_i, self.dI_cat, self.dprof_i,
                 [self._side(self.sc_I, 0), self._side(self.sc_I, 1), None] + [self._side(self.sc_I, 2 + k) for k in range(len(self.keys))], self.flag_i)
@@ -472,11 +477,11 @@ class FusedStep:
                 g = self.bufI
             if L == 0:
                 self._axpy(inv, self.dE_i, m.item_id_embedding.weight.grad, False)
+
             # after the last reader of dE_u / dE_i (this chain and the fusion backward): clear the touched rows
             if ev_fuse is not None:
                 torch.cuda.current_stream().wait_event(ev_fuse)
-            _call("llmrec_bpr_multi_zero_rows_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid),
-                  _p(self.flag_u) if bpr_bwd_done else None, _p(self.flag_i) if bpr_bwd_done else None)
+            _call("llmrec_bpr_multi_zero_rows_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid))
             if self.inline_adamw:                                                 # both tables' gradients are final: update them here,
                 self.opt.step_params(self._emb_params)                            # beside the weight-gradient GEMM
 
@@ -543,7 +548,7 @@ class FusedStep:
     def reset_scatter_targets(self):
         """Dense clear of the buffers the sparse-zero scheme keeps all-zero between steps (set-up, (re)capture, and after a
         step that raised between the loss backward's scatter and its row-wise clean-up)."""
-        for t in (self.dE_u, self.dE_i, self.sc_U, self.sc_I, self.sc_prof, self.flag_u, self.flag_i):
+        for t in (self.dE_u, self.dE_i, self.sc_U, self.sc_I, self.sc_prof):
             t.zero_()
 
     def step_eager(self, users, pos, neg, n_valid=None, sampler=None):

@@ -534,7 +534,7 @@ class FuseBwdProblem(_c.Structure):
     _fields_ = [("rows", _c.c_int64), ("dOut", _c.c_void_p), ("lddo", _c.c_int64), ("n_norm", _c.c_int32), ("norm_terms", _c.c_void_p),
                 ("norm_ld", _c.c_void_p), ("rates", _c.c_void_p), ("d_terms", _c.c_void_p), ("d_ld", _c.c_void_p),
                 ("src_terms", _c.c_void_p), ("src_ld", _c.c_void_p), ("n_reg_terms", _c.c_int32), ("reg_two_coef", _c.c_float),
-                ("row_flags", _c.c_void_p)]
+                ("row_flags", _c.c_void_p), ("row_stamp", _c.c_void_p)]
 
 
 class WgradProblem(_c.Structure):

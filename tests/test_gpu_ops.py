@@ -483,24 +483,25 @@ def test_bpr_select_and_backward_in_one_launch(ops, drop, cap, valid, d):
             arr[i].g_mf, arr[i].g_emb = w[i]
         saved = torch.full((P * ops.bpr_saved_floats(cap),), 7.0, device=DEV)
         out = torch.zeros(P, 2, device=DEV)
-        flag_u, flag_i = torch.zeros(U, dtype=torch.uint8, device=DEV), torch.zeros(I, dtype=torch.uint8, device=DEV)
+        flag_u, flag_i = torch.full((U,), 42, dtype=torch.uint8, device=DEV), torch.zeros(I, dtype=torch.uint8, device=DEV)   # 42: a stale stamp
+        stamp = torch.tensor([41 + 255 * 3], dtype=torch.int32, device=DEV)     # the scores launch advances it: stamp value (42 + 765) % 255 + 1 = 43
         common = (P, arr, d, p_(idx[0]), p_(idx[1]), p_(idx[2]), cap, p_(nv))
         if fused:
-            _lib.call("llmrec_bpr_multi_scores_f32", *common, p_(saved), st)
-            _lib.call("llmrec_bpr_multi_select_bwd_f32", *common, 1 - drop, 1e-5, 64.0, p_(saved), p_(flag_u), p_(flag_i), st)
+            _lib.call("llmrec_bpr_multi_scores_f32", *common, p_(saved), p_(stamp), st)
+            _lib.call("llmrec_bpr_multi_select_bwd_f32", *common, 1 - drop, 1e-5, 64.0, p_(saved), p_(flag_u), p_(flag_i), p_(stamp), st)
             _lib.call("llmrec_bpr_multi_losses_f32", P, cap, p_(nv), 1 - drop, 1e-5, 64.0, p_(out), p_(saved), st)
         else:
             _lib.call("llmrec_bpr_multi_fwd_f32", *common, 1 - drop, 1e-5, 64.0, p_(out), p_(saved), st)
             _lib.call("llmrec_bpr_multi_bwd_f32", *common, 1e-5, 64.0, p_(saved), st)
         torch.cuda.synchronize()
-        if fused:                                            # the rows of the valid samples are flagged, no other; the clean-up lowers them
-            want_u = torch.zeros(U, dtype=torch.uint8); want_u[idx[0][:valid].cpu()] = 1
-            want_i = torch.zeros(I, dtype=torch.uint8); want_i[idx[1][:valid].cpu()] = 1; want_i[idx[2][:valid].cpu()] = 1
+        if fused:                                            # the rows of the valid samples carry the step's stamp, no other row changes
+            assert int(stamp[0]) == 42 + 255 * 3
+            want_u = torch.full((U,), 42, dtype=torch.uint8); want_u[idx[0][:valid].cpu()] = 43
+            want_i = torch.zeros(I, dtype=torch.uint8); want_i[idx[1][:valid].cpu()] = 43; want_i[idx[2][:valid].cpu()] = 43
             assert torch.equal(flag_u.cpu(), want_u) and torch.equal(flag_i.cpu(), want_i)
             keep = [(a.clone(), b.clone()) for a, b in grads]
-            _lib.call("llmrec_bpr_multi_zero_rows_f32", *common, p_(flag_u), p_(flag_i), st)
+            _lib.call("llmrec_bpr_multi_zero_rows_f32", *common, st)
             torch.cuda.synchronize()
-            assert int(flag_u.sum()) == 0 and int(flag_i.sum()) == 0
             assert all(float(a.abs().max()) == 0.0 and float(b.abs().max()) == 0.0 for a, b in grads)
             grads = keep
         return saved.cpu(), out.cpu(), [(a.cpu(), b.cpu()) for a, b in grads]
@@ -750,7 +751,7 @@ def test_fuse_bwd_source_mode_and_zero_rows(ops):
         tgt = dEi[i][:, d:2 * d]                                             # a column slice: ld = 2 d
         probs[i].dEu, probs[i].lddu, probs[i].dEi, probs[i].lddi = dEu[i].data_ptr(), d, tgt.data_ptr(), 2 * d
         probs[i].g_mf, probs[i].g_emb = 1.0, 1.0
-    _lib.call("llmrec_bpr_multi_zero_rows_f32", 2, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), None, None, None)
+    _lib.call("llmrec_bpr_multi_zero_rows_f32", 2, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), None)
     torch.cuda.synchronize()
     for i in range(2):
         want_u = torch.ones(U, d, device=DEV); want_u[users[:nv]] = 0
@@ -825,6 +826,18 @@ def test_fuse_pair_launches_equal_the_single_launches(ops):
             t.fill_(7.0)
     for pr, fl in zip(bwd, flags):
         pr.row_flags = fl.data_ptr()
+    _lib.call("llmrec_fuse_bwd_src_multi_f32", 2, bwd, d, None)
+    torch.cuda.synchronize()
+    for dm, pm in zip(d_multi, plain):
+        assert all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(dm, pm))
+    # stamped flags: active = LLMREC_ROW_STAMP(counter) = counter % 255 + 1; every other byte value (stale stamps) is "not touched"
+    counter = torch.tensor([6 + 255], dtype=torch.int32, device=DEV)
+    stamped = [torch.where(fl != 0, torch.full_like(fl, 7), torch.full_like(fl, 3)) for fl in flags]
+    for dm in d_multi:
+        for t in dm:
+            t.fill_(7.0)
+    for pr, fl in zip(bwd, stamped):
+        pr.row_flags, pr.row_stamp = fl.data_ptr(), counter.data_ptr()
     _lib.call("llmrec_fuse_bwd_src_multi_f32", 2, bwd, d, None)
     torch.cuda.synchronize()
     for dm, pm in zip(d_multi, plain):
@@ -956,3 +969,4 @@ def test_weight_gradient_launch_with_the_adamw_update_inside(ops):
     for x, y in zip(a, b):
         assert torch.equal(x.view(torch.int32), y.view(torch.int32))
     assert float(a[2].abs().max()) > 0 and float(a[3].abs().max()) > 0   # (moments were written)
+
