@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void bpr_scores_kernel(BprTables t, int d, con
     const int prob = blockIdx.y;
     const int gl = threadIdx.x & 15;
     const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (row_stamp && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) row_stamp[0] += 1;   // a new step: new stamp (see the header)
+    if (row_stamp && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) row_stamp[0] = (int32_t)((uint32_t)row_stamp[0] + 1u);   // a new step: new stamp
     if (b >= B) return;
     float* sc = saved_all + (int64_t)prob * saved_stride + B_max + 4;
     const float* u = t.Eu[prob] + users[b] * t.ldu[prob];

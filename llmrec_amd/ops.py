@@ -594,6 +594,8 @@ def linear_wgrad_multi(targets, ws: Optional[torch.Tensor] = None, update=None):
         _lib.call("llmrec_linear_wgrad_multi_bf16x3", len(targets), arr, N, _p(ws), ws.numel(), _stream())
         return
     opt, params = update
+    if opt.dev_state is None:
+        raise RuntimeError("linear_wgrad_multi: the optimizer's step counter has not been advanced (FusedAdamW.advance())")
     upd = (WgradUpdate * len(targets))()
     for i, (W, b) in enumerate(params):
         stW = opt.moments(W)
