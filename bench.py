@@ -999,9 +999,19 @@ def main():
             line.update(ex)
             if world == 1 and not a.no_parity:
                 line["parity"] = w.sampled_row_parity()
-            if world == 1 and not a.no_kernel_roofline:
-                line["spmm_in_situ"] = w.spmm_times_ms()
-                line["eval_sample"] = w.eval_sample()
+            if not a.no_kernel_roofline:
+                sp = w.spmm_times_ms()                       # rank 0's local products (no collective inside)
+                line["spmm_in_situ"] = sp
+                path = {k: v for k, v in sp.items() if "not_on_the_path" not in k}
+                worst = min(path, key=lambda k: path[k]["frac_hbm_algorithmic"])
+                line["roofline"] = {"kernel": "spmm_kernel, the step's dominant kernel (4 L products per step): the slowest direction in situ (%s) on rank 0's shard" % worst,
+                                    "bound": "hbm", "achieved": path[worst]["algorithmic_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": path[worst]["frac_hbm_algorithmic"], "traffic": None,
+                                    "gather_gbs": path[worst]["gather_gbs"],
+                                    "note": "fraction of the ALGORITHMIC-bytes roofline (every X row read once); the kernel moves gather_gbs of row gathers, "
+                                            "the measured ceiling of that access pattern (7.3 - 7.8 TB/s, profiles/r02_gatherbench_v2.txt; DESIGN.md 4)"}
+                if world == 1:
+                    line["eval_sample"] = w.eval_sample()
     if workload not in ("nf", "ml") and world > 1 and auto:
         import gc
         del w, step
