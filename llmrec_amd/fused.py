@@ -478,7 +478,9 @@ class FusedStep:
             if L == 0:
                 self._axpy(inv, self.dE_i, m.item_id_embedding.weight.grad, False)
 
-            # after the last reader of dE_u / dE_i (this chain and the fusion backward): clear the touched rows
+            # after the last reader of dE_u / dE_i (this chain and the fusion backward): clear the touched rows. (The wait below is for
+            # an EARLY event. A wait for a late one anywhere in this stream's chain - e.g. for the transposed side product, had the row
+            # stamps needed a clean-up - makes the graph runtime start the WHOLE chain late: profiles/experiments/r03_wgrad.md, last table.)
             if ev_fuse is not None:
                 torch.cuda.current_stream().wait_event(ev_fuse)
             _call("llmrec_bpr_multi_zero_rows_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid))
