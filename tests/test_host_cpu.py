@@ -150,3 +150,26 @@ def test_device_generator_gives_exactly_the_requested_distinct_edges():
     r2, c2 = synth.bipartite_edges_device(20000, 5000, 400000, 1, "cpu")
     r1, c1 = synth.bipartite_edges_device(20000, 5000, 400000, 1, "cpu")
     assert torch.equal(r1, r2) and torch.equal(c1, c2)                        # a function of the seed
+
+
+def test_bench_finds_its_committed_profile_data():
+    """bench.py quotes three things from profiles/: the PMC traffic of the roofline kernels, their in-step rocprofv3 averages and
+    the per-class kernel time. The look-ups go by kernel NAME - a renamed kernel (or a stale profile) must fail here, not turn
+    `roofline.traffic` into null in the driver's bench line."""
+    import re
+    import bench
+    src = open(bench.__file__).read()
+    # the (kernel-name substring, launches) lists kernel_rooflines() hands to the look-ups
+    names = set(re.findall(r'"((?:linear|reduce)_[a-z0-9_]+kernel)"', src))
+    assert {"linear_fwd_grouped_bf16x3_kernel", "linear_wgrad_bf16x3_v2_multi_kernel", "reduce_chunks_multi_kernel"} <= names
+    for key in sorted(names - {"linear_fwd_grouped_kernel"}):            # (the exact-fp32 projection is not the default step's kernel)
+        byts, src_info = bench.pmc_traffic_bytes([(key, 1)])
+        assert byts is not None and byts > 0, (key, src_info)
+        avg = bench.rocprof_avg_us([(key, 1)])
+        assert avg is not None and avg["avg_us"] > 0, key
+    shares = bench.kernel_time_shares()
+    assert shares is not None and "spmm_kernel" in shares["classes"] and shares["file"].startswith("r03_")
+    # and the kernels exist under these names in the library's source
+    csrc = open(os.path.join(os.path.dirname(_lib.HEADER), "..", "llmrec_amd", "csrc", "dense.hip")).read()
+    for key in names:
+        assert key in csrc, key
