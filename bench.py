@@ -148,11 +148,31 @@ class NetflixShaped:
         self.step_id += 1
         if self.use_graph:
             if self.fused.graph_exec is None:
-                self.fused.capture(batcher=self.batcher)       # the capture's warm-up is a real step
+                self._capture()                                # the capture's warm-up is a real step
                 return self.fused.scal[1:4]
             return self.fused.step()
         u, p, n, nv = self.batcher.next()
         return self.fused.step_eager(u, p, n, nv)
+
+    UNROLL = int(os.environ.get("LLMREC_BENCH_UNROLL", "4"))      # steps per replayed graph in run_steps()
+
+    def _capture(self):
+        f = self.fused
+        if hasattr(f, "run_steps") and not hasattr(f, "gsz"):
+            f.capture(batcher=self.batcher, unroll=self.UNROLL)
+        else:                                                  # batch-sharded replicas: graphs between the exchanges
+            f.capture(batcher=self.batcher)
+
+    def run_steps(self, n: int):
+        """n training steps; single-GPU fused path: graphs of UNROLL steps (FusedStep.run_steps), else n times step()."""
+        f = self.fused
+        if self.use_graph and hasattr(f, "run_steps") and not hasattr(f, "gsz"):
+            if f.graph_exec is None:
+                self._capture(); n -= 1
+            self.step_id += n
+            return f.run_steps(n)
+        for _ in range(n):
+            self.step()
 
     def step_modular(self):
         """The same step through torch.autograd over the per-op Functions (reference-shaped path)."""
@@ -186,7 +206,8 @@ class NetflixShaped:
                  "(1 all-gather of %d B) + 1 all-reduce of the %d B gradient bucket per step; eval shards the users"
                  % (self.world, 4 * self.fused.gsz, 4 * self.fused.bucket.numel())),
                 "step": ("fused (llmrec_amd/fused.py)" if not hasattr(self.fused, "gsz") else "fused, 3 segments between the 2 exchanges (llmrec_amd/dp.py)")
-                        + (" + HIP graph replay" if self.use_graph else "")}
+                        + ((" + HIP graph replay (graphs of %d steps: sampler, forward, losses, backward, AdamW x %d per hipGraphLaunch)" % (self.UNROLL, self.UNROLL)
+                            if not hasattr(self.fused, "gsz") and self.UNROLL > 1 else " + HIP graph replay") if self.use_graph else "")}
 
 
     def _wgrad_launch_ms(self, dY_cat, dYu, iters: int = 20):
@@ -784,14 +805,12 @@ def exact_f32_step_time(w: "NetflixShaped", steps: int):
     a = w.args
     f = FusedStep(w.model, w.graph, w.hp, (a.model_cat_rate, a.user_cat_rate, a.item_cat_rate), w.opt, w.hp.batch_size + w.batcher.n_aug)
     f.gemm = "f32"
-    f.capture(batcher=w.batcher)
-    for _ in range(5):
-        f.step()
+    f.capture(batcher=w.batcher, unroll=w.UNROLL)
+    f.run_steps(5)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter(); e0.record()
-    for _ in range(steps):
-        f.step()
+    f.run_steps(steps)
     e1.record(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"ms_per_step": dt / steps * 1e3, "ms_per_step_hip_events": e0.elapsed_time(e1) / steps, "value": steps * w.hp.batch_size / dt,
@@ -814,13 +833,11 @@ def reference_order_step_time(w: "NetflixShaped", steps: int):
             del os.environ["LLMREC_PREPROPAGATE"]
         else:
             os.environ["LLMREC_PREPROPAGATE"] = old
-    f.capture(batcher=w.batcher)
-    for _ in range(5):
-        f.step()
+    f.capture(batcher=w.batcher, unroll=w.UNROLL)
+    f.run_steps(5)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        f.step()
+    f.run_steps(steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"ms_per_step": dt / steps * 1e3, "value": steps * w.hp.batch_size / dt, "unit": "edges/s", "steps": steps,
@@ -901,15 +918,21 @@ def main():
             print("[bench] parity gate: %s" % json.dumps({k: v for k, v in parity.items() if k != "worst_tensor"}), file=sys.stderr, flush=True)
 
     finish = getattr(getattr(w, "fused", None), "flush", lambda: None)   # batch-sharded replicas defer the last AdamW
-    for _ in range(a.warmup):
-        step()
+    if hasattr(w, "run_steps"):
+        w.run_steps(a.warmup)                                # (the multi-step graph is replayed here first, not inside the timed region)
+    else:
+        for _ in range(a.warmup):
+            step()
     finish()
     barrier(); torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()                                             # HIP events on the stream the step graphs are launched on
-    for _ in range(a.steps):
-        step()
+    if hasattr(w, "run_steps"):
+        w.run_steps(a.steps)                                 # exactly a.steps steps (graphs of several steps + single-step graphs)
+    else:
+        for _ in range(a.steps):
+            step()
     finish()                                                 # inside the timed region: every step's update is applied
     ev1.record()
     torch.cuda.synchronize(); barrier()

@@ -195,6 +195,12 @@ class DataParallelStep(FusedStep):
             gc.replay()
         return self.scal[1], self.scal[2], self.scal[3]
 
+    def run_steps(self, n: int):
+        """n steps (the exchanges sit between this step's graphs: no multi-step graph here)."""
+        for _ in range(n):
+            out = self.step()
+        return out
+
     def flush(self):
         """Apply the deferred AdamW update of the last step (and its loss scalars)."""
         if self.graphs is not None and getattr(self, "_pending_update", False):

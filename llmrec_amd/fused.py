@@ -623,7 +623,7 @@ class FusedStep:
                        "neg": torch.zeros(self.b_max, dtype=torch.int64, device=dev), "n_valid": torch.zeros(1, dtype=torch.int32, device=dev)}
         return self.static
 
-    def capture(self, warm_users=None, warm_pos=None, warm_neg=None, warm_n_valid=None, batcher=None):
+    def capture(self, warm_users=None, warm_pos=None, warm_neg=None, warm_n_valid=None, batcher=None, unroll: int = 1):
         """Capture one step (fixed batch capacity b_max, actual size on the device in n_valid).
         With `batcher` (engine.DeviceBatcher, capacity == b_max) the sampler is part of the graph: a
         training step is then ``step()`` with no arguments = one graph replay, nothing else on the stream."""
@@ -649,6 +649,28 @@ class FusedStep:
         with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (the RCCL watchdog) may touch the runtime
             one_step()
         self.graph_exec = g
+        # with the sampler inside the graph nothing host-side separates two steps: run_steps() replays a graph of `unroll` steps (the
+        # device front end takes ~10 us to start the next graph behind the previous one's last kernel - paid once per `unroll` steps)
+        self.graph_multi, self.graph_unroll = None, 0
+        if batcher is not None and unroll > 1:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                for _ in range(unroll):
+                    one_step()
+            self.graph_multi, self.graph_unroll = g2, unroll
+
+    def run_steps(self, n: int):
+        """n training steps of the captured graph(s) (in-graph sampler only): as many replays of the `unroll`-step graph as fit, single
+        steps for the remainder. Returns the logged scalars of the last step."""
+        if self.graph_exec is None or getattr(self, "batcher", None) is None:
+            raise RuntimeError("FusedStep.run_steps: capture(batcher=...) first")
+        k = self.graph_unroll if self.graph_multi is not None else 0
+        while k and n >= k:
+            self.graph_multi.replay()
+            n -= k
+        for _ in range(n):
+            self.graph_exec.replay()
+        return self.scal[1], self.scal[2], self.scal[3]
 
     def _load(self, users, pos, neg, n_valid):
         st, B = self.static, users.numel()

@@ -229,6 +229,34 @@ def test_fused_graph_step_and_eval_at_movielens_shape_match_oracle():
     assert rep["ok"], rep
 
 
+def test_multi_step_graph_equals_single_step_replays():
+    """FusedStep.run_steps: graphs of four steps + single-step graphs for the remainder run the same steps as single replays - the
+    device sampler's counter, AdamW's step counter and the row stamps all advance inside the graph. Seven steps each way from
+    identical seeds: the sampled batch of the last step and the optimiser's step counter are identical, parameters agree to the rounding
+    of the backward's atomic adds (as two runs of either form do)."""
+    import bench
+    dev = torch.device("cuda")
+    res = []
+    for multi in (False, True):
+        w = bench.NetflixShaped("ml", 0, dev)
+        w.UNROLL = 4
+        if multi:
+            w.run_steps(7)                                        # capture (1 step) + one 4-step graph + 2 single replays
+            assert w.fused.graph_multi is not None and w.fused.graph_unroll == 4
+        else:
+            for _ in range(7):
+                w.step()
+        torch.cuda.synchronize()
+        st = w.fused.static
+        res.append(([st[k].clone() for k in ("users", "pos", "neg")], [p.detach().clone() for p in w.opt.params],
+                    int(w.opt.dev_state[:1].view(torch.int32)[0]), [float(x) for x in w.fused.scal[1:4]]))
+    (b0, p0, t0, l0), (b1, p1, t1, l1) = res
+    assert all(torch.equal(x, y) for x, y in zip(b0, b1)) and t0 == t1 == 7
+    for x, y in zip(p0, p1):
+        assert float((x - y).abs().max()) <= 2e-5 * float(x.abs().max()) + 1e-9      # (Adam turns atomic-order rounding of tiny gradients into ~1e-3 lr)
+    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(l0, l1))
+
+
 # ------------------------------------------------------------------------------------------
 # R2 in its HBM-bound regime: >= 10 M edges, d = 64 and d = 128 (BASELINE.json configs[3] / [4] operand widths), every
 # direction the steps run, sampled rows + the longest rows against fp64
