@@ -439,9 +439,11 @@ int llmrec_zero_rows_f32(int64_t n, const int64_t* ids, int32_t d, float* dst, i
  *   mode 0 (single GPU): scal[1] = sum_p w_mf[p] * mf_p + emb_0 + scal[0]; scal[2] = mf_0; scal[3] = emb_0
  *   mode 1 (batch-sharded replica, before the gradient all-reduce): tail[p] = mf_p (this rank's share),
  *          tail[n_problems] = (emb_0 + scal[0]) * inv_world
- *   mode 2 (after it): scal[2] = tail[0]; scal[3] = emb_0; scal[1] = sum_p w_mf[p] * tail[p] + tail[n_problems] */
+ *   mode 2 (after it): scal[2] = tail[0]; scal[3] = emb_0; scal[1] = sum_p w_mf[p] * tail[p] + tail[n_problems]
+ *   running_sums3 (optional, modes 0 and 2): running_sums3[0..2] += (loss, mf, emb) in double - the epoch sums of the reference's log line
+ *   (main.py:280-283) accumulated inside the step graph, so a loop of graph replays needs no host-side arithmetic per step */
 int llmrec_loss_assemble_f32(int32_t mode, int32_t n_problems, const float* bpr_out, const float* w_mf_host,
-                             float* scal4, float* tail, float inv_world, llmrec_stream_t stream);
+                             float* scal4, float* tail, float inv_world, double* running_sums3, llmrec_stream_t stream);
 
 /* out[b] = scale * sum_t terms[t][idx[b]] for b < n: the layer mean of reference Models.py:185-186 for the rows a batch
  * needs only (row-sharded step: B rows instead of a pass over the 10^7-row user tables) */

@@ -472,7 +472,8 @@ __global__ __launch_bounds__(256) void zero_multi_kernel(ZeroTensors t) {
 
 struct LossWeights { float w[LLMREC_BPR_MAX_PROBLEMS]; };
 
-__global__ void loss_assemble_kernel(int mode, int n_prob, const float* __restrict__ out, LossWeights w, float* scal, float* tail, float inv_world) {
+__global__ void loss_assemble_kernel(int mode, int n_prob, const float* __restrict__ out, LossWeights w, float* scal, float* tail, float inv_world,
+                                     double* running) {
     if (threadIdx.x != 0) return;
     if (mode == 0) {
         float s = 0.f;
@@ -488,6 +489,7 @@ __global__ void loss_assemble_kernel(int mode, int n_prob, const float* __restri
         scal[2] = tail[0]; scal[3] = out[1];
         scal[1] = s + tail[n_prob];
     }
+    if (running && mode != 1) { running[0] += (double)scal[1]; running[1] += (double)scal[2]; running[2] += (double)scal[3]; }
 }
 
 __global__ __launch_bounds__(256) void scale_rows_kernel(int64_t rows, int d, const float* __restrict__ s, const float* __restrict__ X, int64_t ldx,
@@ -869,12 +871,12 @@ int llmrec_zero_multi_f32(int32_t n_tensors, const llmrec_zero_tensor_t* tensors
 }
 
 int llmrec_loss_assemble_f32(int32_t mode, int32_t n_problems, const float* bpr_out, const float* w_mf_host,
-                             float* scal4, float* tail, float inv_world, llmrec_stream_t stream_) {
+                             float* scal4, float* tail, float inv_world, double* running_sums3, llmrec_stream_t stream_) {
     LLMREC_CHECK_ARG(mode >= 0 && mode <= 2 && n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS, "loss_assemble: bad mode / problem count");
     LLMREC_CHECK_ARG(bpr_out && scal4 && (mode == 1 || w_mf_host) && (mode == 0 || tail), "loss_assemble: null pointer");
     LossWeights w = {};
     if (w_mf_host) for (int i = 0; i < n_problems; ++i) w.w[i] = w_mf_host[i];
-    loss_assemble_kernel<<<1, 64, 0, (hipStream_t)stream_>>>(mode, n_problems, bpr_out, w, scal4, tail, inv_world);
+    loss_assemble_kernel<<<1, 64, 0, (hipStream_t)stream_>>>(mode, n_problems, bpr_out, w, scal4, tail, inv_world, running_sums3);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

@@ -75,6 +75,9 @@ class FusedStep:
         self.flag_u = torch.zeros(U, dtype=torch.uint8, device=dev)
         self.flag_i = torch.zeros(I, dtype=torch.uint8, device=dev)
         self.row_stamp = torch.zeros(1, dtype=torch.int32, device=dev)     # advanced by the scores launch (LLMREC_ROW_STAMP)
+        # running sums (double) of the logged scalars [loss, mf, emb] over the steps since the caller last cleared them: the epoch line of
+        # reference main.py:280-283 without any host-side arithmetic between graph replays
+        self.epoch_sums = torch.zeros(3, dtype=torch.float64, device=dev)
         self.dU_cat, self.dI_cat = f(U, S * d), f(I, S * d)
         self.dprof_u, self.dprof_i, self.dP_usr = f(U, d), f(I, d), f(U, d)
         self.bufU, self.bufI, self.tmpU, self.tmpI = f(U, d), f(I, d), f(U, d), f(I, d)
@@ -378,7 +381,8 @@ class FusedStep:
     def _assemble_loss(self, mode: int, tail=None, inv_world: float = 1.0):
         """Logged scalars (main.py:273,280-283) from the 8 BPR results + the regulariser: one single-wave launch."""
         w = (_c.c_float * self.n_prob)(*self.w_mf)
-        _call("llmrec_loss_assemble_f32", mode, self.n_prob, _p(self.out), w, _p(self.scal), _p(tail), float(inv_world))
+        _call("llmrec_loss_assemble_f32", mode, self.n_prob, _p(self.out), w, _p(self.scal), _p(tail), float(inv_world),
+              _p(self.epoch_sums) if mode != 1 else None)
 
     def _feat_reg(self):
         """Feature regulariser (main.py:151-156) over the image/text columns of both cat buffers -> scal[0]."""

@@ -257,6 +257,19 @@ class Trainer(object):
         self._global_step += 1
         return out
 
+    def train_epoch_sampled(self, n_batch: int):
+        """n_batch steps of the in-graph-sampler path as graph replays only; returns the device sums [loss, mf, emb] (float64)."""
+        fused = self._fused_step()
+        self.model_mm.train()
+        fused.epoch_sums.zero_()
+        todo = n_batch
+        if fused.graph_exec is None or getattr(fused, "graph_multi", None) is None:
+            fused.capture(batcher=self._device_batcher(), unroll=4)      # the capture's warm-up is a real step (and is summed)
+            todo -= 1
+        fused.run_steps(todo)
+        self._global_step += n_batch
+        return fused.epoch_sums.clone()
+
     def train_step(self, users, pos_items, neg_items, n_valid=None):
         """Forward, the 8 BPR(+prune) losses, feature regulariser, backward, AdamW.
         Returns the device scalars (batch_loss, mf_loss, emb_loss)."""
@@ -307,15 +320,17 @@ class Trainer(object):
             n_batch = data_generator.n_train // args.batch_size + 1
             sums = torch.zeros(3, dtype=torch.float64, device=device)
             sample_time = 0.
-            for idx in _progress(range(n_batch)):
-                if in_graph_sampler:
-                    parts = self.train_step_sampled()
-                else:
+            if in_graph_sampler:
+                # sampler, forward, losses, backward and AdamW are graph replays (four steps per hipGraphLaunch); the three logged scalars
+                # are summed in double inside the graph (llmrec_loss_assemble_f32): nothing else is enqueued between the replays
+                sums = self.train_epoch_sampled(n_batch)
+            else:
+                for idx in _progress(range(n_batch)):
                     sample_t1 = time()
                     users, pos_items, neg_items = self.sample_batch()
                     sample_time += time() - sample_t1
                     parts = self.train_step(users, pos_items, neg_items)
-                sums += torch.stack(parts).double()
+                    sums += torch.stack(parts).double()
             loss, mf_loss, emb_loss = (float(x) for x in sums.cpu())     # one sync per epoch
             reg_loss, contrastive_loss = 0., 0.
 

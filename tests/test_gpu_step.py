@@ -123,6 +123,29 @@ def test_in_graph_sampler_steps_run_and_learn(golden, monkeypatch):
     assert not torch.equal(before, tr.model_mm.item_id_embedding.weight.detach())
 
 
+def test_in_graph_sampler_epoch_sums_on_the_device(golden, monkeypatch):
+    """Trainer.train_epoch_sampled: n steps as graph replays (graphs of four + single steps) with the logged scalars summed in double
+    inside the graph - equal to the sum of the per-step scalars of the same steps run one replay at a time (same seed: the same
+    batches), and the device step counter advanced by exactly n."""
+    monkeypatch.setenv("LLMREC_DEVICE_SAMPLER", "1"); monkeypatch.setenv("LLMREC_GRAPH", "1"); monkeypatch.setenv("LLMREC_FUSED", "1")
+    n = 7
+    m = load_dropin(golden_argv(golden)); m.set_seed(1)
+    tr = m.Trainer(data_config={})
+    sums = tr.train_epoch_sampled(n).cpu().numpy()
+    assert int(tr._device_batcher().step_dev) == n and tr._fused_step().graph_unroll == 4
+    m2 = load_dropin(golden_argv(golden)); m2.set_seed(1)
+    tr2 = m2.Trainer(data_config={})
+    ref = np.zeros(3)
+    for _ in range(n):
+        ref += np.array([float(x) for x in tr2.train_step_sampled()], dtype=np.float64)
+    assert np.all(np.isfinite(sums)) and np.allclose(sums, ref, rtol=2e-5, atol=0), (sums, ref)
+    a, b = tr.model_mm.item_id_embedding.weight.detach(), tr2.model_mm.item_id_embedding.weight.detach()
+    assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    # a second epoch reuses the captured graphs and starts its sums from zero
+    sums2 = tr.train_epoch_sampled(5).cpu().numpy()
+    assert int(tr._device_batcher().step_dev) == n + 5 and np.all(sums2 < sums) and np.all(sums2 > 0)
+
+
 def test_sharded_trainer_single_rank_matches_oracle():
     """llmrec_amd/dist.py on the HIP backend with a world of one rank (collectives are identities):
     the two-pass sharded BPR and the sharded SpMM operands must reproduce the oracle's steps."""
