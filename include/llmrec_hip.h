@@ -112,7 +112,25 @@ typedef struct {
     const float* S; int64_t lds;
     const float* post_scale;     /* [n_rows] or NULL: Y[r] = post_scale[r] * op(t) - lets the CONSUMER of Y run without a per-edge
                                     col_scale gather (dX = R diag(s) g is computed as R (s . g)) */
+    /* Operand sparsity (the backward of the last propagation layer: the gradient that enters it is non-zero only in the rows of the
+     * batch's items, its product only in the rows of their neighbours - reference Models.py:176-186 differentiated):
+     *   x_row_mask [n_cols] or NULL: rows of X whose byte differs from x_mask_active (1..255) are PROMISED all-zero and are not read
+     *                 (they may hold anything); the result equals the unmasked product on the promised zeros up to the sign of a zero;
+     *   y_row_flag [n_rows] or NULL: written for every row: x_mask_active if the row's result can be non-zero - an active X row was
+     *                 gathered, or z_row_flag[row] == x_mask_active (a non-zero row of Z); rows of the long-row buckets are always
+     *                 flagged - else 0: the mask for the next product in the chain (row-local epilogues map zero rows to zero rows);
+     *   z_row_flag [n_rows] or NULL (may alias y_row_flag);
+     *   y_row_gate [n_rows] or NULL: rows whose byte differs from x_mask_active are PROMISED to have no active neighbour and a zero Z row:
+     *                 they are written as zeros before the row's index list is even read (llmrec_mark_neighbours_u8 computes such a gate
+     *                 from the list of active columns - a sweep over THEIR adjacency instead of every row's). */
+    const uint8_t* x_row_mask; int32_t x_mask_active; uint8_t* y_row_flag; const uint8_t* z_row_flag; const uint8_t* y_row_gate;
 } llmrec_spmm_epilogue_t;
+/* flags[ids[j]] = value for j < n (ids[j] < 0 skipped): marks the rows a batch touches (x_row_mask / z_row_flag above) */
+int llmrec_mark_rows_u8(int64_t n, const int64_t* ids, int32_t value, uint8_t* flags, llmrec_stream_t stream);
+/* flags[c] = value for every column c of the CSR rows ids[j], j < n (ids[j] < 0 skipped): the rows of the transposed operand that have
+ * one of the listed rows as a neighbour - with the by-item CSR and the batch's items: the users whose gradient the items' gradient reaches */
+int llmrec_mark_neighbours_u8(int64_t n, const int64_t* ids, const int32_t* rowptr, const int32_t* colidx, int32_t value, uint8_t* flags,
+                              llmrec_stream_t stream);
 
 /* counts_host[0..3] = n_wave_rows, n_block_rows, n_split_rows, n_segments (synchronises the stream). */
 int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t t_wave, int32_t t_block, int32_t segment,
@@ -218,6 +236,12 @@ int llmrec_softmax_rows_bwd_f32(int64_t rows, int32_t d, const float* Y, int64_t
  * same pass; alpha = 1 is llmrec_softmax_rows_bwd_f32 bit for bit. */
 int llmrec_softmax_rows_bwd_scaled_f32(int64_t rows, int32_t d, float alpha, const float* Y, int64_t ldy, const float* dY, int64_t lddy,
                                        float* dZ, int64_t lddz, llmrec_stream_t stream);
+/* The same for the listed rows only, with a per-row scale of the result: dZ[r] = post_scale[r] * softmax_bwd(Y[r], alpha * dY[r]) for
+ * r = ids[j], j < n (ids[j] < 0 skipped; duplicates write the same values). The other rows of dZ are not touched: the first gradient of
+ * the row-sharded step's backward is needed (and, behind an x_row_mask, read) only in the rows of the batch's items. */
+int llmrec_softmax_rows_bwd_listed_f32(int64_t n, const int64_t* ids, int32_t d, float alpha, const float* Y, int64_t ldy,
+                                       const float* dY, int64_t lddy, const float* post_scale, float* dZ, int64_t lddz,
+                                       llmrec_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * R6  fusion  out = scale * sum_t mean_terms[t] + sum_t rates[t] * normalize(terms[t])

@@ -513,6 +513,46 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(int64_t n, const int64_t
     for (int c = gl; c < d; c += 16) p[c] = 0.f;
 }
 
+__global__ __launch_bounds__(256) void mark_rows_kernel(int64_t n, const int64_t* __restrict__ ids, uint8_t value, uint8_t* __restrict__ flags) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int64_t row = ids[j];
+    if (row >= 0) flags[row] = value;
+}
+
+// softmax backward of listed rows (16 lanes per row; d <= 1024)
+__global__ __launch_bounds__(256) void softmax_bwd_listed_kernel(int64_t n, const int64_t* __restrict__ ids, int d, float alpha,
+                                                                 const float* __restrict__ Y, int64_t ldy, const float* __restrict__ dY, int64_t lddy,
+                                                                 const float* __restrict__ post_scale, float* __restrict__ dZ, int64_t lddz) {
+    const int gl = threadIdx.x & 15;
+    const int64_t j = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (j >= n) return;
+    const int64_t row = ids[j];
+    if (row < 0) return;
+    const float* y = Y + row * ldy; const float* g = dY + row * lddy;
+    float dot = 0.f;
+    for (int c = gl; c < d; c += 16) dot = fmaf(y[c], alpha * g[c], dot);
+    dot = group_sum<16>(dot);
+    const float ps = post_scale ? post_scale[row] : 1.0f;
+    float* o = dZ + row * lddz;
+    for (int c = gl; c < d; c += 16) o[c] = ps * (y[c] * (alpha * g[c] - dot));
+}
+
+// MARK_SPLIT wavefronts per listed row, each takes every MARK_SPLIT-th 64-column piece of the row's adjacency list (a hub row of 10^6
+// columns is 2^14 pieces: one wavefront would walk them for a millisecond)
+constexpr int MARK_SPLIT = 32;
+__global__ __launch_bounds__(256) void mark_neighbours_kernel(int64_t n, const int64_t* __restrict__ ids, const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ colidx, uint8_t value, uint8_t* __restrict__ flags) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t j = w / MARK_SPLIT;
+    const int part = (int)(w - j * MARK_SPLIT);
+    if (j >= n) return;
+    const int64_t row = ids[j];
+    if (row < 0) return;
+    const int32_t s = rowptr[row], e = rowptr[row + 1];
+    for (int64_t k = (int64_t)s + part * 64 + (threadIdx.x & 63); k < e; k += 64 * MARK_SPLIT) flags[colidx[k]] = value;
+}
+
 // ---------------------------------------------------------------------------------------------
 // weighted column sums in 64-column groups: out_g[j] (+)= sum_r w[r] * X[r][64 g + j]. The bias gradient of a projection whose
 // operand was propagated beforehand (Y = (A F) W^T + (A 1) b^T: db = sum_r (A 1)[r] dY[r]). Two levels, fixed order.
@@ -877,6 +917,38 @@ int llmrec_loss_assemble_f32(int32_t mode, int32_t n_problems, const float* bpr_
     LossWeights w = {};
     if (w_mf_host) for (int i = 0; i < n_problems; ++i) w.w[i] = w_mf_host[i];
     loss_assemble_kernel<<<1, 64, 0, (hipStream_t)stream_>>>(mode, n_problems, bpr_out, w, scal4, tail, inv_world, running_sums3);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_mark_rows_u8(int64_t n, const int64_t* ids, int32_t value, uint8_t* flags, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n >= 0 && value >= 0 && value <= 255, "mark_rows: bad argument");
+    if (n == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(ids && flags, "mark_rows: null pointer");
+    LLMREC_CHECK_ARG(n / 256 < 0x7fffffffll, "mark_rows: too many rows for one launch");
+    mark_rows_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, (hipStream_t)stream_>>>(n, ids, (uint8_t)value, flags);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_softmax_rows_bwd_listed_f32(int64_t n, const int64_t* ids, int32_t d, float alpha, const float* Y, int64_t ldy,
+                                       const float* dY, int64_t lddy, const float* post_scale, float* dZ, int64_t lddz,
+                                       llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n >= 0 && d > 0, "softmax_bwd_listed: bad sizes");
+    if (n == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(ids && Y && dY && dZ && ldy >= d && lddy >= d && lddz >= d, "softmax_bwd_listed: null pointer or ld < d");
+    softmax_bwd_listed_kernel<<<(unsigned)ceil_div(n, 16), 256, 0, (hipStream_t)stream_>>>(n, ids, d, alpha, Y, ldy, dY, lddy, post_scale, dZ, lddz);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_mark_neighbours_u8(int64_t n, const int64_t* ids, const int32_t* rowptr, const int32_t* colidx, int32_t value, uint8_t* flags,
+                              llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n >= 0 && value >= 0 && value <= 255, "mark_neighbours: bad argument");
+    if (n == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(ids && rowptr && colidx && flags, "mark_neighbours: null pointer");
+    LLMREC_CHECK_ARG(n * MARK_SPLIT / 4 < 0x7fffffffll, "mark_neighbours: too many rows for one launch");
+    mark_neighbours_kernel<<<(unsigned)ceil_div(n * MARK_SPLIT, 4), 256, 0, (hipStream_t)stream_>>>(n, ids, rowptr, colidx, (uint8_t)value, flags);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

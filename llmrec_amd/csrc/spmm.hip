@@ -92,6 +92,13 @@ struct SpmmArgs {
     const float* S;              // softmax backward: rows of the forward softmax output
     int64_t lds;
     const float* post_scale;     // per-row scale of the output, applied last
+    // operand sparsity (llmrec_spmm_epilogue_t): X rows whose byte in x_mask differs from x_active are all-zero and are not read;
+    // y_flag[row] := x_active if the row's result can be non-zero (an active X row was gathered, or z_flag[row] == x_active), else 0
+    const uint8_t* x_mask;
+    int32_t x_active;
+    uint8_t* y_flag;
+    const uint8_t* z_flag;
+    const uint8_t* y_gate;       // rows whose byte != x_active: no active neighbour, zero Z row - written as zeros at once
     // plan
     const int32_t* wave_rows;
     const int32_t* block_rows;
@@ -103,19 +110,56 @@ struct SpmmArgs {
     int32_t blk_seg, blk_block, blk_wave;     // first block of the block-row / wave-row / short-row ranges
 };
 
-// Accumulate sum_{j in [s, e)} w_j * X[col_j, chunk columns] into acc, in ascending j order.
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
-__device__ __forceinline__ void accumulate_range(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, int gl, Vec<VEC> (&acc)[NCHUNK]) {
+// Accumulate sum_{j in [s, e)} w_j * X[col_j, chunk columns] into acc, in ascending j order. MASKED: rows of X that are not active
+// (a.x_mask) are known to be all-zero and are not fetched; `any` collects whether this lane saw an active column.
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED>
+__device__ __forceinline__ void accumulate_range(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, int gl, Vec<VEC> (&acc)[NCHUNK], int& any) {
     for (int32_t base = s; base < e; base += LPR) {
         const int n = min(LPR, e - base);
         int32_t myc = 0;
         float myw = 0.f;
+        int myact = 0;
         if (gl < n) {
             myc = a.colidx[base + gl];
             if (WEIGHTED) {
                 myw = a.val ? a.val[base + gl] : 1.0f;
                 if (a.col_scale) myw *= a.col_scale[myc];
             }
+            if (MASKED) { myact = (int)a.x_mask[myc] == a.x_active; any |= myact; }
+        }
+        if (MASKED) {
+            // only the ACTIVE columns of this chunk are visited (ascending, as in the dense loop: the skipped terms are exact zeros)
+            const unsigned long long bal = __ballot(myact != 0);
+            const int g0 = (int)(threadIdx.x & 63) / LPR * LPR;
+            unsigned long long bits = LPR >= 64 ? bal : ((bal >> g0) & ((1ull << LPR) - 1ull));      // uniform per lane group
+            while (bits) {
+                Vec<VEC> v[UNROLL][NCHUNK];
+                float w[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const bool valid = bits != 0ull;
+                    const int j = valid ? __builtin_ctzll(bits) : 0;
+                    bits &= bits - 1ull;                                   // (0 stays 0)
+                    const int32_t c = __shfl(myc, j, LPR);
+                    if (WEIGHTED) w[u] = valid ? __shfl(myw, j, LPR) : 0.f; else w[u] = 0.f;
+                    const float* xr = a.X + (int64_t)c * a.ldx + col0;
+#pragma unroll
+                    for (int k = 0; k < NCHUNK; ++k) {
+                        const int col = (k * LPR + gl) * VEC;
+                        if (valid && col < a.d) v[u][k].load(xr + col);
+                        else v[u][k].zero();
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+                    for (int k = 0; k < NCHUNK; ++k) {
+                        if (WEIGHTED) acc[k].fma(w[u], v[u][k]);
+                        else acc[k].add(v[u][k]);
+                    }
+                }
+            }
+            continue;
         }
         for (int t = 0; t < n; t += UNROLL) {
             Vec<VEC> v[UNROLL][NCHUNK];
@@ -145,11 +189,28 @@ __device__ __forceinline__ void accumulate_range(const SpmmArgs& a, int64_t col0
     }
 }
 
+// the output-row flag of a masked product (see SpmmArgs); returns whether the row is known to be all-zero AND may be written as
+// zeros without its epilogue (Z absent or known zero through z_flag; the forward softmax of a zero row is not zero)
+__device__ __forceinline__ bool write_row_flag(const SpmmArgs& a, int64_t row, bool any_active, bool write) {
+    const bool z = a.z_flag && (int)a.z_flag[row] == a.x_active;
+    if (write && a.y_flag) a.y_flag[row] = (any_active || z) ? (uint8_t)a.x_active : (uint8_t)0;
+    return !any_active && !z && (a.Z == nullptr || a.z_flag != nullptr) && a.epi_op != LLMREC_SPMM_EPI_SOFTMAX;
+}
+
 // The finished row (unscaled sum in acc, held by the LPR lanes of one lane group): scale, init term, epilogue, store.
 template <int LPR, int NCHUNK, int VEC>
-__device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t col0, int64_t row, int gl, Vec<VEC> (&acc)[NCHUNK]) {
+__device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t col0, int64_t row, int gl, Vec<VEC> (&acc)[NCHUNK], bool zero_row = false) {
     const float rs = a.row_scale ? a.row_scale[row] : 1.0f;
     float* yr = a.Y + row * a.ldy + col0;
+    if (zero_row) {                                              // (uniform per lane group) a masked product's row without an active neighbour
+#pragma unroll                                                   // and with an unflagged (= zero) Z row: op(0) = 0 for op in {none, softmax
+        for (int k = 0; k < NCHUNK; ++k) {                       // backward} - written without reading Z / S
+            const int col = (k * LPR + gl) * VEC;
+            acc[k].zero();
+            if (col < a.d) acc[k].store(yr + col);
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < NCHUNK; ++k) {
         const int col = (k * LPR + gl) * VEC;
@@ -199,7 +260,7 @@ __device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t col0, int6
 constexpr int TPB = 512;                                        // threads per block: 8 wavefronts
 
 // one lane group per (row, slice) task; rows with more than LLMREC_SPMM_LONG_ROW nnz belong to the other ranges
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED>
 __device__ __forceinline__ void rows_body(const SpmmArgs& a, int64_t block) {
     constexpr int GPB = TPB / LPR;
     const int gl = threadIdx.x & (LPR - 1);
@@ -212,20 +273,40 @@ __device__ __forceinline__ void rows_body(const SpmmArgs& a, int64_t block) {
     Vec<VEC> acc[NCHUNK];
 #pragma unroll
     for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
-    accumulate_range<LPR, NCHUNK, VEC, WEIGHTED>(a, col0, s, e, gl, acc);
-    finish_row<LPR, NCHUNK, VEC>(a, col0, row, gl, acc);
+    int any = 0;
+    bool zero_row = false;
+    if (MASKED && a.y_gate && (int)a.y_gate[row] != a.x_active) {         // (uniform per lane group) gated out: nothing of the row is read
+        if (a.y_flag && slice == 0 && gl == 0) a.y_flag[row] = 0;
+        finish_row<LPR, NCHUNK, VEC>(a, col0, row, gl, acc, true);
+        return;
+    }
+    if (MASKED) {
+        // most rows of a masked product have no active neighbour at all: look at the index list and the mask bytes first (two dependent
+        // loads, no per-edge arithmetic) and leave at once when nothing is active - the accumulation loop runs for the few other rows only
+        for (int32_t base = s; base < e; base += LPR)
+            if (base + gl < e) any |= (int)a.x_mask[a.colidx[base + gl]] == a.x_active;
+        const unsigned long long bal = __ballot(any != 0);                // (uniform per lane group below)
+        const int g0 = (int)(threadIdx.x & 63) / LPR * LPR;
+        const unsigned long long gm = LPR >= 64 ? ~0ull : (((1ull << LPR) - 1ull) << g0);
+        const bool any_g = (bal & gm) != 0ull;
+        zero_row = write_row_flag(a, row, any_g, slice == 0 && gl == 0);
+        if (any_g) accumulate_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, s, e, gl, acc, any);
+    } else {
+        accumulate_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, s, e, gl, acc, any);
+    }
+    finish_row<LPR, NCHUNK, VEC>(a, col0, row, gl, acc, zero_row);
 }
 
 // one wavefront over [s, e): the 64/LPR lane groups take contiguous parts, butterfly sum -> every group holds the total
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
-__device__ __forceinline__ void wave_range(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, int lane, Vec<VEC> (&acc)[NCHUNK]) {
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED>
+__device__ __forceinline__ void wave_range(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, int lane, Vec<VEC> (&acc)[NCHUNK], int& any) {
     constexpr int G = 64 / LPR;
     const int gl = lane & (LPR - 1), g = lane / LPR;
     const int32_t per = (((e - s) + G - 1) / G + LPR - 1) / LPR * LPR;      // multiple of LPR: aligned index loads
     const int32_t gs = min(s + g * per, e), ge = min(gs + per, e);
 #pragma unroll
     for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
-    accumulate_range<LPR, NCHUNK, VEC, WEIGHTED>(a, col0, gs, ge, gl, acc);
+    accumulate_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, gs, ge, gl, acc, any);
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
@@ -242,7 +323,7 @@ __device__ __forceinline__ void list_task(const SpmmArgs& a, const int32_t* list
 }
 
 // one wavefront per (row, slice) of the wave-row list
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED>
 __device__ __forceinline__ void wave_rows_body(const SpmmArgs& a, int32_t block) {
     const int lane = threadIdx.x & 63;
     const int64_t task = (int64_t)block * (TPB / 64) + (threadIdx.x >> 6);
@@ -250,20 +331,36 @@ __device__ __forceinline__ void wave_rows_body(const SpmmArgs& a, int32_t block)
     int32_t row, slot; int64_t col0;
     list_task(a, a.wave_rows, a.n_wave_rows, task, row, col0, slot);
     Vec<VEC> acc[NCHUNK];
-    wave_range<LPR, NCHUNK, VEC, WEIGHTED>(a, col0, a.rowptr[row], a.rowptr[row + 1], lane, acc);
-    if (lane < LPR) finish_row<LPR, NCHUNK, VEC>(a, col0, row, lane, acc);
+    int any = 0;
+    bool zero_row = false;
+    if (MASKED) {                                                        // as in rows_body: scan the mask first, accumulate only if something is active
+        const int32_t rs = a.rowptr[row], re = a.rowptr[row + 1];
+        for (int32_t base = rs; base < re; base += 64)
+            if (base + lane < re) any |= (int)a.x_mask[a.colidx[base + lane]] == a.x_active;
+        const bool any_w = __ballot(any != 0) != 0ull;
+        zero_row = write_row_flag(a, row, any_w, col0 == 0 && lane == 0);
+        if (any_w) wave_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, rs, re, lane, acc, any);
+        else {
+#pragma unroll
+            for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
+        }
+    } else {
+        wave_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, a.rowptr[row], a.rowptr[row + 1], lane, acc, any);
+    }
+    if (lane < LPR) finish_row<LPR, NCHUNK, VEC>(a, col0, row, lane, acc, zero_row);
 }
 
 // one block over [s, e): the 8 waves take contiguous parts, summed through LDS in wave order; the total ends up in the
 // first lane group of wave 0 (returns true there)
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED>
 __device__ __forceinline__ bool block_range(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, float* lds, Vec<VEC> (&acc)[NCHUNK]) {
     constexpr int ROWW = NCHUNK * LPR * VEC;
     constexpr int NW = TPB / 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int32_t per = (((e - s) + NW - 1) / NW + 63) / 64 * 64;
     const int32_t ws = min(s + w * per, e), we = min(ws + per, e);
-    wave_range<LPR, NCHUNK, VEC, WEIGHTED>(a, col0, ws, we, lane, acc);
+    int any = 0;                                                         // (long rows: their output flag is set unconditionally)
+    wave_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, ws, we, lane, acc, any);
     if (w > 0 && lane < LPR) {
 #pragma unroll
         for (int k = 0; k < NCHUNK; ++k) acc[k].store(lds + (w - 1) * ROWW + (k * LPR + lane) * VEC);
@@ -280,19 +377,21 @@ __device__ __forceinline__ bool block_range(const SpmmArgs& a, int64_t col0, int
 
 // ONE launch: [0, blk_seg) segments of the split rows, [blk_seg, blk_block) block rows, [blk_block, blk_wave) wave
 // rows (8 per block), the rest short rows. The heavy blocks come first.
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED>
 __global__ __launch_bounds__(TPB) void spmm_kernel(SpmmArgs a) {
     constexpr int ROWW = NCHUNK * LPR * VEC;
     __shared__ __attribute__((aligned(16))) float red_lds[(TPB / 64 - 1) * ROWW];
     const int32_t b = blockIdx.x;
-    if (b >= a.blk_wave) { rows_body<LPR, NCHUNK, VEC, WEIGHTED>(a, (int64_t)b - a.blk_wave); return; }
-    if (b >= a.blk_block) { wave_rows_body<LPR, NCHUNK, VEC, WEIGHTED>(a, b - a.blk_block); return; }
+    if (b >= a.blk_wave) { rows_body<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, (int64_t)b - a.blk_wave); return; }
+    if (b >= a.blk_block) { wave_rows_body<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, b - a.blk_block); return; }
     Vec<VEC> acc[NCHUNK];
     int32_t row, slot; int64_t col0;
     if (b >= a.blk_seg) {
         list_task(a, a.block_rows, a.n_block_rows, b - a.blk_seg, row, col0, slot);
-        if (block_range<LPR, NCHUNK, VEC, WEIGHTED>(a, col0, a.rowptr[row], a.rowptr[row + 1], red_lds, acc))
+        if (block_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, a.rowptr[row], a.rowptr[row + 1], red_lds, acc)) {
+            if (MASKED && col0 == 0 && threadIdx.x == 0 && a.y_flag) a.y_flag[row] = (uint8_t)a.x_active;   // conservative: "may be non-zero"
             finish_row<LPR, NCHUNK, VEC>(a, col0, row, threadIdx.x, acc);
+        }
         return;
     }
     const int32_t slice = b / a.n_segments, seg = b - slice * a.n_segments;
@@ -303,7 +402,8 @@ __global__ __launch_bounds__(TPB) void spmm_kernel(SpmmArgs a) {
     const int32_t re = a.rowptr[row + 1];
     const int32_t s = a.rowptr[row] + k_in_row * a.segment;
     const int32_t e = min(s + a.segment, re);
-    if (block_range<LPR, NCHUNK, VEC, WEIGHTED>(a, col0, s, e, red_lds, acc)) {
+    if (block_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, s, e, red_lds, acc)) {
+        if (MASKED && col0 == 0 && k_in_row == 0 && threadIdx.x == 0 && a.y_flag) a.y_flag[row] = (uint8_t)a.x_active;   // conservative
         float* pr = a.partials + (int64_t)b * a.d;
 #pragma unroll
         for (int k = 0; k < NCHUNK; ++k) {
@@ -361,8 +461,13 @@ static int launch_spmm(SpmmArgs& a, hipStream_t stream) {
     a.blk_block = a.blk_seg + (int32_t)(a.n_block_rows * S);
     a.blk_wave = a.blk_block + (int32_t)wave_blocks;
     if (total > 0) {
-        if (weighted) spmm_kernel<LPR, NCHUNK, VEC, true><<<(unsigned)total, TPB, 0, stream>>>(a);
-        else spmm_kernel<LPR, NCHUNK, VEC, false><<<(unsigned)total, TPB, 0, stream>>>(a);
+        if (a.x_mask) {
+            if (weighted) spmm_kernel<LPR, NCHUNK, VEC, true, true><<<(unsigned)total, TPB, 0, stream>>>(a);
+            else spmm_kernel<LPR, NCHUNK, VEC, false, true><<<(unsigned)total, TPB, 0, stream>>>(a);
+        } else {
+            if (weighted) spmm_kernel<LPR, NCHUNK, VEC, true, false><<<(unsigned)total, TPB, 0, stream>>>(a);
+            else spmm_kernel<LPR, NCHUNK, VEC, false, false><<<(unsigned)total, TPB, 0, stream>>>(a);
+        }
         LLMREC_LAUNCH_CHECK();
     }
     if (a.n_split_rows > 0) {
@@ -411,6 +516,14 @@ extern "C" int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
         LLMREC_CHECK_ARG(!e.Z || e.ldz >= d, "spmm: epilogue Z with ld < d");
         LLMREC_CHECK_ARG(e.op != LLMREC_SPMM_EPI_SOFTMAX_BWD || (e.S && e.lds >= d), "spmm: softmax backward needs S with ld >= d");
         a.epi_op = e.op; a.alpha = e.alpha; a.Z = e.Z; a.ldz = e.ldz; a.S = e.S; a.lds = e.lds; a.post_scale = e.post_scale;
+        if (e.x_row_mask) {
+            LLMREC_CHECK_ARG(e.x_mask_active >= 1 && e.x_mask_active <= 255, "spmm: x_mask_active must be a byte value 1..255");
+            a.x_mask = e.x_row_mask; a.x_active = e.x_mask_active; a.y_flag = e.y_row_flag; a.z_flag = e.z_row_flag;
+            LLMREC_CHECK_ARG(!e.y_row_gate || e.op != LLMREC_SPMM_EPI_SOFTMAX, "spmm: y_row_gate with the forward softmax (a zero row is not a zero output)");
+            a.y_gate = e.y_row_gate;
+        } else {
+            LLMREC_CHECK_ARG(!e.y_row_flag, "spmm: y_row_flag needs x_row_mask");
+        }
         epi_aligned = (!e.Z || (e.ldz % 4 == 0 && (uintptr_t)e.Z % 16 == 0)) && (!e.S || (e.lds % 4 == 0 && (uintptr_t)e.S % 16 == 0));
     }
     const int dd = a.d;

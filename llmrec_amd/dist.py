@@ -105,13 +105,32 @@ class HipBackend:
         return (csr.rowptr[1:] - csr.rowptr[:-1]).to(torch.float32)
 
     def spmm(self, csr, X, out=None, epilogue=None):
-        """Y = epilogue(A X); epilogue: None or {"op": "none" | "softmax" | "softmax_bwd", "alpha", "Z", "S"}."""
+        """Y = epilogue(A X); epilogue: None or {"op": "none" | "softmax" | "softmax_bwd", "alpha", "Z", "S", "post_scale",
+        "x_row_mask", "x_mask_active", "y_row_flag", "z_row_flag"} (the last four: llmrec_spmm_epilogue_t's operand sparsity)."""
         o = self.ops
         epi = None
         if epilogue is not None:
             op = {"none": o.EPI_NONE, "softmax": o.EPI_SOFTMAX, "softmax_bwd": o.EPI_SOFTMAX_BWD}[epilogue.get("op", "none")]
-            epi = o.spmm_epilogue(op, epilogue.get("alpha", 0.0), epilogue.get("Z"), epilogue.get("S"), epilogue.get("post_scale"))
+            epi = o.spmm_epilogue(op, epilogue.get("alpha", 0.0), epilogue.get("Z"), epilogue.get("S"), epilogue.get("post_scale"),
+                                  epilogue.get("x_row_mask"), epilogue.get("x_mask_active", 0), epilogue.get("y_row_flag"), epilogue.get("z_row_flag"),
+                                  epilogue.get("y_row_gate"))
         return o.spmm_raw(csr, X, out=out, epilogue=epi)
+
+    def mark_rows(self, ids, value: int, flags):
+        """flags[ids] = value (ids < 0 skipped): llmrec_mark_rows_u8."""
+        o = self.ops
+        o._lib.call("llmrec_mark_rows_u8", ids.numel(), o._p(ids), int(value), o._p(flags), o._stream())
+
+    def softmax_bwd_listed_into(self, ids, alpha, Y, dY, post_scale, out):
+        """out[ids] = post_scale[ids] . softmax_bwd(Y[ids], alpha dY[ids]); other rows of out untouched (llmrec_softmax_rows_bwd_listed_f32)."""
+        o = self.ops
+        o._lib.call("llmrec_softmax_rows_bwd_listed_f32", ids.numel(), o._p(ids), Y.shape[1], float(alpha), o._p(Y), o._ld(Y), o._p(dY), o._ld(dY),
+                    o._p(post_scale), o._p(out), o._ld(out), o._stream())
+
+    def mark_neighbours(self, ids, csr, value: int, flags):
+        """flags[c] = value for the columns c of csr's rows ids (llmrec_mark_neighbours_u8)."""
+        o = self.ops
+        o._lib.call("llmrec_mark_neighbours_u8", ids.numel(), o._p(ids), o._p(csr.rowptr), o._p(csr.colidx), int(value), o._p(flags), o._stream())
 
     def row_chunk(self, csr, r0, r1):
         """The operand restricted to rows [r0, r1) (views; its own row plan)."""

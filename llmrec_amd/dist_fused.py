@@ -104,10 +104,11 @@ class ShardedFusedID:
     def __init__(self, graph: ShardedGraph, comm: Comm, backend, d: int, n_layers: int, n_users_global: int, seed: int,
                  lr: float, batch_local: int, drop_rate: float, decay: float, n_chunks: Optional[int] = None,
                  user_init: Optional[torch.Tensor] = None, item_init: Optional[torch.Tensor] = None,
-                 batch_size_flag: Optional[float] = None, exchange: str = "all_reduce"):
+                 batch_size_flag: Optional[float] = None, exchange: str = "all_reduce", sparse_backward: bool = True):
         """batch_size_flag: the divisor of the BPR regulariser - the reference divides by the --batch_size FLAG, not by the
         number of triples in the batch (main.py:340: augmented triples do not change it); default = batch_local * world.
-        exchange: "all_reduce" | "rs_ag" (module docstring)."""
+        exchange: "all_reduce" | "rs_ag" (module docstring). sparse_backward: skip the all-zero operand rows in the two SpMMs of the last
+        layer's backward (False: the dense products, for A/B runs)."""
         self.g, self.comm, self.be = graph, comm, backend
         self.d, self.L, self.B = d, n_layers, batch_local
         self.remember, self.decay = 1.0 - drop_rate, decay
@@ -157,6 +158,14 @@ class ShardedFusedID:
         self.gat_rows = f(comm.world, 2, batch_local, d)
         self.gat_ids = torch.empty(comm.world, 2, batch_local, dtype=torch.int64, device=dev)
         self.my_ids = torch.empty(2, batch_local, dtype=torch.int64, device=dev)
+        # The backward of the LAST propagation layer works on sparse rows: the gradient that enters it (g = softmax_bwd(I_L, inv dE_i))
+        # is non-zero only in the rows of the batch's items, its product A_iu^T g only in the rows of their neighbours (a few per cent of
+        # the users). One byte per row says so (llmrec_spmm_epilogue_t x_row_mask / y_row_flag; the active value is a per-step stamp, so
+        # nothing is ever cleared): those two SpMMs skip the gathers of all-zero rows - 2 of the step's 4 L products.
+        self.sparse_backward = sparse_backward
+        self.graph_items_to_users = graph.ui_bwd                 # rows = items, columns = this rank's users (the pattern is what matters)
+        self.flag_u = torch.zeros(U, dtype=torch.uint8, device=dev)
+        self.flag_i = torch.zeros(I, dtype=torch.uint8, device=dev)
         # item-row chunks of the two SpMMs whose output is all-reduced (>= 32 MB per message unless told otherwise)
         if n_chunks is None:                                  # nothing to overlap in a world of one rank
             n_chunks = 1 if (comm.world == 1 and not comm.force) else max(1, min(8, (4 * I * d) // (32 << 20)))
@@ -258,13 +267,25 @@ class ShardedFusedID:
         comm.all_gather_into(self.gat_rows.view(-1), self.rows3[1:3].reshape(-1))
         comm.all_gather_into(self.gat_ids.view(-1), self.my_ids.view(-1))
         be.scatter_rows(self.gat_ids.view(-1), self.gat_rows.view(-1, self.d), self.dE_i, 1.0)     # same list, same order on every rank
+        stamp = self.step_id % 255 + 1                            # this step's mark of "row touched"
+        if self.sparse_backward:
+            be.mark_rows(u, stamp, self.flag_u)                   # the non-zero rows of dE_u ...
+            be.mark_rows(self.gat_ids.view(-1), stamp, self.flag_i)   # ... and of dE_i (hence of g)
+            # ... and the local users those items reach: the only rows of A_iu^T g that can be non-zero (a sweep over the adjacency of
+            # <= 2 B world items instead of a look at every user's index list)
+            be.mark_neighbours(self.gat_ids.view(-1), self.graph_items_to_users, stamp, self.flag_u)
         inv = 1.0 / (L + 1)
         # dI[L] = inv dE_i -> g = softmax_bwd(I_L, dI[L]); then per layer
         #   dU[l+1] = inv dE_u + A_iu[:, blk]^T g          (local; softmax backward as the epilogue on the last layer)
         #   dI[l]   = inv dE_i + sum_r A_ui[blk_r, :]^T h  (chunked + all-reduced; every rank adds inv / world of the replicated dE_i)
         #   (g and h below are stored PRE-SCALED by s_i / s_u, see __init__)
         g = self.bufI
-        if L >= 1:
+        if L >= 1 and self.sparse_backward:
+            # g = s_i . softmax_bwd(I_L, inv dE_i) in the rows of the batch's items only: the masked product below reads no other row
+            # (three dense passes over the I x d tables otherwise)
+            be.softmax_bwd_listed_into(self.gat_ids.view(-1), inv, self.Il[L - 1], self.dE_i, self.s_i, self.tmpI)
+            g = self.tmpI
+        elif L >= 1:
             be.axpy_into(inv, self.dE_i, self.bufI)
             be.softmax_bwd_into(self.Il[L - 1], self.bufI, self.tmpI)
             be.scale_rows_into(self.s_i, self.tmpI, self.tmpI)
@@ -272,14 +293,20 @@ class ShardedFusedID:
         for l in range(L - 1, -1, -1):
             last = l == L - 1
             epi = {"op": "softmax_bwd" if last else "none", "alpha": inv, "Z": self.dE_u, "post_scale": self.s_u}
+            sparse = last and self.sparse_backward                # (g is the softmax backward of the scattered rows only on the last layer)
             if last:
                 epi["S"] = self.Ul[l]
+            if sparse:                                            # rows of g outside the batch's items are zero: not gathered; flag_u := rows of h that can be non-zero
+                epi.update({"x_row_mask": self.flag_i, "x_mask_active": stamp, "z_row_flag": self.flag_u, "y_row_gate": self.flag_u})
             be.spmm(self.R_user, g, out=self.hU, epilogue=epi)                           # h = s_u . dU[l+1] (softmax backward on the last layer)
             dst = self.item_tab.grad if l == 0 else self.bufI
             w = inv / comm.world
+            # (h itself is NOT sparse enough to mask: the users two hops from the batch - through its most popular items - are ~40 % of
+            #  all users at cfg 4, and the masked product then costs more than the dense one: 9.2 vs 6.2 ms measured)
+            hmask = {}
             self._reduced_spmm(self.ui_bwd_chunks, self.hU, dst,
-                               epilogue_for=lambda r0, r1: {"op": "none", "alpha": w, "Z": self.dE_i[r0:r1],
-                                                            "post_scale": None if l == 0 else self.s_i[r0:r1]})
+                               epilogue_for=lambda r0, r1: dict({"op": "none", "alpha": w, "Z": self.dE_i[r0:r1],
+                                                                 "post_scale": None if l == 0 else self.s_i[r0:r1]}, **hmask))
             g = self.bufI
         if L == 0:
             be.axpy_into(inv, self.dE_i, self.item_tab.grad)

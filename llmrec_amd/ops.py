@@ -64,7 +64,8 @@ class SpmmPlanC(_c.Structure):
 class SpmmEpilogueC(_c.Structure):
     """llmrec_spmm_epilogue_t"""
     _fields_ = [("op", _c.c_int32), ("alpha", _c.c_float), ("Z", _c.c_void_p), ("ldz", _c.c_int64), ("S", _c.c_void_p), ("lds", _c.c_int64),
-                ("post_scale", _c.c_void_p)]
+                ("post_scale", _c.c_void_p), ("x_row_mask", _c.c_void_p), ("x_mask_active", _c.c_int32), ("y_row_flag", _c.c_void_p),
+                ("z_row_flag", _c.c_void_p), ("y_row_gate", _c.c_void_p)]
 
 
 EPI_NONE, EPI_SOFTMAX, EPI_SOFTMAX_BWD = 0, 1, 2
@@ -294,11 +295,23 @@ class BipartiteGraph:
 # R2: SpMM
 # ---------------------------------------------------------------------------------------------
 def spmm_epilogue(op: int = EPI_NONE, alpha: float = 0.0, Z: Optional[torch.Tensor] = None, S: Optional[torch.Tensor] = None,
-                  post_scale: Optional[torch.Tensor] = None):
-    """llmrec_spmm_epilogue_t: Y = post_scale . op(alpha * Z + A X); S = forward softmax rows for EPI_SOFTMAX_BWD."""
+                  post_scale: Optional[torch.Tensor] = None, x_row_mask: Optional[torch.Tensor] = None, x_mask_active: int = 0,
+                  y_row_flag: Optional[torch.Tensor] = None, z_row_flag: Optional[torch.Tensor] = None,
+                  y_row_gate: Optional[torch.Tensor] = None):
+    """llmrec_spmm_epilogue_t: Y = post_scale . op(alpha * Z + A X); S = forward softmax rows for EPI_SOFTMAX_BWD.
+    x_row_mask (uint8 [n_cols]) / x_mask_active: X rows whose byte differs from the active value are promised all-zero and not read;
+    y_row_flag (uint8 [n_rows]): receives the active value for rows whose result can be non-zero (z_row_flag: the non-zero rows of Z);
+    y_row_gate (uint8 [n_rows]): rows without the active value are promised zero results and written as zeros unread."""
+    for t in (x_row_mask, y_row_flag, z_row_flag, y_row_gate):
+        if t is not None and (t.dtype != torch.uint8 or not t.is_contiguous()):
+            raise RuntimeError("spmm_epilogue: row masks / flags are contiguous uint8 tensors")
     return SpmmEpilogueC(op, float(alpha), Z.data_ptr() if Z is not None else None, _ld(Z) if Z is not None else 0,
                          S.data_ptr() if S is not None else None, _ld(S) if S is not None else 0,
-                         post_scale.data_ptr() if post_scale is not None else None)
+                         post_scale.data_ptr() if post_scale is not None else None,
+                         x_row_mask.data_ptr() if x_row_mask is not None else None, int(x_mask_active),
+                         y_row_flag.data_ptr() if y_row_flag is not None else None,
+                         z_row_flag.data_ptr() if z_row_flag is not None else None,
+                         y_row_gate.data_ptr() if y_row_gate is not None else None)
 
 
 def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False, epilogue=None,

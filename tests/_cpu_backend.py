@@ -22,6 +22,20 @@ class CpuBackend:
         return torch.bincount(p.rows, minlength=p.n_rows).float()
 
     def spmm(self, p, X, out=None, epilogue=None):
+        if epilogue is not None and epilogue.get("x_row_mask") is not None:      # the contract of llmrec_spmm_epilogue_t's operand sparsity
+            act = epilogue["x_row_mask"] == epilogue["x_mask_active"]
+            X = torch.where(act[:, None], X, torch.zeros_like(X))                # rows that are not active are never read
+            if epilogue.get("y_row_gate") is not None:                           # gated-out rows are written as zeros unread: check the promise
+                out_of_gate = epilogue["y_row_gate"] != epilogue["x_mask_active"]
+                touched = torch.zeros(p.n_rows, dtype=torch.bool); touched[p.rows[act[p.cols]]] = True
+                assert not bool((touched & out_of_gate).any()), "y_row_gate excludes a row with an active neighbour"
+            if epilogue.get("y_row_flag") is not None:
+                hit = torch.zeros(p.n_rows, dtype=torch.bool)
+                hit[p.rows[act[p.cols]]] = True
+                if epilogue.get("z_row_flag") is not None:
+                    hit |= epilogue["z_row_flag"] == epilogue["x_mask_active"]
+                epilogue["y_row_flag"].copy_(torch.where(hit, torch.full_like(epilogue["y_row_flag"], epilogue["x_mask_active"]),
+                                                         torch.zeros_like(epilogue["y_row_flag"])))
         X = X if p.col_scale is None else X * p.col_scale[:, None]
         A = torch.sparse_coo_tensor(torch.stack([p.rows, p.cols]), torch.ones(p.rows.numel()), (p.n_rows, p.n_cols))
         Y = torch.sparse.mm(A, X)
@@ -41,6 +55,19 @@ class CpuBackend:
             out.copy_(Y)
             return out
         return Y
+
+    def mark_rows(self, ids, value, flags):
+        flags[ids[ids >= 0]] = value
+
+    def softmax_bwd_listed_into(self, ids, alpha, Y, dY, post_scale, out):
+        r = torch.unique(ids[ids >= 0])
+        g = alpha * dY[r]
+        z = Y[r] * (g - (g * Y[r]).sum(-1, keepdim=True))
+        out[r] = z if post_scale is None else z * post_scale[r][:, None]
+
+    def mark_neighbours(self, ids, p, value, flags):
+        sel = torch.isin(p.rows, ids[ids >= 0])
+        flags[p.cols[sel]] = value
 
     def row_chunk(self, p, r0, r1):
         sel = (p.rows >= r0) & (p.rows < r1)

@@ -970,3 +970,112 @@ def test_weight_gradient_launch_with_the_adamw_update_inside(ops):
         assert torch.equal(x.view(torch.int32), y.view(torch.int32))
     assert float(a[2].abs().max()) > 0 and float(a[3].abs().max()) > 0   # (moments were written)
 
+
+
+@pytest.mark.parametrize("d,weighted", [(64, False), (64, True), (128, False), (448, True)])
+def test_spmm_operand_row_mask_and_output_flags(ops, d, weighted):
+    """llmrec_spmm_epilogue_t operand sparsity: with the promised zeros in place (rows of X that are not active are all-zero) the masked
+    product equals the unmasked one; rows that are not active are NOT READ (poisoning them changes nothing); y_row_flag marks exactly
+    the rows with an active neighbour or a flagged Z row in the short / wavefront buckets and every row of the long-row buckets; stale
+    byte values count as not active. All row buckets (hub rows past the split threshold), the softmax-backward epilogue included."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(41)
+    n_rows, n_cols, stamp = 3000, 2500, 77
+    degs = rng.integers(0, 30, size=n_rows); degs[5] = 2400; degs[6] = 0; degs[7] = 700; degs[8] = 150
+    rows, cols = rand_graph(rng, n_rows, n_cols, degs)
+    rp, ci, _ = ops.csr_from_coo(torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV), None, n_rows, n_cols)
+    cs = (torch.rand(n_cols, device=DEV) + 0.5) if weighted else None
+    a = ops.Csr(n_rows, n_cols, rp, ci, None, torch.rand(n_rows, device=DEV) + 0.5, cs, {})
+    act = torch.rand(n_cols, device=DEV) < 0.02
+    mask = torch.where(act, torch.full((n_cols,), stamp, dtype=torch.uint8, device=DEV),
+                       torch.randint(0, 60, (n_cols,), device=DEV).to(torch.uint8))          # stale values everywhere else
+    X = torch.randn(n_cols, d, device=DEV); X[~act] = 0.0
+    Z = torch.zeros(n_rows, d, device=DEV)
+    zrows = torch.tensor([6, 11, 2999], device=DEV); Z[zrows] = torch.randn(3, d, device=DEV)
+    zflag = torch.randint(0, 60, (n_rows,), device=DEV).to(torch.uint8); zflag[zrows] = stamp
+    S = torch.softmax(torch.randn(n_rows, d, device=DEV), dim=1)
+    whole = d <= 128                                                        # (the softmax epilogues need the whole row)
+    op = ops.EPI_SOFTMAX_BWD if whole else ops.EPI_NONE
+    ref = ops.spmm_raw(a, X, epilogue=ops.spmm_epilogue(op, 0.5, Z, S if whole else None))
+    Xp = X.clone(); Xp[~act] = float("nan")                                 # never read
+    yflag = zflag.clone()                                                   # (aliased with z_row_flag, as the row-sharded step uses it)
+    got = ops.spmm_raw(a, Xp, epilogue=ops.spmm_epilogue(op, 0.5, Z, S if whole else None, x_row_mask=mask, x_mask_active=stamp,
+                                                          y_row_flag=yflag, z_row_flag=yflag))
+    assert bool(torch.isfinite(got).all()) and torch.equal(got, ref)
+    A = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(n_rows, n_cols))
+    hit = np.asarray(A @ act.cpu().numpy().astype(np.float64)).ravel() > 0
+    hit[zrows.cpu().numpy()] = True
+    yf = yflag.cpu().numpy()
+    assert set(np.unique(yf)) <= {0, stamp}
+    sw, pl = a.plan_for(d, whole_row=whole and op != ops.EPI_NONE)
+    short = degs <= pl.t_wave                                               # lane-group and wavefront rows: exact flags
+    assert np.array_equal(yf[short] == stamp, hit[short])
+    assert np.all(yf[~short] == stamp) and np.all(yf[hit] == stamp)         # long rows: always flagged; no active row is ever missed
+    assert np.abs(got.cpu().numpy()[yf == 0]).max() == 0.0                  # an unflagged row is a zero row
+    # the same product behind a row GATE built from the active columns' adjacency (llmrec_mark_neighbours_u8 on the transposed CSR)
+    # plus the flagged Z rows (llmrec_mark_rows_u8): gated-out rows are written as zeros unread, the result does not change
+    import ctypes
+    from llmrec_amd import _lib
+    p_ = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = torch.cuda.current_stream().cuda_stream
+    rpT, ciT, _ = ops.csr_from_coo(torch.tensor(cols).to(DEV), torch.tensor(rows).to(DEV), None, n_cols, n_rows)
+    gate = torch.randint(0, 60, (n_rows,), device=DEV).to(torch.uint8)
+    act_ids = torch.nonzero(act).flatten().to(torch.int64)
+    ids = torch.cat([act_ids, torch.tensor([-1], device=DEV)])               # (negative ids are skipped)
+    _lib.call("llmrec_mark_rows_u8", zrows.numel(), p_(zrows), stamp, p_(gate), st)
+    _lib.call("llmrec_mark_neighbours_u8", ids.numel(), p_(ids), p_(rpT), p_(ciT), stamp, p_(gate), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(gate.cpu().numpy() == stamp, hit)
+    got2 = ops.spmm_raw(a, Xp, epilogue=ops.spmm_epilogue(op, 0.5, Z, S if whole else None, x_row_mask=mask, x_mask_active=stamp,
+                                                           z_row_flag=gate, y_row_gate=gate))
+    assert torch.equal(got2, ref)
+
+
+def test_mark_rows_and_neighbours_at_launch_sizes_beyond_one_grid_cap(ops):
+    """llmrec_mark_rows_u8 / llmrec_mark_neighbours_u8 with many ids (more blocks than the row kernels' usual grid cap), duplicate and
+    negative ids, hub rows and empty rows: exactly the listed rows / their columns are marked, nothing else changes."""
+    import ctypes
+    import scipy.sparse as sp
+    from llmrec_amd import _lib
+    rng = np.random.default_rng(43)
+    n_rows, n_cols = 20000, 30000
+    degs = rng.integers(0, 12, size=n_rows); degs[17] = 25000; degs[18] = 0
+    rows, cols = rand_graph(rng, n_rows, n_cols, degs)
+    rp, ci, _ = ops.csr_from_coo(torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV), None, n_rows, n_cols)
+    ids_np = np.concatenate([rng.integers(0, n_rows, size=9000), [17, 18, -1, -1, 17]])
+    ids = torch.tensor(ids_np, dtype=torch.int64, device=DEV)
+    p_ = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = torch.cuda.current_stream().cuda_stream
+    flags = torch.full((n_cols,), 9, dtype=torch.uint8, device=DEV)
+    _lib.call("llmrec_mark_neighbours_u8", ids.numel(), p_(ids), p_(rp), p_(ci), 200, p_(flags), st)
+    rflags = torch.full((n_rows,), 9, dtype=torch.uint8, device=DEV)
+    _lib.call("llmrec_mark_rows_u8", ids.numel(), p_(ids), 201, p_(rflags), st)
+    torch.cuda.synchronize()
+    sel = np.zeros(n_rows, dtype=bool); sel[ids_np[ids_np >= 0]] = True
+    A = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(n_rows, n_cols))
+    want = np.asarray(A.T @ sel.astype(np.float64)).ravel() > 0
+    assert np.array_equal(flags.cpu().numpy(), np.where(want, 200, 9).astype(np.uint8))
+    assert np.array_equal(rflags.cpu().numpy(), np.where(sel, 201, 9).astype(np.uint8))
+
+
+@pytest.mark.parametrize("d", [64, 128, 20])
+def test_softmax_backward_of_listed_rows(ops, d):
+    """llmrec_softmax_rows_bwd_listed_f32 against the dense launches it replaces in the listed rows (axpy, softmax backward, row scale);
+    rows that are not listed keep their contents; negative and duplicate ids."""
+    import ctypes
+    from llmrec_amd import _lib
+    g = torch.Generator(device=DEV); g.manual_seed(7)
+    n = 5000
+    Y = torch.softmax(torch.randn(n, d, generator=g, device=DEV), dim=1)
+    dY = torch.randn(n, d, generator=g, device=DEV) * 1e-3
+    ps = torch.rand(n, generator=g, device=DEV) + 0.5
+    ids = torch.cat([torch.randint(0, n, (700,), generator=g, device=DEV), torch.tensor([-1, 3, 3], device=DEV)]).to(torch.int64)
+    out = torch.full((n, d), 5.0, device=DEV)
+    p_ = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.call("llmrec_softmax_rows_bwd_listed_f32", ids.numel(), p_(ids), d, 0.25, p_(Y), d, p_(dY), d, p_(ps), p_(out), d,
+              torch.cuda.current_stream().cuda_stream)
+    gd = (0.25 * dY).double(); yd = Y.double()
+    want = (ps.double()[:, None] * (yd * (gd - (gd * yd).sum(1, keepdim=True)))).float()
+    sel = torch.zeros(n, dtype=torch.bool, device=DEV); sel[ids[ids >= 0]] = True
+    assert rel_err(out[sel].cpu(), want[sel].cpu()) < 2e-6
+    assert bool((out[~sel] == 5.0).all())
