@@ -154,7 +154,10 @@ class ShardedFusedID:
         self.s_u, self.s_i = graph.ui_fwd.row_scale, graph.s_i
         self.rows3 = f(3, batch_local, d)
         self.Eu_rows = f(batch_local, d)
+        self.Ei_rows = f(2 * batch_local, d)                   # the layer means of the batch's positive, then negative items
+        self.pn_ids = torch.empty(2 * batch_local, dtype=torch.int64, device=dev)
         self.arange_b = torch.arange(batch_local, dtype=torch.int64, device=dev)
+        self.arange_neg = self.arange_b + batch_local
         self.gat_rows = f(comm.world, 2, batch_local, d)
         self.gat_ids = torch.empty(comm.world, 2, batch_local, dtype=torch.int64, device=dev)
         self.my_ids = torch.empty(2, batch_local, dtype=torch.int64, device=dev)
@@ -216,8 +219,9 @@ class ShardedFusedID:
                 after(view)
 
     # -- forward ---------------------------------------------------------------------------------------
-    def forward(self, dense_users: bool = True):
-        """dense_users = False (training): E_u is not materialised (the loss gathers its batch rows)."""
+    def forward(self, dense_users: bool = True, dense_items: bool = True):
+        """dense_users / dense_items = False (training): E_u / E_i are not materialised (the loss gathers the layer means of its batch rows:
+        one pass over B rows instead of one over the whole tables)."""
         be, L = self.be, self.L
         i_prev = self.item_tab.detach()
         for l in range(L):
@@ -228,7 +232,8 @@ class ShardedFusedID:
             i_prev = self.Il[l]
         if dense_users:
             be.layer_mean_into([self.user_tab.detach()] + self.Ul, self.E_u)
-        be.layer_mean_into([self.item_tab.detach()] + self.Il, self.E_i)
+        if dense_items:
+            be.layer_mean_into([self.item_tab.detach()] + self.Il, self.E_i)
         return self.E_u, self.E_i
 
     # -- one training step -------------------------------------------------------------------------------
@@ -242,14 +247,18 @@ class ShardedFusedID:
         u, p, n = triples if triples is not None else self.sample()
         self.step_id += 1
         self.allreduce_bytes = 0
-        self.forward(dense_users=False)
+        self.forward(dense_users=False, dense_items=False)
         # BPR + prune over the global batch (reference main.py:158-165,330-342): two passes around an all-gather of B floats;
         # the user side of the loss is the B x d block of layer-mean rows, indexed 0..B-1
         be.gather_mean_into([self.user_tab.detach()] + self.Ul, u, self.Eu_rows)
-        ar = self.arange_b
-        _, s1 = be.bpr_fwd(self.Eu_rows, self.E_i, ar, p, n, self.remember, self.decay, self.bsz_flag, None, 0, 0, True)
+        B0 = self.arange_b.numel()
+        self.pn_ids[:B0].copy_(p); self.pn_ids[B0:].copy_(n)
+        be.gather_mean_into([self.item_tab.detach()] + self.Il, self.pn_ids, self.Ei_rows)
+        ar, E_i = self.arange_b, self.Ei_rows                  # the loss indexes the compact blocks: user b, positive b, negative B + b
+        p_loc, n_loc = self.arange_b, self.arange_neg
+        _, s1 = be.bpr_fwd(self.Eu_rows, E_i, ar, p_loc, n_loc, self.remember, self.decay, self.bsz_flag, None, 0, 0, True)
         global_m = comm.all_gather_cat(be.bpr_local_m(s1, B).contiguous())
-        out, saved = be.bpr_fwd(self.Eu_rows, self.E_i, ar, p, n, self.remember, self.decay, self.bsz_flag, global_m, global_m.numel(),
+        out, saved = be.bpr_fwd(self.Eu_rows, E_i, ar, p_loc, n_loc, self.remember, self.decay, self.bsz_flag, global_m, global_m.numel(),
                                 comm.rank * B, False)
         small = torch.cat([saved[B:B + 3], out[:1]])
         comm.all_reduce_(small)                                   # the three squared norms + the mf shares
@@ -258,7 +267,7 @@ class ShardedFusedID:
         emb = (self.decay * ((1.0 / (2.0 * small[:3] + 1e-8)).sum() / self.bsz_flag)).reshape(1)
         # backward: compact gradient rows; users scatter locally, item rows are exchanged (all-gather of 2 B rows)
         ones = torch.ones(2, dtype=torch.float32, device=out.device)
-        be.bpr_bwd_rows(self.Eu_rows, self.E_i, ar, p, n, self.decay, self.bsz_flag, saved, ones, self.rows3)
+        be.bpr_bwd_rows(self.Eu_rows, E_i, ar, p_loc, n_loc, self.decay, self.bsz_flag, saved, ones, self.rows3)
         if self._scatter_dirty:                               # only after a step that did not reach its clean-up
             be.zero_([self.dE_u, self.dE_i])
         self._scatter_dirty = True
