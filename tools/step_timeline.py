@@ -8,8 +8,17 @@ name = "name" if "name" in cols else "kernel_name"
 qcol = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
 sel = f"select {name}, start, end" + (f", {qcol}" if qcol else ", 0") + " from kernels order by start"
 rows = c.execute(sel).fetchall()
-# a step = the launches from one in-graph sampler launch (the step's first kernel) up to the next one
+# a step = the launches from one in-graph sampler launch up to the next one; inside a graph of several steps the projection and the
+# sampler are both first (either may start a few us ahead of the other): a projection launched within 40 us before the sampler
+# belongs to the sampler's step
 starts = [i for i, r in enumerate(rows) if "sample_batch_kernel" in r[0]]
+for k, i in enumerate(starts):
+    j = i - 1
+    while j >= 0 and rows[i][1] - rows[j][1] < 40000:
+        if "linear_fwd_grouped" in rows[j][0]:
+            starts[k] = j
+            break
+        j -= 1
 cand = [(starts[i - 1], starts[i]) for i in range(1, len(starts))]
 lo, hi = cand[len(cand) // 2]                                  # a steady-state step from the middle of the run
 step = rows[lo: hi]
