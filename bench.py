@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--synth-chunks", type=int, default=0, help="item-row chunks per all-reduced message (0 = automatic, >= 32 MB each)")
     ap.add_argument("--synth-exchange", default="all_reduce", help="all_reduce | rs_ag: the per-chunk exchange of the row-sharded step (llmrec_amd/dist_fused.py)")
     ap.add_argument("--synth-dense-backward", action="store_true", help="row-sharded step: run the last layer's backward as dense products (A/B of the operand-sparsity path)")
+    ap.add_argument("--synth-dense-forward", action="store_true", help="row-sharded step: compute the last layer's forward products for every row (A/B of forward(needed=...))")
     ap.add_argument("--no-single-gpu-reference", action="store_true", help="N > 1, row-sharded strong scaling: skip rank 0's run of the same workload on one GPU")
     ap.add_argument("--no-row-sharded", action="store_true", help="nf / ml workloads: skip the cfg-4-shaped row-sharded measurements added to the line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -303,7 +304,7 @@ class RowSharded:
     every rank `blocks` of them (2 per GPU = the whole config at 8 GPUs), strong scaling splits all 16 over the ranks."""
 
     def __init__(self, name, scaling, blocks, seed, device, rank, world, n_chunks=0, batch_local=1024, exchange="all_reduce", single=False,
-                 sparse_backward=True):
+                 sparse_backward=True, sparse_forward=True):
         import torch
         from llmrec_amd import dist as ldist, synth
         from llmrec_amd.dist_fused import ShardedFusedID
@@ -338,7 +339,7 @@ class RowSharded:
         self.batch_local = batch_local
         self.step_obj = ShardedFusedID(self.graph, self.comm, self.backend, cfg["d"], cfg["layers"], bu * total, seed, 1e-4, self.B, 0.71, 1e-5,
                                        n_chunks=n_chunks or None, batch_size_flag=float(batch_local * world),      # the FLAG, not B + aug (main.py:340)
-                                       exchange=exchange, sparse_backward=sparse_backward)
+                                       exchange=exchange, sparse_backward=sparse_backward, sparse_forward=sparse_forward)
         if self.n_aug:                                        # the LLM-augmented triples of main.py:216-224: a per-user (pos, neg) table
             g = torch.Generator(device=device); g.manual_seed(seed + 17 + rank)
             self.aug_pos = torch.randint(0, cfg["n_items"], (n_local,), generator=g, device=device)
@@ -906,7 +907,7 @@ def main():
         if name not in SYNTH_CONFIGS:
             raise SystemExit("unknown --workload %s" % workload)
         w = RowSharded(name, a.synth_scaling, a.synth_blocks, a.seed, device, rank, world, n_chunks=a.synth_chunks, exchange=a.synth_exchange,
-                       sparse_backward=not a.synth_dense_backward)
+                       sparse_backward=not a.synth_dense_backward, sparse_forward=not a.synth_dense_forward)
         step, units = w.step, w.units_per_step              # global batch per step
 
     def barrier():

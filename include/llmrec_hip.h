@@ -121,9 +121,16 @@ typedef struct {
      *                 flagged - else 0: the mask for the next product in the chain (row-local epilogues map zero rows to zero rows);
      *   z_row_flag [n_rows] or NULL (may alias y_row_flag);
      *   y_row_gate [n_rows] or NULL: rows whose byte differs from x_mask_active are PROMISED to have no active neighbour and a zero Z row:
-     *                 they are written as zeros before the row's index list is even read (llmrec_mark_neighbours_u8 computes such a gate
-     *                 from the list of active columns - a sweep over THEIR adjacency instead of every row's). */
+     *                 they are written as zeros before the index list of the row is even read (llmrec_mark_neighbours_u8 computes such a gate
+     *                 from the list of active columns - a sweep over THEIR adjacency instead of the one of every row);
+     *   y_row_needed [n_rows] or NULL: output rows whose byte differs from x_mask_active are NOT COMPUTED AND NOT WRITTEN (their previous
+     *                 contents stay) - for a product whose consumers read only marked rows (the last propagation layer of a training step:
+     *                 the loss reads the rows of the batch, the next product the rows those reach). Needs x_mask_active, not x_row_mask;
+     *                 rows of the long-row buckets are always computed.
+     *   rows_listed_only != 0: ONLY the rows in the lists of the plan (wavefront / block / split rows) are computed - with a plan built over an
+     *                 explicit row list this is "these rows of A X"; all other rows of Y keep their contents. */
     const uint8_t* x_row_mask; int32_t x_mask_active; uint8_t* y_row_flag; const uint8_t* z_row_flag; const uint8_t* y_row_gate;
+    const uint8_t* y_row_needed; int32_t rows_listed_only;
 } llmrec_spmm_epilogue_t;
 /* flags[ids[j]] = value for j < n (ids[j] < 0 skipped): marks the rows a batch touches (x_row_mask / z_row_flag above) */
 int llmrec_mark_rows_u8(int64_t n, const int64_t* ids, int32_t value, uint8_t* flags, llmrec_stream_t stream);

@@ -99,6 +99,8 @@ struct SpmmArgs {
     uint8_t* y_flag;
     const uint8_t* z_flag;
     const uint8_t* y_gate;       // rows whose byte != x_active: no active neighbour, zero Z row - written as zeros at once
+    const uint8_t* y_needed;     // rows whose byte != x_active are neither computed nor written (short-row range)
+    int32_t listed_only;         // no short-row range at all: only the plan's row lists are computed
     // plan
     const int32_t* wave_rows;
     const int32_t* block_rows;
@@ -268,6 +270,7 @@ __device__ __forceinline__ void rows_body(const SpmmArgs& a, int64_t block) {
     if (task >= a.n_rows * a.n_slices) return;
     const int64_t slice = task / a.n_rows, row = task - slice * a.n_rows;      // slice-major: neighbouring lane groups take neighbouring rows
     const int64_t col0 = slice * a.d;
+    if (a.y_needed && (int)a.y_needed[row] != a.x_active) return;                // (uniform per lane group) nobody reads this row
     const int32_t s = a.rowptr[row], e = a.rowptr[row + 1];
     if ((e - s) > LLMREC_SPMM_LONG_ROW) return;
     Vec<VEC> acc[NCHUNK];
@@ -453,7 +456,7 @@ static int launch_spmm(SpmmArgs& a, hipStream_t stream) {
     const bool weighted = a.val != nullptr || a.col_scale != nullptr;
     constexpr int GPB = TPB / LPR;
     const int64_t S = a.n_slices;
-    const int64_t row_blocks = ceil_div(a.n_rows * S, GPB);
+    const int64_t row_blocks = a.listed_only ? 0 : ceil_div(a.n_rows * S, GPB);
     const int64_t wave_blocks = ceil_div(a.n_wave_rows * S, TPB / 64);
     const int64_t total = a.n_segments * S + a.n_block_rows * S + wave_blocks + row_blocks;
     if (total > 0x7fffffffll) { set_error("spmm: too many rows for one launch"); return LLMREC_EUNSUPPORTED; }
@@ -516,6 +519,11 @@ extern "C" int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
         LLMREC_CHECK_ARG(!e.Z || e.ldz >= d, "spmm: epilogue Z with ld < d");
         LLMREC_CHECK_ARG(e.op != LLMREC_SPMM_EPI_SOFTMAX_BWD || (e.S && e.lds >= d), "spmm: softmax backward needs S with ld >= d");
         a.epi_op = e.op; a.alpha = e.alpha; a.Z = e.Z; a.ldz = e.ldz; a.S = e.S; a.lds = e.lds; a.post_scale = e.post_scale;
+        a.listed_only = e.rows_listed_only != 0;
+        if (e.y_row_needed) {
+            LLMREC_CHECK_ARG(e.x_mask_active >= 1 && e.x_mask_active <= 255, "spmm: y_row_needed needs x_mask_active in 1..255");
+            a.y_needed = e.y_row_needed; a.x_active = e.x_mask_active;
+        }
         if (e.x_row_mask) {
             LLMREC_CHECK_ARG(e.x_mask_active >= 1 && e.x_mask_active <= 255, "spmm: x_mask_active must be a byte value 1..255");
             a.x_mask = e.x_row_mask; a.x_active = e.x_mask_active; a.y_flag = e.y_row_flag; a.z_flag = e.z_row_flag;

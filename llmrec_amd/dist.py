@@ -106,15 +106,19 @@ class HipBackend:
 
     def spmm(self, csr, X, out=None, epilogue=None):
         """Y = epilogue(A X); epilogue: None or {"op": "none" | "softmax" | "softmax_bwd", "alpha", "Z", "S", "post_scale",
-        "x_row_mask", "x_mask_active", "y_row_flag", "z_row_flag"} (the last four: llmrec_spmm_epilogue_t's operand sparsity)."""
+        "x_row_mask", "x_mask_active", "y_row_flag", "z_row_flag", "y_row_gate", "y_row_needed"} (llmrec_spmm_epilogue_t's row sparsity)."""
         o = self.ops
         epi = None
         if epilogue is not None:
             op = {"none": o.EPI_NONE, "softmax": o.EPI_SOFTMAX, "softmax_bwd": o.EPI_SOFTMAX_BWD}[epilogue.get("op", "none")]
             epi = o.spmm_epilogue(op, epilogue.get("alpha", 0.0), epilogue.get("Z"), epilogue.get("S"), epilogue.get("post_scale"),
                                   epilogue.get("x_row_mask"), epilogue.get("x_mask_active", 0), epilogue.get("y_row_flag"), epilogue.get("z_row_flag"),
-                                  epilogue.get("y_row_gate"))
+                                  epilogue.get("y_row_gate"), epilogue.get("y_row_needed"))
         return o.spmm_raw(csr, X, out=out, epilogue=epi)
+
+    def spmm_listed(self, csr, X, rows, out):
+        """out[r] = (A X)[r] for the listed distinct rows only (ops.spmm_listed); other rows of out keep their contents."""
+        return self.ops.spmm_listed(csr, X, rows, out)
 
     def mark_rows(self, ids, value: int, flags):
         """flags[ids] = value (ids < 0 skipped): llmrec_mark_rows_u8."""

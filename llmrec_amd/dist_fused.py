@@ -104,11 +104,13 @@ class ShardedFusedID:
     def __init__(self, graph: ShardedGraph, comm: Comm, backend, d: int, n_layers: int, n_users_global: int, seed: int,
                  lr: float, batch_local: int, drop_rate: float, decay: float, n_chunks: Optional[int] = None,
                  user_init: Optional[torch.Tensor] = None, item_init: Optional[torch.Tensor] = None,
-                 batch_size_flag: Optional[float] = None, exchange: str = "all_reduce", sparse_backward: bool = True):
+                 batch_size_flag: Optional[float] = None, exchange: str = "all_reduce", sparse_backward: bool = True,
+                 sparse_forward: bool = True):
         """batch_size_flag: the divisor of the BPR regulariser - the reference divides by the --batch_size FLAG, not by the
         number of triples in the batch (main.py:340: augmented triples do not change it); default = batch_local * world.
         exchange: "all_reduce" | "rs_ag" (module docstring). sparse_backward: skip the all-zero operand rows in the two SpMMs of the last
-        layer's backward (False: the dense products, for A/B runs)."""
+        layer's backward (False: the dense products, for A/B runs). sparse_forward: compute the last layer's two forward products only in
+        the rows the step reads (forward(needed=...))."""
         self.g, self.comm, self.be = graph, comm, backend
         self.d, self.L, self.B = d, n_layers, batch_local
         self.remember, self.decay = 1.0 - drop_rate, decay
@@ -166,6 +168,7 @@ class ShardedFusedID:
         # the users). One byte per row says so (llmrec_spmm_epilogue_t x_row_mask / y_row_flag; the active value is a per-step stamp, so
         # nothing is ever cleared): those two SpMMs skip the gathers of all-zero rows - 2 of the step's 4 L products.
         self.sparse_backward = sparse_backward
+        self.sparse_forward = sparse_backward and sparse_forward
         self.graph_items_to_users = graph.ui_bwd                 # rows = items, columns = this rank's users (the pattern is what matters)
         self.flag_u = torch.zeros(U, dtype=torch.uint8, device=dev)
         self.flag_i = torch.zeros(I, dtype=torch.uint8, device=dev)
@@ -219,13 +222,27 @@ class ShardedFusedID:
                 after(view)
 
     # -- forward ---------------------------------------------------------------------------------------
-    def forward(self, dense_users: bool = True, dense_items: bool = True):
+    def forward(self, dense_users: bool = True, dense_items: bool = True, needed=None):
         """dense_users / dense_items = False (training): E_u / E_i are not materialised (the loss gathers the layer means of its batch rows:
-        one pass over B rows instead of one over the whole tables)."""
+        one pass over B rows instead of one over the whole tables).
+        needed = (stamp, item_rows) (training, sparse_forward): the LAST layer's two products are computed for the rows somebody reads -
+        U_L for the users flag_u marks with `stamp` (the batch's users and the users the batch's items reach), I_L for the listed item
+        rows (the items of every rank's batch) - and the message of that layer is those rows instead of the I x d table."""
         be, L = self.be, self.L
         i_prev = self.item_tab.detach()
         for l in range(L):
             last = l == L - 1
+            if last and needed is not None:
+                stamp, rows = needed
+                be.spmm(self.g.ui_fwd, i_prev, out=self.Ul[l], epilogue={"op": "softmax", "y_row_needed": self.flag_u, "x_mask_active": stamp})
+                be.spmm_listed(self.g.iu_fwd, self.Ul[l], rows, self.Il[l])          # this rank's share of the listed rows
+                part = self.Il[l][rows]                                              # compact [n_rows, d]: the layer's message
+                self.allreduce_bytes += part.numel() * 4
+                if self.comm.dist is not None and (self.comm.world > 1 or self.comm.force):
+                    self.comm.all_reduce_(part)
+                be.softmax_rows_into(part, part)
+                self.Il[l][rows] = part
+                break
             be.spmm(self.g.ui_fwd, i_prev, out=self.Ul[l], epilogue={"op": "softmax"} if last else None)      # local users
             self._reduced_spmm(self.iu_fwd_chunks, self.Ul[l], self.Il[l],
                                after=(lambda view: be.softmax_rows_into(view, view)) if last else None)
@@ -247,7 +264,21 @@ class ShardedFusedID:
         u, p, n = triples if triples is not None else self.sample()
         self.step_id += 1
         self.allreduce_bytes = 0
-        self.forward(dense_users=False, dense_items=False)
+        # the rows this step touches, known before the forward: the items of every rank's batch (all-gather of 2 B ids) and, through
+        # their adjacency, the users they reach; byte marks with a per-step stamp (nothing is cleared)
+        stamp = self.step_id % 255 + 1
+        self.my_ids[0].copy_(p); self.my_ids[1].copy_(n)
+        comm.all_gather_into(self.gat_ids.view(-1), self.my_ids.view(-1))
+        needed = None
+        if self.sparse_backward:
+            be.mark_rows(u, stamp, self.flag_u)                   # the non-zero rows of dE_u ...
+            be.mark_rows(self.gat_ids.view(-1), stamp, self.flag_i)   # ... and of dE_i (hence of g)
+            # ... and the local users those items reach: the only rows of A_iu^T g that can be non-zero (a sweep over the adjacency of
+            # <= 2 B world items instead of a look at every user's index list)
+            be.mark_neighbours(self.gat_ids.view(-1), self.graph_items_to_users, stamp, self.flag_u)
+            if self.sparse_forward:
+                needed = (stamp, torch.unique(self.gat_ids.view(-1)))     # (sorted, identical on every rank)
+        self.forward(dense_users=False, dense_items=False, needed=needed)
         # BPR + prune over the global batch (reference main.py:158-165,330-342): two passes around an all-gather of B floats;
         # the user side of the loss is the B x d block of layer-mean rows, indexed 0..B-1
         be.gather_mean_into([self.user_tab.detach()] + self.Ul, u, self.Eu_rows)
@@ -272,17 +303,8 @@ class ShardedFusedID:
             be.zero_([self.dE_u, self.dE_i])
         self._scatter_dirty = True
         be.scatter_rows(u, self.rows3[0], self.dE_u, 1.0)
-        self.my_ids[0].copy_(p); self.my_ids[1].copy_(n)
         comm.all_gather_into(self.gat_rows.view(-1), self.rows3[1:3].reshape(-1))
-        comm.all_gather_into(self.gat_ids.view(-1), self.my_ids.view(-1))
         be.scatter_rows(self.gat_ids.view(-1), self.gat_rows.view(-1, self.d), self.dE_i, 1.0)     # same list, same order on every rank
-        stamp = self.step_id % 255 + 1                            # this step's mark of "row touched"
-        if self.sparse_backward:
-            be.mark_rows(u, stamp, self.flag_u)                   # the non-zero rows of dE_u ...
-            be.mark_rows(self.gat_ids.view(-1), stamp, self.flag_i)   # ... and of dE_i (hence of g)
-            # ... and the local users those items reach: the only rows of A_iu^T g that can be non-zero (a sweep over the adjacency of
-            # <= 2 B world items instead of a look at every user's index list)
-            be.mark_neighbours(self.gat_ids.view(-1), self.graph_items_to_users, stamp, self.flag_u)
         inv = 1.0 / (L + 1)
         # dI[L] = inv dE_i -> g = softmax_bwd(I_L, dI[L]); then per layer
         #   dU[l+1] = inv dE_u + A_iu[:, blk]^T g          (local; softmax backward as the epilogue on the last layer)
@@ -338,5 +360,7 @@ class ShardedFusedID:
 
     # -- accounting for bench.py -------------------------------------------------------------------------
     def message_bytes_per_step(self) -> dict:
-        return {"exchange": self.exchange, "allreduce_I_x_d_bytes": 4 * self.I * self.d * 2 * self.L, "allreduce_messages": 2 * self.L * len(self.chunks),
+        return {"exchange": self.exchange, "allreduce_I_x_d_bytes": 4 * self.I * self.d * (2 * self.L - (1 if self.sparse_forward else 0)),
+                "last_forward_message": "the rows of the batches' items only (<= 2 B world rows)" if self.sparse_forward else "I x d",
+                "exchanged_bytes_last_step": int(self.allreduce_bytes), "allreduce_messages": 2 * self.L * len(self.chunks),
                 "bpr_rows_allgather_bytes_per_rank": 2 * self.B * (4 * self.d + 8), "prune_allgather_bytes_per_rank": 4 * self.B}

@@ -65,7 +65,7 @@ class SpmmEpilogueC(_c.Structure):
     """llmrec_spmm_epilogue_t"""
     _fields_ = [("op", _c.c_int32), ("alpha", _c.c_float), ("Z", _c.c_void_p), ("ldz", _c.c_int64), ("S", _c.c_void_p), ("lds", _c.c_int64),
                 ("post_scale", _c.c_void_p), ("x_row_mask", _c.c_void_p), ("x_mask_active", _c.c_int32), ("y_row_flag", _c.c_void_p),
-                ("z_row_flag", _c.c_void_p), ("y_row_gate", _c.c_void_p)]
+                ("z_row_flag", _c.c_void_p), ("y_row_gate", _c.c_void_p), ("y_row_needed", _c.c_void_p), ("rows_listed_only", _c.c_int32)]
 
 
 EPI_NONE, EPI_SOFTMAX, EPI_SOFTMAX_BWD = 0, 1, 2
@@ -297,12 +297,14 @@ class BipartiteGraph:
 def spmm_epilogue(op: int = EPI_NONE, alpha: float = 0.0, Z: Optional[torch.Tensor] = None, S: Optional[torch.Tensor] = None,
                   post_scale: Optional[torch.Tensor] = None, x_row_mask: Optional[torch.Tensor] = None, x_mask_active: int = 0,
                   y_row_flag: Optional[torch.Tensor] = None, z_row_flag: Optional[torch.Tensor] = None,
-                  y_row_gate: Optional[torch.Tensor] = None):
+                  y_row_gate: Optional[torch.Tensor] = None, y_row_needed: Optional[torch.Tensor] = None, rows_listed_only: bool = False):
     """llmrec_spmm_epilogue_t: Y = post_scale . op(alpha * Z + A X); S = forward softmax rows for EPI_SOFTMAX_BWD.
     x_row_mask (uint8 [n_cols]) / x_mask_active: X rows whose byte differs from the active value are promised all-zero and not read;
     y_row_flag (uint8 [n_rows]): receives the active value for rows whose result can be non-zero (z_row_flag: the non-zero rows of Z);
-    y_row_gate (uint8 [n_rows]): rows without the active value are promised zero results and written as zeros unread."""
-    for t in (x_row_mask, y_row_flag, z_row_flag, y_row_gate):
+    y_row_gate (uint8 [n_rows]): rows without the active value are promised zero results and written as zeros unread;
+    y_row_needed (uint8 [n_rows]): rows without the active value are neither computed nor written; rows_listed_only: compute the rows
+    in the plan's lists only (spmm_listed)."""
+    for t in (x_row_mask, y_row_flag, z_row_flag, y_row_gate, y_row_needed):
         if t is not None and (t.dtype != torch.uint8 or not t.is_contiguous()):
             raise RuntimeError("spmm_epilogue: row masks / flags are contiguous uint8 tensors")
     return SpmmEpilogueC(op, float(alpha), Z.data_ptr() if Z is not None else None, _ld(Z) if Z is not None else 0,
@@ -311,11 +313,44 @@ def spmm_epilogue(op: int = EPI_NONE, alpha: float = 0.0, Z: Optional[torch.Tens
                          x_row_mask.data_ptr() if x_row_mask is not None else None, int(x_mask_active),
                          y_row_flag.data_ptr() if y_row_flag is not None else None,
                          z_row_flag.data_ptr() if z_row_flag is not None else None,
-                         y_row_gate.data_ptr() if y_row_gate is not None else None)
+                         y_row_gate.data_ptr() if y_row_gate is not None else None,
+                         y_row_needed.data_ptr() if y_row_needed is not None else None, 1 if rows_listed_only else 0)
+
+
+def listed_plan(a: Csr, rows: torch.Tensor, d: int, whole_row: bool = False) -> SpmmPlan:
+    """A row plan over an explicit list of DISTINCT rows (int64 device tensor): every listed row lands in the wavefront, block or split
+    list by its length - with rows_listed_only the launch computes exactly these rows. Built with torch ops on the device; reading the
+    three list lengths back synchronises (once per call: the row-sharded training step, whose batch decides the list)."""
+    _, (t_wave, t_block, segment) = spmm_shape(d, a.nnz, whole_row)
+    rp = a.rowptr
+    rows = rows.to(torch.int64)
+    deg = (rp[rows + 1] - rp[rows]).to(torch.int64)
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    w = i32(rows[deg <= t_wave]); b = i32(rows[(deg > t_wave) & (deg <= t_block)])
+    big = deg > t_block
+    sp = i32(rows[big])
+    nseg = (deg[big] + segment - 1) // segment
+    seg_begin = i32(torch.cumsum(nseg, 0) - nseg)
+    seg_split = i32(torch.repeat_interleave(torch.arange(sp.numel(), device=rows.device), nseg))
+    return SpmmPlan(t_wave, t_block, segment, w.numel(), b.numel(), sp.numel(), seg_split.numel(), w if w.numel() else None,
+                    b if b.numel() else None, sp if sp.numel() else None, seg_begin if sp.numel() else None, seg_split if sp.numel() else None)
+
+
+def spmm_listed(a: Csr, X: torch.Tensor, rows: torch.Tensor, out: torch.Tensor, epilogue=None) -> torch.Tensor:
+    """out[r] = epilogue(A X)[r] for the listed DISTINCT rows r only (all other rows of out keep their contents): llmrec_spmm_f32 with a
+    plan over the list and rows_listed_only."""
+    d = X.shape[1]
+    whole = epilogue is not None and epilogue.op != EPI_NONE
+    pl = listed_plan(a, rows, d, whole_row=whole)
+    if epilogue is None:
+        epilogue = spmm_epilogue(EPI_NONE)
+    epilogue.rows_listed_only = 1
+    part = torch.empty(max(pl.n_seg, 1) * d, dtype=torch.float32, device=X.device)
+    return spmm_raw(a, X, out=out, epilogue=epilogue, partials=part, plan=pl)
 
 
 def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False, epilogue=None,
-             partials: Optional[torch.Tensor] = None) -> torch.Tensor:
+             partials: Optional[torch.Tensor] = None, plan: Optional[SpmmPlan] = None) -> torch.Tensor:
     """Y = epilogue(A X) through llmrec_spmm_f32. accumulate: Y += A X (epilogue Z = Y, alpha = 1). partials: scratch of
     plan.n_seg * d floats when the caller runs several SpMMs over this operand at once (default: the plan's own)."""
     _need_gpu(X, a.rowptr)
@@ -325,6 +360,8 @@ def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumu
     d = X.shape[1]
     Y = out if out is not None else torch.empty(a.n_rows, d, dtype=torch.float32, device=X.device)
     sw, pl = a.plan_for(d, whole_row=epilogue is not None and epilogue.op != EPI_NONE)
+    if plan is not None:                                       # (a caller-built plan, e.g. over a row list: whole rows, no column slices)
+        sw, pl = 0, plan
     if partials is None:
         partials = pl.scratch(d, X.device)
     if accumulate:

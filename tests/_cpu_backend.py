@@ -51,10 +51,23 @@ class CpuBackend:
                 Y = S * (Y - (Y * S).sum(-1, keepdim=True))
             if epilogue.get("post_scale") is not None:
                 Y = Y * epilogue["post_scale"][:, None]
+        if epilogue is not None and epilogue.get("x_row_mask") is not None and epilogue.get("y_row_gate") is not None:
+            Y = torch.where((epilogue["y_row_gate"] == epilogue["x_mask_active"])[:, None], Y, torch.zeros_like(Y))   # gated-out rows: zeros, unread
+        if epilogue is not None and epilogue.get("y_row_needed") is not None:       # rows that are not needed keep their (stale) contents
+            need = epilogue["y_row_needed"] == epilogue["x_mask_active"]
+            out[need] = Y[need]
+            out[~need] = float("nan")                                        # poison: nothing may read them
+            return out
         if out is not None:
             out.copy_(Y)
             return out
         return Y
+
+    def spmm_listed(self, p, X, rows, out):
+        Y = self.spmm(p, X)
+        out[:] = float("nan")                                                # poison everything that is not listed
+        out[rows] = Y[rows]
+        return out
 
     def mark_rows(self, ids, value, flags):
         flags[ids[ids >= 0]] = value

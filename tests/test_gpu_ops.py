@@ -1079,3 +1079,35 @@ def test_softmax_backward_of_listed_rows(ops, d):
     sel = torch.zeros(n, dtype=torch.bool, device=DEV); sel[ids[ids >= 0]] = True
     assert rel_err(out[sel].cpu(), want[sel].cpu()) < 2e-6
     assert bool((out[~sel] == 5.0).all())
+
+
+def test_spmm_of_listed_rows_and_of_needed_rows(ops):
+    """ops.spmm_listed (a plan over an explicit row list + rows_listed_only): exactly the listed rows of A X are written - short rows,
+    wavefront / block rows and a hub past the split threshold - equal to the full product's rows to summation-order rounding; y_row_needed: the short-row
+    range skips the rows that are not marked (their previous contents stay), the forward softmax epilogue included."""
+    rng = np.random.default_rng(47)
+    n_rows, n_cols, d = 4000, 3000, 64
+    degs = rng.integers(0, 30, size=n_rows); degs[5] = 2900; degs[6] = 0; degs[7] = 900; degs[8] = 200; degs[9] = 40
+    rows, cols = rand_graph(rng, n_rows, n_cols, degs)
+    rp, ci, _ = ops.csr_from_coo(torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV), None, n_rows, n_cols)
+    a = ops.Csr(n_rows, n_cols, rp, ci, None, torch.rand(n_rows, device=DEV) + 0.5, None, {})
+    X = torch.randn(n_cols, d, device=DEV)
+    full = ops.spmm_raw(a, X)
+    listed = torch.unique(torch.cat([torch.tensor([5, 6, 7, 8, 9, 0, n_rows - 1], device=DEV), torch.randint(0, n_rows, (300,), device=DEV)]))
+    out = torch.full((n_rows, d), 3.0, device=DEV)
+    ops.spmm_listed(a, X, listed, out)
+    sel = torch.zeros(n_rows, dtype=torch.bool, device=DEV); sel[listed] = True
+    # (listed short rows run in the wavefront bucket: another summation order than the short-row range of the full product)
+    assert rel_err(out[sel].cpu(), full[sel].cpu()) < 2e-6 and bool((out[~sel] == 3.0).all())
+    # needed rows, softmax epilogue
+    stamp = 9
+    need = torch.where(torch.rand(n_rows, device=DEV) < 0.3, torch.full((n_rows,), stamp, dtype=torch.uint8, device=DEV),
+                       torch.randint(10, 50, (n_rows,), device=DEV).to(torch.uint8))
+    ref = ops.spmm_raw(a, X, epilogue=ops.spmm_epilogue(ops.EPI_SOFTMAX))
+    got = torch.full((n_rows, d), 3.0, device=DEV)
+    ops.spmm_raw(a, X, out=got, epilogue=ops.spmm_epilogue(ops.EPI_SOFTMAX, y_row_needed=need, x_mask_active=stamp))
+    nd = (need == stamp)
+    sw, pl = a.plan_for(d, whole_row=True)
+    short = torch.tensor(degs <= 32, device=DEV)                      # LLMREC_SPMM_LONG_ROW: the rows of the short-row range
+    assert torch.equal(got[nd], ref[nd])
+    assert bool((got[~nd & short] == 3.0).all()) and torch.equal(got[~nd & ~short], ref[~nd & ~short])
