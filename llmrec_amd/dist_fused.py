@@ -267,6 +267,10 @@ class ShardedFusedID:
         # the rows this step touches, known before the forward: the items of every rank's batch (all-gather of 2 B ids) and, through
         # their adjacency, the users they reach; byte marks with a per-step stamp (nothing is cleared)
         stamp = self.step_id % 255 + 1
+        if stamp == 1 and self.sparse_backward:
+            # the stamps start a new cycle: no mark of the previous one may survive - g below is formed in the marked item rows only,
+            # a stale mark that equals a later stamp would make the masked product read a row of g left over from an earlier step
+            self.flag_u.zero_(); self.flag_i.zero_()
         self.my_ids[0].copy_(p); self.my_ids[1].copy_(n)
         comm.all_gather_into(self.gat_ids.view(-1), self.my_ids.view(-1))
         needed = None

@@ -311,3 +311,35 @@ def test_device_batcher_slices_tile_the_global_batch_shape():
             assert b.n_aug == 4 and b.capacity == 20 and b.rank * b.B == rank * 16
             caps.append(b.capacity)
         assert len(set(caps)) == 1
+
+
+def test_row_restricted_last_layer_equals_dense_step_across_a_stamp_wrap():
+    """The row-restricted last layer (marks with a per-step byte stamp, llmrec_amd/dist_fused.py) against the same step with every
+    product dense, single rank on the CPU stand-in (which poisons every row the contract says is not read): six steps that start at
+    step 252, so the stamp passes 255 -> 1 (the marks are cleared there) and a stamp value is reused; losses and both tables agree."""
+    from llmrec_amd import dist as ld
+    from llmrec_amd.dist_fused import ShardedFusedID
+    from tests._cpu_backend import CpuBackend
+    rows, cols, u_tab, i_tab, batches = _problem()
+    res = []
+    for sparse in (True, False):
+        comm, be = ld.Comm(single=True), CpuBackend()
+        g = ld.ShardedGraph.build(torch.tensor(rows), torch.tensor(cols), U, I, 0, comm, be)
+        st = ShardedFusedID(g, comm, be, D, L, U, seed=1, lr=LR, batch_local=2 * B_LOCAL, drop_rate=DROP, decay=DECAY, n_chunks=2,
+                            user_init=torch.tensor(u_tab), item_init=torch.tensor(i_tab), batch_size_flag=float(2 * B_LOCAL),
+                            sparse_backward=sparse)
+        st.step_id = 251
+        if sparse:                                             # marks left from the beginning of this stamp cycle (steps 1 and 2): their values
+            st.flag_i[:] = 3; st.flag_u[:] = 2                 # come round again right after the wrap - they must not survive it
+            st.tmpI.fill_(float("nan"))                         # (rows of the first gradient outside the marked items are never read)
+        losses = []
+        for k in range(6):
+            per = batches[k % len(batches)]
+            us = np.concatenate([per[0][0], per[1][0]]); ps = np.concatenate([per[0][1], per[1][1]]); ns = np.concatenate([per[0][2], per[1][2]])
+            loss, _ = st.step((torch.tensor(us), torch.tensor(ps), torch.tensor(ns)))
+            losses.append(float(loss))
+        res.append((np.array(losses), st.user_tab.detach().numpy().copy(), st.item_tab.detach().numpy().copy()))
+    (l0, u0_, i0_), (l1, u1_, i1_) = res
+    assert np.all(np.isfinite(i0_)) and np.all(np.isfinite(u0_))
+    assert np.allclose(l0, l1, rtol=1e-6)
+    assert np.abs(u0_ - u1_).max() <= 1e-5 * np.abs(u1_).max() and np.abs(i0_ - i1_).max() <= 1e-5 * np.abs(i1_).max()
