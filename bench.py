@@ -847,9 +847,53 @@ def reference_order_step_time(w: "NetflixShaped", steps: int):
             "order": "project F_k [I x K], then propagate through A_ui and A_iu every step (Models.py:145-157 as written)"}
 
 
+def launch_decision(gpus: int, env, n_devices: int):
+    """What `python bench.py --gpus N` does before any work, as a pure function of (flag, environment, visible devices):
+      ("run", world)      - run in this process as one rank of `world` (world = WORLD_SIZE when a launcher set it, else 1);
+      ("spawn", N)        - no launcher in the environment and N > 1: re-exec under torch.distributed.run with N ranks on this node;
+      ("refuse", reason)  - the request cannot be honoured (fewer devices than ranks, or --gpus contradicting WORLD_SIZE): exit code 2,
+                            never a mislabelled 1-GPU line.
+    LLMREC_BENCH_SINGLE_DEVICE=1 (test hook, with LLMREC_DIST_BACKEND=gloo) puts every rank on cuda:0 and waives the device count."""
+    single = env.get("LLMREC_BENCH_SINGLE_DEVICE", "0") == "1"
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if gpus not in (1, world):                           # (--gpus left at its default under a launcher: the launcher's world counts)
+            return "refuse", "--gpus %d contradicts WORLD_SIZE=%d set by the launcher" % (gpus, world)
+        if world > n_devices and not single:
+            return "refuse", "WORLD_SIZE=%d ranks but this node shows %d GPU(s)" % (world, n_devices)
+        return "run", world
+    if gpus <= 1:
+        return "run", 1
+    if gpus > n_devices and not single:
+        return "refuse", "--gpus %d but this node shows %d GPU(s)" % (gpus, n_devices)
+    return "spawn", gpus
+
+
+def spawn_ranks(n: int, argv):
+    """Re-exec this script as n ranks on this node: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1
+    --master-port <free> bench.py <argv>` (what the driver's own N > 1 command line does); returns the launcher's exit code. Rank 0's
+    JSON line goes to this process' stdout unchanged."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("[bench] --gpus %d without a launcher in the environment: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
     import torch
+    kind, what = launch_decision(a.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    if kind == "refuse":
+        print("[bench] refused: %s" % what, file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    if kind == "spawn":
+        raise SystemExit(spawn_ranks(what, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -885,6 +929,11 @@ def main():
         n_devices_seen = len(set(ids))
     else:
         n_devices_seen = 1
+    if n_ranks_seen != world or (n_devices_seen != world and os.environ.get("LLMREC_BENCH_SINGLE_DEVICE", "0") != "1"):
+        # the line's n_gpus must be what actually ran: n_gpus == n_ranks_seen == n_devices_seen, or no line at all
+        print("[bench] refused: world %d, but the communicator counts %d rank(s) on %d distinct device(s)" % (world, n_ranks_seen, n_devices_seen),
+              file=sys.stderr, flush=True)
+        raise SystemExit(3)
     workload = a.workload
     auto = workload == "auto"
     if auto:

@@ -69,8 +69,13 @@ def _user_degrees(rng: np.random.Generator, n_users: int, n_edges: int, max_deg:
 
 
 def bipartite_edges(n_users: int, n_items: int, n_edges: int, seed: int = 0,
-                    max_deg: int = 10_000, item_alpha: float = 0.8):
-    """Return (rows, cols) int64 arrays, sorted by (row, col), without duplicate pairs."""
+                    max_deg: int = 10_000, item_alpha: float = 0.8, n_communities: int = 0, p_in: float = 0.85):
+    """Return (rows, cols) int64 arrays, sorted by (row, col), without duplicate pairs.
+
+    n_communities > 0 plants a block structure a collaborative-filtering model can learn (the long-horizon accuracy fixtures,
+    oracle/make_trajectory.py): user u belongs to block u % C, the item of popularity rank r to block r % C; a fraction p_in of
+    every user's draws is moved to the nearest rank of the user's own block (same popularity law). 0 (default): popularity only,
+    the generator of every other fixture and workload, unchanged."""
     rng = np.random.default_rng(seed)
     max_deg = min(max_deg, n_items)
     deg = _user_degrees(rng, n_users, n_edges, max_deg)
@@ -78,7 +83,13 @@ def bipartite_edges(n_users: int, n_items: int, n_edges: int, seed: int = 0,
     cdf = np.cumsum(pop / pop.sum())
     item_perm = rng.permutation(n_items)            # popularity rank -> item id
     rows = np.repeat(np.arange(n_users, dtype=np.int64), deg)
-    cols = item_perm[np.minimum(np.searchsorted(cdf, rng.random(rows.size)), n_items - 1)]
+    ranks = np.minimum(np.searchsorted(cdf, rng.random(rows.size)), n_items - 1)
+    if n_communities > 0:
+        C = int(n_communities)
+        own = (ranks // C) * C + rows % C
+        inside = (rng.random(rows.size) < p_in) & (own < n_items)
+        ranks = np.where(inside, own, ranks)
+    cols = item_perm[ranks]
     # de-duplicate (u, i) and top up with fresh draws until exact
     for _ in range(200):
         key = rows * n_items + cols
@@ -173,7 +184,7 @@ def split_train_test(rows: np.ndarray, cols: np.ndarray, n_users: int, seed: int
 def write_dataset(path: str, n_users: int, n_items: int, n_edges: int, seed: int = 0,
                   image_dim: int = 512, text_dim: int = 768, llm_dim: int = 1536,
                   keys=NETFLIX_KEYS, feat_dtype=np.float32, aug_out_of_range: float = 0.05,
-                  max_deg: int = 10_000) -> dict:
+                  max_deg: int = 10_000, n_communities: int = 0) -> dict:
     """Write a complete Stage-2 dataset directory (every file of SURVEY.md Appendix A).
 
     ``n_edges`` counts all interactions; users with >= 3 give one to val and one to test."""
@@ -181,7 +192,7 @@ def write_dataset(path: str, n_users: int, n_items: int, n_edges: int, seed: int
 
     os.makedirs(path, exist_ok=True)
     rng = np.random.default_rng(seed + 7)
-    rows, cols = bipartite_edges(n_users, n_items, n_edges, seed=seed, max_deg=max_deg)
+    rows, cols = bipartite_edges(n_users, n_items, n_edges, seed=seed, max_deg=max_deg, n_communities=n_communities)
     rows, cols, role = split_train_test(rows, cols, n_users, seed)
 
     def as_dict(mask):

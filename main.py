@@ -109,6 +109,7 @@ class Trainer(object):
         self.de_optimizer = torch.optim.AdamW([{'params': self.decoder.parameters()}], lr=args.de_lr)   # never stepped
         self.hyper = engine.Hyper.from_args(args)
         self._on_bpr = None                                   # test hook: called with (mf, emb) of each BPR call
+        self._on_epoch = None                                 # test hook: called with (epoch, loss, mf_loss, emb_loss, ret, (t2 - t1, t3 - t2)) per epoch
         self._fused = None
         self._device_sampler = os.environ.get("LLMREC_DEVICE_SAMPLER", "0") == "1"
         self._global_step = 0
@@ -359,6 +360,8 @@ class Trainer(object):
                             ret['hit_ratio'][0], ret['hit_ratio'][1], ret['hit_ratio'][2], ret['hit_ratio'][-1],
                             ret['ndcg'][0], ret['ndcg'][1], ret['ndcg'][2], ret['ndcg'][-1])
                 self.logger.logging(perf_str)
+            if self._on_epoch is not None:
+                self._on_epoch(epoch, loss, mf_loss, emb_loss, ret, (t2 - t1, t3 - t2))
 
             if ret['recall'][1] > best_recall:
                 best_recall = ret['recall'][1]

@@ -1,0 +1,201 @@
+"""TEST INFRASTRUCTURE ONLY - long-horizon trajectories of the UNMODIFIED reference (tests/golden/<case>/trajectory.npz).
+
+Run in the build container (needs /root/reference):
+
+    python oracle/make_trajectory.py            # all cases
+    python oracle/make_trajectory.py nf_mid     # one case
+
+tests/golden/{nf_tiny,...} (oracle/make_golden.py) pin ONE epoch of 11-17 steps tensor by tensor. This script pins what
+north_star states about accuracy over a training horizon ("Recall@20 within +-0.002 of reference"): a Netflix-shaped
+synthetic dataset of a few thousand users / items (real key set, reduced feature widths), >= 10 epochs of the reference's own
+``Trainer.train()`` (reference main.py:189-327) on CPU, and per epoch
+  * the three logged sums (loss, mf_loss, emb_loss; main.py:280-283) - exact doubles taken from the tensors the reference
+    itself calls float() on - and the epoch's log line (main.py:306-312),
+  * the metric dict of every ``test_torch`` call (utility/batch_test.py:112-169),
+  * the best-recall / early-stopping decisions (main.py:314-325),
+and at the end the evaluation embeddings E_u / E_i of the last epoch.
+The dataset itself is NOT committed (tens of MB of pickled python floats): ``llmrec_amd/synth.write_dataset`` regenerates it
+from the seed; ``meta.json`` carries sha256 digests of every input file so that a consumer can tell that it trains on
+the same bytes. The monitoring hooks below read values, they change no arithmetic and consume no RNG."""
+from __future__ import annotations
+
+import hashlib
+import importlib.util
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+_MID = dict(dataset="netflix_valid_item", n_users=2500, n_items=3500, n_edges=25000, seed=5, image_dim=64, text_dim=96, llm_dim=128,
+            max_deg=60, n_communities=25)      # every user has >= 3 interactions -> 2500 test users (Recall@20 moves in steps of 0.0004)
+CASES = {
+    # cfg 2 in the middle: Netflix keys, L = 2, d = 64, aug 0.1, prune 0.71, lr 1e-4 (all reference defaults), batch 256 so that
+    # an epoch is 79 optimiser steps: 12 epochs = 948 steps (patience raised so that all 12 epochs run)
+    "nf_mid": dict(_MID, argv=["--batch_size", "256", "--epoch", "12", "--seed", "2022", "--debug", "--early_stopping_patience", "20"]),
+    # the same data at ten times the learning rate and the default patience (7): the metrics move further per epoch, so a drift of
+    # the trajectory shows earlier, and the best-epoch / early-stopping decisions of main.py:314-325 are part of what is compared
+    "nf_mid_lr": dict(_MID, argv=["--batch_size", "256", "--epoch", "16", "--seed", "2022", "--debug", "--lr", "0.001"]),
+}
+INPUT_FILES = ("train.json", "val.json", "test.json", "train_mat", "image_feat.npy", "text_feat.npy",
+               "augmented_user_init_embedding", "augmented_atttribute_embedding_dict", "augmented_sample_dict")
+
+
+def _load_synth():
+    spec = importlib.util.spec_from_file_location("_synth", os.path.join(ROOT, "llmrec_amd", "synth.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["_synth"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def write_case_dataset(name: str, data_root: str):
+    """The case's dataset directory under data_root (also used by the tests to regenerate it); returns (dataset dir, stats)."""
+    cfg = CASES[name]
+    synth = _load_synth()
+    ds_dir = os.path.join(data_root, cfg["dataset"])
+    stats = synth.write_dataset(ds_dir, cfg["n_users"], cfg["n_items"], cfg["n_edges"], seed=cfg["seed"],
+                                image_dim=cfg["image_dim"], text_dim=cfg["text_dim"], llm_dim=cfg["llm_dim"],
+                                keys=synth.DATASET_KEYS[cfg["dataset"]], max_deg=cfg["max_deg"], n_communities=cfg["n_communities"])
+    return ds_dir, stats
+
+
+def digests(ds_dir: str):
+    """sha256 of the array CONTENT of every input file (pickle byte streams are not stable across library versions)."""
+    import pickle
+    import numpy as np
+    out = {}
+    for fn in INPUT_FILES:
+        p = os.path.join(ds_dir, fn)
+        h = hashlib.sha256()
+        if fn.endswith(".json"):
+            d = json.load(open(p))
+            for k in sorted(d, key=int):
+                h.update(np.asarray([int(k)] + list(d[k]), dtype=np.int64).tobytes())
+        elif fn.endswith(".npy"):
+            h.update(np.ascontiguousarray(np.load(p)).tobytes())
+        else:
+            obj = pickle.load(open(p, "rb"))
+            if fn == "train_mat":
+                m = obj.tocsr(); m.sort_indices()
+                h.update(m.indptr.astype(np.int64).tobytes()); h.update(m.indices.astype(np.int64).tobytes())
+            elif fn == "augmented_user_init_embedding":
+                h.update(np.asarray([obj[i] for i in range(len(obj))], dtype=np.float64).tobytes())
+            elif fn == "augmented_atttribute_embedding_dict":
+                for k in sorted(obj):
+                    h.update(k.encode()); h.update(np.asarray([obj[k][i] for i in range(len(obj[k]))], dtype=np.float64).tobytes())
+            else:
+                h.update(np.asarray([[u, obj[u][0], obj[u][1]] for u in sorted(obj)], dtype=np.int64).tobytes())
+        out[fn] = h.hexdigest()
+    return out
+
+
+def run_case(name: str):
+    import numpy as np
+
+    cfg = CASES[name]
+    case_dir = os.path.join(GOLD, name)
+    os.makedirs(case_dir, exist_ok=True)
+    data_root = os.path.join("/tmp", "llmrec_traj_" + name)
+    shutil.rmtree(data_root, ignore_errors=True)
+    ds_dir, stats = write_case_dataset(name, data_root)
+    dig = digests(ds_dir)
+
+    sys.path.insert(0, HERE)
+    import ref_loader
+    argv = ["--dataset", cfg["dataset"], "--data_path", data_root + "/"] + cfg["argv"]
+    ref = ref_loader.load_reference(argv)
+    import torch
+    import scipy
+
+    ref.set_seed(ref.args.seed)
+    trainer = ref.Trainer(data_config={"n_users": ref.data_generator.n_users, "n_items": ref.data_generator.n_items})
+    n_batch = ref.data_generator.n_train // ref.args.batch_size + 1          # main.py:203
+    rec = {"step_loss": [], "step_mf": [], "step_emb": [], "bpr_calls": 0, "evals": [], "lines": [], "eval_E": None, "t": []}
+
+    # per-step scalars: the tensor the reference calls .backward() on is batch_loss (main.py:273-277); the first bpr_loss call of a
+    # step returns the (mf, emb) pair it logs (main.py:235,281-282)
+    orig_backward = torch.Tensor.backward
+
+    def backward_wrap(self, *a, **k):
+        rec["step_loss"].append(float(self.detach()))
+        return orig_backward(self, *a, **k)
+    torch.Tensor.backward = backward_wrap
+    orig_bpr = trainer.bpr_loss
+
+    def bpr_wrap(users, pos, neg):
+        mf, emb, reg = orig_bpr(users, pos, neg)
+        if rec["bpr_calls"] % 8 == 0:
+            rec["step_mf"].append(float(mf)); rec["step_emb"].append(float(emb))
+        rec["bpr_calls"] += 1
+        return mf, emb, reg
+    trainer.bpr_loss = bpr_wrap
+
+    def fwd_hook(mod, inp, outp):
+        if not mod.training:
+            rec["eval_E"] = (outp[0].detach().clone().numpy(), outp[1].detach().clone().numpy())
+    trainer.model_mm.register_forward_hook(fwd_hook)
+
+    orig_test_torch = ref.test_torch
+
+    def test_torch_wrap(ua, ia, users_to_test, is_val, *a, **k):
+        res = orig_test_torch(ua, ia, users_to_test, is_val, *a, **k)
+        rec["evals"].append({"after_steps": len(rec["step_loss"]), "n_users": len(users_to_test),
+                             **{m: np.asarray(res[m], dtype=np.float64) for m in ("precision", "recall", "ndcg", "hit_ratio")}})
+        return res
+    ref.test_torch = test_torch_wrap
+
+    orig_logging = trainer.logger.logging
+
+    def logging_wrap(s):
+        rec["lines"].append(str(s))
+        return orig_logging(s)
+    trainer.logger.logging = logging_wrap
+
+    t0 = time.time()
+    best_recall, _ = trainer.train()
+    wall = time.time() - t0
+    torch.Tensor.backward = orig_backward
+
+    n_steps = len(rec["step_loss"])
+    n_epochs = n_steps // n_batch
+    assert n_epochs * n_batch == n_steps and len(rec["step_mf"]) == n_steps, (n_steps, n_batch, len(rec["step_mf"]))
+    sl, sm, se = (np.asarray(rec[k], dtype=np.float64) for k in ("step_loss", "step_mf", "step_emb"))
+    out = {"n_batch": np.int64(n_batch), "n_epochs": np.int64(n_epochs), "best_recall": np.float64(best_recall),
+           "step_loss": sl, "step_mf": sm, "step_emb": se,
+           # the epoch sums as the reference forms them: python-float accumulation in step order (main.py:280-283)
+           "epoch_loss": np.asarray([sum(sl[e * n_batch:(e + 1) * n_batch].tolist()) for e in range(n_epochs)]),
+           "epoch_mf": np.asarray([sum(sm[e * n_batch:(e + 1) * n_batch].tolist()) for e in range(n_epochs)]),
+           "epoch_emb": np.asarray([sum(se[e * n_batch:(e + 1) * n_batch].tolist()) for e in range(n_epochs)]),
+           "eval_after_steps": np.asarray([e["after_steps"] for e in rec["evals"]], dtype=np.int64),
+           "final_E_u": rec["eval_E"][0], "final_E_i": rec["eval_E"][1]}
+    for m in ("precision", "recall", "ndcg", "hit_ratio"):
+        out["eval_" + m] = np.stack([e[m] for e in rec["evals"]])
+    np.savez_compressed(os.path.join(case_dir, "trajectory.npz"), **out)
+    lines = [l for l in rec["lines"] if l.startswith(("Epoch", "Test_Recall", "#####"))]
+    meta = {"case": name, "config": cfg, "stats": stats, "digests": dig,
+            "argv": argv[:2] + ["--data_path", "<regenerated>/"] + cfg["argv"],
+            "versions": {"torch": torch.__version__, "numpy": np.__version__, "scipy": scipy.__version__, "python": sys.version.split()[0]},
+            "torch_threads": torch.get_num_threads(), "n_steps": n_steps, "n_batch": n_batch, "n_epochs": n_epochs,
+            "reference_wall_s": round(wall, 1), "host_cores": os.cpu_count(),
+            "log_lines": lines, "args": {k: v for k, v in vars(ref.args).items()}}
+    with open(os.path.join(case_dir, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    shutil.rmtree(data_root, ignore_errors=True)
+    print("[trajectory] %s: %d epochs x %d steps, %d evaluations, %.0f s -> %s" % (name, n_epochs, n_batch, len(rec["evals"]), wall, case_dir))
+    for l in lines:
+        print("   ", l[:150])
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    if len(names) == 1 and os.environ.get("_GOLDEN_CHILD") == "1":
+        run_case(names[0])
+    else:
+        for n in names:                                       # one process per case: the reference parses sys.argv at import
+            subprocess.run([sys.executable, os.path.abspath(__file__), n], check=True, env=dict(os.environ, _GOLDEN_CHILD="1"), cwd="/tmp")

@@ -173,3 +173,36 @@ def test_bench_finds_its_committed_profile_data():
     csrc = open(os.path.join(os.path.dirname(_lib.HEADER), "..", "llmrec_amd", "csrc", "dense.hip")).read()
     for key in names:
         assert key in csrc, key
+
+
+def test_bench_launcher_decision():
+    """`python bench.py --gpus N` (no launcher in the environment) must become N ranks or refuse - never a 1-GPU line labelled N
+    (VERDICT r03 missing #2). The decision is a pure function of (--gpus, environment, visible devices)."""
+    import bench
+    d = bench.launch_decision
+    assert d(1, {}, 1) == ("run", 1)
+    assert d(1, {}, 8) == ("run", 1)
+    assert d(8, {}, 8) == ("spawn", 8)
+    assert d(2, {}, 8) == ("spawn", 2)
+    assert d(8, {}, 1)[0] == "refuse" and d(2, {}, 0)[0] == "refuse"                      # fewer devices than ranks
+    assert d(2, {"LLMREC_BENCH_SINGLE_DEVICE": "1"}, 1) == ("spawn", 2)                  # the 1-GPU test hook (gloo, all ranks on cuda:0)
+    # under a launcher (the driver's torch.distributed.run command): the launcher's world counts, --gpus must agree with it
+    assert d(8, {"WORLD_SIZE": "8"}, 8) == ("run", 8)
+    assert d(1, {"WORLD_SIZE": "4"}, 8) == ("run", 4)                                     # --gpus left at its default
+    assert d(8, {"WORLD_SIZE": "2"}, 8)[0] == "refuse"
+    assert d(4, {"WORLD_SIZE": "4"}, 2)[0] == "refuse"
+    assert d(2, {"WORLD_SIZE": "2", "LLMREC_BENCH_SINGLE_DEVICE": "1"}, 1) == ("run", 2)
+
+
+def test_bench_spawn_command_is_the_drivers_launcher(monkeypatch):
+    """spawn_ranks re-executes bench.py under torch.distributed.run with one rank per GPU on 127.0.0.1 and passes the flags through."""
+    import subprocess
+    import bench
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    assert bench.spawn_ranks(4, ["--gpus", "4", "--steps", "7"]) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-5:] == [os.path.abspath(bench.__file__), "--gpus", "4", "--steps", "7"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
