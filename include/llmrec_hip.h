@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LLMREC_ABI_VERSION 3
+#define LLMREC_ABI_VERSION 4
 
 enum {
     LLMREC_OK = 0,
@@ -138,6 +138,16 @@ int llmrec_mark_rows_u8(int64_t n, const int64_t* ids, int32_t value, uint8_t* f
  * one of the listed rows as a neighbour - with the by-item CSR and the batch's items: the users whose gradient the items' gradient reaches */
 int llmrec_mark_neighbours_u8(int64_t n, const int64_t* ids, const int32_t* rowptr, const int32_t* colidx, int32_t value, uint8_t* flags,
                               llmrec_stream_t stream);
+/* The user rows a training step's batch reaches, as an ascending row list (two launches, no host read-back - capturable): the batch's
+ * users and every user adjacent to one of the batch's positive / negative items. These are the only rows in which the gradient of the
+ * attribute streams' projected features is non-zero (reference Models.py:160-163 + main.py:249-254: an attribute stream reaches the loss
+ * through the fused embeddings and the BPR terms of the batch's rows; its gradient travels back through A_iu^T from the batch's items) -
+ * the row list of llmrec_wgrad_problem_t. users / pos / neg: the batch (int64, B_cap entries, the first *n_valid valid; n_valid NULL =
+ * all; negative ids skipped); item_rowptr / item_colidx: the by-item CSR (row = item, columns = its users); flags: n_users bytes of
+ * scratch, ALL-ZERO on entry and left all-zero; row_list: n_users + 32 entries; n_rows: device scalar. */
+int llmrec_batch_reach_rows(int64_t n_users, int64_t n_items, const int64_t* users, const int64_t* pos, const int64_t* neg, int32_t B_cap,
+                            const int32_t* n_valid, const int32_t* item_rowptr, const int32_t* item_colidx, uint8_t* flags,
+                            int32_t* row_list, int32_t* n_rows, llmrec_stream_t stream);
 
 /* counts_host[0..3] = n_wave_rows, n_block_rows, n_split_rows, n_segments (synchronises the stream). */
 int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t t_wave, int32_t t_block, int32_t segment,
@@ -183,6 +193,15 @@ int llmrec_linear_fwd_grouped_f32(int32_t n_problems, const llmrec_linear_proble
 typedef struct { const float* dY; int64_t lddy; const float* X; int64_t ldx; int64_t M;
                  const float* db_row_weight;   /* [M] or NULL (= ones): db (+)= sum_r db_row_weight[r] dY[r] - the bias gradient of a projection
                                                   with llmrec_linear_problem_t.bias_scale (bf16x3, N = 64, K % 128 == 0 only) */
+                 /* ROW LIST (llmrec_linear_wgrad_multi_* with every K % 128 == 0 only; NULL elsewhere): the rows of dY that can be non-zero.
+                  * A training step's dY is exactly zero outside the rows its batch reaches (llmrec_batch_reach_rows), and a zero row adds
+                  * nothing to dY^T X: the kernel streams the LISTED rows of dY and X only. Contract: row_list = device int32 ids, ascending,
+                  * distinct, < M, readable up to n_rows rounded up to 16 entries (+ 16); every row of dY NOT listed is all-zero (it is
+                  * never read; a non-zero one would be silently dropped); n_rows = device scalar (<= M), read by the kernel, so the list
+                  * can change between replays of a captured launch. rows_expected (host, 0 = M) sizes the launch geometry: the problem
+                  * gets ceil(rows_expected / slab) slabs, which the kernel re-cuts into equal pieces of the actual n_rows - a poor
+                  * guess costs balance, never correctness. Deterministic; equal to the dense launch up to fp32 summation order. */
+                 const int32_t* row_list; const int32_t* n_rows; int64_t rows_expected;
 } llmrec_wgrad_problem_t;
 int llmrec_linear_wgrad_grouped_f32(int32_t n_problems, const llmrec_wgrad_problem_t* problems_host, int32_t N, int32_t K,
                                     float* dW, int64_t lddw, float* db, int32_t accumulate,

@@ -648,6 +648,8 @@ struct WgradGroup {
     int64_t ldx[LLMREC_LINEAR_MAX_PROBLEMS];
     int64_t M[LLMREC_LINEAR_MAX_PROBLEMS];
     const float* db_w[LLMREC_LINEAR_MAX_PROBLEMS];         // [M] or null: the bias gradient is sum_r db_w[r] dY[r] (v2 body only)
+    const int32_t* rows[LLMREC_LINEAR_MAX_PROBLEMS];       // or null: ascending ids of the rows of dY that can be non-zero (v2 body only)
+    const int32_t* n_rows[LLMREC_LINEAR_MAX_PROBLEMS];     // device scalar: entries of rows[]
     int32_t vec_ok[LLMREC_LINEAR_MAX_PROBLEMS];
     int32_t chunk_begin[LLMREC_LINEAR_MAX_PROBLEMS + 1];   // first partial slab of each problem
     int32_t n_problems;
@@ -1004,70 +1006,93 @@ __device__ __forceinline__ void split16(const float2 (&v)[8], uint4 (&H)[2], uin
 __device__ unsigned long long g_wgrad_clock[3];
 #endif
 
+typedef const int32_t __attribute__((address_space(4))) * const_i32p;   // constant address space: uniform loads become SCALAR loads
+typedef const float __attribute__((address_space(4))) * const_f32p;
 constexpr int W2_KW = 128;                                  // k columns per wave
 constexpr int W2_RED_FLOATS = 4 * 128 * 64 + 4 * 64;        // LDS of the block's final reduction (129 KB)
 
-__device__ __forceinline__ void wgrad_bf16x3_v2_body(const WgradGroup& g, int N, int K, float* __restrict__ partial,
-                                                     float* __restrict__ partial_db, int64_t MC, int n_kslab, int n_slabs, int lb, float* red) {
+// The accumulation loop of one wave over the rows [m_begin, m_end) of one problem. LISTED: the rows are positions in the problem's
+// ascending ROW LIST (llmrec_wgrad_problem_t.row_list: the rows of dY that can be non-zero); position p reads row rows[p] of dY and X.
+//   dense:  a tile's buffer descriptor = (address of its first row, bytes up to the slab's end), the lane's eight row offsets are constants;
+//   listed: one descriptor per operand over the whole tensor; the 16 row ids of a tile arrive by SCALAR loads (their own counter: they
+//           do not queue behind the vector loads) one tile ahead of the tile's operand loads, offset = id * row stride + column.
+// Either way no row past the end is read as anything but zero (the buffer's range check), so ragged tiles and prefetches past the end
+// need no special case.
+template <bool LISTED>
+__device__ __forceinline__ void wgrad_v2_accumulate(const WgradGroup& g, const int prob, const int kslab, const int nblk, const int64_t m_begin64,
+                                                    const int64_t m_end64, const bool want_db, f32x16 (&acc)[2][4], f32x2& dbs2) {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
-    const int kslab = lb % n_kslab;
-    const int group = lb / n_kslab;
-    const int slab_raw = group * 4 + wave;
-    const bool active = slab_raw < n_slabs;
-    const int slab = active ? slab_raw : n_slabs - 1;             // idle waves of the last group recompute a slab and drop it
-    int prob = 0;
-    while (prob + 1 < g.n_problems && slab >= g.chunk_begin[prob + 1]) ++prob;
     const int64_t lddy = g.lddy[prob], ldx = g.ldx[prob], M = g.M[prob];
-    const int nblk = blockIdx.y;
-    const int64_t m_begin = (int64_t)(slab - g.chunk_begin[prob]) * MC;
-    const int64_t m_end = (m_begin + MC < M) ? m_begin + MC : M;
+    // row positions as wave-uniform 32-bit scalars (M < 2^30 is checked by the host)
+    const int m_begin = __builtin_amdgcn_readfirstlane((int)m_begin64), m_end = __builtin_amdgcn_readfirstlane((int)m_end64);
     const int n_base = nblk * 64 + 2 * i;                         // this lane's 2 n's: n_base + t
     const int k_base = kslab * W2_KW + 4 * i;                     // this lane's 4 k's: k_base + c
-
-    f32x16 acc[2][4];                                             // [t][c]
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
-    f32x2 dbs2 = {0.f, 0.f};
     const uint32_t la = 4u * (uint32_t)lddy, lbx = 4u * (uint32_t)ldx;             // row strides in bytes
-    // Operand loads are RAW BUFFER loads: a tile's descriptor = (address of its first row, bytes up to the slab's end), both
-    // wave-uniform (scalar arithmetic); the lane's eight row offsets (rows 8 h + j of a tile, its n / k column) sit in registers.
-    // No vector instruction computes an address, and a row past the slab's end reads as ZERO (the buffer's range check), so
-    // the ragged last tile and the prefetches past the end need no special case.
     uint32_t offa[8], offb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        offa[j] = (uint32_t)(8 * h + j) * la + 4u * (uint32_t)n_base;
-        offb[j] = (uint32_t)(8 * h + j) * lbx + 4u * (uint32_t)k_base;
+        offa[j] = (LISTED ? 0u : (uint32_t)(8 * h + j) * la) + 4u * (uint32_t)n_base;
+        offb[j] = (LISTED ? 0u : (uint32_t)(8 * h + j) * lbx) + 4u * (uint32_t)k_base;
     }
     const char* dYb = reinterpret_cast<const char*>(uniform_u64(g.dY[prob]));
     const char* Xb = reinterpret_cast<const char*>(uniform_u64(g.X[prob]));
-    auto load_tile = [&](int64_t m0, float2 (&aa)[8], float4 (&bb)[8]) {
-        const int64_t mc = m0 < m_end ? m0 : m_end;              // wave-uniform; at m_end the buffers are empty: zeros
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(dYb + (uint64_t)mc * la), 0, (int)((uint32_t)(m_end - mc) * la), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (uint64_t)mc * lbx), 0, (int)((uint32_t)(m_end - mc) * lbx), 0x00020000);
+    const const_i32p rl = LISTED ? (const_i32p)uniform_u64(g.rows[prob]) : (const_i32p)0;
+    const int n_tiles = (m_end - m_begin + 15) / 16;             // the last tile may be ragged: its missing rows read as zero
+    constexpr uint32_t OOB = 0x80000000u;                        // beyond any listed problem's tensor (checked by the host: bytes < 2^31)
+    __amdgpu_buffer_rsrc_t ra_all, rb_all;
+    if (LISTED) {
+        ra_all = __builtin_amdgcn_make_buffer_rsrc((void*)dYb, 0, (int)((uint32_t)M * la), 0x00020000);
+        rb_all = __builtin_amdgcn_make_buffer_rsrc((void*)Xb, 0, (int)((uint32_t)M * lbx), 0x00020000);
+    }
+    // LISTED: the ids of the 16 rows of the tile at position m0 (uniform address: scalar loads); positions past the last tile re-read it
+    const int m_last = n_tiles > 0 ? m_begin + 16 * (n_tiles - 1) : m_begin;
+    auto load_ids = [&](int m0, int32_t (&ids)[16]) {
+        if (LISTED) {
+            const const_i32p q = rl + (m0 < m_last ? m0 : m_last);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const u32x2 va = __builtin_amdgcn_raw_buffer_load_b64(ra, offa[j], 0, 0);
-            const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rb, offb[j], 0, 0);
-            aa[j] = make_float2(__uint_as_float(va.x), __uint_as_float(va.y));
-            bb[j] = make_float4(__uint_as_float(vb.x), __uint_as_float(vb.y), __uint_as_float(vb.z), __uint_as_float(vb.w));
+            for (int r = 0; r < 16; ++r) ids[r] = q[r];
+        }
+    };
+    auto load_tile = [&](int m0, const int32_t (&ids)[16], float2 (&aa)[8], float4 (&bb)[8]) {
+        if (LISTED) {
+            const int left = m_end - m0 - 8 * h;                     // this half's rows j < left are inside the list
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t id = (uint32_t)(h ? ids[8 + j] : ids[j]);
+                const bool ok = j < left;
+                const u32x2 va = __builtin_amdgcn_raw_buffer_load_b64(ra_all, ok ? id * la + offa[j] : OOB, 0, 0);
+                const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rb_all, ok ? id * lbx + offb[j] : OOB, 0, 0);
+                aa[j] = make_float2(__uint_as_float(va.x), __uint_as_float(va.y));
+                bb[j] = make_float4(__uint_as_float(vb.x), __uint_as_float(vb.y), __uint_as_float(vb.z), __uint_as_float(vb.w));
+            }
+        } else {
+            const int mc = m0 < m_end ? m0 : m_end;                  // wave-uniform; at m_end the buffers are empty: zeros
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(dYb + (uint64_t)mc * la), 0, (int)((uint32_t)(m_end - mc) * la), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(Xb + (uint64_t)mc * lbx), 0, (int)((uint32_t)(m_end - mc) * lbx), 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const u32x2 va = __builtin_amdgcn_raw_buffer_load_b64(ra, offa[j], 0, 0);
+                const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rb, offb[j], 0, 0);
+                aa[j] = make_float2(__uint_as_float(va.x), __uint_as_float(va.y));
+                bb[j] = make_float4(__uint_as_float(vb.x), __uint_as_float(vb.y), __uint_as_float(vb.z), __uint_as_float(vb.w));
+            }
         }
     };
     // bias gradient: column sums of dY, optionally weighted per row (a pre-propagated operand: db = sum_r (A 1)[r] dY[r]); only the
     // k-slab-0 waves' sums are written, so only they fetch the weights (16 scalar loads per tile, rows clamped into the problem)
-    const float* dbw = (kslab == 0 && partial_db) ? g.db_w[prob] : nullptr;
-    auto mma_tile = [&](int64_t m0, const float2 (&aa)[8], const float4 (&bb)[8]) {
+    const const_f32p dbw = want_db ? (const_f32p)uniform_u64(g.db_w[prob]) : (const_f32p)0;
+    auto mma_tile = [&](int m0, const int32_t (&ids)[16], const float2 (&aa)[8], const float4 (&bb)[8]) {
         if (dbw) {                                                   // wave-uniform
-            const int64_t last = M - 1;
+            const int last = (int)M - 1;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int64_t r0 = m0 + j < last ? m0 + j : last, r1 = m0 + 8 + j < last ? m0 + 8 + j : last;
+                int r0, r1;
+                if (LISTED) {                                        // (a position past the end has a zero dY row: any weight will do)
+                    r0 = m0 + j < m_end ? ids[j] : 0; r1 = m0 + 8 + j < m_end ? ids[8 + j] : 0;
+                } else {
+                    r0 = m0 + j < last ? m0 + j : last; r1 = m0 + 8 + j < last ? m0 + 8 + j : last;
+                }
                 const float w0 = dbw[r0], w1 = dbw[r1];              // uniform addresses: scalar loads
                 const float wj = h ? w1 : w0;
                 dbs2.x = fmaf(wj, aa[j].x, dbs2.x); dbs2.y = fmaf(wj, aa[j].y, dbs2.y);
@@ -1096,30 +1121,80 @@ __device__ __forceinline__ void wgrad_bf16x3_v2_body(const WgradGroup& g, int N,
             for (int c = 0; c < 4; ++c) acc[t][c] = mfma32_bf16(ah[t], bh[c], acc[t][c]);
         }
     };
-    // two register stages rotate statically; the loop body is straight-line (pairs of tiles), an odd last tile follows it
-    const int n_tiles = (int)((m_end - m_begin + 15) / 16);      // the last tile may be ragged: its missing rows read as zero
+    // two register stages rotate statically; the loop body is straight-line (pairs of tiles), an odd last tile follows it.
+    // (LISTED: c0 / c1 = the ids of the tiles held in stages 0 / 1 (the bias weights of mma_tile index by them); nx = the ids of the NEXT tile
+    //  to load, fetched right after the previous tile's operand loads were issued, i.e. a whole multiply phase ahead of their use)
     float2 a0[8], a1[8];
     float4 b0[8], b1[8];
-    int64_t m0 = m_begin;
-    load_tile(m0, a0, b0);
+    int32_t c0[16] = {}, c1[16] = {}, nx[16] = {};
+    auto keep = [&](int32_t (&dst)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r] = nx[r];
+    };
+    int m0 = m_begin;
+    load_ids(m0, nx);
+    load_tile(m0, nx, a0, b0); keep(c0);
+    load_ids(m0 + 16, nx);
 #ifdef LLMREC_TOOLS_BUILD
     const long long clk0 = clock64(), ref0 = wall_clock64();
 #endif
     for (int g2 = n_tiles >> 1; g2 > 0; --g2) {
-        load_tile(m0 + 16, a1, b1);
+        load_tile(m0 + 16, nx, a1, b1); keep(c1);
+        load_ids(m0 + 32, nx);
         __builtin_amdgcn_sched_barrier(0);
-        mma_tile(m0, a0, b0);
+        mma_tile(m0, c0, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        load_tile(m0 + 32, a0, b0);
+        load_tile(m0 + 32, nx, a0, b0); keep(c0);
+        load_ids(m0 + 48, nx);
         __builtin_amdgcn_sched_barrier(0);
-        mma_tile(m0 + 16, a1, b1);
+        mma_tile(m0 + 16, c1, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         m0 += 32;
     }
 #ifdef LLMREC_TOOLS_BUILD
     if (lane == 0) { atomicAdd(&g_wgrad_clock[0], (unsigned long long)(clock64() - clk0)); atomicAdd(&g_wgrad_clock[1], (unsigned long long)(wall_clock64() - ref0)); atomicAdd(&g_wgrad_clock[2], 1ull); }
 #endif
-    if (n_tiles & 1) mma_tile(m0, a0, b0);
+    if (n_tiles & 1) mma_tile(m0, c0, a0, b0);
+}
+
+__device__ __forceinline__ void wgrad_bf16x3_v2_body(const WgradGroup& g, int N, int K, float* __restrict__ partial,
+                                                     float* __restrict__ partial_db, int64_t MC, int n_kslab, int n_slabs, int lb, float* red) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int kslab = lb % n_kslab;
+    const int group = lb / n_kslab;
+    const int slab_raw = group * 4 + wave;
+    const bool active = slab_raw < n_slabs;
+    const int slab = active ? slab_raw : n_slabs - 1;             // idle waves of the last group recompute a slab and drop it
+    int prob = 0;
+    while (prob + 1 < g.n_problems && slab >= g.chunk_begin[prob + 1]) ++prob;
+    const int nblk = blockIdx.y;
+    const bool listed = g.rows[prob] != nullptr;                  // wave-uniform
+    // a listed problem's slabs are equal pieces of the ACTUAL list length (read here), whatever length the host laid the launch out for
+    int64_t M = g.M[prob], mc = MC;
+    if (listed) {
+        M = *reinterpret_cast<const int32_t*>(uniform_u64(g.n_rows[prob]));
+        M = M < 0 ? 0 : (M > g.M[prob] ? g.M[prob] : M);
+        const int64_t ns = g.chunk_begin[prob + 1] - g.chunk_begin[prob];
+        mc = ((M + ns - 1) / ns + 15) / 16 * 16;
+        if (mc < 16) mc = 16;
+    }
+    int64_t m_begin = (int64_t)(slab - g.chunk_begin[prob]) * mc;
+    if (m_begin > M) m_begin = (M + 15) / 16 * 16;                // an empty slab (16-aligned: the id loads stay aligned and inside the list's padding)
+    const int64_t m_end = (m_begin + mc < M) ? m_begin + mc : (m_begin < M ? M : m_begin);
+
+    f32x16 acc[2][4];                                             // [t][c]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+    f32x2 dbs2 = {0.f, 0.f};
+    const bool want_db = kslab == 0 && partial_db;
+    if (listed) wgrad_v2_accumulate<true>(g, prob, kslab, nblk, m_begin, m_end, want_db, acc, dbs2);
+    else wgrad_v2_accumulate<false>(g, prob, kslab, nblk, m_begin, m_end, want_db, acc, dbs2);
     float2 dbs = make_float2(dbs2.x, dbs2.y);
     dbs.x += __shfl_xor(dbs.x, 32, 64); dbs.y += __shfl_xor(dbs.y, 32, 64);
     // element (t, c, r) of lane l at [wave][((t * 4 + c) * 16 + r) * 64 + l]: conflict-free
@@ -1465,6 +1540,7 @@ static int linear_wgrad_grouped_impl(int32_t n_problems, const llmrec_wgrad_prob
     for (int i = 0; i < n_problems; ++i) {
         g.dY[i] = p[i].dY; g.X[i] = p[i].X; g.lddy[i] = p[i].lddy; g.ldx[i] = p[i].ldx; g.M[i] = p[i].M;
         if (p[i].db_row_weight) { set_error("linear_wgrad: db_row_weight is served by the 128-wide-k-slab bf16x3 organisation only (N = 64, K %% 128 == 0)"); return LLMREC_EUNSUPPORTED; }
+        if (p[i].row_list) { set_error("linear_wgrad: row_list is served by llmrec_linear_wgrad_multi_* (bf16x3, N = 64, K %% 128 == 0) only"); return LLMREC_EUNSUPPORTED; }
         g.vec_ok[i] = (p[i].lddy % 4 == 0) && (p[i].ldx % 4 == 0) && (((uintptr_t)p[i].dY | (uintptr_t)p[i].X) % 16 == 0);
         g.chunk_begin[i] = n_slabs;
         n_slabs += (int)ceil_div(p[i].M, MC);
@@ -1497,6 +1573,11 @@ static int linear_wgrad_grouped_impl(int32_t n_problems, const llmrec_wgrad_prob
     return LLMREC_OK;
 }
 
+// rows the launch geometry is laid out for: a listed problem's expected list length (llmrec_wgrad_problem_t.rows_expected), else M
+static inline int64_t wgrad_rows_eff(const llmrec_wgrad_problem_t& q) {
+    if (!q.row_list || q.rows_expected <= 0) return q.M;
+    return std::min<int64_t>(q.M, std::max<int64_t>(q.rows_expected, 16));
+}
 // which organisation a multi-target launch runs: 2 = wgrad_bf16x3_v2_body (128-wide k slabs: every K % 128 == 0), 1 = wgrad_bf16x3_body
 static int wgrad_multi_version(int32_t n_targets, const llmrec_wgrad_target_t* t) {
     for (int i = 0; i < n_targets; ++i)
@@ -1508,14 +1589,17 @@ static int64_t wgrad_multi_slab_rows(int32_t n_targets, const llmrec_wgrad_targe
     const int kw = wgrad_multi_version(n_targets, t) == 1 ? 64 : W2_KW;
     int64_t m_max = 0, work = 0;
     for (int i = 0; i < n_targets; ++i)
-        for (int j = 0; j < t[i].n_problems; ++j) { m_max = std::max(m_max, t[i].problems[j].M); work += t[i].problems[j].M * ceil_div(t[i].K, kw); }
+        for (int j = 0; j < t[i].n_problems; ++j) {
+            const int64_t me = wgrad_rows_eff(t[i].problems[j]);
+            m_max = std::max(m_max, me); work += me * ceil_div(t[i].K, kw);
+        }
     const int64_t lo = std::max<int64_t>(64, align_up(ceil_div(work, 4 * 512), 32));       // never more than ~2 rounds of blocks
     int64_t best = lo, best_cost = -1;
     for (int64_t mc = lo; mc <= align_up(m_max, 32) + 32; mc += 32) {
         int64_t blocks = 0;
         for (int i = 0; i < n_targets; ++i) {
             int64_t slabs = 0;
-            for (int j = 0; j < t[i].n_problems; ++j) slabs += ceil_div(t[i].problems[j].M, mc);
+            for (int j = 0; j < t[i].n_problems; ++j) slabs += ceil_div(wgrad_rows_eff(t[i].problems[j]), mc);
             blocks += ceil_div(slabs, 4) * ceil_div(t[i].K, kw);
         }
         const int64_t cost = ceil_div(blocks, 256) * (mc + 96);
@@ -1531,6 +1615,8 @@ static bool wgrad_multi_ok(int32_t n_targets, const llmrec_wgrad_target_t* t, in
             const llmrec_wgrad_problem_t& q = t[i].problems[j];
             if (q.M <= 0 || !q.dY || !q.X || q.lddy < N || q.ldx < t[i].K || q.lddy % 4 || q.ldx % 4 || ((uintptr_t)q.dY | (uintptr_t)q.X) % 16) return false;
             if ((q.M + 256) * std::max(q.lddy, q.ldx) >= (1ll << 30)) return false;
+            // a row list: the 128-wide organisation only, a device count, byte offsets below 2^31 (the kernel's out-of-range offset)
+            if (q.row_list && (!q.n_rows || t[i].K % W2_KW || q.M * std::max(q.lddy, q.ldx) * 4 >= (1ll << 31) || (uintptr_t)q.row_list % 64)) return false;
         }
     }
     return true;
@@ -1542,7 +1628,7 @@ int64_t llmrec_linear_wgrad_multi_workspace_bytes(int32_t n_targets, const llmre
     int64_t bytes = 0;
     for (int i = 0; i < n_targets; ++i) {
         int64_t slabs = 0;
-        for (int j = 0; j < t[i].n_problems; ++j) slabs += ceil_div(t[i].problems[j].M, mc);
+        for (int j = 0; j < t[i].n_problems; ++j) slabs += ceil_div(wgrad_rows_eff(t[i].problems[j]), mc);
         bytes += wgrad_ws_bytes(ceil_div(slabs, 4), N, t[i].K);
     }
     return bytes;
@@ -1576,9 +1662,11 @@ static int linear_wgrad_multi_impl(int32_t n_targets, const llmrec_wgrad_target_
         for (int j = 0; j < t[i].n_problems; ++j) {
             const llmrec_wgrad_problem_t& q = t[i].problems[j];
             g.dY[j] = q.dY; g.X[j] = q.X; g.lddy[j] = q.lddy; g.ldx[j] = q.ldx; g.M[j] = q.M; g.vec_ok[j] = 1; g.db_w[j] = q.db_row_weight;
+            g.rows[j] = q.row_list; g.n_rows[j] = q.row_list ? q.n_rows : nullptr;
+            if (q.row_list && version == 1) { set_error("linear_wgrad_multi: row_list needs every K %% %d == 0", W2_KW); return LLMREC_EUNSUPPORTED; }
             if (q.db_row_weight && version == 1) { set_error("linear_wgrad_multi: db_row_weight needs every K %% %d == 0", W2_KW); return LLMREC_EUNSUPPORTED; }
             g.chunk_begin[j] = n_slabs;
-            n_slabs += (int)ceil_div(q.M, m.MC);
+            n_slabs += (int)ceil_div(wgrad_rows_eff(q), m.MC);
         }
         for (int j = t[i].n_problems; j <= LLMREC_LINEAR_MAX_PROBLEMS; ++j) g.chunk_begin[j] = n_slabs;
         const int64_t n_chunks = ceil_div(n_slabs, 4);

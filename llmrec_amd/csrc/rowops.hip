@@ -554,6 +554,57 @@ __global__ __launch_bounds__(256) void mark_neighbours_kernel(int64_t n, const i
 }
 
 // ---------------------------------------------------------------------------------------------
+// llmrec_batch_reach_rows: the user rows a batch reaches, as an ascending list. Launch 1: one wavefront per (sample, role) - role 0
+// flags the sample's user, roles 1 / 2 every user in the adjacency list of its positive / negative item. Launch 2: ONE block turns
+// the byte flags into the ascending list (each thread owns a contiguous 16-aligned run of rows: count, block-wide exclusive scan,
+// write) and clears them again, so the scratch is all-zero between calls and nothing needs a stamp.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void batch_reach_mark_kernel(int B_cap, const int32_t* __restrict__ n_valid, const int64_t* __restrict__ users,
+                                                               const int64_t* __restrict__ pos, const int64_t* __restrict__ neg, int64_t n_users,
+                                                               int64_t n_items, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                               uint8_t* __restrict__ flags) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int nv = n_valid ? *n_valid : B_cap;
+    nv = nv < B_cap ? nv : B_cap;
+    const int b = w / 3, role = w - 3 * b;
+    if (b >= nv) return;
+    if (role == 0) {
+        const int64_t u = users[b];
+        if (lane == 0 && u >= 0 && u < n_users) flags[u] = 1;
+        return;
+    }
+    const int64_t it = role == 1 ? pos[b] : neg[b];
+    if (it < 0 || it >= n_items) return;
+    const int32_t s = rowptr[it], e = rowptr[it + 1];
+    for (int32_t k = s + lane; k < e; k += 64) flags[colidx[k]] = 1;
+}
+
+__global__ __launch_bounds__(1024) void flags_compact_kernel(int64_t n, uint8_t* __restrict__ flags, int32_t* __restrict__ list, int32_t* __restrict__ n_out) {
+    __shared__ int32_t part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = ((n + 1023) / 1024 + 15) / 16 * 16;
+    const int64_t r0 = tid * per, r1 = r0 + per < n ? r0 + per : n;
+    int32_t c = 0;
+    for (int64_t r = r0; r < r1; ++r) c += flags[r] != 0;
+    part[tid] = c;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {               // inclusive scan
+        const int32_t v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const int32_t total = part[1023];
+    int32_t o = part[tid] - c;
+    for (int64_t r = r0; r < r1; ++r)
+        if (flags[r]) { list[o++] = (int32_t)r; flags[r] = 0; }
+    // the entries a 16-wide tile past the end may fetch: defined values
+    const int32_t pad_end = (total + 15) / 16 * 16 + 16;
+    for (int32_t k = total + tid; k < pad_end; k += 1024) list[k] = 0;
+    if (tid == 0) *n_out = total;
+}
+
+// ---------------------------------------------------------------------------------------------
 // weighted column sums in 64-column groups: out_g[j] (+)= sum_r w[r] * X[r][64 g + j]. The bias gradient of a projection whose
 // operand was propagated beforehand (Y = (A F) W^T + (A 1) b^T: db = sum_r (A 1)[r] dY[r]). Two levels, fixed order.
 // ---------------------------------------------------------------------------------------------
@@ -927,6 +978,22 @@ int llmrec_mark_rows_u8(int64_t n, const int64_t* ids, int32_t value, uint8_t* f
     LLMREC_CHECK_ARG(ids && flags, "mark_rows: null pointer");
     LLMREC_CHECK_ARG(n / 256 < 0x7fffffffll, "mark_rows: too many rows for one launch");
     mark_rows_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, (hipStream_t)stream_>>>(n, ids, (uint8_t)value, flags);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_batch_reach_rows(int64_t n_users, int64_t n_items, const int64_t* users, const int64_t* pos, const int64_t* neg, int32_t B_cap,
+                            const int32_t* n_valid, const int32_t* item_rowptr, const int32_t* item_colidx, uint8_t* flags,
+                            int32_t* row_list, int32_t* n_rows, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_users > 0 && n_users < 0x7fffffffll && n_items > 0 && B_cap >= 0, "batch_reach_rows: bad sizes");
+    LLMREC_CHECK_ARG(users && pos && neg && item_rowptr && item_colidx && flags && row_list && n_rows, "batch_reach_rows: null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (B_cap > 0) {
+        batch_reach_mark_kernel<<<(unsigned)ceil_div(3 * (int64_t)B_cap, 4), 256, 0, stream>>>(B_cap, n_valid, users, pos, neg, n_users, n_items,
+                                                                                                item_rowptr, item_colidx, flags);
+        LLMREC_LAUNCH_CHECK();
+    }
+    flags_compact_kernel<<<1, 1024, 0, stream>>>(n_users, flags, row_list, n_rows);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

@@ -590,7 +590,7 @@ class FuseBwdProblem(_c.Structure):
 class WgradProblem(_c.Structure):
     """llmrec_wgrad_problem_t"""
     _fields_ = [("dY", _c.c_void_p), ("lddy", _c.c_int64), ("X", _c.c_void_p), ("ldx", _c.c_int64), ("M", _c.c_int64),
-                ("db_row_weight", _c.c_void_p)]
+                ("db_row_weight", _c.c_void_p), ("row_list", _c.c_void_p), ("n_rows", _c.c_void_p), ("rows_expected", _c.c_int64)]
 
 
 class WgradTarget(_c.Structure):
@@ -612,15 +612,33 @@ def _wgrad_targets(targets):
     N = targets[0][1].shape[0]
     for i, (pairs, dW, db, accumulate) in enumerate(targets):
         probs = (WgradProblem * len(pairs))()
-        for j, pair in enumerate(pairs):                       # (dY, X) or (dY, X, db_row_weight)
+        for j, pair in enumerate(pairs):                       # (dY, X[, db_row_weight[, (row_list, n_rows, rows_expected)]])
             dY, X = pair[:2]
             _need_gpu(dY, X)
             probs[j].dY, probs[j].lddy, probs[j].X, probs[j].ldx, probs[j].M = dY.data_ptr(), _ld(dY), X.data_ptr(), _ld(X), X.shape[0]
             probs[j].db_row_weight = pair[2].data_ptr() if len(pair) > 2 and pair[2] is not None else None
+            if len(pair) > 3 and pair[3] is not None:          # the rows of dY that can be non-zero (llmrec_wgrad_problem_t.row_list)
+                rl, nr, expected = pair[3]
+                if rl.dtype != torch.int32 or nr.dtype != torch.int32 or rl.numel() < X.shape[0] + 32:
+                    raise RuntimeError("linear_wgrad_multi: row_list must be int32 with M + 32 entries, n_rows an int32 device scalar")
+                probs[j].row_list, probs[j].n_rows, probs[j].rows_expected = rl.data_ptr(), nr.data_ptr(), int(expected or 0)
+                keep.append((rl, nr))
         keep.append(probs)
         arr[i].n_problems, arr[i].problems, arr[i].K = len(pairs), _c.cast(probs, _c.c_void_p), dW.shape[1]
         arr[i].dW, arr[i].lddw, arr[i].db, arr[i].accumulate = dW.data_ptr(), _ld(dW), (db.data_ptr() if db is not None else None), 1 if accumulate else 0
     return arr, keep, N
+
+
+def batch_reach_rows(users, pos, neg, n_valid, by_item: "Csr", flags: torch.Tensor, row_list: torch.Tensor, n_rows: torch.Tensor):
+    """llmrec_batch_reach_rows: the ascending list of the user rows a batch reaches (its users + every user adjacent to one of its
+    positive / negative items; by_item = the CSR whose rows are items and whose columns are users). flags: [n_users] uint8 scratch,
+    all-zero on entry and on return; row_list: int32 [n_users + 32]; n_rows: int32 [1]. Two launches, no host sync."""
+    _need_gpu(users, pos, neg, flags, row_list, n_rows)
+    n_users, n_items = by_item.n_cols, by_item.n_rows
+    if flags.numel() < n_users or row_list.numel() < n_users + 32 or flags.dtype != torch.uint8 or row_list.dtype != torch.int32:
+        raise RuntimeError("batch_reach_rows: flags [n_users] uint8, row_list [n_users + 32] int32")
+    _lib.call("llmrec_batch_reach_rows", n_users, n_items, _p(users), _p(pos), _p(neg), users.numel(), _p(n_valid), _p(by_item.rowptr),
+              _p(by_item.colidx), _p(flags), _p(row_list), _p(n_rows), _stream())
 
 
 def linear_wgrad_multi_workspace(targets) -> int:
@@ -671,6 +689,8 @@ def linear_wgrad_grouped(pairs, dW, db, accumulate: bool, ws: Optional[torch.Ten
         _need_gpu(dY, X)
         arr[i].dY, arr[i].lddy, arr[i].X, arr[i].ldx, arr[i].M = dY.data_ptr(), _ld(dY), X.data_ptr(), _ld(X), X.shape[0]
         arr[i].db_row_weight = pair[2].data_ptr() if len(pair) > 2 and pair[2] is not None else None
+        if len(pair) > 3 and pair[3] is not None:              # row list: served by the bf16x3 128-wide organisation only (else refused)
+            arr[i].row_list, arr[i].n_rows, arr[i].rows_expected = pair[3][0].data_ptr(), pair[3][1].data_ptr(), int(pair[3][2] or 0)
         M_total += X.shape[0]
     N, K = dW.shape
     need = _lib.query("llmrec_linear_wgrad_workspace_bytes", M_total, N, K)

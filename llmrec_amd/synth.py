@@ -42,24 +42,24 @@ NF_SHAPE = Shape(n_users=13187, n_items=17366, n_train=55146)   # 80 % of 68933 
 ML_SHAPE = Shape(n_users=12495, n_items=10322, n_train=46368)   # 80 % of 57960
 
 
-def _user_degrees(rng: np.random.Generator, n_users: int, n_edges: int, max_deg: int) -> np.ndarray:
-    """Power-law degrees clipped to [1, max_deg], rescaled so they sum to exactly n_edges."""
+def _user_degrees(rng: np.random.Generator, n_users: int, n_edges: int, max_deg: int, min_deg: int = 1) -> np.ndarray:
+    """Power-law degrees clipped to [min_deg, max_deg], rescaled so they sum to exactly n_edges."""
     max_deg = max(1, min(max_deg, n_edges))
     raw = rng.zipf(1.8, size=n_users).astype(np.float64)
     raw = np.clip(raw, 1, max_deg)
-    deg = np.maximum(1, np.floor(raw * (n_edges / raw.sum()))).astype(np.int64)
+    deg = np.maximum(min_deg, np.floor(raw * (n_edges / raw.sum()))).astype(np.int64)
     deg = np.minimum(deg, max_deg)
     # fix the remainder one edge at a time on random users (keeps 1 <= deg <= max_deg)
     diff = int(n_edges - deg.sum())
     guard = 0
-    while diff != 0 and guard < 64:
+    while diff != 0 and guard < (64 if min_deg == 1 else 4096):
         guard += 1
         if diff > 0:
             cand = np.flatnonzero(deg < max_deg)
             take = rng.choice(cand, size=min(diff, cand.size), replace=False)
             deg[take] += 1
         else:
-            cand = np.flatnonzero(deg > 1)
+            cand = np.flatnonzero(deg > min_deg)
             take = rng.choice(cand, size=min(-diff, cand.size), replace=False)
             deg[take] -= 1
         diff = int(n_edges - deg.sum())
@@ -69,16 +69,18 @@ def _user_degrees(rng: np.random.Generator, n_users: int, n_edges: int, max_deg:
 
 
 def bipartite_edges(n_users: int, n_items: int, n_edges: int, seed: int = 0,
-                    max_deg: int = 10_000, item_alpha: float = 0.8, n_communities: int = 0, p_in: float = 0.85):
+                    max_deg: int = 10_000, item_alpha: float = 0.8, n_communities: int = 0, p_in: float = 0.85,
+                    min_deg: int = 1):
     """Return (rows, cols) int64 arrays, sorted by (row, col), without duplicate pairs.
 
     n_communities > 0 plants a block structure a collaborative-filtering model can learn (the long-horizon accuracy fixtures,
     oracle/make_trajectory.py): user u belongs to block u % C, the item of popularity rank r to block r % C; a fraction p_in of
     every user's draws is moved to the nearest rank of the user's own block (same popularity law). 0 (default): popularity only,
-    the generator of every other fixture and workload, unchanged."""
+    the generator of every other fixture and workload, unchanged. min_deg = 3 gives every user a validation and a test item
+    (split_train_test), as in the survey's probe of the reference (13 187 test users)."""
     rng = np.random.default_rng(seed)
     max_deg = min(max_deg, n_items)
-    deg = _user_degrees(rng, n_users, n_edges, max_deg)
+    deg = _user_degrees(rng, n_users, n_edges, max_deg, min_deg)
     pop = np.arange(1, n_items + 1, dtype=np.float64) ** (-item_alpha)
     cdf = np.cumsum(pop / pop.sum())
     item_perm = rng.permutation(n_items)            # popularity rank -> item id
@@ -184,7 +186,7 @@ def split_train_test(rows: np.ndarray, cols: np.ndarray, n_users: int, seed: int
 def write_dataset(path: str, n_users: int, n_items: int, n_edges: int, seed: int = 0,
                   image_dim: int = 512, text_dim: int = 768, llm_dim: int = 1536,
                   keys=NETFLIX_KEYS, feat_dtype=np.float32, aug_out_of_range: float = 0.05,
-                  max_deg: int = 10_000, n_communities: int = 0) -> dict:
+                  max_deg: int = 10_000, n_communities: int = 0, min_deg: int = 1, attr_rows_as_arrays: bool = False) -> dict:
     """Write a complete Stage-2 dataset directory (every file of SURVEY.md Appendix A).
 
     ``n_edges`` counts all interactions; users with >= 3 give one to val and one to test."""
@@ -192,7 +194,7 @@ def write_dataset(path: str, n_users: int, n_items: int, n_edges: int, seed: int
 
     os.makedirs(path, exist_ok=True)
     rng = np.random.default_rng(seed + 7)
-    rows, cols = bipartite_edges(n_users, n_items, n_edges, seed=seed, max_deg=max_deg, n_communities=n_communities)
+    rows, cols = bipartite_edges(n_users, n_items, n_edges, seed=seed, max_deg=max_deg, n_communities=n_communities, min_deg=min_deg)
     rows, cols, role = split_train_test(rows, cols, n_users, seed)
 
     def as_dict(mask):
@@ -221,7 +223,10 @@ def write_dataset(path: str, n_users: int, n_items: int, n_edges: int, seed: int
     with open(os.path.join(path, "augmented_user_init_embedding"), "wb") as f:
         pickle.dump(user_emb, f)
 
-    attr = {k: {i: rng.standard_normal(llm_dim).astype(np.float64).tolist() for i in range(n_items)}
+    # the reference's file holds python lists (gpt_i_attribute_generate_aug.py:325-355); attr_rows_as_arrays keeps each row an
+    # ndarray - the same values to both readers (np.array([d[k][i] ...]), main.py:73-77), without 133 M python floats at Netflix shape
+    row = (lambda v: v) if attr_rows_as_arrays else (lambda v: v.tolist())
+    attr = {k: {i: row(rng.standard_normal(llm_dim).astype(np.float64)) for i in range(n_items)}
             for k in keys}
     with open(os.path.join(path, "augmented_atttribute_embedding_dict"), "wb") as f:
         pickle.dump(attr, f)

@@ -12,8 +12,12 @@ What differs from the reference, by design (results are unchanged):
   * augmented_sample_dict is unpickled once, not every step (main.py:216);
   * the two pickles the reference re-writes into the dataset directory at start-up
     (main.py:66,78) are not written.
-Environment: LLMREC_DEVICE_SAMPLER=1 switches Data.sample() to the HIP sampler (not
-stream-compatible with the reference's host RNG; default keeps the reference's sample stream).
+Modes:
+  * default: the reference's own sample stream (utility/load_data.py: same seed -> the same (users, pos, neg) triples as the
+    reference, drawn on the host), one H2D copy of the batch, the fused step replayed from a captured HIP graph, the evaluation
+    from another; LLMREC_GRAPH=0 issues the same launches one by one, LLMREC_FUSED=0 runs the per-op autograd path;
+  * LLMREC_DEVICE_SAMPLER=1: the HIP sampler inside the step graph (distribution-equivalent, not stream-equivalent to the
+    reference's host RNG): an epoch is n_batch / 4 graph launches and nothing else - the mode bench.py's headline times.
 """
 from datetime import datetime
 import math
@@ -41,6 +45,14 @@ if torch.cuda.is_available():                              # --gpu_id (reference
         raise SystemExit("--gpu_id %d: this process sees %d GPU(s)" % (args.gpu_id, torch.cuda.device_count()))
     torch.cuda.set_device(args.gpu_id)
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+
+def USE_GRAPH():
+    """LLMREC_GRAPH (default 1): the fused step and the evaluation are replayed from captured HIP graphs; 0 = the same launches
+    issued one by one from Python (debugging, and the A/B of the graph itself)."""
+    return os.environ.get("LLMREC_GRAPH", "1") == "1"
+
 
 ATTRIBUTE_KEYS = {                                         # reference main.py:69-72
     'preprocessed_raw_MovieLens': ['title', 'genre', 'director', 'country', 'language'],
@@ -165,7 +177,7 @@ class Trainer(object):
         self.model_mm.eval()
         fused = self._fused_step()
         with torch.no_grad():
-            if fused and os.environ.get("LLMREC_GRAPH", "0") == "1" and args.test_flag == 'part':
+            if fused and USE_GRAPH() and args.test_flag == 'part':
                 # forward + scoring + masked top-K as ONE graph replay per evaluation
                 # the query tensor is cached on the CONTENT of the user list (a different list of the same length
                 # must not reuse it); the evaluation graph is keyed on that tensor
@@ -212,8 +224,8 @@ class Trainer(object):
 
     def _fused_step(self):
         """The fused step (llmrec_amd/fused.py) when the configuration allows it: no dropout, no
-        --mask. LLMREC_FUSED=0 forces the modular autograd path; LLMREC_GRAPH=1 additionally
-        replays the step from one captured HIP graph."""
+        --mask. LLMREC_FUSED=0 forces the modular autograd path; LLMREC_GRAPH=0 issues the fused step's
+        launches one by one instead of replaying the captured HIP graph."""
         if self._fused is None:
             # the reference masks user features whenever mask_rate > 0, with or without --mask (Models.py:139-142):
             # the fused path reads the unmasked features, so any of the three sends the step down the modular path
@@ -271,17 +283,20 @@ class Trainer(object):
         self._global_step += n_batch
         return fused.epoch_sums.clone()
 
-    def train_step(self, users, pos_items, neg_items, n_valid=None):
+    def train_step(self, users, pos_items, neg_items, n_valid=None, clone=True):
         """Forward, the 8 BPR(+prune) losses, feature regulariser, backward, AdamW.
-        Returns the device scalars (batch_loss, mf_loss, emb_loss)."""
+        Returns the device scalars (batch_loss, mf_loss, emb_loss); clone=False: views of the step's own buffer (the epoch loop reads
+        the running sums the step keeps on the device instead)."""
         fused = self._fused_step()
         if fused:
             self.model_mm.train()
-            if os.environ.get("LLMREC_GRAPH", "0") == "1" and fused.graph_exec is None:
+            if USE_GRAPH() and fused.graph_exec is None:
                 fused.capture(users, pos_items, neg_items, n_valid)      # the capture run itself is a real step
-                out = (fused.scal[1].clone(), fused.scal[2].clone(), fused.scal[3].clone())
+                out = (fused.scal[1], fused.scal[2], fused.scal[3])
             else:
-                out = tuple(x.clone() for x in fused.step(users, pos_items, neg_items, n_valid))
+                out = fused.step(users, pos_items, neg_items, n_valid)
+            if clone:
+                out = tuple(x.clone() for x in out)
             if self._on_bpr is not None:
                 for k in range(fused.n_prob):
                     self._on_bpr(fused.out[k, 0].clone(), fused.out[k, 1].clone())
@@ -315,7 +330,7 @@ class Trainer(object):
         stopping_step = 0
         best_recall = 0
         test_ret = None
-        in_graph_sampler = bool(self._device_sampler and os.environ.get("LLMREC_GRAPH", "0") == "1" and self._fused_step())
+        in_graph_sampler = bool(self._device_sampler and USE_GRAPH() and self._fused_step())
         for epoch in range(args.epoch):
             t1 = time()
             n_batch = data_generator.n_train // args.batch_size + 1
@@ -326,12 +341,19 @@ class Trainer(object):
                 # are summed in double inside the graph (llmrec_loss_assemble_f32): nothing else is enqueued between the replays
                 sums = self.train_epoch_sampled(n_batch)
             else:
+                fused = self._fused_step()
+                if fused:
+                    fused.epoch_sums.zero_()                             # the fused step sums the three logged scalars on the device (double)
                 for idx in _progress(range(n_batch)):
                     sample_t1 = time()
                     users, pos_items, neg_items = self.sample_batch()
                     sample_time += time() - sample_t1
-                    parts = self.train_step(users, pos_items, neg_items)
-                    sums += torch.stack(parts).double()
+                    parts = self.train_step(users, pos_items, neg_items, clone=not fused)
+                    if not fused:
+                        sums += torch.stack(parts).double()
+                if fused:
+                    sums = fused.epoch_sums
+            self.sample_time = sample_time                               # host seconds of this epoch spent in Data.sample() + the aug triples
             loss, mf_loss, emb_loss = (float(x) for x in sums.cpu())     # one sync per epoch
             reg_loss, contrastive_loss = 0., 0.
 

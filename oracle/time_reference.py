@@ -1,0 +1,81 @@
+"""TEST / MEASUREMENT INFRASTRUCTURE ONLY - times the UNMODIFIED reference on CPU on the dataset tools/e2e_main.py times the
+drop-in on. Runs in the build container only (needs /root/reference); the GPU box never sees the reference,
+so the result travels as a committed record:
+
+    python oracle/time_reference.py [--epochs 2] [--out profiles/r04_reference_cpu.json]
+
+The reference is imported through oracle/ref_loader.py (import shims only; its evaluation pool becomes an in-process map - the
+reference would use Pool(cpu_count() // 5) = one worker on this 8-core host, utility/batch_test.py:11,115) and its own
+`Trainer.train()` runs `--epoch N`; the two timers are read from its own log line `Epoch %d [%.1fs + %.1fs]` (main.py:306-312).
+bench.py copies the record into cpu_baseline.reference_unmodified next to the oracle port's live number."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def child(data_root: str, epochs: int):
+    sys.path.insert(0, HERE)
+    import ref_loader
+    ref = ref_loader.load_reference(["--dataset", "netflix_valid_item", "--data_path", data_root + "/", "--epoch", str(epochs), "--debug"], cwd="/tmp")
+    import torch
+    ref.set_seed(ref.args.seed)
+    t0 = time.time()
+    trainer = ref.Trainer(data_config={"n_users": ref.data_generator.n_users, "n_items": ref.data_generator.n_items})
+    init_s = time.time() - t0
+    lines = []
+    orig = trainer.logger.logging
+    trainer.logger.logging = lambda s: (lines.append(str(s)), orig(s))[1]
+    t1 = time.time()
+    trainer.train()
+    total = time.time() - t1
+    ep = []
+    for l in lines:
+        m = re.search(r"Epoch (\d+) \[([0-9.]+)s \+ ([0-9.]+)s\]", l)
+        if m:
+            ep.append({"epoch": int(m.group(1)), "train_s": float(m.group(2)), "eval_s": float(m.group(3)), "line": m.group(0)})
+    n_batch = ref.data_generator.n_train // ref.args.batch_size + 1
+    print("REF_JSON " + json.dumps({"epochs": ep, "n_batch": n_batch, "batch_size": ref.args.batch_size, "n_train": ref.data_generator.n_train,
+                                    "n_test_users": len(ref.data_generator.test_set), "init_s": init_s, "train_call_s": total,
+                                    "torch_threads": torch.get_num_threads(), "torch": torch.__version__}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--epochs", type=int, default=2)
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_reference_cpu.json"))
+    ap.add_argument("--data", default="/tmp/llmrec_e2e")
+    ap.add_argument("--child", action="store_true")
+    a = ap.parse_args()
+    if a.child:
+        return child(a.data, a.epochs)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_main
+    ds, stats = e2e_main.write_dataset(a.data)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--data", a.data, "--epochs", str(a.epochs)], capture_output=True, text=True, cwd="/tmp")
+    js = [l for l in r.stdout.splitlines() if l.startswith("REF_JSON ")]
+    if not js:
+        raise SystemExit("reference run failed:\n" + (r.stderr or r.stdout)[-3000:])
+    c = json.loads(js[-1][9:])
+    best = min(c["epochs"], key=lambda e: e["train_s"])
+    out = {"what": "the UNMODIFIED reference (/root/reference main.py, imported through oracle/ref_loader.py) on CPU, its own Trainer.train() and timers",
+           "dataset": "tools/e2e_main.py's NF-shaped set: U 13187 x I 17366, 68933 interactions (%d train), %d test users, feats 512/768/1536 x (1 + 5)" % (c["n_train"], c["n_test_users"]),
+           "host": {"cores": os.cpu_count(), "torch_threads": c["torch_threads"], "eval_pool": "in-process map (the reference's Pool(cpu_count() // 5) = 1 worker on this host)",
+                    "torch": c["torch"], "where": "build container (no GPU)"},
+           "epochs": c["epochs"], "n_batch": c["n_batch"], "batch_size": c["batch_size"], "n_test_users": c["n_test_users"],
+           "train_s": best["train_s"], "eval_s": best["eval_s"],
+           "edges_per_s": c["n_batch"] * c["batch_size"] / best["train_s"], "users_per_s": c["n_test_users"] / best["eval_s"], "init_s": c["init_s"]}
+    json.dump(out, open(a.out, "w"), indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

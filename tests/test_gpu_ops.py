@@ -1111,3 +1111,80 @@ def test_spmm_of_listed_rows_and_of_needed_rows(ops):
     short = torch.tensor(degs <= 32, device=DEV)                      # LLMREC_SPMM_LONG_ROW: the rows of the short-row range
     assert torch.equal(got[nd], ref[nd])
     assert bool((got[~nd & short] == 3.0).all()) and torch.equal(got[~nd & ~short], ref[~nd & ~short])
+
+
+def test_batch_reach_rows_lists_the_batch_users_and_their_items_neighbours(ops):
+    """llmrec_batch_reach_rows: ascending list of {batch users} U {users adjacent to a batch item}, device count, scratch left all-zero;
+    invalid (negative / out-of-range) ids and the entries past n_valid are ignored; an empty batch gives an empty list."""
+    rng = np.random.default_rng(8)
+    U_, I_ = 5000, 700
+    rows = rng.integers(0, U_, size=9000); cols = (rng.zipf(1.6, size=9000) % I_)
+    key = np.unique(rows * I_ + cols); rows, cols = key // I_, key % I_
+    gr = ops.BipartiteGraph.from_edges(torch.tensor(rows, device=DEV), torch.tensor(cols, device=DEV), U_, I_)
+    by_item = gr.iu.fwd                                                       # rows = items, columns = users
+    adj = {}
+    for u, i in zip(rows.tolist(), cols.tolist()):
+        adj.setdefault(i, set()).add(u)
+    flags = torch.zeros(U_, dtype=torch.uint8, device=DEV)
+    lst = torch.full((U_ + 32,), -7, dtype=torch.int32, device=DEV); n = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for B, nv in ((64, 64), (200, 137), (16, 0), (1, 1)):
+        users = rng.integers(0, U_, size=B); pos = rng.integers(0, I_, size=B); neg = rng.integers(0, I_, size=B)
+        if B >= 64:
+            users[3] = -1; pos[5] = -1; neg[7] = I_ + 3                        # skipped
+        nvt = torch.tensor([nv], dtype=torch.int32, device=DEV)
+        ops.batch_reach_rows(torch.tensor(users, device=DEV), torch.tensor(pos, device=DEV), torch.tensor(neg, device=DEV), nvt, by_item, flags, lst, n)
+        want = set()
+        for b in range(nv):
+            if 0 <= users[b] < U_: want.add(int(users[b]))
+            for it in (pos[b], neg[b]):
+                if 0 <= it < I_: want |= adj.get(int(it), set())
+        got_n = int(n)
+        assert got_n == len(want), (B, nv, got_n, len(want))
+        assert lst[:got_n].cpu().tolist() == sorted(want)
+        assert int(flags.max()) == 0
+        pad = lst[got_n:(got_n + 15) // 16 * 16 + 16].cpu()
+        assert bool((pad == 0).all())                                         # what a 16-wide tile may read past the end is defined
+
+
+def test_weight_gradient_over_a_row_list_equals_the_dense_launch(ops):
+    """llmrec_wgrad_problem_t.row_list: dY is zero outside the listed rows, and the launch that streams only the listed rows gives the
+    dense launch's dW / db (row-weighted) up to fp32 summation order; list lengths 0, 1, ragged, all rows; a length far from
+    rows_expected (the geometry hint) changes nothing; unlisted rows of dY are never read (poisoned with NaN here)."""
+    g = torch.Generator(device=DEV); g.manual_seed(43)
+    rn = lambda *s: torch.randn(*s, generator=g, device=DEV)
+    relmax = lambda a, b: float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+    d, K, M = 64, 384, 3001
+    Xs = [rn(M, K) for _ in range(3)]
+    Xd = rn(1200, 256)                                                        # a dense target in the same launch
+    w = torch.rand(M, generator=g, device=DEV)
+    for n_act, expected in ((0, 0), (1, 0), (517, 600), (1300, 100), (M, 0), (2000, M)):
+        ids = torch.sort(torch.randperm(M, generator=g, device=DEV)[:n_act]).values.to(torch.int32)
+        lst = torch.zeros(M + 32, dtype=torch.int32, device=DEV); lst[:n_act] = ids
+        n = torch.tensor([n_act], dtype=torch.int32, device=DEV)
+        dY = torch.zeros(M, 3 * d, device=DEV)
+        dY[ids.long()] = rn(n_act, 3 * d) * 1e-3
+        dYd = rn(1200, d) * 1e-3
+        dense = [(dY[:, k * d:(k + 1) * d], Xs[k], w) for k in range(3)]
+        dW0, db0 = torch.empty(d, K, device=DEV), torch.empty(d, device=DEV)
+        dWd0, dbd0 = torch.empty(d, 256, device=DEV), torch.empty(d, device=DEV)
+        ops.linear_wgrad_multi([(dense, dW0, db0, False), ([(dYd, Xd)], dWd0, dbd0, False)])
+        poisoned = dY.clone()
+        mask = torch.ones(M, dtype=torch.bool, device=DEV); mask[ids.long()] = False
+        poisoned[mask] = float("nan")
+        listed = [(poisoned[:, k * d:(k + 1) * d], Xs[k], w, (lst, n, expected)) for k in range(3)]
+        dW1, db1 = torch.full((d, K), 7.0, device=DEV), torch.full((d,), 7.0, device=DEV)
+        dWd1, dbd1 = torch.empty(d, 256, device=DEV), torch.empty(d, device=DEV)
+        ops.linear_wgrad_multi([(listed, dW1, db1, False), ([(dYd, Xd)], dWd1, dbd1, False)])
+        want_w = sum(dY[:, k * d:(k + 1) * d].double().t() @ Xs[k].double() for k in range(3))
+        want_b = sum((dY[:, k * d:(k + 1) * d].double() * w.double()[:, None]).sum(0) for k in range(3))
+        if n_act == 0:
+            assert float(dW1.abs().max()) == 0.0 and float(db1.abs().max()) == 0.0
+        else:
+            assert relmax(dW1, want_w) < 3e-6 and relmax(db1, want_b) < 3e-6, (n_act, relmax(dW1, want_w), relmax(db1, want_b))
+            assert relmax(dW1, dW0) < 2e-6 and relmax(db1, db0) < 2e-6
+        assert torch.equal(dWd1, dWd0) or relmax(dWd1, dWd0) < 2e-6          # the dense target beside it
+        a = dW1.clone()
+        ops.linear_wgrad_multi([(listed, dW1, db1, False), ([(dYd, Xd)], dWd1, dbd1, False)])
+        assert torch.equal(a, dW1)                                            # deterministic
+    with pytest.raises(RuntimeError):                                         # the single-target exact-fp32 entry does not serve lists
+        ops.linear_wgrad_grouped([(dY[:, :d], Xs[0], None, (lst, n, 0))], dW1, db1, False, precision="f32")
