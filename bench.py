@@ -51,12 +51,14 @@ def parse():
     ap.add_argument("--synth-chunks", type=int, default=0, help="item-row chunks per all-reduced message (0 = automatic, >= 32 MB each)")
     ap.add_argument("--synth-exchange", default="all_reduce", help="all_reduce | rs_ag: the per-chunk exchange of the row-sharded step (llmrec_amd/dist_fused.py)")
     ap.add_argument("--synth-dense-backward", action="store_true", help="row-sharded step: run the last layer's backward as dense products (A/B of the operand-sparsity path)")
-    ap.add_argument("--synth-dense-forward", action="store_true", help="row-sharded step: compute the last layer's forward products for every row (A/B of forward(needed=...))")
+    ap.add_argument("--synth-dense-forward", action="store_true", help="(the default since round 4: every forward product for every row)")
+    ap.add_argument("--synth-restricted-forward", action="store_true", help="row-sharded step: the labelled variant - the last layer's two forward products only in the rows the step reads (forward(needed=...))")
     ap.add_argument("--no-single-gpu-reference", action="store_true", help="N > 1, row-sharded strong scaling: skip rank 0's run of the same workload on one GPU")
     ap.add_argument("--no-row-sharded", action="store_true", help="nf / ml workloads: skip the cfg-4-shaped row-sharded measurements added to the line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity gate that runs before the timed region")
+    ap.add_argument("--no-end-to-end", action="store_true", help="nf workload: skip the `python main.py` run timed by the drop-in's own epoch timers (tools/e2e_main.py)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -169,9 +171,9 @@ class NetflixShaped:
         """n training steps; single-GPU fused path: graphs of UNROLL steps (FusedStep.run_steps), else n times step()."""
         f = self.fused
         if self.use_graph and hasattr(f, "run_steps") and not hasattr(f, "gsz"):
-            if f.graph_exec is None:
-                self._capture(); n -= 1
             self.step_id += n
+            if f.graph_exec is None:
+                self._capture(); n -= 1                        # (the capture's warm-up is one of the n steps)
             return f.run_steps(n)
         for _ in range(n):
             self.step()
@@ -268,16 +270,32 @@ class NetflixShaped:
         dYu = self.fused.dP_usr
         if bf_ok:
             ms = self._wgrad_launch_ms(dY_cat, dYu)
+            # ALGORITHMIC bytes / flop of the rows this launch streams: a row-listed pair (the five attribute streams, llmrec_amd/fused.py) reads
+            # the listed rows of dY and X only - the list length of the last training step, read back here
+            listed_rows = None
+            byts_w, flop_w = 0.0, 0.0
+            for pairs, dW, db, acc in self.fused.wgrad_targets(dY_cat, dYu):
+                for pr in pairs:
+                    Mp, Kp = pr[1].shape
+                    if len(pr) > 3 and pr[3] is not None:
+                        listed_rows = int(pr[3][1].item())
+                        Mp = listed_rows
+                    byts_w += 4.0 * (Mp * Kp + d * Kp + Mp * d); flop_w += 2.0 * Mp * Kp * d
             out.append({"kernel": "linear_wgrad_bf16x3_v2_multi_kernel + reduce_chunks_multi_kernel: the weight gradients of all four Linears "
                                   "(item_trans x5, user_trans, text_trans, image_trans) in one launch; 3-term bf16 split: tflops are fp32-EQUIVALENT",
                         "pmc": [("linear_wgrad_bf16x3_v2_multi_kernel", 1), ("reduce_chunks_multi_kernel", 1)],
                         "launches": 1, "avg_launch_ms": ms, "timing": t_how,
-                        "bound": "hbm", "calls_per_step": 1, "ms": ms, "tflops": flop_all / ms / 1e9, "frac_mfma_f32": flop_all / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
-                        "gbs": byts_all / ms / 1e6, "frac_hbm": byts_all / ms / 1e6 / HBM_PEAK_GBS,
+                        "bound": "hbm", "calls_per_step": 1, "ms": ms, "tflops": flop_w / ms / 1e9, "frac_mfma_f32": flop_w / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                        "gbs": byts_w / ms / 1e6, "frac_hbm": byts_w / ms / 1e6 / HBM_PEAK_GBS,
+                        "rows": ({"listed_rows_of_the_attribute_pairs": listed_rows, "of": int(dY_cat.shape[0]),
+                                  "what": "the attribute streams' gradient is exactly zero outside the rows the batch reaches (its users + the users adjacent to its "
+                                          "items): the launch streams those rows only (llmrec_wgrad_problem_t.row_list); bytes / flop count the streamed rows"}
+                                 if listed_rows is not None else "every row (dense launch)"),
+                        "dense_equivalent_bytes": byts_all,
                         "note": "power-bound, not bandwidth-bound: the shader clock averages 1.37 GHz in this kernel (2.33 GHz for its load stream alone, "
                                 "1.88 GHz for its MFMAs alone; profiles/experiments/r03_wgrad.md)",
-                        "algorithmic_flop_per_launch": flop_all, "algorithmic_bytes_per_launch": byts_all,
-                        "algorithmic_flop_per_step": flop_all, "algorithmic_bytes_per_step": byts_all})
+                        "algorithmic_flop_per_launch": flop_w, "algorithmic_bytes_per_launch": byts_w,
+                        "algorithmic_flop_per_step": flop_w, "algorithmic_bytes_per_step": byts_w})
         Xi = torch.randn(sh.n_items, d, device=self.device)
         a = self.graph.ui.fwd
         ms = event_time_ms(lambda: ops.spmm_raw(a, Xi), 50)
@@ -370,6 +388,9 @@ class RowSharded:
                 "users_per_gpu": st.U, "edges_per_gpu": self.nnz_local, "embed_size": c["d"], "prop_layers": c["layers"],
                 "batch_per_gpu": self.batch_local, "augmented_triples_per_gpu": self.n_aug, "global_batch": self.B * self.world,
                 "prune_loss_drop_rate": 0.71, "user_blocks_total": self.blocks_total,
+                "last_layer_forward": ("restricted to the rows the step reads (labelled variant, --synth-restricted-forward)" if st.sparse_forward
+                                       else "dense: every forward product for every row"),
+                "last_layer_backward": "products with exactly-zero operand rows skip them" if st.sparse_backward else "dense",
                 "parallelism": ("user-row-sharded x%d (llmrec_amd/dist_fused.py): item tables replicated, per layer and direction one I x d "
                                 "all-reduce in %d asynchronous chunks behind the next chunk's SpMM, BPR gradient rows by all-gather"
                                 % (self.world, len(st.chunks)))}
@@ -558,8 +579,38 @@ def spmm_roofline_large(device, seed, n_users=2_000_000, n_items=1_000_000, n_ed
         gather = nnz * (4.0 + 4.0 * d) + 4.0 * d * a.n_rows
         res[name] = {"ms": ms, "edges_per_s": nnz / ms * 1e3, "algorithmic_gbs": alg / ms / 1e6,
                      "frac_hbm_algorithmic": alg / ms / 1e6 / HBM_PEAK_GBS, "no_reuse_gather_gbs": gather / ms / 1e6,
+                     "frac_gather_model": gather / ms / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "no_reuse_gather_bytes": gather,
                      "n_long_rows": a.plan.n_long}
-    return {"graph": {"n_users": n_users, "n_items": n_items, "nnz": int(nnz), "d": d}, **res}
+    out = {"graph": {"n_users": n_users, "n_items": n_items, "nnz": int(nnz), "d": d},
+           "fractions": "frac_hbm_algorithmic = SURVEY 8(d)'s bytes (every X row read ONCE: 4 nnz + 8 rows + 4 d (rows + cols)) / time / 8 TB/s - north_star's >= 0.40 "
+                        "target, UNMET on a structureless graph; frac_gather_model = the no-reuse gather model (nnz (4 + 4 d) + 4 d rows: every edge fetches "
+                        "its 256-B row) / time / 8 TB/s - above 1 means the L2 served part of the gathers (DESIGN.md section 4)", **res}
+    pmc = spmm_pmc_traffic()
+    if pmc is not None:
+        for name in ("ui", "iu"):
+            if name in pmc.get("directions", {}):
+                t = pmc["directions"][name]
+                out[name]["traffic"] = t["hbm_bytes_per_launch"]
+                out[name]["traffic_over_algorithmic"] = t["hbm_bytes_per_launch"] / out[name]["algorithmic_bytes"]
+                out[name]["l2_hit_rate"] = t.get("l2_hit_rate")
+        out["traffic_source"] = pmc.get("file")
+    return out
+
+
+def spmm_pmc_traffic():
+    """HBM-side bytes per launch of the product SpMM at this function's graph (2 M x 1 M x 40 M, d = 64), both directions, from the newest
+    committed PMC pass (profiles/r*_pmc_spmm_40M.json, tools/pmc_spmm.sh: rocprofv3 --pmc in separate passes with --kernel-trace only;
+    2 x FETCH_SIZE + WRITE_SIZE in KB as MI355X_MICROARCH.md prescribes for gfx950). None when absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_spmm_40M.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+    except Exception:
+        return None
+    d["file"] = os.path.basename(files[-1])
+    return d
 
 
 ORACLE_PARAMS = ["image_trans.weight", "image_trans.bias", "text_trans.weight", "text_trans.bias", "user_trans.weight",
@@ -600,7 +651,7 @@ def parity_check(w: "NetflixShaped", n_eval_users: int = 256, steps: int = 2, to
     sh = w.sh
     opt = O.AdamW(params, lr=cfg.lr)
     rel = lambda a, b: float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
-    worst = {"forward": 0.0, "bpr": 0.0, "loss": 0.0, "grad": 0.0, "adamw": 0.0, "param": 0.0}
+    worst = {"forward": 0.0, "bpr": 0.0, "loss": 0.0, "grad": 0.0, "adamw": 0.0, "param": 0.0, "moment": 0.0, "param_l2": 0.0}
     worst_name = {}
 
     def upd(kind, name, e):
@@ -658,6 +709,14 @@ def parity_check(w: "NetflixShaped", n_eval_users: int = 256, steps: int = 2, to
         opt.step(grads)
         for nm in ORACLE_PARAMS:
             upd("param", "step%d/%s" % (s, nm), rel(gp[nm].detach().cpu(), params[nm].detach()))
+            # end-to-end gates that Adam's first steps do not ill-condition: the two moments are linear / quadratic in the
+            # gradients, and the L2 distance of a whole tensor does not notice the few entries whose near-zero gradient flips sign
+            if gp[nm] in w.opt.state:
+                mg, vg = (t.detach().cpu() for t in w.opt.state[gp[nm]])
+                upd("moment", "step%d/m/%s" % (s, nm), rel(mg, opt.m[nm]))
+                upd("moment", "step%d/v/%s" % (s, nm), rel(vg, opt.v[nm]))
+            a64, b64 = gp[nm].detach().cpu().double(), params[nm].detach().double()
+            upd("param_l2", "step%d/%s" % (s, nm), float((a64 - b64).norm() / b64.norm()))
     # evaluation: forward with the post-step parameters + scoring + masked top-50
     idx, _ = w.eval_once()
     torch.cuda.synchronize()
@@ -679,12 +738,28 @@ def parity_check(w: "NetflixShaped", n_eval_users: int = 256, steps: int = 2, to
     equal = equal_oracle = 0
     test_items = rng.integers(0, sh.n_items, size=sh.n_users)                          # one synthetic held-out item per user
     m_want = np.zeros((4, len(cfg.Ks)))
+    # lists from the ORACLE's embeddings (end to end: oracle steps -> oracle forward -> torch matmul) vs the GPU's lists: where they
+    # differ, the two items at the first differing rank must be a near-tie under BOTH score sets - their gap, in units in the last place
+    # of the score, is bounded by twice the largest difference between the two score matrices on these users (a swap needs
+    # s_a >= s_b on one side and s_a <= s_b on the other)
+    ulp = lambda x: float(np.spacing(np.float32(abs(x))))
+    score_diff_ulps = float((np.abs(S.astype(np.float64) - S_or.astype(np.float64)) / np.spacing(np.abs(S_or).astype(np.float32)).astype(np.float64)).max())
+    gap_ulps, n_mismatch_positions, not_neighbour_swaps = 0.0, 0, 0
     for r, uu in enumerate(users):
         tr = Rc.indices[Rc.indptr[uu]:Rc.indptr[uu + 1]]
         want = O.rank_topk_np(S[r], tr, K)
         got = idx_np[uu][idx_np[uu] >= 0]
         equal += int(got.tolist() == want.tolist())
-        equal_oracle += int(got.tolist() == O.rank_topk_np(S_or[r], tr, K).tolist())
+        want_or = O.rank_topk_np(S_or[r], tr, K)
+        same = got.tolist() == want_or.tolist()
+        equal_oracle += int(same)
+        if not same:
+            for pos_ in np.flatnonzero(got[:len(want_or)] != want_or[:len(got)]):
+                a_, b_ = int(got[pos_]), int(want_or[pos_])
+                n_mismatch_positions += 1
+                gap_ulps = max(gap_ulps, abs(float(S[r][a_]) - float(S[r][b_])) / ulp(S[r][a_]), abs(float(S_or[r][a_]) - float(S_or[r][b_])) / ulp(S_or[r][a_]))
+                nb = [int(x) for x in want_or[max(0, pos_ - 2):pos_ + 3]]           # (three near-tied items rotate by up to two ranks)
+                not_neighbour_swaps += int(a_ not in nb and pos_ < K - 2)      # (at the last rank the partner may sit just outside the list)
         mm = O.metrics_from_hits([1 if int(i) == int(test_items[uu]) else 0 for i in want], 1, cfg.Ks)
         for j, kname in enumerate(("precision", "recall", "ndcg", "hit_ratio")):
             m_want[j] += mm[kname] / len(users)
@@ -702,16 +777,29 @@ def parity_check(w: "NetflixShaped", n_eval_users: int = 256, steps: int = 2, to
            "steps_checked": steps, "tolerance_rel": tol,
            "forward_max_rel": worst["forward"], "bpr_max_rel": worst["bpr"], "loss_rel": worst["loss"],
            "grad_max_rel": worst["grad"], "adamw_given_gpu_grads_max_rel": worst["adamw"], "embeddings_after_steps_max_rel": eval_E,
-           "param_max_rel": worst["param"],
+           "param_max_rel": worst["param"], "param_l2_rel_max": worst["param_l2"], "adam_moments_max_rel": worst["moment"],
            "param_note": "gated end to end: embeddings_after_steps_max_rel (E_u / E_i of the evaluation after the optimiser steps on both sides) "
-                         "and adamw_given_gpu_grads (the optimiser kernel fed with the GPU's own gradients and moments); param_max_rel "
+                         "adamw_given_gpu_grads (the timed path's own update - the AdamW inside the weight-gradient reduction launch for the four Linears, "
+                         "llmrec_adamw_multi for the tables - against the oracle's AdamW fed with the GPU's own gradients and moments), "
+                         "adam_moments_max_rel (exp_avg / exp_avg_sq after the steps, oracle gradients vs GPU gradients: < 1e-4) and param_l2_rel_max "
+                         "(||p_gpu - p_oracle|| / ||p_oracle|| per tensor: < 1e-5); param_max_rel "
                          "(oracle gradients -> oracle AdamW vs GPU gradients -> GPU AdamW, per entry) is reported, not gated: in Adam's first steps "
                          "the update lr * g / (|g| + 1e-8) turns an absolute gradient error on a near-zero entry into a full lr step", "worst_tensor": worst_name,
            "topk_lists_checked": int(len(users)), "topk_lists_equal": int(equal),
-           "topk_lists_equal_oracle_embeddings": int(equal_oracle), "metrics_max_abs": metrics_abs,
+           "topk_lists_equal_oracle_embeddings": int(equal_oracle), "topk_mismatch_positions": int(n_mismatch_positions),
+           "topk_mismatch_max_gap_ulps": gap_ulps, "topk_mismatch_not_neighbour_swaps": int(not_neighbour_swaps),
+           "scores_gpu_vs_oracle_max_diff_ulps": score_diff_ulps,
+           "topk_note": "topk_lists_equal: the GPU's lists vs the reference ranking rule (score desc, item id asc) applied to the kernel's own bit-exact fp32 "
+                        "scores (gated: all equal). topk_lists_equal_oracle_embeddings: vs the lists ranked from the ORACLE's end-to-end embeddings; every "
+                        "differing position is measured: the two items' score gap in ulps of the score under both score sets "
+                        "(topk_mismatch_max_gap_ulps), gated <= max(8, 2 x scores_gpu_vs_oracle_max_diff_ulps) - a swap of two scores that "
+                        "sit closer together than the two embedding sets differ - and every such position must be a swap of list neighbours",
+           "metrics_max_abs": metrics_abs,
            "seconds": time.perf_counter() - t0}
     stagewise = max(worst[k] for k in ("forward", "bpr", "loss", "grad"))
-    rep["ok"] = bool(stagewise < tol and worst["adamw"] < 1e-5 and eval_E < tol and equal == len(users) and metrics_abs < 1e-12)
+    e2e_ok = worst["moment"] < tol and worst["param_l2"] < 1e-5
+    swaps_ok = gap_ulps <= max(8.0, 2.0 * score_diff_ulps) and not_neighbour_swaps == 0
+    rep["ok"] = bool(stagewise < tol and worst["adamw"] < 1e-5 and eval_E < tol and equal == len(users) and metrics_abs < 1e-12 and swaps_ok and e2e_ok)
     return rep
 
 
@@ -772,12 +860,59 @@ def cpu_baseline_nf(w: "NetflixShaped", budget_s: float = 20.0):
             "ms_per_step": dt / steps * 1e3, "eval_users_per_s": 256 / de}
 
 
-def row_sharded_measure(name, scaling, seed, device, rank, world, steps, barrier, exchange="all_reduce", single=False):
+def reference_unmodified_record():
+    """The UNMODIFIED reference timed on CPU in the build container (oracle/time_reference.py -> profiles/r*_reference_cpu.json): the
+    reference tree does not travel to the GPU box, its measurement does. None when absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_cpu.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+    except Exception:
+        return None
+    keep = {k: d[k] for k in ("train_s", "eval_s", "edges_per_s", "users_per_s", "n_batch", "batch_size", "n_test_users", "host", "dataset") if k in d}
+    keep["file"] = os.path.basename(files[-1])
+    keep["how"] = ("oracle/time_reference.py: the reference's own Trainer.train() and its own `Epoch %d [%.1fs + %.1fs]` timers (main.py:200,297,303) on the "
+                   "dataset tools/e2e_main.py writes; recorded where /root/reference exists")
+    return keep
+
+
+def end_to_end_main(epochs: int = 6):
+    """BASELINE.json's metric as the reference defines it: `python main.py` on the full Netflix-shaped dataset, timed by the drop-in's own
+    epoch timers t2 - t1 / t3 - t2 (reference main.py:200,297,303) in its two modes - tools/e2e_main.py, run as a subprocess beside
+    this process (it writes the dataset under /tmp first)."""
+    import subprocess
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(prefix="llmrec_e2e_"), "e2e.json")
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_main.py"), "--epochs", str(epochs), "--out", out,
+                        "--modes", "default,graph_device_sampler"], capture_output=True, text=True,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")})
+    if r.returncode != 0 or not os.path.exists(out):
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    d = json.load(open(out))
+    res = {"command": d["command"], "timers": d["timers"], "dataset": d["dataset"]["shape"], "wall_s": round(time.perf_counter() - t0, 1)}
+    for mode in ("default", "graph_device_sampler"):
+        m = d.get(mode, {})
+        res[mode] = {k: m.get(k) for k in ("train_s", "eval_s", "edges_per_s", "users_per_s", "sample_s", "sample_share_of_train", "epoch0_train_s",
+                                           "epoch0_eval_s", "init_s", "n_batch", "n_test_users", "epochs_timed", "final_loss", "final_recall20")}
+        res[mode]["python_main_py"] = m.get("python_main_py")
+    res["modes"] = {"default": "the reference's host sample stream (utility/load_data.py, same seed -> the reference's batches) + one H2D copy + the fused step "
+                               "and the evaluation replayed from HIP graphs",
+                    "graph_device_sampler": "LLMREC_DEVICE_SAMPLER=1: the HIP sampler inside the step graph (what `value` above times)"}
+    ref = reference_unmodified_record()
+    if ref is not None:
+        res["reference_unmodified_cpu"] = {k: ref.get(k) for k in ("train_s", "eval_s", "edges_per_s", "users_per_s", "host", "file")}
+    return res
+
+
+def row_sharded_measure(name, scaling, seed, device, rank, world, steps, barrier, exchange="all_reduce", single=False, sparse_forward=True):
     """Time `steps` steps of the row-sharded ID path (all ranks call this; max over ranks; result on every rank).
     single: this process alone runs the WHOLE workload (a communicator of one rank) - the 1-GPU reference of a strong-scaling line."""
     import gc
     import torch
-    w = RowSharded(name, scaling, 0, seed, device, rank, world, exchange=exchange, single=single)
+    w = RowSharded(name, scaling, 0, seed, device, rank, world, exchange=exchange, single=single, sparse_forward=sparse_forward)
     for _ in range(2):
         w.step()
     barrier(); torch.cuda.synchronize()
@@ -956,7 +1091,7 @@ def main():
         if name not in SYNTH_CONFIGS:
             raise SystemExit("unknown --workload %s" % workload)
         w = RowSharded(name, a.synth_scaling, a.synth_blocks, a.seed, device, rank, world, n_chunks=a.synth_chunks, exchange=a.synth_exchange,
-                       sparse_backward=not a.synth_dense_backward, sparse_forward=not a.synth_dense_forward)
+                       sparse_backward=not a.synth_dense_backward, sparse_forward=a.synth_restricted_forward)
         step, units = w.step, w.units_per_step              # global batch per step
 
     def barrier():
@@ -1055,13 +1190,31 @@ def main():
             line["spmm_roofline"] = spmm_roofline_large(device, a.seed)
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline_nf(w)
+            ref = reference_unmodified_record()
+            if ref is not None:                               # the real thing, measured where it can run (build container, 8 cores)
+                line["cpu_baseline"]["reference_unmodified"] = ref
+        # the edge traversals behind `value` - the reference's forward runs 20 SpMMs and its backward 20 transposed ones per step
+        # (Models.py:153-180); the fused step forms the same products as fewer, wider launches (7 d operands, pre-propagated A_ui F_k)
+        nnz = int(w.rows.size)
+        line["propagated_edges_per_sec"] = {"value": 40.0 * nnz * a.steps * world / dt, "per_step": 40 * nnz,
+                                            "definition": "steps x (20 forward + 20 transposed SpMMs of the reference's step) x nnz / time"}
+        if workload == "nf" and world == 1 and not a.no_end_to_end:
+            line["end_to_end"] = end_to_end_main()
     if workload in ("nf", "ml") and not a.no_row_sharded:
         # north_star's split (configs[3]): the row-sharded ID path on the cfg-4-shaped graph, next to the replica line above -
         # weak (2 of the 16 user blocks per GPU: cfg 4 exactly at 8 GPUs) and strong (all 16 blocks = cfg 4, split over the ranks)
         rs = {}
         for scaling, steps_rs in (("weak", 20), ("strong", 8)):
             try:
-                rs[scaling] = row_sharded_measure("cfg4", scaling, a.seed, device, rank, world, steps_rs, barrier)
+                # `value` = the step that forms every forward product for every row (VERDICT r03 next #4b); the last layer restricted to
+                # the rows the step reads is the labelled variant beside it (same losses, gradients and parameters: tests/test_dist_cpu.py)
+                rs[scaling] = row_sharded_measure("cfg4", scaling, a.seed, device, rank, world, steps_rs, barrier, sparse_forward=False)
+                rs[scaling]["forward"] = "dense: every product of Models.py:169-186 for every row (this is `value`)"
+                if scaling == "strong":
+                    rr = row_sharded_measure("cfg4", scaling, a.seed, device, rank, world, steps_rs, barrier, sparse_forward=True)
+                    rs[scaling]["row_restricted_forward"] = {"ms_per_step": rr["ms_per_step"], "value": rr["value"], "messages": rr.get("messages"),
+                                                             "what": "the last layer's two forward products formed only in the rows the step reads "
+                                                                     "(llmrec_amd/dist_fused.py forward(needed=...)): a labelled variant, not the headline"}
             except torch.OutOfMemoryError as e:               # pragma: no cover
                 rs[scaling] = {"error": "out of memory: %s" % str(e)[:120]}
             except Exception as e:                            # pragma: no cover - the replica line above must still be printed
@@ -1092,13 +1245,20 @@ def main():
         import gc
         del w, step
         gc.collect(); torch.cuda.empty_cache()
+        # (0) the labelled variant of the same N-rank step: the last layer's forward restricted to the rows the step reads
+        try:
+            rr = row_sharded_measure("cfg4", "strong", a.seed, device, rank, world, 8, barrier, exchange=a.synth_exchange, sparse_forward=True)
+            restricted = {"ms_per_step": rr["ms_per_step"], "value": rr["value"], "messages": rr.get("messages"),
+                          "what": "forward(needed=...): a labelled variant, not `value` (which forms every forward product for every row)"}
+        except Exception as e:                                # pragma: no cover
+            restricted = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         # (a) the same workload on ONE GPU, run by rank 0 alone inside this job (the others wait): the reference the strong-scaling
         #     speed-up is quoted against, measured on the same box in the same run
         ref = None
         if not a.no_single_gpu_reference:
             if rank == 0:
                 try:
-                    ref = row_sharded_measure("cfg4", "strong", a.seed, device, 0, 1, 8, lambda: None, exchange=a.synth_exchange, single=True)
+                    ref = row_sharded_measure("cfg4", "strong", a.seed, device, 0, 1, 8, lambda: None, exchange=a.synth_exchange, single=True, sparse_forward=False)
                 except Exception as e:                        # pragma: no cover
                     ref = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             barrier()
@@ -1128,6 +1288,7 @@ def main():
                                     "Scaling is value / single_gpu_reference.value (the same workload on one GPU, measured by rank 0 inside this run), "
                                     "not value / the N = 1 line's value; the Netflix workload as batch-sharded replicas is netflix_replicas")
             line["netflix_replicas"] = rep
+            line["row_restricted_forward"] = restricted
             if ref is not None:
                 line["single_gpu_reference"] = ref
                 if "value" in ref:

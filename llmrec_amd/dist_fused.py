@@ -189,6 +189,7 @@ class ShardedFusedID:
         self.exist = torch.nonzero(deg > 0).reshape(-1).to(torch.int64)
         self.seed = seed * 1000003 + comm.rank
         self.step_id = 0
+        self._last_stamp = None                               # the stamp of the previous step (marks are cleared when it does not advance by one)
         self.allreduce_bytes = 0
 
     def parameters(self):
@@ -267,10 +268,12 @@ class ShardedFusedID:
         # the rows this step touches, known before the forward: the items of every rank's batch (all-gather of 2 B ids) and, through
         # their adjacency, the users they reach; byte marks with a per-step stamp (nothing is cleared)
         stamp = self.step_id % 255 + 1
-        if stamp == 1 and self.sparse_backward:
-            # the stamps start a new cycle: no mark of the previous one may survive - g below is formed in the marked item rows only,
-            # a stale mark that equals a later stamp would make the masked product read a row of g left over from an earlier step
+        if self.sparse_backward and (stamp == 1 or self._last_stamp != stamp - 1):
+            # the stamps start a new cycle - or step_id was set from outside (a resume): no mark of an earlier cycle may survive - g below
+            # is formed in the marked item rows only, a stale mark that equals a later stamp would make the masked product read a row of g
+            # left over from an earlier step. The marks are cleared whenever the stamp does not advance by exactly one.
             self.flag_u.zero_(); self.flag_i.zero_()
+        self._last_stamp = stamp
         self.my_ids[0].copy_(p); self.my_ids[1].copy_(n)
         comm.all_gather_into(self.gat_ids.view(-1), self.my_ids.view(-1))
         needed = None
@@ -281,7 +284,8 @@ class ShardedFusedID:
             # <= 2 B world items instead of a look at every user's index list)
             be.mark_neighbours(self.gat_ids.view(-1), self.graph_items_to_users, stamp, self.flag_u)
             if self.sparse_forward:
-                needed = (stamp, torch.unique(self.gat_ids.view(-1)))     # (sorted, identical on every rank)
+                ids = self.gat_ids.view(-1)
+                needed = (stamp, torch.unique(ids[ids >= 0]))             # (sorted, identical on every rank; padded ids < 0 are skipped as everywhere else)
         self.forward(dense_users=False, dense_items=False, needed=needed)
         # BPR + prune over the global batch (reference main.py:158-165,330-342): two passes around an all-gather of B floats;
         # the user side of the loss is the B x d block of layer-mean rows, indexed 0..B-1
@@ -338,10 +342,9 @@ class ShardedFusedID:
             w = inv / comm.world
             # (h itself is NOT sparse enough to mask: the users two hops from the batch - through its most popular items - are ~40 % of
             #  all users at cfg 4, and the masked product then costs more than the dense one: 9.2 vs 6.2 ms measured)
-            hmask = {}
             self._reduced_spmm(self.ui_bwd_chunks, self.hU, dst,
-                               epilogue_for=lambda r0, r1: dict({"op": "none", "alpha": w, "Z": self.dE_i[r0:r1],
-                                                                 "post_scale": None if l == 0 else self.s_i[r0:r1]}, **hmask))
+                               epilogue_for=lambda r0, r1: {"op": "none", "alpha": w, "Z": self.dE_i[r0:r1],
+                                                            "post_scale": None if l == 0 else self.s_i[r0:r1]})
             g = self.bufI
         if L == 0:
             be.axpy_into(inv, self.dE_i, self.item_tab.grad)
@@ -366,5 +369,6 @@ class ShardedFusedID:
     def message_bytes_per_step(self) -> dict:
         return {"exchange": self.exchange, "allreduce_I_x_d_bytes": 4 * self.I * self.d * (2 * self.L - (1 if self.sparse_forward else 0)),
                 "last_forward_message": "the rows of the batches' items only (<= 2 B world rows)" if self.sparse_forward else "I x d",
-                "exchanged_bytes_last_step": int(self.allreduce_bytes), "allreduce_messages": 2 * self.L * len(self.chunks),
+                "exchanged_bytes_last_step": int(self.allreduce_bytes),
+                "allreduce_messages": (2 * self.L - (1 if self.sparse_forward else 0)) * len(self.chunks) + (1 if self.sparse_forward else 0),
                 "bpr_rows_allgather_bytes_per_rank": 2 * self.B * (4 * self.d + 8), "prune_allgather_bytes_per_rank": 4 * self.B}

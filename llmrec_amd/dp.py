@@ -198,6 +198,7 @@ class DataParallelStep(FusedStep):
 
     def run_steps(self, n: int):
         """n steps (the exchanges sit between this step's graphs: no multi-step graph here)."""
+        out = self.scal[1], self.scal[2], self.scal[3]
         for _ in range(n):
             out = self.step()
         return out

@@ -372,7 +372,13 @@ def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumu
     if col_scale is not None and a.val is None and a.nnz >= SPMM_LATENCY_NNZ:
         # HBM-bound graphs: A diag(c) X = A (c . X) - one dense pass over X (8 d bytes per row) instead of a second random 4-byte
         # gather per EDGE (PMC, 36.6 M edges: 9.9 GB of memory traffic per launch with the per-edge scale, 6.9 GB without)
-        Xs = torch.empty(X.shape, dtype=torch.float32, device=X.device)
+        # (the scaled copy lives in a scratch cached per operand, shape and stream - as SpmmPlan.scratch is - so that a captured step does
+        #  not add an X-sized block to the graph pool per product; rounding: acc += A (c x) instead of fma(c, x, acc), only in this regime)
+        cache = a.plans.setdefault("_scaled_x", {})
+        key = (tuple(X.shape), torch.cuda.current_stream().cuda_stream)
+        Xs = cache.get(key)
+        if Xs is None or Xs.device != X.device:
+            Xs = cache[key] = torch.empty(X.shape, dtype=torch.float32, device=X.device)
         _lib.call("llmrec_scale_rows_f32", X.shape[0], d, _p(col_scale), _p(X), _ld(X), _p(Xs), _ld(Xs), _stream())
         X, col_scale = Xs, None
     _lib.call("llmrec_spmm_f32", a.n_rows, a.n_cols, _p(a.rowptr), _p(a.colidx), _p(a.val), _p(a.row_scale),

@@ -39,3 +39,9 @@ print("train step + eval replay ms", T(alt))
 print("train step alone ms", T(lambda: tr.train_step(*b, clone=False)))
 print("sample_batch ms", T(lambda: tr.sample_batch(), 20))
 print("Data.sample ms", T(lambda: M.data_generator.sample(), 20))
+
+import cProfile, pstats
+pr = cProfile.Profile(); sync(); pr.enable()
+for _ in range(3): tr.test(users, False)
+sync(); pr.disable()
+pstats.Stats(pr).sort_stats("cumtime").print_stats(18)

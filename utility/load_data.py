@@ -170,6 +170,9 @@ class Data(object):
     def device_state(self, device):
         import torch
         from llmrec_amd import ops
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:           # "cuda" and "cuda:<current>" are the same device: one cached state,
+            device = torch.device("cuda", torch.cuda.current_device())   # not one rebuilt (55 ms at Netflix shape) at every other call
         if self._device_state is not None and self._device_state["device"] == device:
             return self._device_state
 
