@@ -203,7 +203,8 @@ class NetflixShaped:
                 "prune_loss_drop_rate": self.hp.prune_loss_drop_rate, "side_features": "image512+text768+llm1536x(1+5)",
                 "item_side_operands": ("pre-propagated once at set-up: the step projects A_ui F_k [U x K] (llmrec_amd/fused.py; the features and the graph are "
                                        "constants of a run, A (F W^T + 1 b^T) = (A F) W^T + (A 1) b^T), every W-dependent product runs every step"
-                                       if getattr(self.fused, "preprop", False) else "projected, then propagated (the reference's order of operations)"),
+                                       if getattr(self.fused, "preprop", False) else "projected, then propagated (the reference's order of operations); "
+                                       "llmrec_amd/fused.py pre-propagates iff U <= I"),
                 "sampler": "device, inside the step graph (llmrec_sample_batch: BPR triples + LLM-augmented triples, device step counter)", "global_batch": self.hp.batch_size * self.world,
                 "parallelism": "single GPU" if not hasattr(self.fused, "gsz") else
                 ("dp%d: batch-sharded replicas (llmrec_amd/dp.py), graph + tables replicated, prune over the global batch "
@@ -222,16 +223,17 @@ class NetflixShaped:
         import torch
         ops, f = self.ops, self.fused
         targets = f.wgrad_targets(dY_cat, dYu)
-        ws = torch.empty(max(ops.linear_wgrad_multi_workspace(targets), 16), dtype=torch.uint8, device=dY_cat.device)
+        bb = getattr(f, "wgrad_blocks", 0)
+        ws = torch.empty(max(ops.linear_wgrad_multi_workspace(targets, bb), 16), dtype=torch.uint8, device=dY_cat.device)
         st = torch.cuda.Stream()
         st.wait_stream(torch.cuda.current_stream())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(st):
             for _ in range(3):
-                ops.linear_wgrad_multi(targets, ws)
+                ops.linear_wgrad_multi(targets, ws, block_budget=bb)
             e0.record()
             for _ in range(iters):
-                ops.linear_wgrad_multi(targets, ws)
+                ops.linear_wgrad_multi(targets, ws, block_budget=bb)
             e1.record()
         torch.cuda.current_stream().wait_stream(st)
         torch.cuda.synchronize()
@@ -742,8 +744,11 @@ def parity_check(w: "NetflixShaped", n_eval_users: int = 256, steps: int = 2, to
     # differ, the two items at the first differing rank must be a near-tie under BOTH score sets - their gap, in units in the last place
     # of the score, is bounded by twice the largest difference between the two score matrices on these users (a swap needs
     # s_a >= s_b on one side and s_a <= s_b on the other)
-    ulp = lambda x: float(np.spacing(np.float32(abs(x))))
-    score_diff_ulps = float((np.abs(S.astype(np.float64) - S_or.astype(np.float64)) / np.spacing(np.abs(S_or).astype(np.float32)).astype(np.float64)).max())
+    # one unit in the last place at the scale of a user's scores (its largest |score|): a difference between two scores of one user in
+    # these units says how many fp32 roundings of a score-sized number apart they are (a score near zero has a tiny ulp of its own)
+    row_ulp = np.spacing(np.maximum(np.abs(S).max(axis=1), np.abs(S_or).max(axis=1)).astype(np.float32)).astype(np.float64)
+    ulp = lambda r_: float(row_ulp[r_])
+    score_diff_ulps = float((np.abs(S.astype(np.float64) - S_or.astype(np.float64)).max(axis=1) / row_ulp).max())
     gap_ulps, n_mismatch_positions, not_neighbour_swaps = 0.0, 0, 0
     for r, uu in enumerate(users):
         tr = Rc.indices[Rc.indptr[uu]:Rc.indptr[uu + 1]]
@@ -757,7 +762,7 @@ def parity_check(w: "NetflixShaped", n_eval_users: int = 256, steps: int = 2, to
             for pos_ in np.flatnonzero(got[:len(want_or)] != want_or[:len(got)]):
                 a_, b_ = int(got[pos_]), int(want_or[pos_])
                 n_mismatch_positions += 1
-                gap_ulps = max(gap_ulps, abs(float(S[r][a_]) - float(S[r][b_])) / ulp(S[r][a_]), abs(float(S_or[r][a_]) - float(S_or[r][b_])) / ulp(S_or[r][a_]))
+                gap_ulps = max(gap_ulps, abs(float(S[r][a_]) - float(S[r][b_])) / ulp(r), abs(float(S_or[r][a_]) - float(S_or[r][b_])) / ulp(r))
                 nb = [int(x) for x in want_or[max(0, pos_ - 2):pos_ + 3]]           # (three near-tied items rotate by up to two ranks)
                 not_neighbour_swaps += int(a_ not in nb and pos_ < K - 2)      # (at the last rank the partner may sit just outside the list)
         mm = O.metrics_from_hits([1 if int(i) == int(test_items[uu]) else 0 for i in want], 1, cfg.Ks)
@@ -791,7 +796,7 @@ def parity_check(w: "NetflixShaped", n_eval_users: int = 256, steps: int = 2, to
            "scores_gpu_vs_oracle_max_diff_ulps": score_diff_ulps,
            "topk_note": "topk_lists_equal: the GPU's lists vs the reference ranking rule (score desc, item id asc) applied to the kernel's own bit-exact fp32 "
                         "scores (gated: all equal). topk_lists_equal_oracle_embeddings: vs the lists ranked from the ORACLE's end-to-end embeddings; every "
-                        "differing position is measured: the two items' score gap in ulps of the score under both score sets "
+                        "differing position is measured: the two items' score gap under both score sets, in ulps at the scale of that user's largest |score| "
                         "(topk_mismatch_max_gap_ulps), gated <= max(8, 2 x scores_gpu_vs_oracle_max_diff_ulps) - a swap of two scores that "
                         "sit closer together than the two embedding sets differ - and every such position must be a swap of list neighbours",
            "metrics_max_abs": metrics_abs,
@@ -955,15 +960,16 @@ def exact_f32_step_time(w: "NetflixShaped", steps: int):
             "unit": "edges/s", "steps": steps, "gemm": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32) in projections and weight-gradients"}
 
 
-def reference_order_step_time(w: "NetflixShaped", steps: int):
-    """The same step with the item-side features projected first and propagated afterwards, as the reference orders the two products
-    (LLMREC_PREPROPAGATE=0: no A_ui F_k operands formed at set-up): a second FusedStep over the same model / optimizer, graph-captured
-    like the timed one."""
+def other_order_step_time(w: "NetflixShaped", steps: int):
+    """The same step with the OTHER order of the two constant products on the item side (llmrec_amd/fused.py chooses by shape:
+    pre-propagated operands (A_ui F_k) W^T iff U <= I, else projection then propagation A_ui (F_k W^T) as the reference writes it,
+    Models.py:145-157): a second FusedStep over the same model / optimizer, graph-captured like the timed one."""
     import torch
     from llmrec_amd.fused import FusedStep
     a = w.args
+    to_preprop = not getattr(w.fused, "preprop", False)
     old = os.environ.get("LLMREC_PREPROPAGATE")
-    os.environ["LLMREC_PREPROPAGATE"] = "0"
+    os.environ["LLMREC_PREPROPAGATE"] = "1" if to_preprop else "0"
     try:
         f = FusedStep(w.model, w.graph, w.hp, (a.model_cat_rate, a.user_cat_rate, a.item_cat_rate), w.opt, w.hp.batch_size + w.batcher.n_aug)
     finally:
@@ -979,7 +985,9 @@ def reference_order_step_time(w: "NetflixShaped", steps: int):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"ms_per_step": dt / steps * 1e3, "value": steps * w.hp.batch_size / dt, "unit": "edges/s", "steps": steps,
-            "order": "project F_k [I x K], then propagate through A_ui and A_iu every step (Models.py:145-157 as written)"}
+            "order": ("pre-propagated operands: the step projects A_ui F_k [U x K] (formed once at set-up)" if to_preprop else
+                      "project F_k [I x K], then propagate through A_ui and A_iu every step (Models.py:145-157 as written)"),
+            "chosen_by_shape": "no: the timed step runs the other order (U %s I)" % ("<=" if not to_preprop else ">")}
 
 
 def launch_decision(gpus: int, env, n_devices: int):
@@ -1159,8 +1167,7 @@ def main():
                         "includes": "no-grad full-graph forward + fp32 MFMA scoring + masked top-50"}
         if world == 1 and not a.no_kernel_roofline and getattr(w.fused, "gemm", "f32") == "bf16x3" and os.environ.get("LLMREC_FORCE_DP", "0") != "1":
             line["exact_f32"] = exact_f32_step_time(w, min(a.steps, 100))
-            if getattr(w.fused, "preprop", False):
-                line["reference_order"] = reference_order_step_time(w, min(a.steps, 100))
+            line["reference_order" if getattr(w.fused, "preprop", False) else "pre_propagated_order"] = other_order_step_time(w, min(a.steps, 100))
         if not a.no_kernel_roofline:
             ks = w.kernel_rooflines()
             line["kernels"] = ks

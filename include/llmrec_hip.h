@@ -220,7 +220,11 @@ int llmrec_linear_wgrad_grouped_bf16x3(int32_t n_problems, const llmrec_wgrad_pr
  * target. Deterministic (fixed slab order); the slab length differs from the single-target launches', so the sums are
  * equal to those only up to fp32 rounding. */
 #define LLMREC_WGRAD_MAX_TARGETS 4
-typedef struct { int32_t n_problems; const llmrec_wgrad_problem_t* problems; int32_t K; float* dW; int64_t lddw; float* db; int32_t accumulate; } llmrec_wgrad_target_t;
+typedef struct { int32_t n_problems; const llmrec_wgrad_problem_t* problems; int32_t K; float* dW; int64_t lddw; float* db; int32_t accumulate;
+                 int32_t block_budget;   /* read from targets[0] only: lay the launch out as whole rounds of this many blocks (0 = 256, one block per
+                                            CU). A budget below 256 leaves CUs to kernels on other streams: a block of this launch owns its CU's
+                                            whole register file, so whatever runs beside a 256-block round waits for it to drain */
+} llmrec_wgrad_target_t;
 int64_t llmrec_linear_wgrad_multi_workspace_bytes(int32_t n_targets, const llmrec_wgrad_target_t* targets_host, int32_t N);
 int llmrec_linear_wgrad_multi_bf16x3(int32_t n_targets, const llmrec_wgrad_target_t* targets_host, int32_t N,
                                      void* workspace, int64_t workspace_bytes, llmrec_stream_t stream);

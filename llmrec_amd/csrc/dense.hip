@@ -1587,13 +1587,14 @@ static int wgrad_multi_version(int32_t n_targets, const llmrec_wgrad_target_t* t
 // one slab length for every target of a multi-target launch: the launch is ceil(blocks / 256) rounds of (mc + a fixed cost)
 static int64_t wgrad_multi_slab_rows(int32_t n_targets, const llmrec_wgrad_target_t* t) {
     const int kw = wgrad_multi_version(n_targets, t) == 1 ? 64 : W2_KW;
+    const int64_t budget = (t[0].block_budget > 0 && t[0].block_budget <= 256) ? t[0].block_budget : 256;   // resident blocks per round
     int64_t m_max = 0, work = 0;
     for (int i = 0; i < n_targets; ++i)
         for (int j = 0; j < t[i].n_problems; ++j) {
             const int64_t me = wgrad_rows_eff(t[i].problems[j]);
             m_max = std::max(m_max, me); work += me * ceil_div(t[i].K, kw);
         }
-    const int64_t lo = std::max<int64_t>(64, align_up(ceil_div(work, 4 * 512), 32));       // never more than ~2 rounds of blocks
+    const int64_t lo = std::max<int64_t>(64, align_up(ceil_div(work, 4 * 2 * budget), 32)); // never more than ~2 rounds of blocks
     int64_t best = lo, best_cost = -1;
     for (int64_t mc = lo; mc <= align_up(m_max, 32) + 32; mc += 32) {
         int64_t blocks = 0;
@@ -1602,7 +1603,7 @@ static int64_t wgrad_multi_slab_rows(int32_t n_targets, const llmrec_wgrad_targe
             for (int j = 0; j < t[i].n_problems; ++j) slabs += ceil_div(wgrad_rows_eff(t[i].problems[j]), mc);
             blocks += ceil_div(slabs, 4) * ceil_div(t[i].K, kw);
         }
-        const int64_t cost = ceil_div(blocks, 256) * (mc + 96);
+        const int64_t cost = ceil_div(blocks, budget) * (mc + 96);
         if (best_cost < 0 || cost <= best_cost) { best = mc; best_cost = cost; }
     }
     return best;

@@ -559,6 +559,7 @@ __global__ __launch_bounds__(256) void mark_neighbours_kernel(int64_t n, const i
 // the byte flags into the ascending list (each thread owns a contiguous 16-aligned run of rows: count, block-wide exclusive scan,
 // write) and clears them again, so the scratch is all-zero between calls and nothing needs a stamp.
 // ---------------------------------------------------------------------------------------------
+constexpr int REACH_SPLIT = 8;                             // wavefronts per (sample, item): a hub item's adjacency list is walked in 8 interleaved parts
 __global__ __launch_bounds__(256) void batch_reach_mark_kernel(int B_cap, const int32_t* __restrict__ n_valid, const int64_t* __restrict__ users,
                                                                const int64_t* __restrict__ pos, const int64_t* __restrict__ neg, int64_t n_users,
                                                                int64_t n_items, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
@@ -566,38 +567,53 @@ __global__ __launch_bounds__(256) void batch_reach_mark_kernel(int B_cap, const 
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     int nv = n_valid ? *n_valid : B_cap;
     nv = nv < B_cap ? nv : B_cap;
-    const int b = w / 3, role = w - 3 * b;
+    const int part = w % REACH_SPLIT, job = w / REACH_SPLIT;
+    const int b = job / 3, role = job - 3 * b;
     if (b >= nv) return;
     if (role == 0) {
         const int64_t u = users[b];
-        if (lane == 0 && u >= 0 && u < n_users) flags[u] = 1;
+        if (part == 0 && lane == 0 && u >= 0 && u < n_users) flags[u] = 1;
         return;
     }
     const int64_t it = role == 1 ? pos[b] : neg[b];
     if (it < 0 || it >= n_items) return;
     const int32_t s = rowptr[it], e = rowptr[it + 1];
-    for (int32_t k = s + lane; k < e; k += 64) flags[colidx[k]] = 1;
+    for (int32_t k = s + part * 64 + lane; k < e; k += 64 * REACH_SPLIT) flags[colidx[k]] = 1;
 }
 
+// ONE block of 1024 threads: thread t owns the 16-aligned run of `per` rows starting at t * per; count, block-wide exclusive scan
+// (wave64 shuffles + the 16 wave totals through LDS), write the ids in order, clear the flags.
 __global__ __launch_bounds__(1024) void flags_compact_kernel(int64_t n, uint8_t* __restrict__ flags, int32_t* __restrict__ list, int32_t* __restrict__ n_out) {
-    __shared__ int32_t part[1024];
-    const int tid = threadIdx.x;
+    __shared__ int32_t wave_total[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t per = ((n + 1023) / 1024 + 15) / 16 * 16;
     const int64_t r0 = tid * per, r1 = r0 + per < n ? r0 + per : n;
     int32_t c = 0;
-    for (int64_t r = r0; r < r1; ++r) c += flags[r] != 0;
-    part[tid] = c;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {               // inclusive scan
-        const int32_t v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    for (int64_t r = r0; r < r1; r += 16) {                  // 16 flags per load (r0 and the allocation are 16-byte aligned; the tail is masked)
+        const uint4 v = *reinterpret_cast<const uint4*>(flags + r);
+        const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+                c += (r + 4 * q + bb < r1) && ((wd[q] >> (8 * bb)) & 0xffu);
     }
-    const int32_t total = part[1023];
-    int32_t o = part[tid] - c;
-    for (int64_t r = r0; r < r1; ++r)
-        if (flags[r]) { list[o++] = (int32_t)r; flags[r] = 0; }
+    int32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    int32_t base = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 16; ++w2) { const int32_t t = wave_total[w2]; if (w2 < wave) base += t; total += t; }
+    int32_t o = base + incl - c;
+    if (c) {
+        for (int64_t r = r0; r < r1; ++r)
+            if (flags[r]) { list[o++] = (int32_t)r; flags[r] = 0; }
+    }
     // the entries a 16-wide tile past the end may fetch: defined values
     const int32_t pad_end = (total + 15) / 16 * 16 + 16;
     for (int32_t k = total + tid; k < pad_end; k += 1024) list[k] = 0;
@@ -987,9 +1003,10 @@ int llmrec_batch_reach_rows(int64_t n_users, int64_t n_items, const int64_t* use
                             int32_t* row_list, int32_t* n_rows, llmrec_stream_t stream_) {
     LLMREC_CHECK_ARG(n_users > 0 && n_users < 0x7fffffffll && n_items > 0 && B_cap >= 0, "batch_reach_rows: bad sizes");
     LLMREC_CHECK_ARG(users && pos && neg && item_rowptr && item_colidx && flags && row_list && n_rows, "batch_reach_rows: null pointer");
+    LLMREC_CHECK_ARG((uintptr_t)flags % 16 == 0, "batch_reach_rows: flags must be 16-byte aligned (and readable up to n_users rounded up to 16 bytes)");
     hipStream_t stream = (hipStream_t)stream_;
     if (B_cap > 0) {
-        batch_reach_mark_kernel<<<(unsigned)ceil_div(3 * (int64_t)B_cap, 4), 256, 0, stream>>>(B_cap, n_valid, users, pos, neg, n_users, n_items,
+        batch_reach_mark_kernel<<<(unsigned)ceil_div(3 * (int64_t)B_cap * REACH_SPLIT, 4), 256, 0, stream>>>(B_cap, n_valid, users, pos, neg, n_users, n_items,
                                                                                                 item_rowptr, item_colidx, flags);
         LLMREC_LAUNCH_CHECK();
     }

@@ -177,6 +177,29 @@ class HipBackend:
         opt.grad_scale = dict(grad_scales)
         opt.step()
 
+    def optimizer_advance(self, opt):
+        """The step counter / bias corrections of this step (once per step, before any optimizer_step_params / optimizer_step_rows)."""
+        opt.advance()
+
+    def optimizer_step_params(self, opt, params, grad_scales):
+        """AdamW over a subset of opt's parameters (counter advanced already)."""
+        opt.grad_scale = dict(grad_scales)
+        opt.step_params(params)
+
+    def optimizer_step_rows(self, opt, param, row0, row1, grad_rows):
+        """AdamW over rows [row0, row1) of `param` with the gradient rows given in a separate [row1 - row0, d] buffer (the piece of a
+        reduce-scattered gradient this rank owns): llmrec_adamw_multi_f32 on the row ranges of parameter and moments."""
+        o = self.ops
+        if row1 <= row0:
+            return
+        m, v = opt.moments(param)
+        d = param.shape[1]
+        arr = (o.AdamwTensor * 1)()
+        off = row0 * d * 4
+        arr[0].p, arr[0].g, arr[0].m, arr[0].v = param.data_ptr() + off, grad_rows.data_ptr(), m.data_ptr() + off, v.data_ptr() + off
+        arr[0].n, arr[0].g_scale = (row1 - row0) * d, 1.0
+        o._lib.call("llmrec_adamw_multi_f32", 1, arr, o._p(opt.dev_state), opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.wd, o._stream())
+
     def zero_(self, tensors):
         o = self.ops
         arr = (o.ZeroTensor * len(tensors))()

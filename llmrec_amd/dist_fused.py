@@ -17,7 +17,8 @@ exchanges are organised for xGMI:
     of llmrec_amd/dist.py's per-op autograd path (256 MB at cfg 4) - so replicas stay bit-identical;
   * prune threshold over the GLOBAL batch: all-gather of B floats (llmrec_bpr_prune_fwd_sharded_f32, two passes),
     norms / mf share: one all-reduce of 4 floats.
-The item table's gradient is complete on every rank after the layer all-reduces, so its AdamW update is replicated.
+With all-reduces the item table's gradient is complete on every rank, so its AdamW update is replicated; with "rs_ag" the update is
+sharded (owner_updates_items): the last backward message is reduce-scattered, each owner updates its rows, updated rows are all-gathered.
 
 ``exchange="rs_ag"`` replaces each chunk's all-reduce by the DIRECT form of SURVEY.md 8(e) for a fully connected xGMI
 mesh: a reduce-scatter (every rank sends 1/world of the chunk to each peer over its own link and reduces the piece it
@@ -50,10 +51,13 @@ class _Done:
 class _ShardedExchange:
     """reduce-scatter -> (row-local op on the owned piece) -> all-gather of one item-row chunk; see the module docstring.
     start() queues the reduce-scatter behind the kernel that produced the chunk; finish_local() orders the current stream
-    after it, runs the epilogue on the owned rows and queues the all-gather; wait() orders the current stream after that."""
+    after it, runs the epilogue on the owned rows and queues the all-gather; wait() orders the current stream after that.
+    gather = (dst_view [rows of the chunk, d], own_rows [piece, d] = dst_view's piece of this rank): the all-gather then moves THAT tensor's
+    owned piece into dst_view in place instead of the reduced piece into `view` - the owner-updates form of the item table's step (the
+    reduced gradient piece is consumed by `after`, which updates the owned parameter rows; what travels back are parameters)."""
 
-    def __init__(self, comm: Comm, view: torch.Tensor, shard: torch.Tensor, after):
-        self.comm, self.view, self.shard, self.after = comm, view, shard, after
+    def __init__(self, comm: Comm, view: torch.Tensor, shard: torch.Tensor, after, gather=None):
+        self.comm, self.view, self.shard, self.after, self.gather = comm, view, shard, after, gather
         self.h = None
         d = comm.dist
         if comm._host_staged():                            # gloo stand-in (CPU tests / two processes on one GPU): reduce each piece at its owner
@@ -72,13 +76,14 @@ class _ShardedExchange:
         if self.after is not None:
             self.after(self.shard)
         d, comm = self.comm.dist, self.comm
+        dst, src = (self.view, self.shard) if self.gather is None else self.gather
         if comm._host_staged():
-            parts = [torch.empty(self.shard.numel(), dtype=self.shard.dtype) for _ in range(comm.world)]
-            d.all_gather(parts, self.shard.detach().cpu().reshape(-1))
-            self.view.copy_(torch.cat(parts).reshape(self.view.shape))
+            parts = [torch.empty(src.numel(), dtype=src.dtype) for _ in range(comm.world)]
+            d.all_gather(parts, src.detach().cpu().reshape(-1))
+            dst.copy_(torch.cat(parts).reshape(dst.shape))
             self.h = None
         else:
-            self.h = d.all_gather_into_tensor(self.view.reshape(-1), self.shard.view(-1), async_op=True)
+            self.h = d.all_gather_into_tensor(dst.reshape(-1), src.reshape(-1), async_op=True)   # (in place when src is dst's own piece)
 
     def wait(self):
         if self.h is not None:
@@ -105,12 +110,14 @@ class ShardedFusedID:
                  lr: float, batch_local: int, drop_rate: float, decay: float, n_chunks: Optional[int] = None,
                  user_init: Optional[torch.Tensor] = None, item_init: Optional[torch.Tensor] = None,
                  batch_size_flag: Optional[float] = None, exchange: str = "all_reduce", sparse_backward: bool = True,
-                 sparse_forward: bool = True):
+                 sparse_forward: bool = True, owner_updates_items: Optional[bool] = None):
         """batch_size_flag: the divisor of the BPR regulariser - the reference divides by the --batch_size FLAG, not by the
         number of triples in the batch (main.py:340: augmented triples do not change it); default = batch_local * world.
         exchange: "all_reduce" | "rs_ag" (module docstring). sparse_backward: skip the all-zero operand rows in the two SpMMs of the last
         layer's backward (False: the dense products, for A/B runs). sparse_forward: compute the last layer's two forward products only in
-        the rows the step reads (forward(needed=...))."""
+        the rows the step reads (forward(needed=...)). owner_updates_items (default: on with "rs_ag"): the item table's AdamW is SHARDED - the
+        last backward message's gradient is reduce-scattered, each rank updates the rows it owns (parameters + both moments: 28 B per
+        parameter once per row instead of once per rank) and the all-gather returns updated table rows instead of gradient rows."""
         self.g, self.comm, self.be = graph, comm, backend
         self.d, self.L, self.B = d, n_layers, batch_local
         self.remember, self.decay = 1.0 - drop_rate, decay
@@ -118,6 +125,7 @@ class ShardedFusedID:
         if exchange not in ("all_reduce", "rs_ag"):
             raise ValueError("ShardedFusedID: exchange must be all_reduce or rs_ag")
         self.exchange = exchange
+        self.owner_updates_items = (exchange == "rs_ag") if owner_updates_items is None else bool(owner_updates_items and exchange == "rs_ag")
         dev = graph.s_i.device
         U, I = graph.n_users_local, graph.n_items
         self.U, self.I = U, I
@@ -196,10 +204,13 @@ class ShardedFusedID:
         return [self.user_tab, self.item_tab]
 
     # -- the chunked, overlapped all-reduce ----------------------------------------------------------
-    def _reduced_spmm(self, chunk_ops, X, out, epilogue_for=None, after=None):
+    def _reduced_spmm(self, chunk_ops, X, out, epilogue_for=None, after=None, owner_update=None):
         """out[rows_c] = sum over ranks of chunk_ops[c] @ X, chunk by chunk: the exchange of chunk c is in flight
         while chunk c + 1 is computed. after(view): optional row-local op on reduced rows (the softmax) - on the whole
-        chunk after an all-reduce, on the owned piece between the reduce-scatter and the all-gather of "rs_ag"."""
+        chunk after an all-reduce, on the owned piece between the reduce-scatter and the all-gather of "rs_ag".
+        owner_update = (table, fn(row0, row1, reduced_rows)) ("rs_ag" only; `out` is the table's gradient): the rank that owns a piece
+        of a chunk applies fn to ITS rows of `table` with the reduced gradient piece and the all-gather moves the updated TABLE rows (in
+        place) instead of the gradient; chunks that do not split evenly are all-reduced and every rank applies fn to all their rows."""
         comm = self.comm
         collective = comm.dist is not None and (comm.world > 1 or comm.force)
         pending, started = [], []
@@ -208,18 +219,27 @@ class ShardedFusedID:
             self.be.spmm(chunk_ops[c], X, out=view, epilogue=epilogue_for(r0, r1) if epilogue_for else None)
             self.allreduce_bytes += view.numel() * 4
             if collective and self.exchange == "rs_ag" and self.shards[c] is not None:
-                ex = _ShardedExchange(comm, view, self.shards[c], after)
+                if owner_update is not None:
+                    table, fn = owner_update
+                    piece = (r1 - r0) // comm.world
+                    o0 = r0 + comm.rank * piece
+                    ex = _ShardedExchange(comm, view, self.shards[c], (lambda sh, a=o0, b=o0 + piece: fn(a, b, sh)),
+                                          gather=(table[r0:r1], table[o0:o0 + piece]))
+                else:
+                    ex = _ShardedExchange(comm, view, self.shards[c], after)
                 if started:                                   # one chunk of lag: its reduce-scatter ran beside this chunk's SpMM
                     started.pop().finish_local()
                 started.append(ex)
-                pending.append((ex, view, False))
+                pending.append((ex, view, False, (r0, r1)))
             else:
-                pending.append((all_reduce_start(comm, view), view, True))
+                pending.append((all_reduce_start(comm, view), view, True, (r0, r1)))
         while started:
             started.pop().finish_local()
-        for h, view, whole in pending:
+        for h, view, whole, (r0, r1) in pending:
             h.wait()
-            if whole and after is not None:
+            if whole and owner_update is not None:
+                owner_update[1](r0, r1, view)                 # (replicated update of the rows of a chunk that went through an all-reduce)
+            elif whole and after is not None:
                 after(view)
 
     # -- forward ---------------------------------------------------------------------------------------
@@ -342,14 +362,22 @@ class ShardedFusedID:
             w = inv / comm.world
             # (h itself is NOT sparse enough to mask: the users two hops from the batch - through its most popular items - are ~40 % of
             #  all users at cfg 4, and the masked product then costs more than the dense one: 9.2 vs 6.2 ms measured)
+            sharded_update = l == 0 and self.owner_updates_items
+            if sharded_update:                                    # this message IS the item table's gradient: owners update, parameters travel back
+                be.optimizer_advance(self.opt)
+                upd = (self.item_tab.data, lambda a, b, rows: be.optimizer_step_rows(self.opt, self.item_tab, a, b, rows))
             self._reduced_spmm(self.ui_bwd_chunks, self.hU, dst,
                                epilogue_for=lambda r0, r1: {"op": "none", "alpha": w, "Z": self.dE_i[r0:r1],
-                                                            "post_scale": None if l == 0 else self.s_i[r0:r1]})
+                                                            "post_scale": None if l == 0 else self.s_i[r0:r1]},
+                               owner_update=upd if sharded_update else None)
             g = self.bufI
         if L == 0:
             be.axpy_into(inv, self.dE_i, self.item_tab.grad)
         # user_tab.grad = inv * dE_u (U^0 only enters the mean): the factor rides in AdamW instead of a pass over the table
-        be.optimizer_step(self.opt, {self.user_tab: inv})
+        if self.owner_updates_items and L >= 1:
+            be.optimizer_step_params(self.opt, [self.user_tab], {self.user_tab: inv})
+        else:
+            be.optimizer_step(self.opt, {self.user_tab: inv})
         # last readers done (the l = 0 message read dE_i, AdamW read dE_u as the user table's gradient): clear the touched rows
         be.zero_rows(u, self.dE_u)
         be.zero_rows(self.gat_ids.view(-1), self.dE_i)

@@ -30,7 +30,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib, ops
-from .fused import FusedStep, _call, _p
+from .fused import FusedStep, _capture_without_gc, _call, _p
 
 
 def gather_floats(n_prob: int, b_max: int) -> int:
@@ -161,7 +161,7 @@ class DataParallelStep(FusedStep):
         graphs = []
         for fn in (first, lambda: self.phase_b(*args), self.phase_c, first_with_update):
             g = torch.cuda.CUDAGraph()                         # capturing records, it does not execute: one step ran (the warm-up)
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (the RCCL watchdog) may touch the runtime
+            with _capture_without_gc(g):                       # (no Python garbage collection inside a stream capture: llmrec_amd/fused.py)
                 fn()
             graphs.append(g)
         self.graphs = graphs

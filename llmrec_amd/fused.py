@@ -36,6 +36,38 @@ def _call(name, *a):
     _lib.call(name, *a, ops._stream())
 
 
+class _capture_without_gc:
+    """torch.cuda.graph(g) with Python's cyclic garbage collector held off for the duration of the capture. torch.cuda.graph collects
+    garbage once, on entry; the body of a captured step then creates tens of thousands of container objects (ctypes argument arrays,
+    tuples), so generation-0/1/2 collections run INSIDE the capture and may finalise whatever cyclic garbage exists by then - e.g. a
+    previously imported drop-in module with its device tensors, or an older step object with its graph executables - i.e. free device
+    memory and destroy executables in the middle of a stream capture. Round 4 chased a host-side segfault in hipGraphLaunch that
+    appeared at the 129th test of the GPU suite only, moved with any change of the allocation pattern, and went away with this."""
+
+    def __init__(self, graph):
+        self.ctx = torch.cuda.graph(graph, capture_error_mode="thread_local")   # other threads (the RCCL watchdog) may touch the runtime
+
+    def __enter__(self):
+        import gc
+        self.was_enabled = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            return self.ctx.__enter__()
+        except BaseException:
+            if self.was_enabled:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            if self.was_enabled:
+                gc.enable()
+
+
 class FusedStep:
     def __init__(self, model, graph, hp: Hyper, rates, optimizer: ops.FusedAdamW, b_max: int):
         """model: Models.MM_Model (parameters + constant feature tensors); graph: ops.BipartiteGraph
@@ -123,7 +155,12 @@ class FusedStep:
         # [.., 7 d] SpMMs through A_ui (forward and transposed) from the critical path and shrinks both GEMMs from I = 17 366 to
         # U = 13 187 rows; every parameter-dependent product is still computed every step, only the order of the (associative)
         # products changes: results agree with the other order to fp32 rounding (tests/test_gpu_step.py, the bench's parity gate).
-        self.preprop = os.environ.get("LLMREC_PREPROPAGATE", "1") == "1" and d <= 64
+        # SHAPE-AWARE (VERDICT r03 next #4c): pre-propagation moves both GEMMs from I rows to U rows and takes the two [., 7 d] SpMMs off the
+        # critical path. It wins when the user side is the smaller one (Netflix shape, U / I = 0.76: 0.46 vs 0.62 ms per step) and loses
+        # when it is the larger one (MovieLens shape, U / I = 1.21: 0.49 vs 0.48 ms, measured with the row-listed weight gradient on):
+        # default = pre-propagate iff U <= I. LLMREC_PREPROPAGATE=1 / 0 forces either order.
+        want = os.environ.get("LLMREC_PREPROPAGATE", "auto")
+        self.preprop = d <= 64 and (want == "1" or (want not in ("0", "1") and U <= I))
         if not self.preprop:
             self.P_cat, self.dP_cat = f(I, S * d), f(I, S * d)        # the projected features and their gradient (reference order)
         if self.preprop:
@@ -141,8 +178,10 @@ class FusedStep:
         # and so does user_trans (its gradient is two hops wide: 66 % of the rows).
         self.wgrad_rows = (getattr(type(self), "WGRAD_ROWS", True) and os.environ.get("LLMREC_WGRAD_ROWS", "1") == "1" and self.preprop
                            and len(self.keys) > 0)
+        # resident blocks the weight-gradient launch is laid out for (llmrec_wgrad_target_t.block_budget; 0 = 256, one per CU)
+        self.wgrad_blocks = int(os.environ.get("LLMREC_WGRAD_BLOCKS", "0"))
         if self.wgrad_rows:
-            self.act_flags = torch.zeros(U, dtype=torch.uint8, device=dev)            # all-zero between calls
+            self.act_flags = torch.zeros(U + 16, dtype=torch.uint8, device=dev)[:U]   # all-zero between calls (readable in 16-byte words)
             self.act_rows = torch.zeros(U + 32, dtype=torch.int32, device=dev)
             self.act_n = torch.zeros(1, dtype=torch.int32, device=dev)
             self.act_expected = None      # rows the launch geometry is laid out for: set from the first step's count (capture() / step_eager())
@@ -152,6 +191,7 @@ class FusedStep:
         # (Batch-sharded replicas all-reduce the gradients first and update afterwards: llmrec_amd/dp.py sets this to False.)
         self.inline_adamw = getattr(type(self), "INLINE_ADAMW", True)
         self._zero_in_forward = False                         # set by step_eager: forward() alone (evaluation) must not advance AdamW
+        self._reach_args, self._ev_reach = None, None
         self._emb_params = [model.user_id_embedding.weight, model.item_id_embedding.weight]
         self._lin_params = [p for p in optimizer.params if p.grad is not None and all(p is not e for e in self._emb_params)]
         # Launch (= capture) order at the fork points decides which branch the graph runs behind its parent without a cross-queue
@@ -303,6 +343,7 @@ class FusedStep:
         with self._on(self.s2):                                          # ID chain: needs no projection
             if sampler is not None and self.multi_stream:                # the batch is first read by the losses, after the join below:
                 sampler()                                                # sampling rides beside the projection instead of ahead of it
+            ev_batch = self._mark() if getattr(self, "_reach_args", None) is not None else None
             if self._zero_in_forward:
                 self.opt.advance()                                       # AdamW's step counter / bias corrections, off the critical path
             i_prev = m.item_id_embedding.weight
@@ -329,6 +370,13 @@ class FusedStep:
             self._fork(self.s3)                                          # captured HERE it runs beside the fusion and the BPR launches (captured
             with self._on(self.s3):                                      # after the BPR backward, round 2, the graph ran it last: the step's tail)
                 self._feat_reg()
+                self._ev_reach = None
+                if getattr(self, "_reach_args", None) is not None:       # the rows the batch reaches -> the weight gradient's row list
+                    if ev_batch is not None:
+                        torch.cuda.current_stream().wait_event(ev_batch)
+                    u_, p_, n_, nv_ = self._reach_args
+                    ops.batch_reach_rows(u_, p_, n_, nv_, self.iu.fwd, self.act_flags, self.act_rows, self.act_n)
+                    self._ev_reach = self._mark()
         self._join(self.s1, self.s2)
 
         # E_u and E_i (Models.py:185-197) in ONE launch: llmrec_fuse_fwd_multi_f32 (two independent row ranges)
@@ -478,6 +526,8 @@ class FusedStep:
             # this stream still has queued when the weight-gradient GEMM takes every CU (about when the chain's last SpMM starts)
             # waits for the GEMM's blocks to retire and becomes the step's tail.
             self._axpy(inv, self.dE_u, m.user_id_embedding.weight.grad, False)
+            if self.inline_adamw:                                                 # U^0 only enters the mean: the user table's gradient is final here
+                self.opt.step_params(self._emb_params[:1])
             if side_work is not None:
                 side_work()
             g = self.bufI
@@ -504,8 +554,8 @@ class FusedStep:
             if ev_fuse is not None:
                 torch.cuda.current_stream().wait_event(ev_fuse)
             _call("llmrec_bpr_multi_zero_rows_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid))
-            if self.inline_adamw:                                                 # both tables' gradients are final: update them here,
-                self.opt.step_params(self._emb_params)                            # beside the weight-gradient GEMM
+            if self.inline_adamw:                                                 # the item table's gradient is final: update it here,
+                self.opt.step_params(self._emb_params[1:])                        # beside the weight-gradient GEMM
 
         # the ID chain depends on the BPR rows only, not on the fusion backward: it starts beside it (captured after it, so that the
         # fusion backward stays the graph's same-queue successor of the BPR launch) and has most of its SpMMs behind it when the
@@ -529,16 +579,18 @@ class FusedStep:
             # operands nothing separates the two launches in time any more, and side by side each ran at half speed (the chip is
             # power-bound here: profiles/experiments/r03_wgrad.md). The bias gradients (row-weighted when pre-propagated) come out of it too.
             self._join(self.s1)                                          # dP_usr (the profile chain is long done by now)
+            if getattr(self, "_ev_reach", None) is not None:             # the row list (built beside the fusion / loss launches)
+                torch.cuda.current_stream().wait_event(self._ev_reach)
             if self.ws_wgrad_multi is None:
-                need = ops.linear_wgrad_multi_workspace(targets)
+                need = ops.linear_wgrad_multi_workspace(targets, self.wgrad_blocks)
                 self.ws_wgrad_multi = torch.empty(max(need, 0), dtype=torch.uint8, device=dY_cat.device) if need >= 0 else False
             if self.ws_wgrad_multi is not False:
                 if self.inline_adamw:                                    # the four Linears' AdamW rides in the slab-reduction launch
                     lins = (m.item_trans, m.user_trans, m.text_trans, m.image_trans)          # (wgrad_targets' order)
-                    ops.linear_wgrad_multi(targets, self.ws_wgrad_multi, update=(self.opt, [(l.weight, l.bias) for l in lins]))
+                    ops.linear_wgrad_multi(targets, self.ws_wgrad_multi, update=(self.opt, [(l.weight, l.bias) for l in lins]), block_budget=self.wgrad_blocks)
                     updated = [p_ for l in lins for p_ in (l.weight, l.bias)]
                 else:
-                    ops.linear_wgrad_multi(targets, self.ws_wgrad_multi)
+                    ops.linear_wgrad_multi(targets, self.ws_wgrad_multi, block_budget=self.wgrad_blocks)
                 done = True
             else:                                                        # outside the multi-target fast path: user_trans' on its own
                 self._wgrad(self.dP_usr, m.user_feats, m.user_trans, False, ws=self.ws_wgrad_b)
@@ -577,12 +629,9 @@ class FusedStep:
         """sampler: optional callable that fills (users, pos, neg, n_valid) on the current stream first (inside the same
         graph when captured; running it on a side stream beside the forward measured no faster)."""
         side = self.multi_stream                                 # the sampler rides beside the projection (forward())
-        if self.wgrad_rows:                                      # ... and so does the list of the rows the batch reaches (needed by the
-            fill = sampler                                       # weight gradient only, at the far end of the step)
-            def sampler():
-                if fill is not None:
-                    fill()
-                ops.batch_reach_rows(users, pos, neg, n_valid, self.iu.fwd, self.act_flags, self.act_rows, self.act_n)
+        # the list of the rows the batch reaches (needed by the weight gradient only, at the far end of the step): built on the regulariser's
+        # stream during the fusion / loss launches (forward())
+        self._reach_args = (users, pos, neg, n_valid) if self.wgrad_rows else None
         try:
             if sampler is not None and not side:
                 sampler()
@@ -607,7 +656,7 @@ class FusedStep:
         the workspace is re-sized here (outside any capture)."""
         n = int(self.act_n.item())
         self.act_expected = max(64, min(self.U, int(n * 1.10) + 32))
-        need = ops.linear_wgrad_multi_workspace(self.wgrad_targets(self.dU_cat if self.preprop else self.dP_cat, self.dP_usr))
+        need = ops.linear_wgrad_multi_workspace(self.wgrad_targets(self.dU_cat if self.preprop else self.dP_cat, self.dP_usr), self.wgrad_blocks)
         self.ws_wgrad_multi = torch.empty(max(need, 0), dtype=torch.uint8, device=self.dP_usr.device) if need >= 0 else False
 
     def flush(self):
@@ -642,7 +691,7 @@ class FusedStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (the RCCL watchdog) may touch the runtime
+            with _capture_without_gc(g):
                 run()
             ev = self._eval_graphs[key] = (g, idx, sc, q, train, ws)     # keeps the captured operands alive
         ev[0].replay()
@@ -683,7 +732,7 @@ class FusedStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (the RCCL watchdog) may touch the runtime
+        with _capture_without_gc(g):
             one_step()
         self.graph_exec = g
         # with the sampler inside the graph nothing host-side separates two steps: run_steps() replays a graph of `unroll` steps (the
@@ -691,7 +740,7 @@ class FusedStep:
         self.graph_multi, self.graph_unroll = None, 0
         if batcher is not None and unroll > 1:
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+            with _capture_without_gc(g2):
                 for _ in range(unroll):
                     one_step()
             self.graph_multi, self.graph_unroll = g2, unroll
@@ -702,16 +751,9 @@ class FusedStep:
         if self.graph_exec is None or getattr(self, "batcher", None) is None:
             raise RuntimeError("FusedStep.run_steps: capture(batcher=...) first")
         k = self.graph_unroll if self.graph_multi is not None else 0
-        replayed_multi = False
         while k and n >= k:
             self.graph_multi.replay()
-            replayed_multi = True
             n -= k
-        if n and replayed_multi:
-            # switching from one graph executable to another: let the first one drain. (Round 4: hipGraphLaunch of the single-step graph
-            # right behind the four-step graph's launch segfaulted on the host in the 128th test of the GPU suite - same test, same
-            # place, three runs - and in no smaller combination of test files; the executables share every buffer and all five streams.)
-            torch.cuda.current_stream().synchronize()
         for _ in range(n):
             self.graph_exec.replay()
         return self.scal[1], self.scal[2], self.scal[3]

@@ -602,7 +602,7 @@ class WgradProblem(_c.Structure):
 class WgradTarget(_c.Structure):
     """llmrec_wgrad_target_t"""
     _fields_ = [("n_problems", _c.c_int32), ("problems", _c.c_void_p), ("K", _c.c_int32), ("dW", _c.c_void_p), ("lddw", _c.c_int64),
-                ("db", _c.c_void_p), ("accumulate", _c.c_int32)]
+                ("db", _c.c_void_p), ("accumulate", _c.c_int32), ("block_budget", _c.c_int32)]
 
 
 class WgradUpdate(_c.Structure):
@@ -611,9 +611,10 @@ class WgradUpdate(_c.Structure):
                 ("g_scale", _c.c_float)]
 
 
-def _wgrad_targets(targets):
-    """targets: [(pairs, dW, db, accumulate)] -> (ctypes array, keep-alive list, N)"""
+def _wgrad_targets(targets, block_budget: int = 0):
+    """targets: [(pairs, dW, db, accumulate)] -> (ctypes array, keep-alive list, N); block_budget: llmrec_wgrad_target_t.block_budget"""
     arr = (WgradTarget * len(targets))()
+    arr[0].block_budget = int(block_budget)
     keep = []
     N = targets[0][1].shape[0]
     for i, (pairs, dW, db, accumulate) in enumerate(targets):
@@ -647,18 +648,19 @@ def batch_reach_rows(users, pos, neg, n_valid, by_item: "Csr", flags: torch.Tens
               _p(by_item.colidx), _p(flags), _p(row_list), _p(n_rows), _stream())
 
 
-def linear_wgrad_multi_workspace(targets) -> int:
+def linear_wgrad_multi_workspace(targets, block_budget: int = 0) -> int:
     """Bytes of workspace llmrec_linear_wgrad_multi_bf16x3 needs for these targets; -1 = outside its fast path."""
-    arr, keep, N = _wgrad_targets(targets)
+    arr, keep, N = _wgrad_targets(targets, block_budget)
     return _lib.query("llmrec_linear_wgrad_multi_workspace_bytes", len(targets), arr, N)
 
 
-def linear_wgrad_multi(targets, ws: Optional[torch.Tensor] = None, update=None):
+def linear_wgrad_multi(targets, ws: Optional[torch.Tensor] = None, update=None, block_budget: int = 0):
     """The bf16x3 weight gradients of several Linears in one launch + one reduction launch (llmrec_linear_wgrad_multi_bf16x3).
     targets: [(pairs, dW, db, accumulate)], pairs = [(dY, X)] as in linear_wgrad_grouped; all dW have N rows.
     update = (FusedAdamW, [(W, b)] per target): the AdamW update of those parameters rides in the reduction launch
-    (llmrec_linear_wgrad_multi_adamw_bf16x3; the optimizer's step counter has been advanced already)."""
-    arr, keep, N = _wgrad_targets(targets)
+    (llmrec_linear_wgrad_multi_adamw_bf16x3; the optimizer's step counter has been advanced already).
+    block_budget: resident blocks per round the launch is laid out for (0 = 256: one per CU)."""
+    arr, keep, N = _wgrad_targets(targets, block_budget)
     need = _lib.query("llmrec_linear_wgrad_multi_workspace_bytes", len(targets), arr, N)
     if need < 0:
         raise RuntimeError("linear_wgrad_multi: shapes outside the fast path (use linear_wgrad_grouped per target)")

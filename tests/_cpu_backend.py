@@ -194,4 +194,44 @@ class CpuBackend:
         return dEu, dEi
 
     def optimizer(self, params, lr):
-        return torch.optim.AdamW([{"params": params}], lr=lr)
+        return _CpuAdamW(params, lr)
+
+    def optimizer_advance(self, opt):
+        opt.t += 1
+
+    def optimizer_step_params(self, opt, params, grad_scales):
+        with torch.no_grad():
+            for p in params:
+                opt.update(p, slice(None), p.grad * grad_scales.get(p, 1.0))
+
+    def optimizer_step_rows(self, opt, param, row0, row1, grad_rows):
+        with torch.no_grad():
+            opt.update(param, slice(row0, row1), grad_rows)
+
+
+class _CpuAdamW:
+    """torch.optim.AdamW(lr, betas (.9, .999), eps 1e-8, weight_decay 0.01) written out, with an update over a row range."""
+
+    def __init__(self, params, lr):
+        self.params, self.lr, self.t = list(params), lr, 0
+        self.m = {p: torch.zeros_like(p) for p in self.params}
+        self.v = {p: torch.zeros_like(p) for p in self.params}
+
+    def update(self, p, rows, g):
+        b1, b2, eps, wd = 0.9, 0.999, 1e-8, 0.01
+        m, v = self.m[p][rows], self.v[p][rows]
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t
+        p.data[rows] = p.data[rows] * (1 - self.lr * wd) - (self.lr / bc1) * m / (v.sqrt() / bc2 ** 0.5 + eps)
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
+
+    def step(self):
+        self.t += 1
+        with torch.no_grad():
+            for p in self.params:
+                if p.grad is not None:
+                    self.update(p, slice(None), p.grad)

@@ -20,6 +20,8 @@ def load_dropin(argv):
         return importlib.import_module("main")
     finally:
         sys.argv = old
+        import gc
+        gc.collect()          # the modules of the previous import (their data_generator holds device tensors) go NOW, not inside a later stream capture
 
 
 def golden_argv(g):

@@ -18,12 +18,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _install_segv_bt():
+    """Debug aid: LLMREC_SEGV_BT=<file> -> a native backtrace of a host-side SIGSEGV goes to that file (tools/dbg/segv_bt.c)."""
+    path = os.environ.get("LLMREC_SEGV_BT")
+    so = os.path.join(ROOT, "tools", "dbg", "segv_bt.so")
+    if path and os.path.exists(so):
+        import ctypes
+        ctypes.CDLL(so).segv_bt_install(path.encode())
+
+
 @pytest.fixture(autouse=True)
 def _release_gpu_objects(request):
     """After every GPU test: collect cyclic garbage NOW (a test's Trainer / FusedStep / captured HIP graphs sit in reference cycles
     through the re-imported drop-in modules) and hand cached blocks back. Without this, graph execs and their private pools of tens
     of earlier tests stay alive until some later generation-2 collection; round 4 saw hipGraphLaunch segfault in the 128th test of
     the suite - and in no pair of test files - until the executables were released test by test."""
+    _install_segv_bt()                                       # (re-installed per test: runtimes loaded later may have replaced the handler)
     yield
     if request.node.get_closest_marker("gpu") is not None:
         import gc

@@ -139,6 +139,83 @@ def test_fused_sharded_step_two_processes_one_gpu_match_oracle(tmp_path, D, n_au
     assert np.abs(r[0]["items"] - ref_i).max() <= 1e-4 * np.abs(ref_i).max()
 
 
+def _rccl_worker(rank, port, out_dir, D, n_aug, exchange, sparse_forward):
+    """ONE rank over the real RCCL communicator with LLMREC_FORCE_COLLECTIVES=1: every collective of the step is issued (all-reduce /
+    reduce_scatter_tensor / all_gather_into_tensor with async_op=True on the communicator's stream, the BPR rows' all-gather, the
+    4-float exchange) - the non-gloo branches of llmrec_amd/dist_fused.py execute under pytest instead of only on an 8-GPU node."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LLMREC_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from llmrec_amd import dist as ld
+    assert ld.Comm().force and not ld.Comm()._host_staged()
+    import llmrec_amd.dist_fused as df
+    calls = {"rs": 0, "ag": 0, "ar": 0}
+    orig = (dist.reduce_scatter_tensor, dist.all_gather_into_tensor, dist.all_reduce)
+    def count(name, fn):
+        def wrapped(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return wrapped
+    dist.reduce_scatter_tensor, dist.all_gather_into_tensor, dist.all_reduce = count("rs", orig[0]), count("ag", orig[1]), count("ar", orig[2])
+    st, losses = _run_rank(0, 1, 5, D, n_aug, exchange) if not sparse_forward else _run_rank_variant(0, 1, 5, D, n_aug, exchange, sparse_forward=True)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rccl.npz"), users=st.user_tab.detach().cpu().numpy(), items=st.item_tab.detach().cpu().numpy(),
+             losses=np.array(losses), calls=np.array([calls["rs"], calls["ag"], calls["ar"]]))
+    dist.destroy_process_group()
+
+
+def _run_rank_variant(rank, world, n_chunks, D, n_aug, exchange, **kw):
+    from llmrec_amd import dist as ld
+    from llmrec_amd.dist_fused import ShardedFusedID
+    rows, cols, u_tab, i_tab, batches = _problem(world, D, n_aug)
+    comm, be = ld.Comm(), ld.HipBackend()
+    u0, u1 = ld.user_block(U, rank, world)
+    sel = (rows >= u0) & (rows < u1)
+    g = ld.ShardedGraph.build(torch.tensor(rows[sel] - u0).cuda(), torch.tensor(cols[sel]).cuda(), u1 - u0, I, u0, comm, be)
+    st = ShardedFusedID(g, comm, be, D, L, U, seed=1, lr=LR, batch_local=B_LOCAL + n_aug, drop_rate=DROP, decay=DECAY, n_chunks=n_chunks,
+                        user_init=torch.tensor(u_tab[u0:u1]), item_init=torch.tensor(i_tab), batch_size_flag=float(world * B_LOCAL), exchange=exchange, **kw)
+    losses = []
+    for per_rank in batches:
+        us, ps, ns = per_rank[rank]
+        loss, _ = st.step((torch.tensor(us - u0).cuda(), torch.tensor(ps).cuda(), torch.tensor(ns).cuda()))
+        losses.append(float(loss))
+    return st, losses
+
+
+@pytest.mark.parametrize("exchange,sparse_forward", [("all_reduce", False), ("rs_ag", False), ("rs_ag", True)])
+def test_fused_sharded_step_one_rank_over_rccl_with_forced_collectives(tmp_path, exchange, sparse_forward):
+    D, n_aug = 128, 6
+    ref_u, ref_i, ref_losses = _oracle_run(1, D, n_aug)
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path), D, n_aug, exchange, sparse_forward), nprocs=1, join=True)
+    r = np.load(tmp_path / "rccl.npz")
+    assert np.allclose(r["losses"], ref_losses, rtol=2e-5), (r["losses"], ref_losses)
+    assert np.abs(r["users"] - ref_u).max() <= 1e-4 * np.abs(ref_u).max()
+    assert np.abs(r["items"] - ref_i).max() <= 1e-4 * np.abs(ref_i).max()
+    rs, ag, ar = (int(x) for x in r["calls"])
+    if exchange == "rs_ag":
+        assert rs > 0 and ag > rs                            # the chunk exchanges (+ the ids / rows / log-sigmoid all-gathers)
+    else:
+        assert rs == 0 and ar > 0 and ag > 0
+
+
+def test_sharded_step_with_the_dense_forward_never_synchronises_the_host():
+    """no .item() / host read-back inside ShardedFusedID.step on the headline (dense-forward) path - asserted with
+    torch's sync debug mode after the warm-up steps have built the row plans."""
+    st, _ = _run_rank_variant(0, 1, 3, 64, 0, "all_reduce", sparse_forward=False)
+    rows, cols, u_tab, i_tab, batches = _problem(1, 64, 0)
+    us, ps, ns = batches[0][0]
+    triples = (torch.tensor(us).cuda(), torch.tensor(ps).cuda(), torch.tensor(ns).cuda())
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        loss, parts = st.step(triples)
+        loss2, _ = st.step()                                       # the device sampler path
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert np.isfinite(float(loss)) and np.isfinite(float(loss2))
+
+
 def test_zero_rows_clears_exactly_the_listed_rows():
     from llmrec_amd import dist as ld
     be = ld.HipBackend()

@@ -92,7 +92,7 @@ def test_training_trajectory_tracks_reference(case, path, datasets, monkeypatch)
         for got, want in ((tr._fused.E_u, z["final_E_u"]), (tr._fused.E_i, z["final_E_i"])):
             got = got.detach().cpu().numpy().astype(np.float64)
             e_rel.append(float(np.linalg.norm(got - want) / np.linalg.norm(want)))
-    print("[trajectory %s/%s] %d epochs, %d evaluations: max |metric diff| %.5f (recall@20 %.5f, ndcg@20 %.5f), loss rel %.2e, mf rel %.2e, emb rel %.2e, "
+    print("[trajectory %s/%s] %d epochs, %d evaluations: max |metric diff| %.2e (recall@20 %.2e, ndcg@20 %.2e), loss rel %.2e, mf rel %.2e, emb rel %.2e, "
           "evaluations with all 12 metrics EQUAL: %d/%d, final E_u / E_i rel L2 %s" % (case, path, n_ep, len(evals), worst_metric, float(diff[:, 1, 1].max()), float(diff[:, 2, 1].max()),
                                                             float(loss_rel.max()), float(mf_rel.max()), float(emb_rel.max()),
                                                             int((diff.max(axis=(1, 2)) == 0).sum()), len(evals), ["%.2e" % e for e in e_rel]))

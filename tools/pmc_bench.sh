@@ -11,6 +11,6 @@ SETS=${PMC_SETS:-"FETCH_SIZE|WRITE_SIZE|TCC_HIT_sum TCC_MISS_sum|SQ_VALU_MFMA_BU
 IFS="|" read -ra ARR <<< "$SETS"
 for SET in "${ARR[@]}"; do
   i=$((i+1))
-  (cd /tmp && LLMREC_GRAPH=0 timeout 240 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d /tmp/pmc_runs/p$i -o run -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-roofline --no-parity --no-row-sharded > /tmp/pmc_runs/p$i.log 2>&1; echo "pass $i ($SET) exit $?")
+  (cd /tmp && LLMREC_GRAPH=0 timeout 240 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d /tmp/pmc_runs/p$i -o run -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-roofline --no-parity --no-row-sharded --no-end-to-end > /tmp/pmc_runs/p$i.log 2>&1; echo "pass $i ($SET) exit $?")
 done
 python $REPO/tools/pmc_aggregate.py /tmp/pmc_runs $OUT | cut -c1-400

@@ -1,0 +1,13 @@
+#!/bin/bash
+# rocprofv3 kernel summary + one-step timeline of the default bench workload, and the PMC passes over its step (round-4 evidence set)
+OUT=gpurun_out/r04prof; mkdir -p $OUT
+export TMPDIR=/tmp
+REPO=$PWD
+rm -rf /tmp/prof_p
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_p -o bench -- python $REPO/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-kernel-roofline --no-parity --no-row-sharded --no-end-to-end > $REPO/$OUT/prof_p.log 2>&1; echo "prof exit $?")
+DB=$(find /tmp/prof_p -name "*.db" | head -1)
+python tools/rocpd_stats.py $DB $OUT/bench_nf_kernel_stats.csv 121 "rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-kernel-roofline --no-parity --no-row-sharded --no-end-to-end (121 steps + 7 evaluations)"
+python tools/step_timeline.py $DB $OUT/step_timeline.txt > /dev/null
+cut -c1-110 $OUT/step_timeline.txt
+tail -1 $OUT/prof_p.log | cut -c1-200
+bash tools/pmc_bench.sh $OUT/pmc_bench_step.json 2>&1 | tail -4 | cut -c1-300
