@@ -30,6 +30,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before torch / HIP initialise: see llmrec_amd/__init__.py
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -39,10 +39,10 @@ def _call(name, *a):
 class _capture_without_gc:
     """torch.cuda.graph(g) with Python's cyclic garbage collector held off for the duration of the capture. torch.cuda.graph collects
     garbage once, on entry; the body of a captured step then creates tens of thousands of container objects (ctypes argument arrays,
-    tuples), so generation-0/1/2 collections run INSIDE the capture and may finalise whatever cyclic garbage exists by then - e.g. a
-    previously imported drop-in module with its device tensors, or an older step object with its graph executables - i.e. free device
-    memory and destroy executables in the middle of a stream capture. Round 4 chased a host-side segfault in hipGraphLaunch that
-    appeared at the 129th test of the GPU suite only, moved with any change of the allocation pattern, and went away with this."""
+    tuples), so generation-0/1/2 collections run INSIDE the capture and may finalise whatever cyclic garbage exists by then - a
+    previously imported drop-in module with its device tensors, an older step object with its graph executables - i.e. free device
+    memory and destroy executables in the middle of a stream capture. Hygiene, not a fix for anything observed: the host fault round 4
+    chased through the GPU suite turned out to be hipGraphLaunch's own (llmrec_amd/__init__.py)."""
 
     def __init__(self, graph):
         self.ctx = torch.cuda.graph(graph, capture_error_mode="thread_local")   # other threads (the RCCL watchdog) may touch the runtime
@@ -130,7 +130,7 @@ class FusedStep:
         # run on five HIP streams in forward and in backward; under capture the fork / join become graph edges, so the
         # latency-bound Netflix-scale SpMMs overlap the GEMMs. LLMREC_STREAMS=0 keeps everything on one stream (debugging).
         self.multi_stream = os.environ.get("LLMREC_STREAMS", "1") == "1"
-        self.s1, self.s2, self.s3, self.s4 = (torch.cuda.Stream(device=dev) for _ in range(4))
+        self.s1, self.s2, self.s3 = (torch.cuda.Stream(device=dev) for _ in range(3))
         for p in model.parameters():
             if p.requires_grad and p.grad is None and p is not model.batch_norm.weight and p is not model.batch_norm.bias:
                 p.grad = torch.zeros_like(p)
@@ -178,8 +178,11 @@ class FusedStep:
         # and so does user_trans (its gradient is two hops wide: 66 % of the rows).
         self.wgrad_rows = (getattr(type(self), "WGRAD_ROWS", True) and os.environ.get("LLMREC_WGRAD_ROWS", "1") == "1" and self.preprop
                            and len(self.keys) > 0)
-        # resident blocks the weight-gradient launch is laid out for (llmrec_wgrad_target_t.block_budget; 0 = 256, one per CU)
-        self.wgrad_blocks = int(os.environ.get("LLMREC_WGRAD_BLOCKS", "0"))
+        # resident blocks the weight-gradient launch is laid out for (llmrec_wgrad_target_t.block_budget; 0 = 256, one per CU). A block of
+        # that launch owns its CU's whole register file, so a 256-block round starves whatever runs beside it: the ID chain's last SpMM took
+        # 81 us beside it and 12 us alone and, once the row list had shortened the GEMM, had become the step's tail. 224 blocks leave 32 CUs
+        # to the other streams: 256 / 240 / 224 / 208 / 192 blocks -> 0.474 / 0.459 / 0.454 / 0.456 / 0.469 ms per step on one box.
+        self.wgrad_blocks = int(os.environ.get("LLMREC_WGRAD_BLOCKS", "224"))
         if self.wgrad_rows:
             self.act_flags = torch.zeros(U + 16, dtype=torch.uint8, device=dev)[:U]   # all-zero between calls (readable in 16-byte words)
             self.act_rows = torch.zeros(U + 32, dtype=torch.int32, device=dev)
@@ -191,7 +194,6 @@ class FusedStep:
         # (Batch-sharded replicas all-reduce the gradients first and update afterwards: llmrec_amd/dp.py sets this to False.)
         self.inline_adamw = getattr(type(self), "INLINE_ADAMW", True)
         self._zero_in_forward = False                         # set by step_eager: forward() alone (evaluation) must not advance AdamW
-        self._reach_args, self._ev_reach = None, None
         self._emb_params = [model.user_id_embedding.weight, model.item_id_embedding.weight]
         self._lin_params = [p for p in optimizer.params if p.grad is not None and all(p is not e for e in self._emb_params)]
         # Launch (= capture) order at the fork points decides which branch the graph runs behind its parent without a cross-queue
@@ -343,7 +345,6 @@ class FusedStep:
         with self._on(self.s2):                                          # ID chain: needs no projection
             if sampler is not None and self.multi_stream:                # the batch is first read by the losses, after the join below:
                 sampler()                                                # sampling rides beside the projection instead of ahead of it
-            ev_batch = self._mark() if getattr(self, "_reach_args", None) is not None else None
             if self._zero_in_forward:
                 self.opt.advance()                                       # AdamW's step counter / bias corrections, off the critical path
             i_prev = m.item_id_embedding.weight
@@ -370,13 +371,6 @@ class FusedStep:
             self._fork(self.s3)                                          # captured HERE it runs beside the fusion and the BPR launches (captured
             with self._on(self.s3):                                      # after the BPR backward, round 2, the graph ran it last: the step's tail)
                 self._feat_reg()
-                self._ev_reach = None
-                if getattr(self, "_reach_args", None) is not None:       # the rows the batch reaches -> the weight gradient's row list
-                    if ev_batch is not None:
-                        torch.cuda.current_stream().wait_event(ev_batch)
-                    u_, p_, n_, nv_ = self._reach_args
-                    ops.batch_reach_rows(u_, p_, n_, nv_, self.iu.fwd, self.act_flags, self.act_rows, self.act_n)
-                    self._ev_reach = self._mark()
         self._join(self.s1, self.s2)
 
         # E_u and E_i (Models.py:185-197) in ONE launch: llmrec_fuse_fwd_multi_f32 (two independent row ranges)
@@ -579,8 +573,6 @@ class FusedStep:
             # operands nothing separates the two launches in time any more, and side by side each ran at half speed (the chip is
             # power-bound here: profiles/experiments/r03_wgrad.md). The bias gradients (row-weighted when pre-propagated) come out of it too.
             self._join(self.s1)                                          # dP_usr (the profile chain is long done by now)
-            if getattr(self, "_ev_reach", None) is not None:             # the row list (built beside the fusion / loss launches)
-                torch.cuda.current_stream().wait_event(self._ev_reach)
             if self.ws_wgrad_multi is None:
                 need = ops.linear_wgrad_multi_workspace(targets, self.wgrad_blocks)
                 self.ws_wgrad_multi = torch.empty(max(need, 0), dtype=torch.uint8, device=dY_cat.device) if need >= 0 else False
@@ -629,9 +621,14 @@ class FusedStep:
         """sampler: optional callable that fills (users, pos, neg, n_valid) on the current stream first (inside the same
         graph when captured; running it on a side stream beside the forward measured no faster)."""
         side = self.multi_stream                                 # the sampler rides beside the projection (forward())
-        # the list of the rows the batch reaches (needed by the weight gradient only, at the far end of the step): built on the regulariser's
-        # stream during the fusion / loss launches (forward())
-        self._reach_args = (users, pos, neg, n_valid) if self.wgrad_rows else None
+        # (Built on the regulariser's stream instead - forked from the main stream, waiting for the sampler's event of the ID chain's stream,
+        #  its own event awaited by the weight gradient - hipGraphInstantiate of this image recursed until the stack ran out: not kept.)
+        if self.wgrad_rows:                                      # the row list right behind the sampler, on the ID chain's stream (needed by the
+            fill = sampler                                       # weight gradient only, at the far end of the step)
+            def sampler():
+                if fill is not None:
+                    fill()
+                ops.batch_reach_rows(users, pos, neg, n_valid, self.iu.fwd, self.act_flags, self.act_rows, self.act_n)
         try:
             if sampler is not None and not side:
                 sampler()

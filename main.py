@@ -22,6 +22,8 @@ Modes:
 from datetime import datetime
 import math
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before torch / HIP initialise: see llmrec_amd/__init__.py
 import pickle
 import random
 import sys

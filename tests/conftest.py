@@ -3,6 +3,8 @@ import json
 import os
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before torch / HIP initialise: see llmrec_amd/__init__.py
+
 import numpy as np
 import pytest
 
@@ -30,9 +32,8 @@ def _install_segv_bt():
 @pytest.fixture(autouse=True)
 def _release_gpu_objects(request):
     """After every GPU test: collect cyclic garbage NOW (a test's Trainer / FusedStep / captured HIP graphs sit in reference cycles
-    through the re-imported drop-in modules) and hand cached blocks back. Without this, graph execs and their private pools of tens
-    of earlier tests stay alive until some later generation-2 collection; round 4 saw hipGraphLaunch segfault in the 128th test of
-    the suite - and in no pair of test files - until the executables were released test by test."""
+    through the re-imported drop-in modules) and hand cached blocks back, so that graph executables and their private pools do not pile
+    up over the ~150 tests of the suite. (Hygiene; the host fault of round 4 was hipGraphLaunch's own: llmrec_amd/__init__.py.)"""
     _install_segv_bt()                                       # (re-installed per test: runtimes loaded later may have replaced the handler)
     yield
     if request.node.get_closest_marker("gpu") is not None:
