@@ -942,54 +942,38 @@ def row_sharded_measure(name, scaling, seed, device, rank, world, steps, barrier
     return out
 
 
+def variant_step_time(w: "NetflixShaped", steps: int, env: dict, what: dict):
+    """The same workload with one switch of llmrec_amd/fused.py flipped, timed in a FRESH process (python bench.py --workload ... with the switch in
+    the environment): a second and third FusedStep inside this process share the HIP runtime's hardware queues with the timed one's graph
+    executables, and with GPU_MAX_HW_QUEUES=8 (llmrec_amd/__init__.py) the third one's step measured 2 x slower than the same step alone."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", w.shape_name, "--steps", str(steps), "--warmup", "20", "--seed", "0", "--no-parity",
+           "--no-kernel-roofline", "--no-cpu-baseline", "--no-row-sharded", "--no-end-to-end"]
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=e)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return dict(what, error=(r.stderr or r.stdout)[-300:])
+    d = json.loads(lines[-1])
+    return dict(what, ms_per_step=d["ms_per_step"], ms_per_step_hip_events=d["ms_per_step_hip_events"], value=d["value"], unit="edges/s", steps=d["steps"],
+                how="a fresh process: python bench.py --workload %s --steps %d with %s" % (w.shape_name, steps, " ".join("%s=%s" % kv for kv in env.items())))
+
+
 def exact_f32_step_time(w: "NetflixShaped", steps: int):
-    """The same step with the exact fp32 MFMA chain in the 12 GEMM launches (LLMREC_GEMM=f32) instead of the default
-    3-term bf16 split: a second FusedStep over the same model / optimizer, graph-captured like the timed one."""
-    import torch
-    from llmrec_amd.fused import FusedStep
-    a = w.args
-    f = FusedStep(w.model, w.graph, w.hp, (a.model_cat_rate, a.user_cat_rate, a.item_cat_rate), w.opt, w.hp.batch_size + w.batcher.n_aug)
-    f.gemm = "f32"
-    f.capture(batcher=w.batcher, unroll=w.UNROLL)
-    f.run_steps(5)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter(); e0.record()
-    f.run_steps(steps)
-    e1.record(); torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"ms_per_step": dt / steps * 1e3, "ms_per_step_hip_events": e0.elapsed_time(e1) / steps, "value": steps * w.hp.batch_size / dt,
-            "unit": "edges/s", "steps": steps, "gemm": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32) in projections and weight-gradients"}
+    """The same step with the exact fp32 MFMA chain in the 12 GEMM launches (LLMREC_GEMM=f32) instead of the default 3-term bf16 split."""
+    return variant_step_time(w, steps, {"LLMREC_GEMM": "f32"}, {"gemm": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32) in projections and weight-gradients"})
 
 
 def other_order_step_time(w: "NetflixShaped", steps: int):
     """The same step with the OTHER order of the two constant products on the item side (llmrec_amd/fused.py chooses by shape:
     pre-propagated operands (A_ui F_k) W^T iff U <= I, else projection then propagation A_ui (F_k W^T) as the reference writes it,
-    Models.py:145-157): a second FusedStep over the same model / optimizer, graph-captured like the timed one."""
-    import torch
-    from llmrec_amd.fused import FusedStep
-    a = w.args
+    Models.py:145-157)."""
     to_preprop = not getattr(w.fused, "preprop", False)
-    old = os.environ.get("LLMREC_PREPROPAGATE")
-    os.environ["LLMREC_PREPROPAGATE"] = "1" if to_preprop else "0"
-    try:
-        f = FusedStep(w.model, w.graph, w.hp, (a.model_cat_rate, a.user_cat_rate, a.item_cat_rate), w.opt, w.hp.batch_size + w.batcher.n_aug)
-    finally:
-        if old is None:
-            del os.environ["LLMREC_PREPROPAGATE"]
-        else:
-            os.environ["LLMREC_PREPROPAGATE"] = old
-    f.capture(batcher=w.batcher, unroll=w.UNROLL)
-    f.run_steps(5)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    f.run_steps(steps)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"ms_per_step": dt / steps * 1e3, "value": steps * w.hp.batch_size / dt, "unit": "edges/s", "steps": steps,
-            "order": ("pre-propagated operands: the step projects A_ui F_k [U x K] (formed once at set-up)" if to_preprop else
-                      "project F_k [I x K], then propagate through A_ui and A_iu every step (Models.py:145-157 as written)"),
-            "chosen_by_shape": "no: the timed step runs the other order (U %s I)" % ("<=" if not to_preprop else ">")}
+    return variant_step_time(w, steps, {"LLMREC_PREPROPAGATE": "1" if to_preprop else "0"},
+                             {"order": ("pre-propagated operands: the step projects A_ui F_k [U x K] (formed once at set-up)" if to_preprop else
+                                        "project F_k [I x K], then propagate through A_ui and A_iu every step (Models.py:145-157 as written)"),
+                              "chosen_by_shape": "no: the timed step runs the other order (U %s I)" % ("<=" if not to_preprop else ">")})
 
 
 def launch_decision(gpus: int, env, n_devices: int):
