@@ -66,5 +66,29 @@ def build(force: bool = False, verbose: bool = True, tools: bool = False) -> str
     return lib
 
 
+HOST_LIB = os.path.join(LIBDIR, "libllmrec_host.so")
+
+
+def build_host(force: bool = False, verbose: bool = True) -> str:
+    """libllmrec_host.so: the plain-C host helper of the drop-in's Data.sample() (csrc/host_sampler.c, gcc). Optional: without it the
+    same draws run as a Python loop."""
+    src = os.path.join(CSRC, "host_sampler.c")
+    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= os.path.getmtime(src):
+        return HOST_LIB
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        raise RuntimeError("no C compiler for llmrec_amd/csrc/host_sampler.c")
+    os.makedirs(LIBDIR, exist_ok=True)
+    tmp = HOST_LIB + ".tmp"
+    r = subprocess.run([cc, "-O2", "-shared", "-fPIC", "-std=c99", "-Wall", "-o", tmp, src], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("gcc failed on host_sampler.c:\n" + r.stderr)
+    os.replace(tmp, HOST_LIB)
+    if verbose:
+        print("[llmrec_amd.build] built", HOST_LIB)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, tools="--tools" in sys.argv)
+    build_host(force="--force" in sys.argv)

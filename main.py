@@ -212,17 +212,34 @@ class Trainer(object):
             users = u.tolist()
         else:
             users, pos_items, neg_items = data_generator.sample()
-        aug = self.augmented_sample_dict
-        users_aug = random.sample(users, int(len(users) * args.aug_sample_rate))
-        users_aug = [u_ for u_ in users_aug if (aug[u_][0] < self.n_items and aug[u_][1] < self.n_items)]
-        self.new_batch_size = len(users_aug)
-        pos_aug = [aug[u_][0] for u_ in users_aug]
-        neg_aug = [aug[u_][1] for u_ in users_aug]
+        # the LLM-augmented triples (reference main.py:216-224): random.sample over the batch's users (the reference's stream), then the
+        # dictionary look-ups and the `< n_items` filter as array operations
+        users_aug = np.asarray(random.sample(users, int(len(users) * args.aug_sample_rate)), dtype=np.int64)
+        ap, an = self._aug_arrays()
+        pos_aug, neg_aug = ap[users_aug], an[users_aug]
+        ok = (pos_aug < self.n_items) & (neg_aug < self.n_items)
+        users_aug, pos_aug, neg_aug = users_aug[ok], pos_aug[ok], neg_aug[ok]
+        self.new_batch_size = int(users_aug.size)
         if self._device_sampler:
-            extra = torch.tensor([users_aug, pos_aug, neg_aug], dtype=torch.int64).reshape(3, -1).to(device)
+            extra = torch.from_numpy(np.stack([users_aug, pos_aug, neg_aug])).to(device)
             return torch.cat([u, extra[0]]), torch.cat([p, extra[1]]), torch.cat([n, extra[2]])
-        packed = torch.tensor([users + users_aug, pos_items + pos_aug, neg_items + neg_aug], dtype=torch.int64).to(device)
+        B, k = len(users), int(users_aug.size)
+        packed = np.empty((3, B + k), dtype=np.int64)
+        packed[0, :B], packed[1, :B], packed[2, :B] = users, pos_items, neg_items
+        packed[0, B:], packed[1, B:], packed[2, B:] = users_aug, pos_aug, neg_aug
+        packed = torch.from_numpy(packed).to(device)
         return packed[0], packed[1], packed[2]
+
+    def _aug_arrays(self):
+        """augmented_sample_dict as two int64 arrays indexed by user (a user without an entry gets ids past every item: filtered)."""
+        if getattr(self, "_aug_np", None) is None:
+            big = np.iinfo(np.int64).max
+            ap = np.full(self.n_users, big, dtype=np.int64); an = np.full(self.n_users, big, dtype=np.int64)
+            for u_, pair in self.augmented_sample_dict.items():
+                if 0 <= int(u_) < self.n_users:
+                    ap[int(u_)], an[int(u_)] = int(pair[0]), int(pair[1])
+            self._aug_np = (ap, an)
+        return self._aug_np
 
     def _fused_step(self):
         """The fused step (llmrec_amd/fused.py) when the configuration allows it: no dropout, no
@@ -248,12 +265,7 @@ class Trainer(object):
         """engine.DeviceBatcher over the training CSR and the augmented_sample_dict (LLMREC_DEVICE_SAMPLER=1)."""
         if getattr(self, "_batcher", None) is None:
             st = data_generator.device_state(device)
-            aug = self.augmented_sample_dict
-            big = np.iinfo(np.int64).max
-            ap = np.full(self.n_users, big, dtype=np.int64); an = np.full(self.n_users, big, dtype=np.int64)
-            for u_, pair in aug.items():
-                if 0 <= int(u_) < self.n_users:
-                    ap[int(u_)], an[int(u_)] = int(pair[0]), int(pair[1])
+            ap, an = self._aug_arrays()
             self._batcher = engine.DeviceBatcher(st["train"], st["exist_users"], self.n_items, self.batch_size,
                                                  torch.from_numpy(ap).to(device), torch.from_numpy(an).to(device),
                                                  args.aug_sample_rate, args.seed)

@@ -206,3 +206,41 @@ def test_bench_spawn_command_is_the_drivers_launcher(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-5:] == [os.path.abspath(bench.__file__), "--gpus", "4", "--steps", "7"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_block_sampler_and_c_helper_reproduce_the_per_call_stream(monkeypatch):
+    """Data.sample(): the block form (raw MT19937 words replayed in Python) and the C helper (llmrec_amd/csrc/host_sampler.c) draw the
+    same (users, pos, neg) as the reference's per-call np.random.randint form AND leave both global streams where it leaves them -
+    users with one item (no word consumed), hub users (many rejections), item counts at and just past a power of two."""
+    import random
+    import sys
+    monkeypatch.setattr(sys, "argv", ["main.py", "--dataset", "netflix_valid_item"])
+    sys.modules.pop("utility.load_data", None)
+    import utility.load_data as LD
+    from llmrec_amd import build as _build
+    _build.build_host(force=False)
+    rng = np.random.default_rng(3)
+    for n_items in (64, 65, 1000, 4097):
+        n_users = 300
+        D = LD.Data.__new__(LD.Data)
+        D.batch_size, D.n_users, D.n_items = 128, n_users, n_items
+        D.train_items = {}
+        for u in range(n_users):
+            deg = 1 if u % 5 == 0 else (n_items * 3 // 4 if u % 97 == 1 else int(rng.integers(1, 12)))
+            D.train_items[u] = rng.choice(n_items, size=deg, replace=False).tolist()
+        D.exist_users = list(D.train_items)
+        D._train_sets = {u: set(v) for u, v in D.train_items.items()}
+        results = {}
+        for mode in ("reference", "python_block", "c_helper"):
+            D._fast_sampler, D._host = (False if mode == "reference" else None), (False if mode == "python_block" else None)
+            D._fast_users, D._users_scratch = (None if mode == "c_helper" else False), None
+            np.random.seed(11); random.seed(11)
+            out = [D.sample() for _ in range(6)]
+            if mode == "c_helper":
+                assert D._host not in (None, False), "libllmrec_host.so was not loaded"
+                assert D._fast_users is True                  # the C replay of random.sample agreed with the interpreter's on the first batch
+            if mode != "reference":
+                assert D._fast_sampler is True
+            results[mode] = ([(u, p, [int(x) for x in n]) for u, p, n in out], np.random.get_state()[1].tolist(), np.random.get_state()[2], random.getstate())
+        assert results["python_block"] == results["reference"]
+        assert results["c_helper"] == results["reference"]

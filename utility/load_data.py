@@ -54,6 +54,8 @@ class Data(object):
         self._train_sets = {u: set(v) for u, v in self.train_items.items()}
         self._R = None
         self._fast_sampler = None                                    # decided on the first batch (sample())
+        self._host = None                                            # the C helper of the draw loop, loaded on first use
+        self._fast_users, self._users_scratch = None, None           # the C replay of random.sample: decided on the first batch
         self._device_state = None
         self.print_statistics()
 
@@ -71,7 +73,7 @@ class Data(object):
 
     def sample(self):
         if self.batch_size <= self.n_users:
-            users = rd.sample(self.exist_users, self.batch_size)
+            users = self._sample_users()
         else:
             users = [rd.choice(self.exist_users) for _ in range(self.batch_size)]
         if self._fast_sampler is None:                               # first batch: both forms from the same state must agree
@@ -92,6 +94,41 @@ class Data(object):
             return users, slow[0], slow[1]
         pos_items, neg_items = self._draw_items_fast(users) if self._fast_sampler else self._draw_items_reference(users)
         return users, pos_items, neg_items
+
+    def _sample_users(self):
+        """rd.sample(self.exist_users, self.batch_size) (reference load_data.py:159) - through the C replay of CPython's random.sample on
+        CPython's own generator state when the host helper is there (llmrec_host_py_sample: 0.19 -> 0.07 ms at B = 1024); the first call
+        draws both ways from the same state and compares, as the item draws do."""
+        host = self._host_lib()
+        if host is None or self._fast_users is False:
+            return rd.sample(self.exist_users, self.batch_size)
+        import math
+        n, k = len(self.exist_users), self.batch_size
+        setsize = 21
+        if k > 5:
+            setsize += 4 ** math.ceil(math.log(k * 3, 4))           # (random.sample's own expression, Lib/random.py)
+        st = rd.getstate()
+        if st[0] != 3 or len(st[1]) != 625:
+            self._fast_users = False
+            return rd.sample(self.exist_users, self.batch_size)
+        words = np.array(st[1], dtype=np.uint32)
+        if self._users_scratch is None:
+            self._users_scratch = np.empty(max(n, (n + 63) // 64), dtype=np.int64)
+            self._users_pos = np.empty(k, dtype=np.int64)
+            self._exist_arr = np.asarray(self.exist_users, dtype=np.int64)
+        if host.llmrec_host_py_sample(words.ctypes.data, n, k, 1 if n <= setsize else 0, self._users_scratch.ctypes.data, self._users_pos.ctypes.data) != 0:
+            self._fast_users = False
+            return rd.sample(self.exist_users, self.batch_size)
+        users = self._exist_arr[self._users_pos].tolist()
+        if self._fast_users is None:                                 # first call: the interpreter's own random.sample must agree
+            want = rd.sample(self.exist_users, self.batch_size)      # (advances the stream exactly as the replay claims to have done)
+            after = rd.getstate()
+            self._fast_users = bool(want == users and tuple(words.tolist()) == after[1])
+            if not self._fast_users:
+                print("utility.load_data: the C replay of random.sample does not reproduce this interpreter's stream; using random.sample")
+            return want
+        rd.setstate((st[0], tuple(words.tolist()), st[2]))
+        return users
 
     def _draw_items_reference(self, users):
         """One positive and one rejected negative per user, one np.random.randint(size=1) call per draw as the reference
@@ -116,6 +153,25 @@ class Data(object):
         the reference's draw sequence on it in plain integers, then advance the global stream by exactly the words consumed. The
         first batch of a run is drawn both ways and compared (sample())."""
         state = np.random.get_state()
+        host = self._host_lib()
+        if host is not None:                                         # the same replay in C (llmrec_amd/csrc/host_sampler.c)
+            import ctypes
+            u = np.asarray(users, dtype=np.int64)
+            pos, neg = np.empty(u.size, dtype=np.int64), np.empty(u.size, dtype=np.int64)
+            need = 4 * u.size + 64
+            while True:
+                raw = np.random.randint(0, 1 << 32, size=need, dtype=np.uint32)
+                k = host.llmrec_host_draw_items(u.size, u.ctypes.data, self._list_ptr.ctypes.data, self._list_items.ctypes.data, self.n_items,
+                                                raw.ctypes.data, raw.size, pos.ctypes.data, neg.ctypes.data)
+                np.random.set_state(state)
+                if k >= 0:
+                    break
+                if k == -2:
+                    raise RuntimeError("Data.sample: a user owns every item - no negative exists")
+                need *= 2
+            if k:
+                np.random.randint(0, 1 << 32, size=int(k), dtype=np.uint32)
+            return pos.tolist(), neg.tolist()
         n_mask = self._mask(self.n_items - 1)
         n_rng = self.n_items - 1
         need = 4 * len(users) + 64
@@ -158,6 +214,33 @@ class Data(object):
         if k:
             np.random.randint(0, 1 << 32, size=k, dtype=np.uint32)   # the stream position the per-call form would have left
         return pos_items, neg_items
+
+    def _host_lib(self):
+        """libllmrec_host.so (gcc, llmrec_amd/build.py::build_host) + the train lists as one int64 array with offsets, or None."""
+        if self._host is None:
+            self._host = False
+            try:
+                import ctypes
+                import os
+                so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llmrec_amd", "lib", "libllmrec_host.so")
+                if os.path.exists(so):
+                    lib = ctypes.CDLL(so)
+                    lib.llmrec_host_draw_items.restype = ctypes.c_int64
+                    lib.llmrec_host_draw_items.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                           ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+                    lib.llmrec_host_py_sample.restype = ctypes.c_int32
+                    lib.llmrec_host_py_sample.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+                    ptr = np.zeros(self.n_users + 1, dtype=np.int64)
+                    for u_, items in self.train_items.items():
+                        ptr[u_ + 1] = len(items)
+                    np.cumsum(ptr, out=ptr)
+                    flat = np.zeros(int(ptr[-1]), dtype=np.int64)
+                    for u_, items in self.train_items.items():
+                        flat[ptr[u_]:ptr[u_ + 1]] = items                # the file's order: positives are drawn by position
+                    self._list_ptr, self._list_items, self._host = ptr, flat, lib
+            except Exception:
+                self._host = False
+        return self._host or None
 
     @staticmethod
     def _mask(rng):
