@@ -359,9 +359,10 @@ def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumu
         raise RuntimeError("spmm: X has %d rows, operand has %d columns" % (X.shape[0], a.n_cols))
     d = X.shape[1]
     Y = out if out is not None else torch.empty(a.n_rows, d, dtype=torch.float32, device=X.device)
-    sw, pl = a.plan_for(d, whole_row=epilogue is not None and epilogue.op != EPI_NONE)
-    if plan is not None:                                       # (a caller-built plan, e.g. over a row list: whole rows, no column slices)
-        sw, pl = 0, plan
+    if plan is not None:                                       # (a caller-built plan, e.g. over a row list: whole rows, no column slices;
+        sw, pl = 0, plan                                       #  the operand's own full plan is not built for it - ADVICE r03)
+    else:
+        sw, pl = a.plan_for(d, whole_row=epilogue is not None and epilogue.op != EPI_NONE)
     if partials is None:
         partials = pl.scratch(d, X.device)
     if accumulate:

@@ -206,7 +206,8 @@ class Trainer(object):
 
     # -- one step ---------------------------------------------------------------------------------
     def sample_batch(self):
-        """(users, pos, neg) int64 device tensors incl. the LLM-augmented triples (main.py:213-224)."""
+        """(users, pos, neg) int64 device tensors incl. the LLM-augmented triples (main.py:213-224). On the GPU the three tensors are views
+        of ONE staging buffer that the next call overwrites (in stream order): consume them - train_step() - before sampling again."""
         if self._device_sampler:
             u, p, n = data_generator.sample_device(args.seed, self._global_step, device)
             users = u.tolist()
@@ -224,11 +225,30 @@ class Trainer(object):
             extra = torch.from_numpy(np.stack([users_aug, pos_aug, neg_aug])).to(device)
             return torch.cat([u, extra[0]]), torch.cat([p, extra[1]]), torch.cat([n, extra[2]])
         B, k = len(users), int(users_aug.size)
-        packed = np.empty((3, B + k), dtype=np.int64)
-        packed[0, :B], packed[1, :B], packed[2, :B] = users, pos_items, neg_items
-        packed[0, B:], packed[1, B:], packed[2, B:] = users_aug, pos_aug, neg_aug
-        packed = torch.from_numpy(packed).to(device)
-        return packed[0], packed[1], packed[2]
+        n = B + k
+        if device.type != "cuda":
+            packed = np.empty((3, n), dtype=np.int64)
+            packed[0, :B], packed[1, :B], packed[2, :B] = users, pos_items, neg_items
+            packed[0, B:], packed[1, B:], packed[2, B:] = users_aug, pos_aug, neg_aug
+            packed = torch.from_numpy(packed).to(device)
+            return packed[0], packed[1], packed[2]
+        # one ASYNCHRONOUS H2D copy per batch from one of two pinned staging buffers: a pageable copy would make the host wait for the
+        # previous step's graph, i.e. serialise sampling and the GPU step (an epoch was 0.58 ms per step for a 0.46 ms step)
+        if getattr(self, "_stage", None) is None or self._stage["cap"] < 3 * n:
+            cap = 3 * (n + 64)
+            pins = [torch.empty(cap, dtype=torch.int64).pin_memory() for _ in range(2)]
+            self._stage = {"cap": cap, "pin": pins, "np": [p_.numpy() for p_ in pins], "dev": torch.empty(cap, dtype=torch.int64, device=device),
+                           "busy": [None, None], "i": 0}
+        st = self._stage
+        i = st["i"]; st["i"] = 1 - i
+        if st["busy"][i] is not None:
+            st["busy"][i].synchronize()                          # the copy that read this pinned buffer two batches ago has finished
+        buf = st["np"][i]
+        buf[0:B], buf[n:n + B], buf[2 * n:2 * n + B] = users, pos_items, neg_items
+        buf[B:n], buf[n + B:2 * n], buf[2 * n + B:3 * n] = users_aug, pos_aug, neg_aug
+        st["dev"][:3 * n].copy_(st["pin"][i][:3 * n], non_blocking=True)
+        ev = torch.cuda.Event(); ev.record(); st["busy"][i] = ev
+        return st["dev"][0:n], st["dev"][n:2 * n], st["dev"][2 * n:3 * n]
 
     def _aug_arrays(self):
         """augmented_sample_dict as two int64 arrays indexed by user (a user without an entry gets ids past every item: filtered)."""
