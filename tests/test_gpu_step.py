@@ -321,3 +321,20 @@ def test_data_parallel_replicas_match_single_step_on_concatenated_batch(golden, 
     a_, b_ = dict(reps[0][0].model_mm.named_parameters()), dict(reps[1][0].model_mm.named_parameters())
     for nm in TRAINABLE:
         assert torch.equal(a_[nm], b_[nm]), nm
+
+
+def test_device_state_is_built_once_per_device(golden):
+    """Data.device_state: "cuda" and "cuda:<current>" are one device - the cached CSRs are returned, not rebuilt at every other call (round 4:
+    Trainer.test() in graph mode spent 80 ms per evaluation rebuilding them, and captured a new evaluation graph each time)."""
+    m = load_dropin(golden_argv(golden))
+    dg = m.data_generator
+    a = dg.device_state(torch.device("cuda"))
+    b = dg.device_state(torch.device("cuda", torch.cuda.current_device()))
+    c = dg.device_state("cuda")
+    assert a is b and b is c and a["train"] is c["train"]
+    tr = m.Trainer(data_config={})
+    users = list(dg.test_set.keys())
+    tr.test(users, is_val=False); tr.test(users, is_val=False)
+    fused = tr._fused_step()
+    if fused:
+        assert len(fused._eval_graphs) == 1                       # one captured evaluation, replayed

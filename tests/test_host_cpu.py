@@ -244,3 +244,17 @@ def test_block_sampler_and_c_helper_reproduce_the_per_call_stream(monkeypatch):
             results[mode] = ([(u, p, [int(x) for x in n]) for u, p, n in out], np.random.get_state()[1].tolist(), np.random.get_state()[2], random.getstate())
         assert results["python_block"] == results["reference"]
         assert results["c_helper"] == results["reference"]
+
+
+def test_host_helper_library_exports_what_its_header_declares():
+    """include/llmrec_host.h <-> llmrec_amd/lib/libllmrec_host.so (plain C, gcc): both entry points load."""
+    import ctypes
+    import re
+    from llmrec_amd import build as _build
+    so = _build.build_host(force=False)
+    hdr = open(os.path.join(os.path.dirname(_lib.HEADER), "llmrec_host.h")).read()
+    names = re.findall(r"\b(llmrec_host_\w+)\s*\(", hdr)
+    assert set(names) == {"llmrec_host_draw_items", "llmrec_host_py_sample"}
+    lib = ctypes.CDLL(so)
+    for n in names:
+        getattr(lib, n)
