@@ -41,6 +41,11 @@ CASES = {
     # the same data at ten times the learning rate and the default patience (7): the metrics move further per epoch, so a drift of
     # the trajectory shows earlier, and the best-epoch / early-stopping decisions of main.py:314-325 are part of what is compared
     "nf_mid_lr": dict(_MID, argv=["--batch_size", "256", "--epoch", "16", "--seed", "2022", "--debug", "--lr", "0.001"]),
+    # cfg 3 in the middle: MovieLens keys, THREE propagation layers, more users than items (the shape for which the drop-in projects first and
+    # propagates afterwards, llmrec_amd/fused.py), lr 1e-3, 10 epochs of 87 steps
+    "ml_mid": dict(dataset="preprocessed_raw_MovieLens", n_users=3000, n_items=2400, n_edges=28000, seed=9, image_dim=48, text_dim=80, llm_dim=112,
+                   max_deg=50, n_communities=20,
+                   argv=["--batch_size", "256", "--epoch", "10", "--seed", "2022", "--debug", "--lr", "0.001", "--weight_size", "[64,64,64]"]),
 }
 INPUT_FILES = ("train.json", "val.json", "test.json", "train_mat", "image_feat.npy", "text_feat.npy",
                "augmented_user_init_embedding", "augmented_atttribute_embedding_dict", "augmented_sample_dict")

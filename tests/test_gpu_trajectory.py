@@ -1,7 +1,8 @@
 """Long-horizon accuracy parity (north_star: "Recall@20 within +-0.002 of reference").
 
-tests/golden/{nf_mid,nf_mid_lr}/trajectory.npz hold 12 / 16 epochs (948 / 1264 optimiser steps) of the UNMODIFIED reference's
-``Trainer.train()`` on a 2500-user x 3500-item Netflix-shaped set with planted communities (oracle/make_trajectory.py): per
+tests/golden/{nf_mid,nf_mid_lr,ml_mid}/trajectory.npz hold 12 / 16 / 10 epochs (948 / 1264 / 860 optimiser steps) of the UNMODIFIED reference's
+``Trainer.train()`` on a 2500-user x 3500-item Netflix-shaped set and a 3000 x 2400 MovieLens-shaped one (three propagation layers, more users than
+items) with planted communities (oracle/make_trajectory.py): per
 epoch the logged sums, the metric dict of every evaluation and the best-epoch / early-stopping log lines. Here the drop-in
 (`main.Trainer.train()`, reference main.py:189-327) trains on the regenerated dataset (content digests checked) with the HOST
 sampler - the reference's RNG stream, so every batch is identical - on each execution path, and must stay on the reference's
@@ -26,14 +27,19 @@ LOSS_RTOL = 1e-3
 
 @pytest.fixture(scope="module")
 def datasets(tmp_path_factory):
-    """name -> data root of the regenerated dataset (identical for the two cases: one directory serves both)."""
-    root = str(tmp_path_factory.mktemp("traj"))
-    ds_dir, _ = MT.write_case_dataset("nf_mid", root)
-    got = MT.digests(ds_dir)
-    for name in MT.CASES:
+    """case -> data root of its regenerated dataset (nf_mid and nf_mid_lr train on the same one), content digests checked."""
+    roots, by_cfg = {}, {}
+    for name, cfg in MT.CASES.items():
+        key = json.dumps({k: v for k, v in cfg.items() if k != "argv"}, sort_keys=True)
+        if key not in by_cfg:
+            root = str(tmp_path_factory.mktemp("traj_" + name))
+            ds_dir, _ = MT.write_case_dataset(name, root)
+            by_cfg[key] = (root, MT.digests(ds_dir))
+        root, got = by_cfg[key]
         want = json.load(open(os.path.join(GOLDEN, name, "meta.json")))["digests"]
         assert got == want, "the regenerated dataset differs from the one the reference trained on: %s" % [k for k in want if got[k] != want[k]]
-    return root
+        roots[name] = root
+    return roots
 
 
 def _decisions(lines):
@@ -49,17 +55,22 @@ def _decisions(lines):
 
 
 @pytest.mark.parametrize("path", ["fused", "graph", "fused_reference_order", "modular"])
-@pytest.mark.parametrize("case", ["nf_mid", "nf_mid_lr"])
+@pytest.mark.parametrize("case", ["nf_mid", "nf_mid_lr", "ml_mid"])
 def test_training_trajectory_tracks_reference(case, path, datasets, monkeypatch):
-    if path == "modular" and case == "nf_mid":
+    if path == "modular" and case != "nf_mid_lr":
         pytest.skip("the per-op autograd path runs the nf_mid_lr horizon only (same code, the faster-moving trajectory)")
     z = np.load(os.path.join(GOLDEN, case, "trajectory.npz"))
     meta = json.load(open(os.path.join(GOLDEN, case, "meta.json")))
     monkeypatch.setenv("LLMREC_FUSED", "0" if path == "modular" else "1")
     monkeypatch.setenv("LLMREC_GRAPH", "1" if path == "graph" else "0")
-    monkeypatch.setenv("LLMREC_PREPROPAGATE", "0" if path == "fused_reference_order" else "1")
+    # the order of the two constant products on the item side: forced either way on the two fused paths, LEFT TO THE SHAPE RULE on the graph path
+    # (pre-propagated iff U <= I: the Netflix-shaped cases pre-propagate, the MovieLens-shaped one projects first)
+    if path == "graph":
+        monkeypatch.delenv("LLMREC_PREPROPAGATE", raising=False)
+    else:
+        monkeypatch.setenv("LLMREC_PREPROPAGATE", "0" if path == "fused_reference_order" else "1")
     monkeypatch.delenv("LLMREC_DEVICE_SAMPLER", raising=False)            # host sampler = the reference's sample stream
-    argv = ["--dataset", meta["config"]["dataset"], "--data_path", datasets + "/"] + meta["config"]["argv"]
+    argv = ["--dataset", meta["config"]["dataset"], "--data_path", datasets[case] + "/"] + meta["config"]["argv"]
     m = load_dropin(argv)
     m._progress = lambda it: it
     m.set_seed(m.args.seed)

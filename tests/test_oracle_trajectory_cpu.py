@@ -23,21 +23,27 @@ EPOCHS = 4
 
 @pytest.fixture(scope="module")
 def dataset(tmp_path_factory):
-    root = str(tmp_path_factory.mktemp("traj_cpu"))
-    ds_dir, _ = MT.write_case_dataset("nf_mid", root)
-    got = MT.digests(ds_dir)
-    for name in MT.CASES:                                   # the bytes the reference trained on (content digests in meta.json)
-        assert got == json.load(open(os.path.join(GOLDEN, name, "meta.json")))["digests"], name
-    return root
+    """case -> data root of its regenerated dataset; the bytes the reference trained on (content digests in meta.json)."""
+    roots = {}
+    for name in ("nf_mid", "ml_mid"):
+        root = str(tmp_path_factory.mktemp("traj_cpu_" + name))
+        ds_dir, _ = MT.write_case_dataset(name, root)
+        got = MT.digests(ds_dir)
+        for case, cfg in MT.CASES.items():
+            if cfg["dataset"] == MT.CASES[name]["dataset"]:
+                assert got == json.load(open(os.path.join(GOLDEN, case, "meta.json")))["digests"], case
+                roots[case] = root
+    return roots
 
 
 def test_regenerated_dataset_has_every_user_in_the_test_split(dataset):
-    d = json.load(open(os.path.join(dataset, "netflix_valid_item", "test.json")))
+    d = json.load(open(os.path.join(dataset["nf_mid"], "netflix_valid_item", "test.json")))
     assert len(d) == 2500 and all(len(v) == 1 for v in d.values())
 
 
-@pytest.mark.parametrize("case", ["nf_mid_lr"])
-def test_oracle_follows_the_reference_trajectory(case, dataset):
+@pytest.mark.parametrize("case,n_epochs", [("nf_mid_lr", EPOCHS), ("ml_mid", 2)])
+def test_oracle_follows_the_reference_trajectory(case, n_epochs, dataset):
+    dataset = dataset[case]
     z = np.load(os.path.join(GOLDEN, case, "trajectory.npz"))
     meta = json.load(open(os.path.join(GOLDEN, case, "meta.json")))
     keys = DATASET_KEYS[meta["config"]["dataset"]]
@@ -60,7 +66,7 @@ def test_oracle_follows_the_reference_trajectory(case, dataset):
     users_to_test = list(data.test_set.keys())
     ev = 0
     best = 0.0
-    for epoch in range(EPOCHS):
+    for epoch in range(n_epochs):
         for b in range(n_batch):
             s = epoch * n_batch + b
             u, p, n = O.sample_batch(exist, data.train_items, data.n_items, data.n_users, cfg.batch_size)
