@@ -258,3 +258,14 @@ def test_host_helper_library_exports_what_its_header_declares():
     lib = ctypes.CDLL(so)
     for n in names:
         getattr(lib, n)
+
+
+def test_hardware_queue_pool_is_widened_before_hip_initialises():
+    """llmrec_amd/__init__.py (and tests/conftest.py, bench.py, main.py, __graft_entry__.py) set GPU_MAX_HW_QUEUES - the work-around for
+    hipGraphLaunch's unchecked walk over an executable's internal streams - unless the user chose a value."""
+    import llmrec_amd                                             # noqa: F401
+    assert int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) >= 8
+    for f in ("bench.py", "main.py", "__graft_entry__.py", os.path.join("tests", "conftest.py"), os.path.join("llmrec_amd", "__init__.py")):
+        src = open(os.path.join(os.path.dirname(_lib.HEADER), "..", f)).read()
+        assert 'os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")' in src, f
+        assert src.index("GPU_MAX_HW_QUEUES") < (src.index("import torch") if "import torch" in src else len(src)), f
