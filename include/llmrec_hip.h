@@ -75,6 +75,10 @@ int llmrec_csr_row_constant(int64_t n_rows, const int32_t* rowptr, const float* 
  *                                        :153-157,162-163,166-167,176-180) and, with col_scale,
  *                                        the transposed SpMM autograd runs for dX = A^T dY.
  * val, row_scale, col_scale may each be NULL (= all ones). d = columns of X and Y.
+ * Rounding of the col_scale form: the kernel accumulates fma(col_scale[c], X[c], acc). The Python host (llmrec_amd/ops.py::spmm_raw) runs
+ * pattern-only operands of HBM-bound graphs (nnz >= 4 M) as A (c . X) instead - X pre-scaled by one dense pass into a cached scratch, then
+ * this call with col_scale = NULL: acc += round(c x), one rounding more per term (<= 1 ulp of each product; the sums agree to fp32 round-off,
+ * not bit for bit, with the fma form used below that size).
  * Rows are bucketed by length (the plan calls below; thresholds chosen by the host) and all buckets run in ONE launch:
  *   nnz <= LLMREC_SPMM_LONG_ROW   one lane group (d/4 lanes) per row,
  *   nnz <= t_wave                 one wavefront per row                  (list wave_rows),
