@@ -1,6 +1,7 @@
 """bench.py - the driver's measurement contract for the LLMRec Stage-2 hot path on MI355X.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N ...                         # no launcher in the environment: bench.py re-executes itself as N ranks, or refuses
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one mini-batch: on-device BPR sampling + LLM-augmented
@@ -12,14 +13,15 @@ distributable): U=13187, I=17366, 55146 train edges, d=64, 2 propagation layers,
 side features (512/768/1536-d, 5 attribute keys), batch 1024 + 10 % augmented triples, prune 0.71.
 metric value = BPR train edges/s = steps * batch_size / time (the reference's own timer
 definition, main.py:200,297); the full-rank eval rate (users/s, main.py:297-303) is reported in
-"eval". Inputs are resident in HBM before the timed region.
+"eval", `python main.py` itself timed by its own epoch timers in "end_to_end". Inputs are resident in HBM
+before the timed region. Beside `value`: the oracle parity gate (run before the timed region), `roofline` of
+the dominant kernel with PMC traffic, `cpu_baseline` (the oracle port live + the unmodified reference's record),
+`spmm_roofline`, the cfg-4-shaped `row_sharded` lines.
 
-N > 1 (one process per GPU, RCCL): the SAME workload with the global batch N x 1024 sharded over
-batch-sharded replicas (llmrec_amd/dp.py): graph and tables replicated (they are < 1 GB), prune
-threshold and regulariser norms over the GLOBAL batch (one 36 KB all-gather), one all-reduce of
-the flat gradient bucket (8.9 MB) per step - weak scaling in the batch. Evaluation shards the
-users. The user-ROW-sharded path for graphs that need it (cfg 4/5, SURVEY.md 8(e): per-layer
-all-reduce of the item messages, llmrec_amd/dist.py) is --workload synth.
+N > 1 (one process per GPU, RCCL): BASELINE.json configs[3] - the user-ROW-sharded ID path (llmrec_amd/dist_fused.py:
+per layer and direction one I x d exchange) on the 10 M x 1 M x 200 M-edge graph, STRONG scaling, with rank 0's
+single-GPU run of the same workload, the row-restricted-forward variant and the Netflix workload as batch-sharded
+replicas (llmrec_amd/dp.py) in the same line. --workload nf|ml|cfg4|cfg5 selects one explicitly.
 One JSON line on rank 0.
 """
 from __future__ import annotations
