@@ -183,7 +183,8 @@ class Trainer(object):
                 # forward + scoring + masked top-K as ONE graph replay per evaluation
                 # the query tensor is cached on the CONTENT of the user list (a different list of the same length
                 # must not reuse it); the evaluation graph is keyed on that tensor
-                users_key = tuple(int(u_) for u_ in users_to_test)
+                users_np = np.asarray(users_to_test, dtype=np.int64)
+                users_key = users_np.tobytes()                  # (the list's content as one bytes object: hashed and compared in ~30 us for 13 k users)
                 cache = getattr(self, "_eval_queries", None)
                 if cache is None:
                     cache = self._eval_queries = {}
@@ -191,7 +192,7 @@ class Trainer(object):
                     if len(cache) >= 4:                        # bound the number of live evaluation graphs: drop the oldest query
                         old_q = cache.pop(next(iter(cache)))   # AND the graph / lists / workspace FusedStep keeps for it
                         fused.drop_eval_graph(old_q)
-                    cache[users_key] = torch.as_tensor(users_key, dtype=torch.int64, device=device)
+                    cache[users_key] = torch.from_numpy(users_np.copy()).to(device)
                 q = cache[users_key]
                 st = data_generator.device_state(device)
                 idx, _ = fused.eval_topk(q, st["train"], max(eval(args.Ks)), use_graph=True)

@@ -22,8 +22,8 @@ def T(fn, n=5):
     sync(); return (time.perf_counter() - t) / n * 1e3
 print("whole test() ms", T(lambda: tr.test(users, False)))
 print("tuple build ms", T(lambda: tuple(int(u) for u in users)))
-key = tuple(int(u) for u in users)
-q = tr._eval_queries[key]
+import numpy as np
+q = tr._eval_queries[np.asarray(users, dtype=np.int64).tobytes()]
 st = M.data_generator.device_state(M.device)
 print("eval_topk graph replay ms", T(lambda: fused.eval_topk(q, st["train"], 50, use_graph=True)))
 idx, _ = fused.eval_topk(q, st["train"], 50, use_graph=True)
