@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+OUT=gpurun_out/r04last; mkdir -p $OUT
+timeout 1500 python -m pytest tests/ -x -q -m gpu > $OUT/pytest.log 2>&1; echo "pytest exit $?"; tail -1 $OUT/pytest.log | cut -c1-200
+timeout 600 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -1 | cut -c1-200
+timeout 900 python tools/e2e_main.py --epochs 8 --modes default,graph_device_sampler --out $OUT/e2e_main.json > $OUT/e2e.log 2>&1; echo "e2e rc $?"
+grep "^\[e2e\]" $OUT/e2e.log | cut -c1-420
