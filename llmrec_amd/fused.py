@@ -702,8 +702,12 @@ class FusedStep:
     # -- HIP graph --------------------------------------------------------------------------------
     def _make_static(self):
         dev = self.E_u.device
-        self.static = {"users": torch.zeros(self.b_max, dtype=torch.int64, device=dev), "pos": torch.zeros(self.b_max, dtype=torch.int64, device=dev),
-                       "neg": torch.zeros(self.b_max, dtype=torch.int64, device=dev), "n_valid": torch.zeros(1, dtype=torch.int32, device=dev)}
+        # ONE int64 block [users | pos | neg | n_valid] so that a host-sampled batch can arrive in a single asynchronous H2D copy
+        # (step_packed): b_max ids each, then one slot whose LOW 32 bits are the int32 n_valid the kernels read (little-endian)
+        b = self.b_max
+        blk = torch.zeros(3 * b + 1, dtype=torch.int64, device=dev)
+        self.static_block = blk
+        self.static = {"users": blk[0:b], "pos": blk[b:2 * b], "neg": blk[2 * b:3 * b], "n_valid": blk[3 * b:3 * b + 1].view(torch.int32)[:1]}
         return self.static
 
     def capture(self, warm_users=None, warm_pos=None, warm_neg=None, warm_n_valid=None, batcher=None, unroll: int = 1):
@@ -764,6 +768,20 @@ class FusedStep:
             st["n_valid"].fill_(B)
         else:
             st["n_valid"].copy_(n_valid)
+
+    def packed_layout(self):
+        """(slots, b_max): a batch for step_packed is an int64 block of `slots` = 3 b_max + 1 entries - users at [0, B'), positives at
+        [b_max, b_max + B'), negatives at [2 b_max, 2 b_max + B'), the number of triples B' in the last slot."""
+        return 3 * self.b_max + 1, self.b_max
+
+    def step_packed(self, host_block: torch.Tensor):
+        """One training step from a host-sampled batch already laid out as packed_layout() says (pinned memory): ONE asynchronous H2D copy
+        into the captured step's static buffers, then the graph replay - no per-tensor device copies (step(users, pos, neg) issues four)."""
+        if self.graph_exec is None or getattr(self, "batcher", None) is not None:
+            raise RuntimeError("FusedStep.step_packed: capture(users, pos, neg) first (a graph without an in-graph sampler)")
+        self.static_block.copy_(host_block, non_blocking=True)
+        self.graph_exec.replay()
+        return self.scal[1], self.scal[2], self.scal[3]
 
     def step(self, users=None, pos=None, neg=None, n_valid=None):
         """One training step; replays the captured graph when there is one (no arguments when the

@@ -206,25 +206,45 @@ class Trainer(object):
         return test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val)
 
     # -- one step ---------------------------------------------------------------------------------
-    def sample_batch(self):
-        """(users, pos, neg) int64 device tensors incl. the LLM-augmented triples (main.py:213-224). On the GPU the three tensors are views
-        of ONE staging buffer that the next call overwrites (in stream order): consume them - train_step() - before sampling again."""
-        if self._device_sampler:
-            u, p, n = data_generator.sample_device(args.seed, self._global_step, device)
-            users = u.tolist()
-        else:
-            users, pos_items, neg_items = data_generator.sample()
-        # the LLM-augmented triples (reference main.py:216-224): random.sample over the batch's users (the reference's stream), then the
-        # dictionary look-ups and the `< n_items` filter as array operations
+    def _sample_host(self):
+        """The reference's batch on the host (utility/load_data.py + main.py:213-224, same two RNG streams): users / pos / neg lists and the
+        LLM-augmented triples as int64 arrays (random.sample over the batch's users, then the dictionary look-ups and the `< n_items` filter
+        as array operations)."""
+        users, pos_items, neg_items = data_generator.sample()
         users_aug = np.asarray(random.sample(users, int(len(users) * args.aug_sample_rate)), dtype=np.int64)
         ap, an = self._aug_arrays()
         pos_aug, neg_aug = ap[users_aug], an[users_aug]
         ok = (pos_aug < self.n_items) & (neg_aug < self.n_items)
         users_aug, pos_aug, neg_aug = users_aug[ok], pos_aug[ok], neg_aug[ok]
         self.new_batch_size = int(users_aug.size)
+        return users, pos_items, neg_items, users_aug, pos_aug, neg_aug
+
+    def _pinned_pair(self, slots):
+        """Two pinned int64 staging buffers used alternately; a buffer is reused only after the copy that read it has finished."""
+        st = getattr(self, "_stage", None)
+        if st is None or st["cap"] < slots:
+            pins = [torch.empty(slots, dtype=torch.int64).pin_memory() for _ in range(2)]
+            st = self._stage = {"cap": slots, "pin": pins, "np": [p_.numpy() for p_ in pins], "dev": None, "busy": [None, None], "i": 0}
+        i = st["i"]; st["i"] = 1 - i
+        if st["busy"][i] is not None:
+            st["busy"][i].synchronize()
+        return st, i
+
+    def sample_batch(self):
+        """(users, pos, neg) int64 device tensors incl. the LLM-augmented triples (main.py:213-224). On the GPU the three tensors are views
+        of ONE staging buffer that the next call overwrites (in stream order): consume them - train_step() - before sampling again."""
         if self._device_sampler:
+            u, p, n = data_generator.sample_device(args.seed, self._global_step, device)
+            users = u.tolist()
+            users_aug = np.asarray(random.sample(users, int(len(users) * args.aug_sample_rate)), dtype=np.int64)
+            ap, an = self._aug_arrays()
+            pos_aug, neg_aug = ap[users_aug], an[users_aug]
+            ok = (pos_aug < self.n_items) & (neg_aug < self.n_items)
+            users_aug, pos_aug, neg_aug = users_aug[ok], pos_aug[ok], neg_aug[ok]
+            self.new_batch_size = int(users_aug.size)
             extra = torch.from_numpy(np.stack([users_aug, pos_aug, neg_aug])).to(device)
             return torch.cat([u, extra[0]]), torch.cat([p, extra[1]]), torch.cat([n, extra[2]])
+        users, pos_items, neg_items, users_aug, pos_aug, neg_aug = self._sample_host()
         B, k = len(users), int(users_aug.size)
         n = B + k
         if device.type != "cuda":
@@ -235,21 +255,37 @@ class Trainer(object):
             return packed[0], packed[1], packed[2]
         # one ASYNCHRONOUS H2D copy per batch from one of two pinned staging buffers: a pageable copy would make the host wait for the
         # previous step's graph, i.e. serialise sampling and the GPU step (an epoch was 0.58 ms per step for a 0.46 ms step)
-        if getattr(self, "_stage", None) is None or self._stage["cap"] < 3 * n:
-            cap = 3 * (n + 64)
-            pins = [torch.empty(cap, dtype=torch.int64).pin_memory() for _ in range(2)]
-            self._stage = {"cap": cap, "pin": pins, "np": [p_.numpy() for p_ in pins], "dev": torch.empty(cap, dtype=torch.int64, device=device),
-                           "busy": [None, None], "i": 0}
-        st = self._stage
-        i = st["i"]; st["i"] = 1 - i
-        if st["busy"][i] is not None:
-            st["busy"][i].synchronize()                          # the copy that read this pinned buffer two batches ago has finished
+        st, i = self._pinned_pair(3 * (self.batch_size + int(self.batch_size * args.aug_sample_rate) + 64))
+        if st["dev"] is None or st["dev"].numel() < st["cap"]:
+            st["dev"] = torch.empty(st["cap"], dtype=torch.int64, device=device)
         buf = st["np"][i]
         buf[0:B], buf[n:n + B], buf[2 * n:2 * n + B] = users, pos_items, neg_items
         buf[B:n], buf[n + B:2 * n], buf[2 * n + B:3 * n] = users_aug, pos_aug, neg_aug
         st["dev"][:3 * n].copy_(st["pin"][i][:3 * n], non_blocking=True)
         ev = torch.cuda.Event(); ev.record(); st["busy"][i] = ev
         return st["dev"][0:n], st["dev"][n:2 * n], st["dev"][2 * n:3 * n]
+
+    def train_step_packed(self):
+        """Default mode, steady state: the host-sampled batch is written in the captured step's own layout into pinned memory and the step is
+        ONE asynchronous H2D copy + ONE graph replay (FusedStep.step_packed)."""
+        fused = self._fused_step()
+        t0 = time()
+        users, pos_items, neg_items, users_aug, pos_aug, neg_aug = self._sample_host()
+        t_sample = time() - t0
+        slots, b = fused.packed_layout()
+        B, k = len(users), int(users_aug.size)
+        if B + k > b:
+            raise RuntimeError("train_step_packed: batch of %d exceeds the captured capacity %d" % (B + k, b))
+        st, i = self._pinned_pair(max(slots, 3 * (b + 64)))
+        buf = st["np"][i]
+        buf[0:B], buf[b:b + B], buf[2 * b:2 * b + B] = users, pos_items, neg_items
+        buf[B:B + k], buf[b + B:b + B + k], buf[2 * b + B:2 * b + B + k] = users_aug, pos_aug, neg_aug
+        buf[3 * b] = B + k
+        self.model_mm.train()
+        fused.step_packed(st["pin"][i][:slots])
+        ev = torch.cuda.Event(); ev.record(); st["busy"][i] = ev
+        self._global_step += 1
+        return t_sample
 
     def _aug_arrays(self):
         """augmented_sample_dict as two int64 arrays indexed by user (a user without an entry gets ids past every item: filtered)."""
@@ -379,7 +415,11 @@ class Trainer(object):
                 fused = self._fused_step()
                 if fused:
                     fused.epoch_sums.zero_()                             # the fused step sums the three logged scalars on the device (double)
+                packed_ok = bool(fused) and USE_GRAPH() and not self._device_sampler and self._on_bpr is None and device.type == "cuda"
                 for idx in _progress(range(n_batch)):
+                    if packed_ok and fused.graph_exec is not None and getattr(fused, "batcher", None) is None:
+                        sample_time += self.train_step_packed()          # sampling + one H2D copy + one graph replay
+                        continue
                     sample_t1 = time()
                     users, pos_items, neg_items = self.sample_batch()
                     sample_time += time() - sample_t1
