@@ -211,7 +211,7 @@ class Trainer(object):
         LLM-augmented triples as int64 arrays (random.sample over the batch's users, then the dictionary look-ups and the `< n_items` filter
         as array operations)."""
         users, pos_items, neg_items = data_generator.sample()
-        users_aug = np.asarray(random.sample(users, int(len(users) * args.aug_sample_rate)), dtype=np.int64)
+        users_aug = np.asarray(data_generator.py_sample(users, int(len(users) * args.aug_sample_rate)), dtype=np.int64)   # = random.sample(users, k)
         ap, an = self._aug_arrays()
         pos_aug, neg_aug = ap[users_aug], an[users_aug]
         ok = (pos_aug < self.n_items) & (neg_aug < self.n_items)

@@ -233,7 +233,7 @@ def test_block_sampler_and_c_helper_reproduce_the_per_call_stream(monkeypatch):
         results = {}
         for mode in ("reference", "python_block", "c_helper"):
             D._fast_sampler, D._host = (False if mode == "reference" else None), (False if mode == "python_block" else None)
-            D._fast_users, D._users_scratch = (None if mode == "c_helper" else False), None
+            D._fast_users, D._users_scratch, D._exist_arr = (None if mode == "c_helper" else False), None, None
             np.random.seed(11); random.seed(11)
             out = [D.sample() for _ in range(6)]
             if mode == "c_helper":

@@ -55,7 +55,7 @@ class Data(object):
         self._R = None
         self._fast_sampler = None                                    # decided on the first batch (sample())
         self._host = None                                            # the C helper of the draw loop, loaded on first use
-        self._fast_users, self._users_scratch = None, None           # the C replay of random.sample: decided on the first batch
+        self._fast_users, self._users_scratch, self._exist_arr = None, None, None   # the C replay of random.sample: decided on the first batch
         self._device_state = None
         self.print_statistics()
 
@@ -96,39 +96,46 @@ class Data(object):
         return users, pos_items, neg_items
 
     def _sample_users(self):
-        """rd.sample(self.exist_users, self.batch_size) (reference load_data.py:159) - through the C replay of CPython's random.sample on
-        CPython's own generator state when the host helper is there (llmrec_host_py_sample: 0.19 -> 0.07 ms at B = 1024); the first call
-        draws both ways from the same state and compares, as the item draws do."""
+        """rd.sample(self.exist_users, self.batch_size) (reference load_data.py:159)."""
+        if self._exist_arr is None:
+            self._exist_arr = np.asarray(self.exist_users, dtype=np.int64)
+        return self.py_sample(self.exist_users, self.batch_size, self._exist_arr)
+
+    def py_sample(self, population, k, population_arr=None):
+        """random.sample(population, k) on python's global generator - through the C replay of CPython's random.sample on CPython's own
+        generator state when the host helper is there (llmrec_host_py_sample: 0.19 -> 0.07 ms at k = 1024 of 13 187); the first call draws
+        both ways from the same state and compares, as the item draws do. population_arr: the population as an int64 array, if the caller has it."""
         host = self._host_lib()
-        if host is None or self._fast_users is False:
-            return rd.sample(self.exist_users, self.batch_size)
+        n = len(population)
+        if host is None or self._fast_users is False or k > n or k <= 0:
+            return rd.sample(population, k)
         import math
-        n, k = len(self.exist_users), self.batch_size
         setsize = 21
         if k > 5:
             setsize += 4 ** math.ceil(math.log(k * 3, 4))           # (random.sample's own expression, Lib/random.py)
         st = rd.getstate()
         if st[0] != 3 or len(st[1]) != 625:
             self._fast_users = False
-            return rd.sample(self.exist_users, self.batch_size)
+            return rd.sample(population, k)
         words = np.array(st[1], dtype=np.uint32)
-        if self._users_scratch is None:
-            self._users_scratch = np.empty(max(n, (n + 63) // 64), dtype=np.int64)
-            self._users_pos = np.empty(k, dtype=np.int64)
-            self._exist_arr = np.asarray(self.exist_users, dtype=np.int64)
-        if host.llmrec_host_py_sample(words.ctypes.data, n, k, 1 if n <= setsize else 0, self._users_scratch.ctypes.data, self._users_pos.ctypes.data) != 0:
+        need = max(n, (n + 63) // 64)
+        if self._users_scratch is None or self._users_scratch.size < need:
+            self._users_scratch = np.empty(need, dtype=np.int64)
+        pos = np.empty(k, dtype=np.int64)
+        if host.llmrec_host_py_sample(words.ctypes.data, n, k, 1 if n <= setsize else 0, self._users_scratch.ctypes.data, pos.ctypes.data) != 0:
             self._fast_users = False
-            return rd.sample(self.exist_users, self.batch_size)
-        users = self._exist_arr[self._users_pos].tolist()
+            return rd.sample(population, k)
+        arr = population_arr if population_arr is not None else np.asarray(population, dtype=np.int64)
+        out = arr[pos].tolist()
         if self._fast_users is None:                                 # first call: the interpreter's own random.sample must agree
-            want = rd.sample(self.exist_users, self.batch_size)      # (advances the stream exactly as the replay claims to have done)
+            want = rd.sample(population, k)                          # (advances the stream exactly as the replay claims to have done)
             after = rd.getstate()
-            self._fast_users = bool(want == users and tuple(words.tolist()) == after[1])
+            self._fast_users = bool(want == out and tuple(words.tolist()) == after[1])
             if not self._fast_users:
                 print("utility.load_data: the C replay of random.sample does not reproduce this interpreter's stream; using random.sample")
             return want
         rd.setstate((st[0], tuple(words.tolist()), st[2]))
-        return users
+        return out
 
     def _draw_items_reference(self, users):
         """One positive and one rejected negative per user, one np.random.randint(size=1) call per draw as the reference
