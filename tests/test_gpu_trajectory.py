@@ -170,3 +170,44 @@ def test_in_graph_sampler_path_tracks_the_oracle_over_many_steps(datasets, monke
     assert worst["loss"] <= 1e-5 and worst["mf"] <= 1e-5 and worst["emb"] <= 1e-5, worst     # measured 4e-7 / 3e-7 / 2e-7
     assert all(e <= 1e-5 for e in e_rel), e_rel                                                  # measured 3.7e-7
     assert mdiff <= METRIC_TOL
+
+
+def test_python_main_py_prints_the_reference_log(datasets):
+    """The drop-in as a user runs it: `python main.py <the reference's flags>` in a fresh process (default mode), its log lines against the
+    lines the UNMODIFIED reference logged on the same dataset (meta.json `log_lines`): the same sequence of epoch / best-epoch / early-stopping
+    lines, every printed metric equal to the 5 decimals of the log format, the epoch losses within 1e-3 relative (the timings differ)."""
+    import re
+    import subprocess
+    import sys
+    case = "nf_mid_lr"
+    meta = json.load(open(os.path.join(GOLDEN, case, "meta.json")))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = ["--dataset", meta["config"]["dataset"], "--data_path", datasets[case] + "/"] + meta["config"]["argv"]
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LLMREC_")}
+    r = subprocess.run([sys.executable, "main.py"] + argv, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def parse(lines):
+        out = []
+        for l in lines:
+            l = re.sub(r"^\d{4}-\d\d-\d\d \d\d:\d\d:\s+", "", l.strip())
+            if l.startswith("Epoch") and "recall=" in l:
+                nums = [float(x) for x in re.findall(r"-?\d+\.\d+", re.sub(r"\[[0-9.]+s \+ [0-9.]+s\]", "", l))]
+                out.append(("epoch", int(re.match(r"Epoch (\d+)", l).group(1)), nums))
+            elif l.startswith("Test_Recall"):
+                out.append(("best", None, [float(x) for x in re.findall(r"-?\d+\.\d+", l.split(":", 1)[1])]))
+            elif l.startswith("#####"):
+                out.append(("stop", l, []))
+        return out
+    got, want = parse((r.stdout + r.stderr).splitlines()), parse(meta["log_lines"])
+    assert [(k, t) for k, t, _ in got] == [(k, t) for k, t, _ in want], ([(k, t) for k, t, _ in got][:8], [(k, t) for k, t, _ in want][:8])
+    worst_metric, worst_loss = 0.0, 0.0
+    for (kind, _, a), (_, _, b) in zip(got, want):
+        assert len(a) == len(b)
+        if kind == "epoch":                                        # train==[loss=mf + emb + reg], then 16 metrics
+            worst_loss = max(worst_loss, max(abs(x - y) / max(abs(y), 1e-12) for x, y in zip(a[:2], b[:2])))
+            worst_metric = max(worst_metric, max(abs(x - y) for x, y in zip(a[4:], b[4:])))
+        elif kind == "best":
+            worst_metric = max(worst_metric, max(abs(x - y) for x, y in zip(a, b)))
+    print("[python main.py vs the reference's log] %d lines: max |metric diff| %.1e, loss rel %.1e" % (len(got), worst_metric, worst_loss))
+    assert worst_metric <= 1.5e-5 and worst_loss <= LOSS_RTOL
