@@ -148,7 +148,8 @@ class NetflixShaped:
             self.fused = DataParallelStep(self.model, self.graph, self.hp, rates, self.opt, cap, comm=comm)
         else:
             self.fused = FusedStep(self.model, self.graph, self.hp, rates, self.opt, cap)
-        self.use_graph = os.environ.get("LLMREC_GRAPH", "1") == "1"
+        import llmrec_amd
+        self.use_graph = os.environ.get("LLMREC_GRAPH", "1") == "1" and llmrec_amd.graph_replay_safe()
 
     def step(self):
         """One training step. With the HIP graph: sampler + forward + losses + backward + AdamW are ONE graph
@@ -242,6 +243,46 @@ class NetflixShaped:
         torch.cuda.current_stream().wait_stream(st)
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters
+
+    def in_graph_durations(self, iters: int = 20):
+        """Durations INSIDE the replayed step graph, live: the step is re-captured with llmrec_timestamp launches (a single lane storing the
+        device's constant-rate counter) around the whole step, the projection launch and the weight-gradient + reduction launches
+        (FusedStep.stamps), replayed `iters` times, the slot differences averaged. HIP events cannot do this (ROCm refuses event-record
+        nodes for external events in a captured graph); the committed rocprofv3 summary of this command is the cross-check
+        (in_step_us_rocprof). Each bracket includes the one or two dispatch gaps between the stamp launches and the bracketed kernel.
+        Returns {"projection_us", "wgrad_us", "span_us", "rate_hz"} or None (path without a single captured graph)."""
+        import torch
+        from llmrec_amd import _lib
+        f = self.fused
+        if not self.use_graph or not hasattr(f, "run_steps") or hasattr(f, "gsz") or getattr(f, "batcher", None) is None:
+            return None
+        rate = _lib.query("llmrec_timestamp_rate_hz")
+        if rate <= 0:
+            return None
+        f.stamps = torch.zeros(f.STAMP_SLOTS, dtype=torch.int64, device=self.device)
+        try:
+            f.capture(batcher=self.batcher, unroll=1)
+            acc = [0.0, 0.0, 0.0]
+            for _ in range(3):
+                f.graph_exec.replay()
+            torch.cuda.synchronize()
+            n = 0
+            for _ in range(iters):
+                f.graph_exec.replay()
+                torch.cuda.synchronize()
+                t = f.stamps.tolist()
+                if not (t[0] <= t[1] <= t[2] and t[5] >= t[0]):
+                    continue
+                acc[0] += t[2] - t[1]; acc[1] += (t[4] - t[3]) if t[4] >= t[3] > 0 else 0.0; acc[2] += t[5] - t[0]
+                n += 1
+        finally:
+            f.stamps = None
+        if n == 0:
+            return None
+        us = lambda ticks: ticks / n / rate * 1e6
+        f.capture(batcher=self.batcher, unroll=self.UNROLL)     # back to the uninstrumented graphs
+        return {"projection_us": us(acc[0]), "wgrad_us": us(acc[1]) if acc[1] > 0 else None, "span_us": us(acc[2]), "rate_hz": rate, "replays": n,
+                "how": "llmrec_timestamp launches inside the re-captured step graph (FusedStep.stamps), averaged over the replays"}
 
     # ---- per-kernel roofline (dominant kernels of this workload, timed in isolation) -------------
     def kernel_rooflines(self):
@@ -907,6 +948,8 @@ def end_to_end_main(epochs: int = 6):
         res[mode] = {k: m.get(k) for k in ("train_s", "eval_s", "edges_per_s", "users_per_s", "sample_s", "sample_share_of_train", "epoch0_train_s",
                                            "epoch0_eval_s", "init_s", "n_batch", "n_test_users", "epochs_timed", "final_loss", "final_recall20")}
         res[mode]["python_main_py"] = m.get("python_main_py")
+        if "vs_reference" in m:                               # the headline shape against the reference ITSELF (profiles/r05_reference_cpu.json)
+            res[mode]["vs_reference"] = m["vs_reference"]
     res["modes"] = {"default": "the reference's host sample stream (utility/load_data.py, same seed -> the reference's batches) + one H2D copy + the fused step "
                                "and the evaluation replayed from HIP graphs",
                     "graph_device_sampler": "LLMREC_DEVICE_SAMPLER=1: the HIP sampler inside the step graph (what `value` above times)"}
@@ -976,6 +1019,143 @@ def other_order_step_time(w: "NetflixShaped", steps: int):
                              {"order": ("pre-propagated operands: the step projects A_ui F_k [U x K] (formed once at set-up)" if to_preprop else
                                         "project F_k [I x K], then propagate through A_ui and A_iu every step (Models.py:145-157 as written)"),
                               "chosen_by_shape": "no: the timed step runs the other order (U %s I)" % ("<=" if not to_preprop else ">")})
+
+
+COMPACT_LIMIT = 6144          # bytes: the driver keeps a bounded tail of stdout (BENCH_r04.json: a 20.5 KB line came back unparsed)
+
+
+def _r(x, sig=6):
+    """Round a float to `sig` significant digits (ints, None, bools, strings pass through; NaN / inf become None: strict JSON)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        x = float(x)
+    except (TypeError, ValueError):
+        return None
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    if x == 0.0:
+        return 0.0
+    return float("%.*g" % (sig, x))
+
+
+def _pick(d, keys, sig=6):
+    return {k: _r(d[k], sig) for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(line: dict) -> dict:
+    """The ONE stdout line: numbers only, <= COMPACT_LIMIT bytes. Everything else - notes, definitions, kernel lists,
+    messages, ingest times, log lines - is the detail record (bench_detail.json + stderr). A pure function of the detail dict
+    (tests/test_bench_line_cpu.py builds it from a canned one)."""
+    out = _pick(line, ("metric", "value", "unit", "n_gpus", "n_ranks_seen", "n_devices_seen", "steps", "warmup", "ms_per_step", "ms_per_step_hip_events",
+                       "higher_is_better", "scaling", "vs_baseline", "dtype", "data"), 7)
+    cfg = line.get("config", {})
+    out["config"] = {k: (_r(v) if not isinstance(v, str) else v) for k, v in cfg.items()
+                     if k == "workload" or (not isinstance(v, (str, dict, list)) and v is not None)}
+    out["config"] = dict(list(out["config"].items())[:14])
+
+    def roof(r):
+        if not isinstance(r, dict):
+            return None
+        o = {"kernel": str(r.get("kernel", "")).split(" ")[0].split("(")[0].rstrip(",:;")[:48]}
+        o.update(_pick(r, ("bound", "achieved", "peak", "unit", "frac", "frac_isolated", "traffic", "algorithmic_bytes_per_launch", "in_step_us",
+                           "in_step_us_rocprof", "isolated_us", "gather_gbs"), 5))
+        if isinstance(r.get("in_step_us_rocprof"), dict):
+            o["in_step_us_rocprof"] = _r(r["in_step_us_rocprof"].get("avg_us"), 5)
+        return o
+    if "roofline" in line:
+        out["roofline"] = roof(line["roofline"])
+        if isinstance(line["roofline"].get("second"), dict):
+            out["roofline"]["second"] = roof(line["roofline"]["second"])
+    sp = line.get("spmm_roofline")
+    if isinstance(sp, dict):
+        out["spmm_roofline"] = {k: _pick(sp[k], ("ms", "frac_hbm_algorithmic", "frac_gather_model", "traffic_over_algorithmic", "l2_hit_rate"), 4)
+                                for k in ("ui", "iu") if k in sp}
+        if "cache_policy" in sp:
+            out["spmm_roofline"]["cache_policy"] = sp["cache_policy"]
+    cb = line.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "ms_per_step", "eval_users_per_s"), 5)
+        out["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:80]
+        ru = cb.get("reference_unmodified")
+        if isinstance(ru, dict):
+            o = _pick(ru, ("edges_per_s", "users_per_s", "train_s", "eval_s"), 5)
+            o["cores"] = (ru.get("host") or {}).get("cores")
+            out["cpu_baseline"]["reference_unmodified"] = o
+    par = line.get("parity")
+    if isinstance(par, dict):
+        keys = ("ok", "forward_max_rel", "bpr_max_rel", "loss_rel", "grad_max_rel", "adamw_given_gpu_grads_max_rel", "embeddings_after_steps_max_rel",
+                "param_l2_rel_max", "adam_moments_max_rel", "topk_lists_checked", "topk_lists_equal", "topk_lists_equal_oracle_embeddings",
+                "topk_mismatch_max_gap_ulps", "metrics_max_abs",
+                "rows_checked", "max_rel", "tolerance_rel")           # (the row-sharded workloads' sampled-row gate)
+        out["parity"] = _pick(par, keys, 3)
+    if isinstance(line.get("eval"), dict):
+        out["eval"] = _pick(line["eval"], ("value", "ms", "n_users"), 6)
+        out["eval"]["unit"] = "users/s"
+    for k in ("exact_f32", "reference_order", "pre_propagated_order"):
+        if isinstance(line.get(k), dict):
+            out[k] = _pick(line[k], ("ms_per_step", "value", "error"), 6)
+    pe = line.get("propagated_edges_per_sec")
+    if isinstance(pe, dict):
+        out["propagated_edges_per_sec"] = _pick(pe, ("executed", "reference_equivalent", "executed_per_step", "reference_equivalent_per_step"), 6)
+    ee = line.get("end_to_end")
+    if isinstance(ee, dict):
+        o = {}
+        for mode in ("default", "graph_device_sampler"):
+            if isinstance(ee.get(mode), dict):
+                o[mode] = _pick(ee[mode], ("edges_per_s", "users_per_s", "train_s", "eval_s"), 5)
+                if isinstance(ee[mode].get("vs_reference"), dict):
+                    o[mode]["vs_reference"] = _pick(ee[mode]["vs_reference"], ("ok", "epochs", "loss_rel", "mf_rel", "emb_rel", "metric_max_abs", "recall20", "recall20_reference"), 4)
+        if "error" in ee:
+            o["error"] = str(ee["error"])[-160:]
+        out["end_to_end"] = o
+    rs = line.get("row_sharded")
+    if isinstance(rs, dict):
+        o = {}
+        for k in ("weak", "strong"):
+            if isinstance(rs.get(k), dict):
+                o[k] = _pick(rs[k], ("ms_per_step", "value", "propagated_edges_per_sec"), 6)
+                if "error" in rs[k]:
+                    o[k]["error"] = str(rs[k]["error"])[:120]
+                if isinstance(rs[k].get("row_restricted_forward"), dict):
+                    o[k]["row_restricted_forward_ms"] = _r(rs[k]["row_restricted_forward"].get("ms_per_step"))
+                if "vs_prev" in rs[k]:
+                    o[k]["vs_prev"] = str(rs[k]["vs_prev"])[:100]
+        out["row_sharded"] = o
+    # row-sharded workloads (--workload cfg4 / cfg5, and N > 1)
+    for k in ("propagated_edges_per_step", "spmm_algorithmic_bytes_per_step_per_gpu", "speedup_vs_single_gpu", "peak_memory_gb"):
+        if k in line:
+            out[k] = _r(line[k])
+    if isinstance(line.get("messages"), dict):
+        out["messages"] = _pick(line["messages"], ("exchange", "n_chunks", "bytes_per_step", "bytes_per_message", "messages_per_step"), 5)
+    for k in ("single_gpu_reference", "netflix_replicas", "row_restricted_forward"):
+        if isinstance(line.get(k), dict):
+            out[k] = _pick(line[k], ("ms_per_step", "value", "error"), 6)
+    if isinstance(line.get("step_in_graph"), dict):
+        out["step_in_graph"] = _pick(line["step_in_graph"], ("span_us", "entry_point_calls", "projection_us", "wgrad_us"), 5)
+    out["detail"] = line.get("detail_file", "bench_detail.json")
+    text = json.dumps(out, allow_nan=False)
+    # a last guard: drop optional blocks, least important first, until the line fits
+    for k in ("pre_propagated_order", "reference_order", "messages", "step_in_graph", "row_sharded", "spmm_roofline", "end_to_end"):
+        if len(text) <= COMPACT_LIMIT:
+            break
+        out.pop(k, None)
+        text = json.dumps(out, allow_nan=False)
+    return out
+
+
+def write_detail(line: dict):
+    """The full record next to the compact line: bench_detail.json at the repo root and under gpurun_out/ (the directory gpurun merges back)."""
+    paths = []
+    for p in (os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+        try:
+            os.makedirs(os.path.dirname(p), exist_ok=True)
+            with open(p, "w") as f:
+                json.dump(line, f, indent=1, default=str)
+            paths.append(p)
+        except OSError:
+            pass
+    return paths
 
 
 def launch_decision(gpus: int, env, n_devices: int):
@@ -1159,19 +1339,33 @@ def main():
         if not a.no_kernel_roofline:
             ks = w.kernel_rooflines()
             line["kernels"] = ks
+            ig = w.in_graph_durations() if world == 1 else None
+            if ig is not None:
+                line["step_in_graph"] = dict(ig, entry_point_calls=getattr(w.fused, "entry_point_calls_per_step", None))
             # dominant kernel = the largest share of the step's GPU time: the weight-gradient launches (rocprofv3 round 1:
             # 25 % of the step) ahead of the single grouped-projection launch; both are reported, the dominant one first
             gemms = [k for k in ks if "algorithmic_bytes_per_launch" in k]
-            dom = max(gemms, key=lambda k: k["ms"])
-            other = min(gemms, key=lambda k: k["ms"])
+            dur = lambda k: ((ig or {}).get("projection_us" if "linear_fwd" in k["kernel"] else "wgrad_us") or k["ms"] * 1e3)
+            dom = max(gemms, key=dur)
+            other = min(gemms, key=dur)
 
             def roof(k):
                 hbm = k.get("bound") == "hbm"
                 traffic, src = pmc_traffic_bytes(k["pmc"])
                 n = k.get("launches", 1)
+                # `achieved` / `frac`: the launch's duration INSIDE the replayed step graph, measured live by device timestamps
+                # (in_graph_durations); `frac_isolated`: HIP events around 20 launches back to back on the launch's stream
+                iso = k["frac_hbm"] if hbm else k["frac_mfma_f32"]
+                us = None if ig is None else ig.get("projection_us" if "linear_fwd" in k["kernel"] else "wgrad_us")
+                if us:
+                    ach = (k["algorithmic_bytes_per_launch"] / us / 1e3) if hbm else (k["algorithmic_flop_per_launch"] / us / 1e6)
+                else:
+                    ach = k["gbs"] if hbm else k["tflops"]
+                peak = HBM_PEAK_GBS if hbm else MFMA_F32_PEAK_TFLOPS
                 return {"kernel": k["kernel"], "bound": k.get("bound", "mfma"),
-                        "achieved": k["gbs"] if hbm else k["tflops"], "peak": HBM_PEAK_GBS if hbm else MFMA_F32_PEAK_TFLOPS,
-                        "unit": "GB/s" if hbm else "TFLOP/s", "frac": k["frac_hbm"] if hbm else k["frac_mfma_f32"],
+                        "achieved": ach, "peak": peak,
+                        "unit": "GB/s" if hbm else "TFLOP/s", "frac": ach / peak, "frac_isolated": iso, "in_step_us": us, "isolated_us": k["ms"] / n * 1e3,
+                        "frac_source": "device timestamps inside the replayed step graph" if us else "HIP events, isolated launches",
                         "traffic": None if traffic is None else traffic / n, "traffic_source": src,
                         "launches_per_step": n, "ms_per_launch": k["ms"] / n, "ms_per_step": k["ms"], "in_step_us_rocprof": rocprof_avg_us(k["pmc"]),
                         "algorithmic_flop_per_launch": k["algorithmic_flop_per_launch"],
@@ -1190,9 +1384,15 @@ def main():
                 line["cpu_baseline"]["reference_unmodified"] = ref
         # the edge traversals behind `value` - the reference's forward runs 20 SpMMs and its backward 20 transposed ones per step
         # (Models.py:153-180); the fused step forms the same products as fewer, wider launches (7 d operands, pre-propagated A_ui F_k)
+        # `executed` = the traversals the step's SpMM launches actually perform (sum over the launches the graph was built
+        # from of nnz x d / 64: FusedStep.spmm_edge_units - the pre-propagated A_ui F_k products are formed once at set-up and are NOT counted),
+        # `reference_equivalent` = the reference's 40 d = 64 SpMMs per step
         nnz = int(w.rows.size)
-        line["propagated_edges_per_sec"] = {"value": 40.0 * nnz * a.steps * world / dt, "per_step": 40 * nnz,
-                                            "definition": "steps x (20 forward + 20 transposed SpMMs of the reference's step) x nnz / time"}
+        ex_units = float(getattr(w.fused, "spmm_edge_units", 0.0)) or None
+        line["propagated_edges_per_sec"] = {"executed": None if ex_units is None else ex_units * a.steps * world / dt, "executed_per_step": ex_units,
+                                            "reference_equivalent": 40.0 * nnz * a.steps * world / dt, "reference_equivalent_per_step": 40 * nnz,
+                                            "definition": "executed: steps x sum over the step's SpMM launches of nnz x d / 64, / time; reference_equivalent: "
+                                                          "steps x (20 forward + 20 transposed SpMMs of the reference's step) x nnz / time"}
         if workload == "nf" and world == 1 and not a.no_end_to_end:
             line["end_to_end"] = end_to_end_main()
     if workload in ("nf", "ml") and not a.no_row_sharded:
@@ -1205,6 +1405,8 @@ def main():
                 # the rows the step reads is the labelled variant beside it (same losses, gradients and parameters: tests/test_dist_cpu.py)
                 rs[scaling] = row_sharded_measure("cfg4", scaling, a.seed, device, rank, world, steps_rs, barrier, sparse_forward=False)
                 rs[scaling]["forward"] = "dense: every product of Models.py:169-186 for every row (this is `value`)"
+                if scaling == "strong":
+                    rs[scaling]["vs_prev"] = "r03 51.0 ms was the row-restricted forward; `value` is the dense forward since r04"
                 if scaling == "strong":
                     rr = row_sharded_measure("cfg4", scaling, a.seed, device, rank, world, steps_rs, barrier, sparse_forward=True)
                     rs[scaling]["row_restricted_forward"] = {"ms_per_step": rr["ms_per_step"], "value": rr["value"], "messages": rr.get("messages"),
@@ -1289,7 +1491,9 @@ def main():
                 if "value" in ref:
                     line["speedup_vs_single_gpu"] = line["value"] / ref["value"]
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        write_detail(line)
+        print("[bench] detail: %s" % json.dumps(line, default=str), file=sys.stderr, flush=True)
+        print(json.dumps(compact_line(line), allow_nan=False), flush=True)   # the ONE stdout line (<= COMPACT_LIMIT bytes)
     if use_pg:
         import torch.distributed as dist
         dist.barrier()                                       # rank 0's per-kernel measurements are done

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LLMREC_ABI_VERSION 4
+#define LLMREC_ABI_VERSION 5
 
 enum {
     LLMREC_OK = 0,
@@ -596,6 +596,16 @@ int llmrec_sample_batch(uint64_t seed, uint64_t* step_dev, int64_t n_exist_users
                         int32_t B_global, int32_t slice_begin, int32_t B, int32_t n_aug,
                         const int64_t* aug_pos, const int64_t* aug_neg,
                         int64_t* users, int64_t* pos, int64_t* neg, int32_t* n_valid_dev, llmrec_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement aid (bench.py `roofline`; nothing on the product path calls it). One single-lane launch that
+ * stores the device's constant-rate real-time counter (s_memrealtime) into *slot when the stream reaches it.
+ * A captured HIP graph cannot carry event-record nodes for external events; a pair of these around a launch
+ * gives that launch's duration INSIDE the replayed graph. llmrec_timestamp_rate_hz: ticks per second of
+ * that counter on the current device (hipDeviceAttributeWallClockRate), <= 0 on error.
+ * ------------------------------------------------------------------------------------------ */
+int llmrec_timestamp(uint64_t* slot, llmrec_stream_t stream);
+int64_t llmrec_timestamp_rate_hz(void);
 
 #ifdef __cplusplus
 }

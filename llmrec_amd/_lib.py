@@ -85,8 +85,13 @@ def load():
     return lib
 
 
+n_calls = 0      # entry-point invocations so far (FusedStep reports the per-step delta: a launch-count proxy without a profiler)
+
+
 def call(name: str, *args):
     """Invoke an int-returning entry point; raise on a non-zero status."""
+    global n_calls
+    n_calls += 1
     lib = load()
     status = getattr(lib, name)(*args)
     if status != 0:

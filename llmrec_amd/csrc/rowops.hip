@@ -369,6 +369,8 @@ __global__ void adamw_advance_kernel(float* state, float lr, float b1, float b2)
     state[2] = (float)sqrt(bc2);
 }
 
+__global__ void timestamp_kernel(uint64_t* slot) { *slot = wall_clock64(); }
+
 __global__ __launch_bounds__(256) void adamw_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     const float* __restrict__ state, float decay_mul, float b1, float b2, float eps) {
@@ -1102,6 +1104,21 @@ int llmrec_weighted_colsum_f32(int64_t rows, int32_t n_groups, int32_t group_wid
     colsum_final_kernel<<<1, COLSUM_MAX_D, 0, stream>>>(blocks, d, group_width, partial, g, accumulate);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
+}
+
+// measurement aid: the constant-rate counter at the moment the stream reaches this launch
+int llmrec_timestamp(uint64_t* slot, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(slot, "timestamp: null slot");
+    timestamp_kernel<<<1, 1, 0, (hipStream_t)stream_>>>(slot);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int64_t llmrec_timestamp_rate_hz(void) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return -1;
+    return (int64_t)khz * 1000;
 }
 
 }  // extern "C"

@@ -45,6 +45,8 @@ class _capture_without_gc:
     chased through the GPU suite turned out to be hipGraphLaunch's own (llmrec_amd/__init__.py)."""
 
     def __init__(self, graph):
+        from . import require_graph_replay
+        require_graph_replay("llmrec_amd: stream capture")      # the hardware-queue work-around must be in force (llmrec_amd/__init__.py)
         self.ctx = torch.cuda.graph(graph, capture_error_mode="thread_local")   # other threads (the RCCL watchdog) may touch the runtime
 
     def __enter__(self):
@@ -144,6 +146,10 @@ class FusedStep:
         self.graph_exec = None
         self.static = None
         self._eval_graphs = {}
+        # measurement only (bench.py `roofline`): a uint64 tensor of STAMP_SLOTS device timestamps written by llmrec_timestamp launches around
+        # the step, the projection launch and the weight-gradient launches - the durations INSIDE a replayed graph, which cannot carry events
+        self.stamps = None
+        self.spmm_edge_units = 0.0                            # edge traversals (nnz x d / 64) of the SpMM launches of the last step built
         # projection / weight-gradient arithmetic: "bf16x3" (default) = exact 3-term bf16 split of both operands, six bf16
         # MFMAs, fp32-roundoff-class error (2e-6 measured); "f32" = the exact fp32 MFMA fma chain
         self.gemm = os.environ.get("LLMREC_GEMM", "bf16x3")
@@ -177,7 +183,7 @@ class FusedStep:
         # without the terms that are zero. The image / text streams stay dense (the feature regulariser reads every row, main.py:151-156),
         # and so does user_trans (its gradient is two hops wide: 66 % of the rows).
         self.wgrad_rows = (getattr(type(self), "WGRAD_ROWS", True) and os.environ.get("LLMREC_WGRAD_ROWS", "1") == "1" and self.preprop
-                           and len(self.keys) > 0)
+                           and len(self.keys) > 0 and self.gemm == "bf16x3")     # (the exact-fp32 launches ignore the list: do not build it)
         # resident blocks the weight-gradient launch is laid out for (llmrec_wgrad_target_t.block_budget; 0 = 256, one per CU). A block of
         # that launch owns its CU's whole register file, so a 256-block round starves whatever runs beside it: the ID chain's last SpMM took
         # 81 us beside it and 12 us alone and, once the row list had shortened the GEMM, had become the step's tail. 224 blocks leave 32 CUs
@@ -241,9 +247,16 @@ class FusedStep:
         """Context: launch on side stream `st` (or stay on the current stream when disabled)."""
         return torch.cuda.stream(st) if self.multi_stream else torch.cuda.stream(torch.cuda.current_stream())
 
+    STAMP_SLOTS = 6       # step begin, projection begin / end, weight gradient begin / end (reduction included), step end
+
+    def _stamp(self, slot: int):
+        if self.stamps is not None:
+            _call("llmrec_timestamp", self.stamps.data_ptr() + 8 * slot)
+
     def _spmm(self, a: ops.Csr, X, Y, accumulate=False, tag=0, epilogue=None):
         """Y = epilogue(A X) (llmrec_spmm_f32); accumulate: Y += A X. tag: one partial-sum scratch per concurrent chain."""
         d = X.shape[1]
+        self.spmm_edge_units += a.nnz * (d / 64.0)
         sw, pl = a.plan_for(d, whole_row=epilogue is not None and epilogue.op != ops.EPI_NONE)
         partials = None
         if pl.n_seg:
@@ -358,7 +371,9 @@ class FusedStep:
                     self._spmm(self.ui.fwd, i_prev, self.Ul[l], tag=2)
                     self._spmm(self.iu.fwd, self.Ul[l], self.Il[l], tag=2)
                 i_prev = self.Il[l]
+        self._stamp(1)
         self._project_all()
+        self._stamp(2)
         ev1 = self._mark()
         if not self.preprop:
             self._spmm(self.ui.fwd, self.P_cat, self.U_cat)              # 7 streams, one adjacency pass
@@ -577,12 +592,14 @@ class FusedStep:
                 need = ops.linear_wgrad_multi_workspace(targets, self.wgrad_blocks)
                 self.ws_wgrad_multi = torch.empty(max(need, 0), dtype=torch.uint8, device=dY_cat.device) if need >= 0 else False
             if self.ws_wgrad_multi is not False:
+                self._stamp(3)
                 if self.inline_adamw:                                    # the four Linears' AdamW rides in the slab-reduction launch
                     lins = (m.item_trans, m.user_trans, m.text_trans, m.image_trans)          # (wgrad_targets' order)
                     ops.linear_wgrad_multi(targets, self.ws_wgrad_multi, update=(self.opt, [(l.weight, l.bias) for l in lins]), block_budget=self.wgrad_blocks)
                     updated = [p_ for l in lins for p_ in (l.weight, l.bias)]
                 else:
                     ops.linear_wgrad_multi(targets, self.ws_wgrad_multi, block_budget=self.wgrad_blocks)
+                self._stamp(4)
                 done = True
             else:                                                        # outside the multi-target fast path: user_trans' on its own
                 self._wgrad(self.dP_usr, m.user_feats, m.user_trans, False, ws=self.ws_wgrad_b)
@@ -629,13 +646,18 @@ class FusedStep:
                 if fill is not None:
                     fill()
                 ops.batch_reach_rows(users, pos, neg, n_valid, self.iu.fwd, self.act_flags, self.act_rows, self.act_n)
+        self.spmm_edge_units = 0.0
+        calls0 = _lib.n_calls
         try:
+            self._stamp(0)
             if sampler is not None and not side:
                 sampler()
             self._train_forward(sampler if side else None)
             self.loss_backward(users, pos, neg, n_valid)
             if not self.inline_adamw:
                 self.opt.step(advanced=True)
+            self._stamp(5)
+            self.entry_point_calls_per_step = _lib.n_calls - calls0 - (2 if self.stamps is not None else 0) * 3
             if self.wgrad_rows and self.act_expected is None and not torch.cuda.is_current_stream_capturing():
                 self._size_wgrad_for_rows()                      # first step: one read-back of the list length
         except Exception:

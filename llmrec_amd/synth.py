@@ -240,3 +240,36 @@ def write_dataset(path: str, n_users: int, n_items: int, n_edges: int, seed: int
 
     return {"n_users": n_users, "n_items": n_items, "n_train": int(tr.sum()),
             "n_test": int((role == 2).sum()), "n_val": int((role == 1).sum())}
+
+
+DATASET_INPUT_FILES = ("train.json", "val.json", "test.json", "train_mat", "image_feat.npy", "text_feat.npy",
+                       "augmented_user_init_embedding", "augmented_atttribute_embedding_dict", "augmented_sample_dict")
+
+
+def dataset_digests(ds_dir: str):
+    """sha256 of the array CONTENT of every input file (pickle byte streams are not stable across library versions)."""
+    import hashlib
+    out = {}
+    for fn in DATASET_INPUT_FILES:
+        p = os.path.join(ds_dir, fn)
+        h = hashlib.sha256()
+        if fn.endswith(".json"):
+            d = json.load(open(p))
+            for k in sorted(d, key=int):
+                h.update(np.asarray([int(k)] + list(d[k]), dtype=np.int64).tobytes())
+        elif fn.endswith(".npy"):
+            h.update(np.ascontiguousarray(np.load(p)).tobytes())
+        else:
+            obj = pickle.load(open(p, "rb"))
+            if fn == "train_mat":
+                m = obj.tocsr(); m.sort_indices()
+                h.update(m.indptr.astype(np.int64).tobytes()); h.update(m.indices.astype(np.int64).tobytes())
+            elif fn == "augmented_user_init_embedding":
+                h.update(np.asarray([obj[i] for i in range(len(obj))], dtype=np.float64).tobytes())
+            elif fn == "augmented_atttribute_embedding_dict":
+                for k in sorted(obj):
+                    h.update(k.encode()); h.update(np.asarray([obj[k][i] for i in range(len(obj[k]))], dtype=np.float64).tobytes())
+            else:
+                h.update(np.asarray([[u, obj[u][0], obj[u][1]] for u in sorted(obj)], dtype=np.int64).tobytes())
+        out[fn] = h.hexdigest()
+    return out

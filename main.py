@@ -53,7 +53,10 @@ device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 def USE_GRAPH():
     """LLMREC_GRAPH (default 1): the fused step and the evaluation are replayed from captured HIP graphs; 0 = the same launches
     issued one by one from Python (debugging, and the A/B of the graph itself)."""
-    return os.environ.get("LLMREC_GRAPH", "1") == "1"
+    if os.environ.get("LLMREC_GRAPH", "1") != "1":
+        return False
+    import llmrec_amd
+    return llmrec_amd.graph_replay_safe()                  # False (with a RuntimeWarning at import) when the hardware-queue work-around cannot hold
 
 
 ATTRIBUTE_KEYS = {                                         # reference main.py:69-72
@@ -223,8 +226,10 @@ class Trainer(object):
         """Two pinned int64 staging buffers used alternately; a buffer is reused only after the copy that read it has finished."""
         st = getattr(self, "_stage", None)
         if st is None or st["cap"] < slots:
-            pins = [torch.empty(slots, dtype=torch.int64).pin_memory() for _ in range(2)]
-            st = self._stage = {"cap": slots, "pin": pins, "np": [p_.numpy() for p_ in pins], "dev": None, "busy": [None, None], "i": 0}
+            # zero-filled once: train_step_packed copies the WHOLE 3 b_max + 1 block, so the slots past the batch must hold valid ids (0), never
+            # uninitialised host memory - today's kernels bound on n_valid, a future one reading B_cap entries must not gather out of range (ADVICE r04)
+            pins = [torch.zeros(slots, dtype=torch.int64).pin_memory() for _ in range(2)]
+            st = self._stage = {"cap": slots, "pin": pins, "np": [p_.numpy() for p_ in pins], "dev": [None, None], "busy": [None, None], "i": 0}
         i = st["i"]; st["i"] = 1 - i
         if st["busy"][i] is not None:
             st["busy"][i].synchronize()
@@ -232,7 +237,8 @@ class Trainer(object):
 
     def sample_batch(self):
         """(users, pos, neg) int64 device tensors incl. the LLM-augmented triples (main.py:213-224). On the GPU the three tensors are views
-        of ONE staging buffer that the next call overwrites (in stream order): consume them - train_step() - before sampling again."""
+        of one of TWO alternating device staging buffers (like the pinned ones): a batch stays intact across ONE further sample_batch() call;
+        the call after that overwrites it (in stream order)."""
         if self._device_sampler:
             u, p, n = data_generator.sample_device(args.seed, self._global_step, device)
             users = u.tolist()
@@ -256,14 +262,14 @@ class Trainer(object):
         # one ASYNCHRONOUS H2D copy per batch from one of two pinned staging buffers: a pageable copy would make the host wait for the
         # previous step's graph, i.e. serialise sampling and the GPU step (an epoch was 0.58 ms per step for a 0.46 ms step)
         st, i = self._pinned_pair(3 * (self.batch_size + int(self.batch_size * args.aug_sample_rate) + 64))
-        if st["dev"] is None or st["dev"].numel() < st["cap"]:
-            st["dev"] = torch.empty(st["cap"], dtype=torch.int64, device=device)
-        buf = st["np"][i]
+        if st["dev"][i] is None or st["dev"][i].numel() < st["cap"]:
+            st["dev"][i] = torch.zeros(st["cap"], dtype=torch.int64, device=device)
+        buf, dev = st["np"][i], st["dev"][i]
         buf[0:B], buf[n:n + B], buf[2 * n:2 * n + B] = users, pos_items, neg_items
         buf[B:n], buf[n + B:2 * n], buf[2 * n + B:3 * n] = users_aug, pos_aug, neg_aug
-        st["dev"][:3 * n].copy_(st["pin"][i][:3 * n], non_blocking=True)
+        dev[:3 * n].copy_(st["pin"][i][:3 * n], non_blocking=True)
         ev = torch.cuda.Event(); ev.record(); st["busy"][i] = ev
-        return st["dev"][0:n], st["dev"][n:2 * n], st["dev"][2 * n:3 * n]
+        return dev[0:n], dev[n:2 * n], dev[2 * n:3 * n]
 
     def train_step_packed(self):
         """Default mode, steady state: the host-sampled batch is written in the captured step's own layout into pinned memory and the step is
@@ -280,6 +286,10 @@ class Trainer(object):
         buf = st["np"][i]
         buf[0:B], buf[b:b + B], buf[2 * b:2 * b + B] = users, pos_items, neg_items
         buf[B:B + k], buf[b + B:b + B + k], buf[2 * b + B:2 * b + B + k] = users_aug, pos_aug, neg_aug
+        last = st.setdefault("filled", [0, 0])
+        if B + k < last[i]:                                   # a shorter batch than this buffer's previous one: the stale tail goes back to id 0
+            buf[B + k:last[i]] = 0; buf[b + B + k:b + last[i]] = 0; buf[2 * b + B + k:2 * b + last[i]] = 0
+        last[i] = B + k
         buf[3 * b] = B + k
         self.model_mm.train()
         fused.step_packed(st["pin"][i][:slots])

@@ -71,33 +71,8 @@ def write_case_dataset(name: str, data_root: str):
 
 
 def digests(ds_dir: str):
-    """sha256 of the array CONTENT of every input file (pickle byte streams are not stable across library versions)."""
-    import pickle
-    import numpy as np
-    out = {}
-    for fn in INPUT_FILES:
-        p = os.path.join(ds_dir, fn)
-        h = hashlib.sha256()
-        if fn.endswith(".json"):
-            d = json.load(open(p))
-            for k in sorted(d, key=int):
-                h.update(np.asarray([int(k)] + list(d[k]), dtype=np.int64).tobytes())
-        elif fn.endswith(".npy"):
-            h.update(np.ascontiguousarray(np.load(p)).tobytes())
-        else:
-            obj = pickle.load(open(p, "rb"))
-            if fn == "train_mat":
-                m = obj.tocsr(); m.sort_indices()
-                h.update(m.indptr.astype(np.int64).tobytes()); h.update(m.indices.astype(np.int64).tobytes())
-            elif fn == "augmented_user_init_embedding":
-                h.update(np.asarray([obj[i] for i in range(len(obj))], dtype=np.float64).tobytes())
-            elif fn == "augmented_atttribute_embedding_dict":
-                for k in sorted(obj):
-                    h.update(k.encode()); h.update(np.asarray([obj[k][i] for i in range(len(obj[k]))], dtype=np.float64).tobytes())
-            else:
-                h.update(np.asarray([[u, obj[u][0], obj[u][1]] for u in sorted(obj)], dtype=np.int64).tobytes())
-        out[fn] = h.hexdigest()
-    return out
+    """sha256 of the array CONTENT of every input file (llmrec_amd/synth.dataset_digests: the generator's own fingerprint)."""
+    return _load_synth().dataset_digests(ds_dir)
 
 
 def run_case(name: str):

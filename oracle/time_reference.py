@@ -34,16 +34,39 @@ def child(data_root: str, epochs: int):
     lines = []
     orig = trainer.logger.logging
     trainer.logger.logging = lambda s: (lines.append(str(s)), orig(s))[1]
+    # read-only monitors (round 5: the headline shape pinned against the reference itself): the unrounded metric dict of every
+    # test_torch call (utility/batch_test.py:112-169); they change no arithmetic and consume no RNG
+    evals = []
+    orig_test_torch = ref.test_torch
+
+    def test_torch_wrap(ua, ia, users_to_test, is_val, *a, **k):
+        res = orig_test_torch(ua, ia, users_to_test, is_val, *a, **k)
+        evals.append({m: [float(x) for x in res[m]] for m in ("precision", "recall", "ndcg", "hit_ratio")})
+        return res
+    ref.test_torch = test_torch_wrap
     t1 = time.time()
     trainer.train()
     total = time.time() - t1
     ep = []
+    num = r"(-?[0-9.]+(?:e-?[0-9]+)?|nan|inf)"
     for l in lines:
-        m = re.search(r"Epoch (\d+) \[([0-9.]+)s \+ ([0-9.]+)s\]", l)
+        m = re.search(r"Epoch (\d+) \[([0-9.]+)s \+ ([0-9.]+)s\]: train==\[%s=%s \+ %s \+ %s\]" % (num, num, num, num), l)
         if m:
-            ep.append({"epoch": int(m.group(1)), "train_s": float(m.group(2)), "eval_s": float(m.group(3)), "line": m.group(0)})
+            # the evaluation whose result this line prints is the FIRST test_torch call of the epoch (main.py:299); a second one follows
+            # when recall@20 improved (main.py:316)
+            ep.append({"epoch": int(m.group(1)), "train_s": float(m.group(2)), "eval_s": float(m.group(3)), "line": l.strip(),
+                       "loss": float(m.group(4)), "mf_loss": float(m.group(5)), "emb_loss": float(m.group(6)), "reg_loss": float(m.group(7))})
+    # pair each epoch line with its evaluation: metrics printed to 5 decimals in the line identify the call
+    k = 0
+    for e in ep:
+        r20 = float(re.search(r"recall=\[[-0-9.e]+, ([-0-9.e]+),", e["line"]).group(1))
+        while k < len(evals) and abs(evals[k]["recall"][1] - r20) > 6e-6:
+            k += 1
+        if k < len(evals):
+            e["metrics"] = evals[k]
+            k += 1
     n_batch = ref.data_generator.n_train // ref.args.batch_size + 1
-    print("REF_JSON " + json.dumps({"epochs": ep, "n_batch": n_batch, "batch_size": ref.args.batch_size, "n_train": ref.data_generator.n_train,
+    print("REF_JSON " + json.dumps({"epochs": ep, "n_evaluations": len(evals), "args": {k: (v if isinstance(v, (int, float, str, bool)) else str(v)) for k, v in vars(ref.args).items()}, "n_batch": n_batch, "batch_size": ref.args.batch_size, "n_train": ref.data_generator.n_train,
                                     "n_test_users": len(ref.data_generator.test_set), "init_s": init_s, "train_call_s": total,
                                     "torch_threads": torch.get_num_threads(), "torch": torch.__version__}), flush=True)
 
@@ -51,7 +74,7 @@ def child(data_root: str, epochs: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--epochs", type=int, default=2)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_reference_cpu.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_reference_cpu.json"))
     ap.add_argument("--data", default="/tmp/llmrec_e2e")
     ap.add_argument("--child", action="store_true")
     a = ap.parse_args()
@@ -60,6 +83,9 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import e2e_main
     ds, stats = e2e_main.write_dataset(a.data)
+    sys.path.insert(0, HERE)
+    import make_trajectory
+    dig = make_trajectory.digests(ds)                        # sha256 of the array content of every input file: the consumer trains on the same bytes
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--data", a.data, "--epochs", str(a.epochs)], capture_output=True, text=True, cwd="/tmp")
     js = [l for l in r.stdout.splitlines() if l.startswith("REF_JSON ")]
     if not js:
@@ -70,6 +96,7 @@ def main():
            "dataset": "tools/e2e_main.py's NF-shaped set: U 13187 x I 17366, 68933 interactions (%d train), %d test users, feats 512/768/1536 x (1 + 5)" % (c["n_train"], c["n_test_users"]),
            "host": {"cores": os.cpu_count(), "torch_threads": c["torch_threads"], "eval_pool": "in-process map (the reference's Pool(cpu_count() // 5) = 1 worker on this host)",
                     "torch": c["torch"], "where": "build container (no GPU)"},
+           "digests": dig, "seed": c["args"].get("seed"), "args": c["args"], "n_evaluations": c["n_evaluations"],
            "epochs": c["epochs"], "n_batch": c["n_batch"], "batch_size": c["batch_size"], "n_test_users": c["n_test_users"],
            "train_s": best["train_s"], "eval_s": best["eval_s"],
            "edges_per_s": c["n_batch"] * c["batch_size"] / best["train_s"], "users_per_s": c["n_test_users"] / best["eval_s"], "init_s": c["init_s"]}

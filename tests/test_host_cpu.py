@@ -238,12 +238,47 @@ def test_block_sampler_and_c_helper_reproduce_the_per_call_stream(monkeypatch):
             out = [D.sample() for _ in range(6)]
             if mode == "c_helper":
                 assert D._host not in (None, False), "libllmrec_host.so was not loaded"
-                assert D._fast_users is True                  # the C replay of random.sample agreed with the interpreter's on the first batch
+                assert D._fast_users and all(v is True for v in D._fast_users.values())   # the C replay of random.sample agreed with the interpreter's, on each branch hit
             if mode != "reference":
                 assert D._fast_sampler is True
             results[mode] = ([(u, p, [int(x) for x in n]) for u, p, n in out], np.random.get_state()[1].tolist(), np.random.get_state()[2], random.getstate())
         assert results["python_block"] == results["reference"]
         assert results["c_helper"] == results["reference"]
+
+
+def test_py_sample_replay_is_verified_on_each_branch_of_random_sample(monkeypatch):
+    """CPython's random.sample has two branches (pool: n <= setsize; set: larger populations). The production stream hits the set
+    branch first (exist_users, n = 13 187, k = 1 024) and the pool branch every step after it (the augmented-triple draw, n = B, k = B / 10):
+    the C replay is cross-checked against the interpreter the first time EACH branch is taken, and every draw equals random.sample's."""
+    import random
+    import sys
+    monkeypatch.setattr(sys, "argv", ["main.py", "--dataset", "netflix_valid_item"])
+    sys.modules.pop("utility.load_data", None)
+    import utility.load_data as LD
+    from llmrec_amd import build as _build
+    _build.build_host(force=False)
+    D = LD.Data.__new__(LD.Data)
+    D._host, D._fast_users, D._users_scratch, D._exist_arr = None, {}, None, None
+    D.n_users, D.train_items = 4, {0: [1], 1: [2, 3]}                # (what _host_lib lays out beside loading the helper)
+    big, small = list(range(3, 13190)), list(range(100, 1124))      # n = 1024, k = 102: setsize = 21 + 4^5 = 1045 >= n -> the pool branch
+    calls = [(big, 1024), (small, 102), (small, 102), (big, 1024), (small, 7), (big, 5)]
+    random.seed(2022)
+    want = [random.sample(p, k) for p, k in calls]
+    state_want = random.getstate()
+    random.seed(2022)
+    got = []
+    for i, (p, k) in enumerate(calls):
+        got.append(D.py_sample(p, k))
+        if i == 0:
+            assert D._host not in (None, False), "libllmrec_host.so was not loaded"
+            assert D._fast_users == {False: True}                  # only the set branch has been verified so far
+        if i == 1:
+            assert D._fast_users == {False: True, True: True}      # ... and now the pool branch, by its own draw-both-and-compare
+    assert got == want and random.getstate() == state_want
+    # a branch that fails its check is switched off alone
+    D._fast_users = {False: True, True: False}
+    random.seed(5); a = D.py_sample(small, 102); random.seed(5); b = random.sample(small, 102)
+    assert a == b and D._fast_users == {False: True, True: False}
 
 
 def test_host_helper_library_exports_what_its_header_declares():
@@ -265,7 +300,39 @@ def test_hardware_queue_pool_is_widened_before_hip_initialises():
     hipGraphLaunch's unchecked walk over an executable's internal streams - unless the user chose a value."""
     import llmrec_amd                                             # noqa: F401
     assert int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) >= 8
-    for f in ("bench.py", "main.py", "__graft_entry__.py", os.path.join("tests", "conftest.py"), os.path.join("llmrec_amd", "__init__.py")):
+    for f in ("bench.py", "main.py", "__graft_entry__.py", os.path.join("tests", "conftest.py")):
         src = open(os.path.join(os.path.dirname(_lib.HEADER), "..", f)).read()
         assert 'os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")' in src, f
         assert src.index("GPU_MAX_HW_QUEUES") < (src.index("import torch") if "import torch" in src else len(src)), f
+
+
+def test_queue_work_around_decision_is_loud():
+    """VERDICT r04 next #8 / ADVICE r04: the work-around only holds if GPU_MAX_HW_QUEUES >= 8 is in the environment before the HIP runtime
+    initialises; when it cannot hold, graph replay is refused (not silently left to fault)."""
+    import llmrec_amd
+    qd = llmrec_amd.queue_decision
+    assert qd(None, False) == ("set", True, None)                       # the normal import: set it
+    act, safe, msg = qd(None, True)                                      # the embedder touched the GPU first
+    assert (act, safe) == ("keep", False) and "after the HIP runtime initialised" in msg
+    act, safe, msg = qd("4", False)                                      # a smaller user value is kept, and flagged
+    assert (act, safe) == ("keep", False) and "below 8" in msg
+    assert qd("4", True)[1] is False and qd("junk", False)[1] is False
+    assert qd("8", False) == ("keep", True, None) and qd("16", True) == ("keep", True, None)
+    assert llmrec_amd.graph_replay_safe()                                # this process: conftest set it before torch was imported
+    # a process that initialised torch.cuda first would be refused a capture; simulate the module state
+    saved = (llmrec_amd._graph_safe, llmrec_amd._message)
+    llmrec_amd._graph_safe, llmrec_amd._message = False, "simulated"
+    try:
+        assert not llmrec_amd.graph_replay_safe()
+        try:
+            llmrec_amd.require_graph_replay("test")
+            raise AssertionError("capture was not refused")
+        except RuntimeError as e:
+            assert "refused" in str(e)
+        os.environ["LLMREC_UNSAFE_GRAPH"] = "1"
+        try:
+            llmrec_amd.require_graph_replay("test")                      # the explicit override
+        finally:
+            del os.environ["LLMREC_UNSAFE_GRAPH"]
+    finally:
+        llmrec_amd._graph_safe, llmrec_amd._message = saved

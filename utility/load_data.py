@@ -55,7 +55,7 @@ class Data(object):
         self._R = None
         self._fast_sampler = None                                    # decided on the first batch (sample())
         self._host = None                                            # the C helper of the draw loop, loaded on first use
-        self._fast_users, self._users_scratch, self._exist_arr = None, None, None   # the C replay of random.sample: decided on the first batch
+        self._fast_users, self._users_scratch, self._exist_arr = {}, None, None   # the C replay of random.sample: verified once PER BRANCH (pool / set) of CPython's algorithm; False = off
         self._device_state = None
         self.print_statistics()
 
@@ -104,9 +104,12 @@ class Data(object):
     def py_sample(self, population, k, population_arr=None):
         """random.sample(population, k) on python's global generator - through the C replay of CPython's random.sample on CPython's own
         generator state when the host helper is there (llmrec_host_py_sample: 0.19 -> 0.07 ms at k = 1024 of 13 187); the first call draws
-        both ways from the same state and compares, as the item draws do. population_arr: the population as an int64 array, if the caller has it."""
+        both ways from the same state and compares, as the item draws do - once for each of random.sample's two branches (the pool branch, n <= setsize:
+        the per-step augmented-triple draw; the set branch: the exist_users draw): ADVICE r04. population_arr: the population as an int64 array, if the caller has it."""
         host = self._host_lib()
         n = len(population)
+        if self._fast_users is None:                                 # (tests reset the latch with None)
+            self._fast_users = {}
         if host is None or self._fast_users is False or k > n or k <= 0:
             return rd.sample(population, k)
         import math
@@ -122,17 +125,21 @@ class Data(object):
         if self._users_scratch is None or self._users_scratch.size < need:
             self._users_scratch = np.empty(need, dtype=np.int64)
         pos = np.empty(k, dtype=np.int64)
-        if host.llmrec_host_py_sample(words.ctypes.data, n, k, 1 if n <= setsize else 0, self._users_scratch.ctypes.data, pos.ctypes.data) != 0:
+        use_pool = n <= setsize
+        if self._fast_users.get(use_pool) is False:
+            return rd.sample(population, k)
+        if host.llmrec_host_py_sample(words.ctypes.data, n, k, 1 if use_pool else 0, self._users_scratch.ctypes.data, pos.ctypes.data) != 0:
             self._fast_users = False
             return rd.sample(population, k)
         arr = population_arr if population_arr is not None else np.asarray(population, dtype=np.int64)
         out = arr[pos].tolist()
-        if self._fast_users is None:                                 # first call: the interpreter's own random.sample must agree
+        if use_pool not in self._fast_users:                         # first call of this branch: the interpreter's own random.sample must agree
             want = rd.sample(population, k)                          # (advances the stream exactly as the replay claims to have done)
             after = rd.getstate()
-            self._fast_users = bool(want == out and tuple(words.tolist()) == after[1])
-            if not self._fast_users:
-                print("utility.load_data: the C replay of random.sample does not reproduce this interpreter's stream; using random.sample")
+            ok = self._fast_users[use_pool] = bool(want == out and tuple(words.tolist()) == after[1])
+            if not ok:
+                print("utility.load_data: the C replay of random.sample (%s branch) does not reproduce this interpreter's stream; using random.sample"
+                      % ("pool" if use_pool else "set"))
             return want
         rd.setstate((st[0], tuple(words.tolist()), st[2]))
         return out
