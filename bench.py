@@ -268,7 +268,8 @@ class NetflixShaped:
             torch.cuda.synchronize()
             n = 0
             for _ in range(iters):
-                f.graph_exec.replay()
+                for _ in range(6):                              # back to back, as in the timed region: the slots keep the LAST replay's stamps
+                    f.graph_exec.replay()
                 torch.cuda.synchronize()
                 t = f.stamps.tolist()
                 if not (t[0] <= t[1] <= t[2] and t[5] >= t[0]):
@@ -1105,7 +1106,7 @@ def compact_line(line: dict) -> dict:
             if isinstance(ee.get(mode), dict):
                 o[mode] = _pick(ee[mode], ("edges_per_s", "users_per_s", "train_s", "eval_s"), 5)
                 if isinstance(ee[mode].get("vs_reference"), dict):
-                    o[mode]["vs_reference"] = _pick(ee[mode]["vs_reference"], ("ok", "epochs", "loss_rel", "mf_rel", "emb_rel", "metric_max_abs", "recall20", "recall20_reference"), 4)
+                    o[mode]["vs_reference"] = _pick(ee[mode]["vs_reference"], ("ok", "epochs", "loss_rel", "mf_rel", "emb_rel", "metric_max_abs"), 4)
         if "error" in ee:
             o["error"] = str(ee["error"])[-160:]
         out["end_to_end"] = o

@@ -135,6 +135,11 @@ typedef struct {
      *                 explicit row list this is "these rows of A X"; all other rows of Y keep their contents. */
     const uint8_t* x_row_mask; int32_t x_mask_active; uint8_t* y_row_flag; const uint8_t* z_row_flag; const uint8_t* y_row_gate;
     const uint8_t* y_row_needed; int32_t rows_listed_only;
+    /* Cache policy (round 5 experiment, profiles/experiments/r05_spmm_nt.md): x_nt_from_row > 0 gathers the X rows with index >= x_nt_from_row
+     * with non-temporal loads, the rows below it with the default policy - meant for operands whose columns are ordered by descending
+     * degree (hot rows first), so that the cold 256-B rows stream through the L2 without displacing the hot set. A hint only: results are
+     * bit-identical. Pattern-only, unmasked products; ignored otherwise. 0 = off. */
+    int32_t x_nt_from_row;
 } llmrec_spmm_epilogue_t;
 /* flags[ids[j]] = value for j < n (ids[j] < 0 skipped): marks the rows a batch touches (x_row_mask / z_row_flag above) */
 int llmrec_mark_rows_u8(int64_t n, const int64_t* ids, int32_t value, uint8_t* flags, llmrec_stream_t stream);

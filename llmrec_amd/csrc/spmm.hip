@@ -38,6 +38,12 @@ template <> struct Vec<4> {
     float4 v;
     __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    // the same 16 bytes with the non-temporal cache policy (global_load_dwordx4 ... nt): a hint that the line will not be reused
+    __device__ __forceinline__ void load_nt(const float* p) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+        v = make_float4(t.x, t.y, t.z, t.w);
+    }
     __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
     __device__ __forceinline__ void add(const Vec& o) { v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w; }
     __device__ __forceinline__ void fma(float w, const Vec& o) {
@@ -59,6 +65,7 @@ template <> struct Vec<1> {
     float v;
     __device__ __forceinline__ void zero() { v = 0.f; }
     __device__ __forceinline__ void load(const float* p) { v = *p; }
+    __device__ __forceinline__ void load_nt(const float* p) { v = __builtin_nontemporal_load(p); }
     __device__ __forceinline__ void store(float* p) const { *p = v; }
     __device__ __forceinline__ void add(const Vec& o) { v += o.v; }
     __device__ __forceinline__ void fma(float w, const Vec& o) { v = fmaf(w, o.v, v); }
@@ -101,6 +108,7 @@ struct SpmmArgs {
     const uint8_t* y_gate;       // rows whose byte != x_active: no active neighbour, zero Z row - written as zeros at once
     const uint8_t* y_needed;     // rows whose byte != x_active are neither computed nor written (short-row range)
     int32_t listed_only;         // no short-row range at all: only the plan's row lists are computed
+    int32_t nt_from;             // (NT kernels) X rows with index >= nt_from are gathered with the non-temporal policy: cache hint only
     // plan
     const int32_t* wave_rows;
     const int32_t* block_rows;
@@ -114,7 +122,7 @@ struct SpmmArgs {
 
 // Accumulate sum_{j in [s, e)} w_j * X[col_j, chunk columns] into acc, in ascending j order. MASKED: rows of X that are not active
 // (a.x_mask) are known to be all-zero and are not fetched; `any` collects whether this lane saw an active column.
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED>
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED, bool NT>
 __device__ __forceinline__ void accumulate_range(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, int gl, Vec<VEC> (&acc)[NCHUNK], int& any) {
     for (int32_t base = s; base < e; base += LPR) {
         const int n = min(LPR, e - base);
@@ -175,8 +183,10 @@ __device__ __forceinline__ void accumulate_range(const SpmmArgs& a, int64_t col0
 #pragma unroll
                 for (int k = 0; k < NCHUNK; ++k) {
                     const int col = (k * LPR + gl) * VEC;
-                    if (tt < n && col < a.d) v[u][k].load(xr + col);
-                    else v[u][k].zero();
+                    if (tt < n && col < a.d) {
+                        if (NT && c >= a.nt_from) v[u][k].load_nt(xr + col);     // (uniform per lane group) cold row: do not displace the hot set
+                        else v[u][k].load(xr + col);
+                    } else v[u][k].zero();
                 }
             }
 #pragma unroll
@@ -262,7 +272,7 @@ __device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t col0, int6
 constexpr int TPB = 512;                                        // threads per block: 8 wavefronts
 
 // one lane group per (row, slice) task; rows with more than LLMREC_SPMM_LONG_ROW nnz belong to the other ranges
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED>
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED, bool NT>
 __device__ __forceinline__ void rows_body(const SpmmArgs& a, int64_t block) {
     constexpr int GPB = TPB / LPR;
     const int gl = threadIdx.x & (LPR - 1);
@@ -293,15 +303,15 @@ __device__ __forceinline__ void rows_body(const SpmmArgs& a, int64_t block) {
         const unsigned long long gm = LPR >= 64 ? ~0ull : (((1ull << LPR) - 1ull) << g0);
         const bool any_g = (bal & gm) != 0ull;
         zero_row = write_row_flag(a, row, any_g, slice == 0 && gl == 0);
-        if (any_g) accumulate_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, s, e, gl, acc, any);
+        if (any_g) accumulate_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, col0, s, e, gl, acc, any);
     } else {
-        accumulate_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, s, e, gl, acc, any);
+        accumulate_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, col0, s, e, gl, acc, any);
     }
     finish_row<LPR, NCHUNK, VEC>(a, col0, row, gl, acc, zero_row);
 }
 
 // one wavefront over [s, e): the 64/LPR lane groups take contiguous parts, butterfly sum -> every group holds the total
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED>
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED, bool NT>
 __device__ __forceinline__ void wave_range(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, int lane, Vec<VEC> (&acc)[NCHUNK], int& any) {
     constexpr int G = 64 / LPR;
     const int gl = lane & (LPR - 1), g = lane / LPR;
@@ -309,7 +319,7 @@ __device__ __forceinline__ void wave_range(const SpmmArgs& a, int64_t col0, int3
     const int32_t gs = min(s + g * per, e), ge = min(gs + per, e);
 #pragma unroll
     for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
-    accumulate_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, gs, ge, gl, acc, any);
+    accumulate_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, col0, gs, ge, gl, acc, any);
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
@@ -326,7 +336,7 @@ __device__ __forceinline__ void list_task(const SpmmArgs& a, const int32_t* list
 }
 
 // one wavefront per (row, slice) of the wave-row list
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED>
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED, bool NT>
 __device__ __forceinline__ void wave_rows_body(const SpmmArgs& a, int32_t block) {
     const int lane = threadIdx.x & 63;
     const int64_t task = (int64_t)block * (TPB / 64) + (threadIdx.x >> 6);
@@ -342,20 +352,20 @@ __device__ __forceinline__ void wave_rows_body(const SpmmArgs& a, int32_t block)
             if (base + lane < re) any |= (int)a.x_mask[a.colidx[base + lane]] == a.x_active;
         const bool any_w = __ballot(any != 0) != 0ull;
         zero_row = write_row_flag(a, row, any_w, col0 == 0 && lane == 0);
-        if (any_w) wave_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, rs, re, lane, acc, any);
+        if (any_w) wave_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, col0, rs, re, lane, acc, any);
         else {
 #pragma unroll
             for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
         }
     } else {
-        wave_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, a.rowptr[row], a.rowptr[row + 1], lane, acc, any);
+        wave_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, col0, a.rowptr[row], a.rowptr[row + 1], lane, acc, any);
     }
     if (lane < LPR) finish_row<LPR, NCHUNK, VEC>(a, col0, row, lane, acc, zero_row);
 }
 
 // one block over [s, e): the 8 waves take contiguous parts, summed through LDS in wave order; the total ends up in the
 // first lane group of wave 0 (returns true there)
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED>
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED, bool NT>
 __device__ __forceinline__ bool block_range(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, float* lds, Vec<VEC> (&acc)[NCHUNK]) {
     constexpr int ROWW = NCHUNK * LPR * VEC;
     constexpr int NW = TPB / 64;
@@ -363,7 +373,7 @@ __device__ __forceinline__ bool block_range(const SpmmArgs& a, int64_t col0, int
     const int32_t per = (((e - s) + NW - 1) / NW + 63) / 64 * 64;
     const int32_t ws = min(s + w * per, e), we = min(ws + per, e);
     int any = 0;                                                         // (long rows: their output flag is set unconditionally)
-    wave_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, ws, we, lane, acc, any);
+    wave_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, col0, ws, we, lane, acc, any);
     if (w > 0 && lane < LPR) {
 #pragma unroll
         for (int k = 0; k < NCHUNK; ++k) acc[k].store(lds + (w - 1) * ROWW + (k * LPR + lane) * VEC);
@@ -380,18 +390,18 @@ __device__ __forceinline__ bool block_range(const SpmmArgs& a, int64_t col0, int
 
 // ONE launch: [0, blk_seg) segments of the split rows, [blk_seg, blk_block) block rows, [blk_block, blk_wave) wave
 // rows (8 per block), the rest short rows. The heavy blocks come first.
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED>
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED, bool NT>
 __global__ __launch_bounds__(TPB) void spmm_kernel(SpmmArgs a) {
     constexpr int ROWW = NCHUNK * LPR * VEC;
     __shared__ __attribute__((aligned(16))) float red_lds[(TPB / 64 - 1) * ROWW];
     const int32_t b = blockIdx.x;
-    if (b >= a.blk_wave) { rows_body<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, (int64_t)b - a.blk_wave); return; }
-    if (b >= a.blk_block) { wave_rows_body<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, b - a.blk_block); return; }
+    if (b >= a.blk_wave) { rows_body<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, (int64_t)b - a.blk_wave); return; }
+    if (b >= a.blk_block) { wave_rows_body<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, b - a.blk_block); return; }
     Vec<VEC> acc[NCHUNK];
     int32_t row, slot; int64_t col0;
     if (b >= a.blk_seg) {
         list_task(a, a.block_rows, a.n_block_rows, b - a.blk_seg, row, col0, slot);
-        if (block_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, a.rowptr[row], a.rowptr[row + 1], red_lds, acc)) {
+        if (block_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, col0, a.rowptr[row], a.rowptr[row + 1], red_lds, acc)) {
             if (MASKED && col0 == 0 && threadIdx.x == 0 && a.y_flag) a.y_flag[row] = (uint8_t)a.x_active;   // conservative: "may be non-zero"
             finish_row<LPR, NCHUNK, VEC>(a, col0, row, threadIdx.x, acc);
         }
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(TPB) void spmm_kernel(SpmmArgs a) {
     const int32_t re = a.rowptr[row + 1];
     const int32_t s = a.rowptr[row] + k_in_row * a.segment;
     const int32_t e = min(s + a.segment, re);
-    if (block_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED>(a, col0, s, e, red_lds, acc)) {
+    if (block_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, col0, s, e, red_lds, acc)) {
         if (MASKED && col0 == 0 && k_in_row == 0 && threadIdx.x == 0 && a.y_flag) a.y_flag[row] = (uint8_t)a.x_active;   // conservative
         float* pr = a.partials + (int64_t)b * a.d;
 #pragma unroll
@@ -465,11 +475,13 @@ static int launch_spmm(SpmmArgs& a, hipStream_t stream) {
     a.blk_wave = a.blk_block + (int32_t)wave_blocks;
     if (total > 0) {
         if (a.x_mask) {
-            if (weighted) spmm_kernel<LPR, NCHUNK, VEC, true, true><<<(unsigned)total, TPB, 0, stream>>>(a);
-            else spmm_kernel<LPR, NCHUNK, VEC, false, true><<<(unsigned)total, TPB, 0, stream>>>(a);
+            if (weighted) spmm_kernel<LPR, NCHUNK, VEC, true, true, false><<<(unsigned)total, TPB, 0, stream>>>(a);
+            else spmm_kernel<LPR, NCHUNK, VEC, false, true, false><<<(unsigned)total, TPB, 0, stream>>>(a);
+        } else if (a.nt_from > 0 && !weighted) {             // cache-policy split (pattern-only operands: the propagation products)
+            spmm_kernel<LPR, NCHUNK, VEC, false, false, true><<<(unsigned)total, TPB, 0, stream>>>(a);
         } else {
-            if (weighted) spmm_kernel<LPR, NCHUNK, VEC, true, false><<<(unsigned)total, TPB, 0, stream>>>(a);
-            else spmm_kernel<LPR, NCHUNK, VEC, false, false><<<(unsigned)total, TPB, 0, stream>>>(a);
+            if (weighted) spmm_kernel<LPR, NCHUNK, VEC, true, false, false><<<(unsigned)total, TPB, 0, stream>>>(a);
+            else spmm_kernel<LPR, NCHUNK, VEC, false, false, false><<<(unsigned)total, TPB, 0, stream>>>(a);
         }
         LLMREC_LAUNCH_CHECK();
     }
@@ -520,6 +532,8 @@ extern "C" int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
         LLMREC_CHECK_ARG(e.op != LLMREC_SPMM_EPI_SOFTMAX_BWD || (e.S && e.lds >= d), "spmm: softmax backward needs S with ld >= d");
         a.epi_op = e.op; a.alpha = e.alpha; a.Z = e.Z; a.ldz = e.ldz; a.S = e.S; a.lds = e.lds; a.post_scale = e.post_scale;
         a.listed_only = e.rows_listed_only != 0;
+        LLMREC_CHECK_ARG(e.x_nt_from_row >= 0, "spmm: negative x_nt_from_row");
+        a.nt_from = e.x_nt_from_row;
         if (e.y_row_needed) {
             LLMREC_CHECK_ARG(e.x_mask_active >= 1 && e.x_mask_active <= 255, "spmm: y_row_needed needs x_mask_active in 1..255");
             a.y_needed = e.y_row_needed; a.x_active = e.x_mask_active;

@@ -65,7 +65,8 @@ class SpmmEpilogueC(_c.Structure):
     """llmrec_spmm_epilogue_t"""
     _fields_ = [("op", _c.c_int32), ("alpha", _c.c_float), ("Z", _c.c_void_p), ("ldz", _c.c_int64), ("S", _c.c_void_p), ("lds", _c.c_int64),
                 ("post_scale", _c.c_void_p), ("x_row_mask", _c.c_void_p), ("x_mask_active", _c.c_int32), ("y_row_flag", _c.c_void_p),
-                ("z_row_flag", _c.c_void_p), ("y_row_gate", _c.c_void_p), ("y_row_needed", _c.c_void_p), ("rows_listed_only", _c.c_int32)]
+                ("z_row_flag", _c.c_void_p), ("y_row_gate", _c.c_void_p), ("y_row_needed", _c.c_void_p), ("rows_listed_only", _c.c_int32),
+                ("x_nt_from_row", _c.c_int32)]
 
 
 EPI_NONE, EPI_SOFTMAX, EPI_SOFTMAX_BWD = 0, 1, 2
@@ -297,13 +298,14 @@ class BipartiteGraph:
 def spmm_epilogue(op: int = EPI_NONE, alpha: float = 0.0, Z: Optional[torch.Tensor] = None, S: Optional[torch.Tensor] = None,
                   post_scale: Optional[torch.Tensor] = None, x_row_mask: Optional[torch.Tensor] = None, x_mask_active: int = 0,
                   y_row_flag: Optional[torch.Tensor] = None, z_row_flag: Optional[torch.Tensor] = None,
-                  y_row_gate: Optional[torch.Tensor] = None, y_row_needed: Optional[torch.Tensor] = None, rows_listed_only: bool = False):
+                  y_row_gate: Optional[torch.Tensor] = None, y_row_needed: Optional[torch.Tensor] = None, rows_listed_only: bool = False,
+                  x_nt_from_row: int = 0):
     """llmrec_spmm_epilogue_t: Y = post_scale . op(alpha * Z + A X); S = forward softmax rows for EPI_SOFTMAX_BWD.
     x_row_mask (uint8 [n_cols]) / x_mask_active: X rows whose byte differs from the active value are promised all-zero and not read;
     y_row_flag (uint8 [n_rows]): receives the active value for rows whose result can be non-zero (z_row_flag: the non-zero rows of Z);
     y_row_gate (uint8 [n_rows]): rows without the active value are promised zero results and written as zeros unread;
     y_row_needed (uint8 [n_rows]): rows without the active value are neither computed nor written; rows_listed_only: compute the rows
-    in the plan's lists only (spmm_listed)."""
+    in the plan's lists only (spmm_listed); x_nt_from_row > 0: X rows from that index on are gathered with non-temporal loads (cache hint)."""
     for t in (x_row_mask, y_row_flag, z_row_flag, y_row_gate, y_row_needed):
         if t is not None and (t.dtype != torch.uint8 or not t.is_contiguous()):
             raise RuntimeError("spmm_epilogue: row masks / flags are contiguous uint8 tensors")
@@ -314,7 +316,7 @@ def spmm_epilogue(op: int = EPI_NONE, alpha: float = 0.0, Z: Optional[torch.Tens
                          y_row_flag.data_ptr() if y_row_flag is not None else None,
                          z_row_flag.data_ptr() if z_row_flag is not None else None,
                          y_row_gate.data_ptr() if y_row_gate is not None else None,
-                         y_row_needed.data_ptr() if y_row_needed is not None else None, 1 if rows_listed_only else 0)
+                         y_row_needed.data_ptr() if y_row_needed is not None else None, 1 if rows_listed_only else 0, int(x_nt_from_row))
 
 
 def listed_plan(a: Csr, rows: torch.Tensor, d: int, whole_row: bool = False) -> SpmmPlan:
