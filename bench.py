@@ -642,7 +642,28 @@ def spmm_roofline_large(device, seed, n_users=2_000_000, n_items=1_000_000, n_ed
                 out[name]["traffic_over_algorithmic"] = t["hbm_bytes_per_launch"] / out[name]["algorithmic_bytes"]
                 out[name]["l2_hit_rate"] = t.get("l2_hit_rate")
         out["traffic_source"] = pmc.get("file")
+    cp = spmm_cache_policy_record()
+    if cp is not None:
+        out["cache_policy"] = cp
     return out
+
+
+def spmm_cache_policy_record():
+    """The round-5 cache-policy experiment (non-temporal loads for cold columns: profiles/r*_pmc_spmm_nt.json, tools/spmm_nt.sh) as six numbers:
+    default policy vs the best-traffic threshold. None when absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_spmm_nt.json")))
+    if not files:
+        return None
+    try:
+        v = {x["H"]: x for x in json.load(open(files[-1]))["variants"]}
+        base, best = v[0], min((x for h, x in v.items() if h > 0), key=lambda x: x["ui"].get("hbm_bytes_per_launch", 1e30))
+        return {"experiment": "nt_loads_for_cold_columns", "outcome": "negative" if best["ui"]["ms"] >= base["ui"]["ms"] else "positive", "H": best["H"],
+                "ui_ms": [_r(base["ui"]["ms"], 4), _r(best["ui"]["ms"], 4)], "ui_l2_hit": [_r(base["ui"].get("l2_hit_rate"), 3), _r(best["ui"].get("l2_hit_rate"), 3)],
+                "ui_traffic_gb": [_r(base["ui"].get("hbm_bytes_per_launch", 0) / 1e9, 3), _r(best["ui"].get("hbm_bytes_per_launch", 0) / 1e9, 3)],
+                "file": os.path.basename(files[-1])}
+    except Exception:
+        return None
 
 
 def spmm_pmc_traffic():

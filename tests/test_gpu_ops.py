@@ -160,6 +160,33 @@ def test_spmm_row_buckets_split_rows_and_epilogues(ops):
     assert rel_err(ops.spmm_raw(op.bwd, G_cpu.to(DEV)).cpu(), torch.sparse.mm(A_cpu.t(), G_cpu)) < 2e-6
 
 
+@pytest.mark.parametrize("d", [64, 128, 20])
+def test_spmm_nontemporal_policy_is_bit_identical(ops, d):
+    """llmrec_spmm_epilogue_t.x_nt_from_row (round-5 cache-policy experiment, profiles/experiments/r05_spmm_nt.md): gathered rows from that
+    index on are loaded non-temporally - a hint, so every row bucket (lane group, wavefront, block, split segments) must give the SAME
+    BITS as the default policy, whatever the threshold, with and without an init term."""
+    rng = np.random.default_rng(500 + d)
+    n_rows, n_cols = 600, 45000
+    degs = rng.integers(0, 40, size=n_rows)
+    for k, dg in enumerate([0, 1, 32, 33, 511, 512, 513, 4095, 4097, 16385, 20000]):
+        degs[(k * 13 + 1) % n_rows] = dg
+    rows, cols = rand_graph(rng, n_rows, n_cols, degs)
+    deg = np.bincount(rows, minlength=n_rows)
+    s = np.where(deg > 0, 1.0 / np.sqrt(np.maximum(deg, 1)), 0).astype(np.float32)
+    A = torch.sparse_coo_tensor(torch.tensor(np.vstack([rows, cols])), torch.tensor(s[rows]), (n_rows, n_cols)).to(DEV)
+    a = ops.operand_from_sparse_tensor(A).fwd
+    assert a.val is None                                                 # pattern-only: the products the policy applies to
+    X = torch.tensor(rng.standard_normal((n_cols, d)).astype(np.float32)).to(DEV)
+    Z = torch.tensor(rng.standard_normal((n_rows, d)).astype(np.float32)).to(DEV)
+    want = ops.spmm_raw(a, X)
+    want_z = ops.spmm_raw(a, X, epilogue=ops.spmm_epilogue(ops.EPI_NONE, 0.5, Z))
+    for H in (1, 100, 20000, n_cols, n_cols + 7):
+        got = ops.spmm_raw(a, X, epilogue=ops.spmm_epilogue(ops.EPI_NONE, x_nt_from_row=H))
+        assert torch.equal(got, want), H
+        got_z = ops.spmm_raw(a, X, epilogue=ops.spmm_epilogue(ops.EPI_NONE, 0.5, Z, x_nt_from_row=H))
+        assert torch.equal(got_z, want_z), H
+
+
 def test_spmm_general_values_and_strided_operands(ops):
     rng = np.random.default_rng(5)
     n_rows, n_cols, d = 120, 900, 64
