@@ -319,6 +319,13 @@ typedef struct {
     float* out; int64_t ldo;
 } llmrec_fuse_fwd_problem_t;
 int llmrec_fuse_fwd_multi_f32(int32_t n_problems, const llmrec_fuse_fwd_problem_t* problems_host, int32_t d, llmrec_stream_t stream);
+/* The same launch, which ALSO leaves the sum of squares of the first n_sumsq_terms norm terms of every problem (the image / text streams the
+ * feature regulariser of reference main.py:151-156 sums: the kernel holds those rows and their squared norms in registers anyway) as one
+ * partial sum per block: sumsq_partial[0 .. *n_partial_host) (fixed block partition, fixed in-block tree: deterministic). *n_partial_host is
+ * written on the HOST at call time (a pure function of the problems' row counts, <= partial_capacity or the call fails); the consumer is
+ * llmrec_bpr_multi_losses_assemble_f32. Replaces the four llmrec_sumsq_f32 launches of a step. */
+int llmrec_fuse_fwd_multi_sumsq_f32(int32_t n_problems, const llmrec_fuse_fwd_problem_t* problems_host, int32_t d, int32_t n_sumsq_terms,
+                                    float* sumsq_partial, int32_t partial_capacity, int32_t* n_partial_host, llmrec_stream_t stream);
 typedef struct {
     int64_t rows; const float* dOut; int64_t lddo;
     int32_t n_norm; const float* const* norm_terms; const int64_t* norm_ld; const float* rates;
@@ -433,6 +440,21 @@ int llmrec_bpr_multi_select_bwd_f32(int32_t n_problems, const llmrec_bpr_problem
                                     llmrec_stream_t stream);
 int llmrec_bpr_multi_losses_f32(int32_t n_problems, int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
                                 float batch_size_flag, float* out, float* saved, llmrec_stream_t stream);
+/* Round 5 - fewer launches per step:
+ * llmrec_bpr_multi_scores_step_f32 = llmrec_bpr_multi_scores_f32 that also BEGINS THE STEP on the device: beside the row stamp it advances
+ *   AdamW's step counter / bias corrections (llmrec_adamw_advance on adamw_state3; NULL = leave it) - every AdamW launch of the step is
+ *   stream-ordered behind the loss launches anyway;
+ * llmrec_bpr_multi_losses_assemble_f32 = llmrec_bpr_multi_losses_f32 (same trees, same bits in out / saved) followed, in the same single-block
+ *   launch, by the feature regulariser's value feat_reg = feat_reg_coef * sum(sumsq_partial[0 .. n_partial)) (llmrec_fuse_fwd_multi_sumsq_f32;
+ *   fixed-order tree) -> scal4[0] and by llmrec_loss_assemble_f32 mode 0 (scal4[1..3] = loss, mf, emb; running_sums3 += them in double). */
+int llmrec_bpr_multi_scores_step_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
+                                     const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                     int32_t B_max, const int32_t* n_valid_dev, float* saved, int32_t* row_stamp,
+                                     float* adamw_state3, float lr, float beta1, float beta2, llmrec_stream_t stream);
+int llmrec_bpr_multi_losses_assemble_f32(int32_t n_problems, int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
+                                         float batch_size_flag, float* out, float* saved, const float* w_mf_host,
+                                         const float* sumsq_partial, int32_t n_partial, float feat_reg_coef,
+                                         float* scal4, double* running_sums3, llmrec_stream_t stream);
 /* Clears exactly the rows llmrec_bpr_multi_bwd_f32 added into (dEu[u_b], dEi[p_b], dEi[q_b] of every problem, b < n_valid),
  * so scatter targets that start all-zero are all-zero again. */
 int llmrec_bpr_multi_zero_rows_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
@@ -527,9 +549,20 @@ int llmrec_adamw_f32(int64_t n, float* p, const float* g, float* m, float* v, co
 #define LLMREC_ADAMW_MAX_TENSORS 16
 typedef struct { float* p; const float* g; float* m; float* v; int64_t n;
                  float g_scale;   /* the gradient is g_scale * g (non-zero; 1 = plain): saves a scaling pass over a large table */
+                 float* g_out;    /* optional: receives the gradient the update used (g_scale * g) - the parameter's .grad when g is another
+                                     buffer (the user table's gradient IS inv * dE_u: no separate axpy launch); NULL = not stored */
 } llmrec_adamw_tensor_t;
 int llmrec_adamw_multi_f32(int32_t n_tensors, const llmrec_adamw_tensor_t* tensors_host, const float* state3,
                            float lr, float beta1, float beta2, float eps, float weight_decay, llmrec_stream_t stream);
+/* The same update and, in the same launch (extra blocks), the row-wise clean-up of scatter targets: for every job j < n_jobs and every
+ * b < min(*n_valid_dev, B_cap): dst_j[ids_j[b], 0 .. d_j) = 0 (what llmrec_bpr_multi_zero_rows_f32 does with its own launch; a job may span
+ * the adjacent column slices several problems scattered into). The caller orders the launch behind the last reader of those rows. */
+#define LLMREC_ZERO_ROWS_MAX_JOBS 24
+typedef struct { const int64_t* ids; float* dst; int64_t ldd; int32_t d; } llmrec_zero_rows_job_t;
+int llmrec_adamw_multi_zero_rows_f32(int32_t n_tensors, const llmrec_adamw_tensor_t* tensors_host, const float* state3,
+                                     float lr, float beta1, float beta2, float eps, float weight_decay,
+                                     int32_t n_jobs, const llmrec_zero_rows_job_t* jobs_host, int32_t B_cap, const int32_t* n_valid_dev,
+                                     llmrec_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * R9/R10  full-rank scoring + masked top-K + hit vectors

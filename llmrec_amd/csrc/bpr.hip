@@ -45,15 +45,33 @@ __device__ __forceinline__ int bpr_batch(const int32_t* n_valid_dev, int B_max) 
     return B > B_max ? B_max : (B < 0 ? 0 : B);
 }
 
+// what "a new step begins" means on the device (one thread of the scores launch): a new row stamp and, when given, AdamW's step
+// counter / bias corrections (adamw_advance_kernel's arithmetic, rowops.hip)
+struct StepBegin {
+    int32_t* row_stamp;
+    float* adamw_state;
+    float lr, b1, b2;
+};
+
 __global__ __launch_bounds__(256) void bpr_scores_kernel(BprTables t, int d, const int64_t* __restrict__ users,
                                                          const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
                                                          int B_max, const int32_t* __restrict__ n_valid_dev,
-                                                         float* __restrict__ saved_all, int saved_stride, int32_t* __restrict__ row_stamp) {
+                                                         float* __restrict__ saved_all, int saved_stride, StepBegin sb) {
     const int B = bpr_batch(n_valid_dev, B_max);
     const int prob = blockIdx.y;
     const int gl = threadIdx.x & 15;
     const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (row_stamp && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) row_stamp[0] = (int32_t)((uint32_t)row_stamp[0] + 1u);   // a new step: new stamp
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (sb.row_stamp) sb.row_stamp[0] = (int32_t)((uint32_t)sb.row_stamp[0] + 1u);   // a new step: new stamp
+        if (sb.adamw_state) {
+            const int tt = __float_as_int(sb.adamw_state[0]) + 1;
+            sb.adamw_state[0] = __int_as_float(tt);
+            const double bc1 = 1.0 - pow((double)sb.b1, (double)tt);
+            const double bc2 = 1.0 - pow((double)sb.b2, (double)tt);
+            sb.adamw_state[1] = (float)((double)sb.lr / bc1);
+            sb.adamw_state[2] = (float)sqrt(bc2);
+        }
+    }
     if (b >= B) return;
     float* sc = saved_all + (int64_t)prob * saved_stride + B_max + 4;
     const float* u = t.Eu[prob] + users[b] * t.ldu[prob];
@@ -166,13 +184,11 @@ __global__ __launch_bounds__(256) void bpr_rank_kernel(int B_max, const int32_t*
 // with fixed-order trees (deterministic) and writes the two loss values. With a gathered layout the
 // norms (and the batch size) are the sums over the ranks' blocks in rank order - identical on every
 // rank - while out[0] stays this rank's share of mf.
-__global__ __launch_bounds__(BPR_THREADS) void bpr_reduce_kernel(int B_max, const int32_t* __restrict__ n_valid_dev,
-                                                                 double remember_rate, float decay, float bsz,
-                                                                 float* __restrict__ out_all, float* __restrict__ saved_all,
-                                                                 int saved_stride, BprGather ga) {
-    __shared__ float red[BPR_THREADS];
+__device__ __forceinline__ void bpr_reduce_problem(int prob, int B_max, const int32_t* __restrict__ n_valid_dev,
+                                                   double remember_rate, float decay, float bsz,
+                                                   float* __restrict__ out_all, float* __restrict__ saved_all,
+                                                   int saved_stride, const BprGather& ga, float* red) {
     const int B = bpr_batch(n_valid_dev, B_max);
-    const int prob = blockIdx.x;
     float* saved = saved_all + (int64_t)prob * saved_stride;
     const float* sc = saved + B_max + 4;
     const int Bg = ga.g ? gather_batch(ga) : B;
@@ -197,6 +213,44 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_reduce_kernel(int B_max, cons
         out_all[prob * 2 + 1] = decay * (reg / bsz);
         saved[B_max + 0] = Su; saved[B_max + 1] = Sp; saved[B_max + 2] = Sq; saved[B_max + 3] = (float)k;
     }
+}
+
+__global__ __launch_bounds__(BPR_THREADS) void bpr_reduce_kernel(int B_max, const int32_t* __restrict__ n_valid_dev,
+                                                                 double remember_rate, float decay, float bsz,
+                                                                 float* __restrict__ out_all, float* __restrict__ saved_all,
+                                                                 int saved_stride, BprGather ga) {
+    __shared__ float red[BPR_THREADS];
+    bpr_reduce_problem(blockIdx.x, B_max, n_valid_dev, remember_rate, decay, bsz, out_all, saved_all, saved_stride, ga, red);
+}
+
+// The logged scalars of a fused step in ONE single-block launch (llmrec_bpr_multi_losses_assemble_f32): the loss values of every
+// problem (bpr_reduce_kernel's trees: the same bits), the feature regulariser from the fusion launch's per-block partial sums
+// (thread t adds partial[t], partial[t + 1024], ...; then the pairwise tree), and the assembly of llmrec_loss_assemble_f32 mode 0.
+struct LossW { float w[LLMREC_BPR_MAX_PROBLEMS]; };
+__global__ __launch_bounds__(BPR_THREADS) void bpr_losses_assemble_kernel(int n_prob, int B_max, const int32_t* __restrict__ n_valid_dev,
+                                                                          double remember_rate, float decay, float bsz,
+                                                                          float* __restrict__ out_all, float* __restrict__ saved_all, int saved_stride,
+                                                                          LossW w, const float* __restrict__ partial, int n_partial, float reg_coef,
+                                                                          float* __restrict__ scal, double* __restrict__ running) {
+    __shared__ float red[BPR_THREADS];
+    const BprGather none = {};
+    for (int p = 0; p < n_prob; ++p) {
+        bpr_reduce_problem(p, B_max, n_valid_dev, remember_rate, decay, bsz, out_all, saved_all, saved_stride, none, red);
+        __syncthreads();
+    }
+    float feat = scal[0];                                              // no partial sums: whatever llmrec_sumsq_f32 left there
+    if (partial) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n_partial; i += BPR_THREADS) s += partial[i];
+        feat = reg_coef * block_tree_sum(s, red);
+    }
+    if (threadIdx.x != 0) return;
+    float s = 0.f;
+    for (int p = 0; p < n_prob; ++p) s += out_all[2 * p] * w.w[p];     // (thread 0 wrote out_all itself: same-thread order)
+    scal[0] = feat;
+    scal[2] = out_all[0]; scal[3] = out_all[1];
+    scal[1] = s + out_all[1] + feat;
+    if (running) { running[0] += (double)scal[1]; running[1] += (double)scal[2]; running[2] += (double)scal[3]; }
 }
 
 // pass 1 of the batch-sharded forward: this rank's block of the gathered layout
@@ -565,12 +619,12 @@ extern "C" {
 static int launch_bpr_fwd(const BprTables& t, int n_prob, int d, const int64_t* users, const int64_t* pos, const int64_t* neg,
                           int B_max, const int32_t* n_valid_dev, double remember_rate, float decay, float bsz,
                           float* out, float* saved, const BprGather& ga, bool do_scores, bool do_select, float* pack_out,
-                          hipStream_t stream, int32_t* row_stamp = nullptr) {
+                          hipStream_t stream, StepBegin step_begin = StepBegin{}) {
     const int stride = LLMREC_BPR_SAVED_FLOATS(B_max);
     const BprGather none = {};
     if (do_scores && B_max > 0) {
         dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_prob);
-        bpr_scores_kernel<<<grid, 256, 0, stream>>>(t, d, users, pos, neg, B_max, n_valid_dev, saved, stride, row_stamp);
+        bpr_scores_kernel<<<grid, 256, 0, stream>>>(t, d, users, pos, neg, B_max, n_valid_dev, saved, stride, step_begin);
         LLMREC_LAUNCH_CHECK();
     }
     if (pack_out) {                                                     // local norm sums, then this rank's gather block
@@ -704,8 +758,25 @@ int llmrec_bpr_multi_scores_f32(int32_t n_problems, const llmrec_bpr_problem_t* 
     LLMREC_CHECK_ARG(B_max == 0 || (users && pos && neg), "bpr_multi_scores: null index pointer");
     BprTables t = {};
     LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, false), "bpr_multi_scores: bad problem table");
+    StepBegin sb = {};
+    sb.row_stamp = row_stamp;
     return launch_bpr_fwd(t, n_problems, d, users, pos, neg, B_max, n_valid_dev, 0.0, 0.f, 1.f, nullptr, saved, BprGather{}, true, false,
-                          nullptr, (hipStream_t)stream_, row_stamp);
+                          nullptr, (hipStream_t)stream_, sb);
+}
+
+int llmrec_bpr_multi_scores_step_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
+                                     const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                     int32_t B_max, const int32_t* n_valid_dev, float* saved, int32_t* row_stamp,
+                                     float* adamw_state3, float lr, float beta1, float beta2, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && problems_host && d > 0 && saved, "bpr_multi_scores_step: bad argument");
+    if (B_max > LLMREC_BPR_MAX_B) { set_error("bpr_multi_scores_step: B_max %d > %d", B_max, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
+    LLMREC_CHECK_ARG(B_max > 0 && users && pos && neg, "bpr_multi_scores_step: empty batch capacity or null index pointer (the launch carries the step's counters)");
+    BprTables t = {};
+    LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, false), "bpr_multi_scores_step: bad problem table");
+    StepBegin sb = {};
+    sb.row_stamp = row_stamp; sb.adamw_state = adamw_state3; sb.lr = lr; sb.b1 = beta1; sb.b2 = beta2;
+    return launch_bpr_fwd(t, n_problems, d, users, pos, neg, B_max, n_valid_dev, 0.0, 0.f, 1.f, nullptr, saved, BprGather{}, true, false,
+                          nullptr, (hipStream_t)stream_, sb);
 }
 
 int llmrec_bpr_multi_select_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
@@ -733,6 +804,23 @@ int llmrec_bpr_multi_losses_f32(int32_t n_problems, int32_t B_max, const int32_t
     if (B_max > LLMREC_BPR_MAX_B) { set_error("bpr_multi_losses: B_max %d > %d", B_max, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
     bpr_reduce_kernel<<<n_problems, BPR_THREADS, 0, (hipStream_t)stream_>>>(B_max, n_valid_dev, remember_rate, decay, batch_size_flag, out, saved,
                                                                            LLMREC_BPR_SAVED_FLOATS(B_max), BprGather{});
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_bpr_multi_losses_assemble_f32(int32_t n_problems, int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
+                                         float batch_size_flag, float* out, float* saved, const float* w_mf_host,
+                                         const float* sumsq_partial, int32_t n_partial, float feat_reg_coef,
+                                         float* scal4, double* running_sums3, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && B_max >= 0 && out && saved && w_mf_host && scal4,
+                     "bpr_multi_losses_assemble: bad argument");
+    LLMREC_CHECK_ARG(n_partial >= 0 && (n_partial == 0 || sumsq_partial), "bpr_multi_losses_assemble: partial sums without a buffer");
+    if (B_max > LLMREC_BPR_MAX_B) { set_error("bpr_multi_losses_assemble: B_max %d > %d", B_max, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
+    LossW w = {};
+    for (int i = 0; i < n_problems; ++i) w.w[i] = w_mf_host[i];
+    bpr_losses_assemble_kernel<<<1, BPR_THREADS, 0, (hipStream_t)stream_>>>(n_problems, B_max, n_valid_dev, remember_rate, decay, batch_size_flag, out, saved,
+                                                                           LLMREC_BPR_SAVED_FLOATS(B_max), w, n_partial > 0 ? sumsq_partial : nullptr,
+                                                                           n_partial, feat_reg_coef, scal4, running_sums3);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

@@ -213,6 +213,8 @@ struct FuseMulti {
     const uint8_t* row_flags[FUSE_MAX_PROBLEMS];                              // backward: not active = dOut and the sources of this row are all-zero
     const int32_t* row_stamp[FUSE_MAX_PROBLEMS];                              // device counter defining "active" (NULL: non-zero)
     int block_begin;                                                          // first block of problem 1
+    int n_sumsq;                                                              // forward: the first n_sumsq norm terms' squared norms are summed
+    float* sumsq_partial;                                                     // ... into one partial per block [gridDim.x]
 };
 #define ROW_LOOP_MULTI(m)                                                                          \
     const int prob = (int)blockIdx.x >= (m).block_begin ? 1 : 0;                                   \
@@ -226,6 +228,8 @@ struct FuseMulti {
 
 template <int VEC, int NCHUNK>
 __global__ __launch_bounds__(256) void fuse_fwd_multi_kernel(int d, FuseMulti m) {
+    __shared__ float ss_red[256];
+    float ss = 0.f;                                                     // this thread's share of sum ||x||^2 over the first n_sumsq terms
     ROW_LOOP_MULTI(m) {
         RowReg<VEC, NCHUNK> acc, t;
         acc.fill(0.f);
@@ -242,7 +246,9 @@ __global__ __launch_bounds__(256) void fuse_fwd_multi_kernel(int d, FuseMulti m)
             for (int q = 0; q < VEC; ++q) acc.x[k][q] *= a.mean_scale;
         for (int i = 0; i < a.n_norm; ++i) {
             t.load(a.norm_terms[i] + row * a.norm_ld[i], gl, d);
-            const float nrm = fmaxf(sqrtf(t.dot(t)), 1e-12f);           // F.normalize eps
+            const float sq = t.dot(t);
+            if (i < m.n_sumsq && gl == 0) ss += sq;                     // (rows of a thread in ascending order, terms in order: fixed)
+            const float nrm = fmaxf(sqrtf(sq), 1e-12f);                 // F.normalize eps
             const float w = a.rates[i] / nrm;
 #pragma unroll
             for (int k = 0; k < NCHUNK; ++k)
@@ -250,6 +256,15 @@ __global__ __launch_bounds__(256) void fuse_fwd_multi_kernel(int d, FuseMulti m)
                 for (int q = 0; q < VEC; ++q) acc.x[k][q] = fmaf(w, t.x[k][q], acc.x[k][q]);
         }
         acc.store(m.out[prob] + row * m.ldo[prob], gl, d);
+    }
+    if (m.n_sumsq > 0) {                                                // uniform: one partial per block, pairwise tree over the 256 threads
+        ss_red[threadIdx.x] = ss;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) ss_red[threadIdx.x] += ss_red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) m.sumsq_partial[blockIdx.x] = ss_red[0];
     }
 }
 
@@ -394,14 +409,45 @@ struct AdamwTensors {
     float* v[LLMREC_ADAMW_MAX_TENSORS];
     int64_t n[LLMREC_ADAMW_MAX_TENSORS];
     float gscale[LLMREC_ADAMW_MAX_TENSORS];
+    float* gout[LLMREC_ADAMW_MAX_TENSORS];
     int32_t block_begin[LLMREC_ADAMW_MAX_TENSORS + 1];
     int32_t n_tensors;
 };
 constexpr int ADAMW_PER_BLOCK = 256 * 16;
 
+struct ZeroRowJobs {
+    const int64_t* ids[LLMREC_ZERO_ROWS_MAX_JOBS];
+    float* dst[LLMREC_ZERO_ROWS_MAX_JOBS];
+    int64_t ldd[LLMREC_ZERO_ROWS_MAX_JOBS];
+    int32_t d[LLMREC_ZERO_ROWS_MAX_JOBS];
+    int32_t n_jobs, B_cap, blocks_per_job, first_block;      // blocks >= first_block belong to the clean-up: (job, 16 samples) each
+    const int32_t* n_valid;
+};
+
+__device__ __forceinline__ void adamw_block(const AdamwTensors& t, const float* __restrict__ state, float decay_mul, float b1, float b2, float eps);
+
 // all parameters of the model in one launch: block -> (tensor, 4096-element chunk)
 __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamwTensors t, const float* __restrict__ state, float decay_mul,
                                                           float b1, float b2, float eps) {
+    adamw_block(t, state, decay_mul, b1, b2, eps);
+}
+
+// the same + the row-wise clean-up of the step's scatter targets in the trailing blocks (llmrec_adamw_multi_zero_rows_f32)
+__global__ __launch_bounds__(256) void adamw_multi_zero_rows_kernel(AdamwTensors t, const float* __restrict__ state, float decay_mul,
+                                                                    float b1, float b2, float eps, ZeroRowJobs z) {
+    if ((int)blockIdx.x < z.first_block) { adamw_block(t, state, decay_mul, b1, b2, eps); return; }
+    const int rel = (int)blockIdx.x - z.first_block;
+    const int job = rel / z.blocks_per_job, blk = rel - job * z.blocks_per_job;
+    int B = z.n_valid ? z.n_valid[0] : z.B_cap;
+    B = B > z.B_cap ? z.B_cap : (B < 0 ? 0 : B);
+    const int gl = threadIdx.x & 15;
+    const int b = blk * 16 + (threadIdx.x >> 4);
+    if (b >= B) return;
+    float* row = z.dst[job] + z.ids[job][b] * z.ldd[job];
+    for (int c = gl; c < z.d[job]; c += 16) row[c] = 0.f;
+}
+
+__device__ __forceinline__ void adamw_block(const AdamwTensors& t, const float* __restrict__ state, float decay_mul, float b1, float b2, float eps) {
     int k = 0;
     while (k + 1 < t.n_tensors && (int)blockIdx.x >= t.block_begin[k + 1]) ++k;
     const int64_t base = (int64_t)(blockIdx.x - t.block_begin[k]) * ADAMW_PER_BLOCK;
@@ -409,6 +455,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamwTensors t, const 
     float* __restrict__ m = t.m[k]; float* __restrict__ v = t.v[k];
     const int64_t n = t.n[k];
     const float gs = t.gscale[k];
+    float* __restrict__ go = t.gout[k];
     const float step_size = state[1], bc2s = state[2];
     const float w1 = 1.0f - b1, w2 = 1.0f - b2;
 #pragma unroll 4
@@ -416,6 +463,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamwTensors t, const 
         const int64_t i = base + j * 256 + threadIdx.x;
         if (i >= n) break;
         const float gi = gs == 1.0f ? g[i] : gs * g[i];
+        if (go) go[i] = gi;
         float pi = p[i] * decay_mul;
         const float mi = m[i] + w1 * (gi - m[i]);
         const float vi = fmaf(w2 * gi, gi, v[i] * b2);
@@ -813,8 +861,14 @@ static int fuse_bwd_impl(int64_t rows, int32_t d, const float* dOut, int64_t ldd
 }
 
 int llmrec_fuse_fwd_multi_f32(int32_t n_problems, const llmrec_fuse_fwd_problem_t* p, int32_t d, llmrec_stream_t stream_) {
+    return llmrec_fuse_fwd_multi_sumsq_f32(n_problems, p, d, 0, nullptr, 0, nullptr, stream_);
+}
+
+int llmrec_fuse_fwd_multi_sumsq_f32(int32_t n_problems, const llmrec_fuse_fwd_problem_t* p, int32_t d, int32_t n_sumsq_terms,
+                                    float* sumsq_partial, int32_t partial_capacity, int32_t* n_partial_host, llmrec_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= FUSE_MAX_PROBLEMS && p && d > 0, "fuse_fwd_multi: 1..%d problems", FUSE_MAX_PROBLEMS);
+    LLMREC_CHECK_ARG(n_sumsq_terms >= 0 && (n_sumsq_terms == 0 || (sumsq_partial && n_partial_host)), "fuse_fwd_multi: sum of squares without a partial buffer");
     FuseMulti m = {};
     bool vec4 = d % 4 == 0;
     int blocks[FUSE_MAX_PROBLEMS] = {0, 0};
@@ -841,6 +895,12 @@ int llmrec_fuse_fwd_multi_f32(int32_t n_problems, const llmrec_fuse_fwd_problem_
     }
     m.block_begin = blocks[0];
     const int grid = blocks[0] + blocks[1];
+    if (n_sumsq_terms > 0) {
+        for (int k = 0; k < n_problems; ++k) LLMREC_CHECK_ARG(n_sumsq_terms <= p[k].n_norm, "fuse_fwd_multi: problem %d has fewer than %d norm terms", k, n_sumsq_terms);
+        if (grid > partial_capacity) { set_error("fuse_fwd_multi: %d partial sums > capacity %d", grid, partial_capacity); return LLMREC_EWORKSPACE; }
+        *n_partial_host = grid;
+        m.n_sumsq = n_sumsq_terms; m.sumsq_partial = sumsq_partial;
+    }
     if (grid == 0) return LLMREC_OK;
     int rc = dispatch_rows(d, vec4,
         [&](auto nc) { fuse_fwd_multi_kernel<4, decltype(nc)::value><<<grid, 256, 0, stream>>>(d, m); return 0; },
@@ -936,25 +996,56 @@ int llmrec_adamw_f32(int64_t n, float* p, const float* g, float* m, float* v, co
     return LLMREC_OK;
 }
 
-int llmrec_adamw_multi_f32(int32_t n_tensors, const llmrec_adamw_tensor_t* tensors_host, const float* state3,
-                           float lr, float beta1, float beta2, float eps, float weight_decay, llmrec_stream_t stream_) {
+static int fill_adamw(AdamwTensors& t, int32_t n_tensors, const llmrec_adamw_tensor_t* tensors_host, const float* state3, int& blocks) {
     LLMREC_CHECK_ARG(n_tensors >= 0 && n_tensors <= LLMREC_ADAMW_MAX_TENSORS && state3 && (n_tensors == 0 || tensors_host),
                      "adamw_multi: bad argument (at most %d tensors)", LLMREC_ADAMW_MAX_TENSORS);
-    AdamwTensors t = {};
     t.n_tensors = n_tensors;
-    int blocks = 0;
+    blocks = 0;
     for (int i = 0; i < n_tensors; ++i) {
         const llmrec_adamw_tensor_t& x = tensors_host[i];
         LLMREC_CHECK_ARG(x.n >= 0 && (x.n == 0 || (x.p && x.g && x.m && x.v)), "adamw_multi: tensor %d has a null pointer", i);
         LLMREC_CHECK_ARG(x.g_scale != 0.0f, "adamw_multi: tensor %d has g_scale 0 (set 1 for a plain gradient)", i);
-        t.p[i] = x.p; t.g[i] = x.g; t.m[i] = x.m; t.v[i] = x.v; t.n[i] = x.n; t.gscale[i] = x.g_scale;
+        t.p[i] = x.p; t.g[i] = x.g; t.m[i] = x.m; t.v[i] = x.v; t.n[i] = x.n; t.gscale[i] = x.g_scale; t.gout[i] = x.g_out;
         t.block_begin[i] = blocks;
         blocks += (int)ceil_div(x.n, ADAMW_PER_BLOCK);
     }
     for (int i = n_tensors; i <= LLMREC_ADAMW_MAX_TENSORS; ++i) t.block_begin[i] = blocks;
+    return LLMREC_OK;
+}
+
+int llmrec_adamw_multi_f32(int32_t n_tensors, const llmrec_adamw_tensor_t* tensors_host, const float* state3,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, llmrec_stream_t stream_) {
+    AdamwTensors t = {};
+    int blocks = 0;
+    if (int rc = fill_adamw(t, n_tensors, tensors_host, state3, blocks)) return rc;
     if (blocks == 0) return LLMREC_OK;
     const float decay_mul = (float)(1.0 - (double)lr * (double)weight_decay);
     adamw_multi_kernel<<<blocks, 256, 0, (hipStream_t)stream_>>>(t, state3, decay_mul, beta1, beta2, eps);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_adamw_multi_zero_rows_f32(int32_t n_tensors, const llmrec_adamw_tensor_t* tensors_host, const float* state3,
+                                     float lr, float beta1, float beta2, float eps, float weight_decay,
+                                     int32_t n_jobs, const llmrec_zero_rows_job_t* jobs_host, int32_t B_cap, const int32_t* n_valid_dev,
+                                     llmrec_stream_t stream_) {
+    AdamwTensors t = {};
+    int blocks = 0;
+    if (int rc = fill_adamw(t, n_tensors, tensors_host, state3, blocks)) return rc;
+    LLMREC_CHECK_ARG(n_jobs >= 0 && n_jobs <= LLMREC_ZERO_ROWS_MAX_JOBS && B_cap >= 0 && (n_jobs == 0 || jobs_host),
+                     "adamw_multi_zero_rows: bad clean-up table (at most %d jobs)", LLMREC_ZERO_ROWS_MAX_JOBS);
+    ZeroRowJobs z = {};
+    z.n_jobs = n_jobs; z.B_cap = B_cap; z.n_valid = n_valid_dev; z.first_block = blocks;
+    z.blocks_per_job = (int)ceil_div(B_cap, 16);
+    for (int j = 0; j < n_jobs; ++j) {
+        LLMREC_CHECK_ARG(B_cap == 0 || (jobs_host[j].ids && jobs_host[j].dst && jobs_host[j].d > 0 && jobs_host[j].ldd >= jobs_host[j].d),
+                         "adamw_multi_zero_rows: job %d: null pointer or ld < d", j);
+        z.ids[j] = jobs_host[j].ids; z.dst[j] = jobs_host[j].dst; z.ldd[j] = jobs_host[j].ldd; z.d[j] = jobs_host[j].d;
+    }
+    const int total = blocks + n_jobs * z.blocks_per_job;
+    if (total == 0) return LLMREC_OK;
+    const float decay_mul = (float)(1.0 - (double)lr * (double)weight_decay);
+    adamw_multi_zero_rows_kernel<<<total, 256, 0, (hipStream_t)stream_>>>(t, state3, decay_mul, beta1, beta2, eps, z);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

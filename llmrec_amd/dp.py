@@ -80,6 +80,7 @@ class DataParallelStep(FusedStep):
     # -- the three compute phases -----------------------------------------------------------------
     WGRAD_ROWS = False          # (the replicas keep the dense weight-gradient launch: their gradients are summed over ranks afterwards)
     INLINE_ADAMW = False        # the gradients are all-reduced over the replicas first (exchange_grads), then phase_c updates
+    FOLD = False                # (the folded launches of the single-GPU step assume the in-step AdamW)
 
     def _bpr_phase(self, phase, users, pos, neg, n_valid):
         hp = self.hp

@@ -199,6 +199,17 @@ class FusedStep:
         # step's tail is then one small launch instead of reduction -> cross-stream join -> a 1.96 M-parameter update.
         # (Batch-sharded replicas all-reduce the gradients first and update afterwards: llmrec_amd/dp.py sets this to False.)
         self.inline_adamw = getattr(type(self), "INLINE_ADAMW", True)
+        # FOLDED launches (round 5; LLMREC_FOLD=0 restores the 36-launch step): AdamW's counter advances inside the scores
+        # launch ("a new step begins": llmrec_bpr_multi_scores_step_f32), the feature regulariser's sum of squares comes out of the fusion launch
+        # as per-block partials (llmrec_fuse_fwd_multi_sumsq_f32: it holds those rows anyway) and is reduced by the ONE launch that also forms
+        # the loss values and assembles the logged scalars (llmrec_bpr_multi_losses_assemble_f32), the user table's AdamW reads inv * dE_u
+        # directly and stores it as the table's .grad on the way (no axpy), and the row-wise clean-up of the scatter targets rides in the item
+        # table's AdamW launch (llmrec_adamw_multi_zero_rows_f32): 36 -> 28 launches, same arithmetic except the regulariser's summation tree.
+        self.fold = getattr(type(self), "FOLD", True) and os.environ.get("LLMREC_FOLD", "1") == "1" and self.inline_adamw
+        if self.fold:
+            self.ss_cap = 2 * 2048                                # >= the fusion launch's grid (two problems, <= 2048 blocks each)
+            self.ss_partial = torch.zeros(self.ss_cap, dtype=torch.float32, device=dev)
+            self.ss_n = 0
         self._zero_in_forward = False                         # set by step_eager: forward() alone (evaluation) must not advance AdamW
         self._emb_params = [model.user_id_embedding.weight, model.item_id_embedding.weight]
         self._lin_params = [p for p in optimizer.params if p.grad is not None and all(p is not e for e in self._emb_params)]
@@ -358,7 +369,7 @@ class FusedStep:
         with self._on(self.s2):                                          # ID chain: needs no projection
             if sampler is not None and self.multi_stream:                # the batch is first read by the losses, after the join below:
                 sampler()                                                # sampling rides beside the projection instead of ahead of it
-            if self._zero_in_forward:
+            if self._zero_in_forward and not self.fold:
                 self.opt.advance()                                       # AdamW's step counter / bias corrections, off the critical path
             i_prev = m.item_id_embedding.weight
             for l in range(self.L):
@@ -382,7 +393,7 @@ class FusedStep:
         with self._on(self.s1):                                          # profile stream: items first
             self._spmm(self.iu.fwd, self.P_usr, self.prof_i, tag=1)
             self._spmm(self.ui.fwd, self.prof_i, self.prof_u, tag=1)
-        if self._zero_in_forward:                                        # training: the feature regulariser's value needs only U_cat / I_cat -
+        if self._zero_in_forward and not self.fold:                      # training: the feature regulariser's value needs only U_cat / I_cat -
             self._fork(self.s3)                                          # captured HERE it runs beside the fusion and the BPR launches (captured
             with self._on(self.s3):                                      # after the BPR backward, round 2, the graph ran it last: the step's tail)
                 self._feat_reg()
@@ -404,7 +415,12 @@ class FusedStep:
         arr = (ops.FuseFwdProblem * 2)()
         problem(arr[0], self.E_i, m.item_id_embedding.weight, self.Il, self.I_cat, self.prof_i)
         problem(arr[1], self.E_u, m.user_id_embedding.weight, self.Ul, self.U_cat, self.prof_u)
-        _call("llmrec_fuse_fwd_multi_f32", 2, arr, d)
+        if self.fold and self._zero_in_forward:                          # + the regulariser's sum of squares over the image / text streams (terms 0, 1)
+            n_part = _c.c_int32(0)
+            _call("llmrec_fuse_fwd_multi_sumsq_f32", 2, arr, d, 2, _p(self.ss_partial), self.ss_cap, _c.byref(n_part))
+            self.ss_n = int(n_part.value)
+        else:
+            _call("llmrec_fuse_fwd_multi_f32", 2, arr, d)
 
     def outputs(self):
         """The reference's 14-tuple as views of the forward buffers (Models.py:199)."""
@@ -438,18 +454,32 @@ class FusedStep:
         # critical path: scores -> [selection + gradient rows] (two launches); the loss VALUES (one more launch) and their assembly for
         # the log line ride on the ID chain's stream (a branch of their own right behind the BPR launches: the graph ran it as the step's tail)
         self._check_scatter_targets()
-        _call("llmrec_bpr_multi_scores_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), _p(self.saved),
-              _p(self.row_stamp))
+        if self.fold:                                                    # the scores launch begins the step: row stamp + AdamW's counter
+            o = self.opt
+            if o.dev_state is None:
+                o.dev_state = torch.zeros(3, dtype=torch.float32, device=self.E_u.device)
+            _call("llmrec_bpr_multi_scores_step_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), _p(self.saved),
+                  _p(self.row_stamp), _p(o.dev_state), o.lr, o.betas[0], o.betas[1])
+        else:
+            _call("llmrec_bpr_multi_scores_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), _p(self.saved),
+                  _p(self.row_stamp))
         _call("llmrec_bpr_multi_select_bwd_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), remember,
               float(hp.decay), float(hp.batch_size), _p(self.saved), _p(self.flag_u), _p(self.flag_i), _p(self.row_stamp))
 
         def side():                              # (runs on the ID chain's stream, _backward places it)
+            if self.fold:                        # loss values + regulariser (the fusion launch's partial sums) + assembly: one launch
+                w = (_c.c_float * self.n_prob)(*self.w_mf)
+                _call("llmrec_bpr_multi_losses_assemble_f32", self.n_prob, B, _p(n_valid), remember, float(hp.decay), float(hp.batch_size),
+                      _p(self.out), _p(self.saved), w, _p(self.ss_partial), self.ss_n, float(hp.feat_reg_decay * 0.5 / self.I),
+                      _p(self.scal), _p(self.epoch_sums))
+                return
             _call("llmrec_bpr_multi_losses_f32", self.n_prob, B, _p(n_valid), remember, float(hp.decay), float(hp.batch_size),
                   _p(self.out), _p(self.saved))
             self._join(self.s3)                  # the regulariser's value (s3, during the forward)
             self._assemble_loss(0)               # loss = sum_p w_mf[p] * mf_p + emb_0 + feat_reg
         self._backward(probs, users, pos, neg, n_valid, side_work=side, bpr_bwd_done=True)
-        self._join(self.s3)
+        if not self.fold:
+            self._join(self.s3)
 
     def _assemble_loss(self, mode: int, tail=None, inv_world: float = 1.0):
         """Logged scalars (main.py:273,280-283) from the 8 BPR results + the regulariser: one single-wave launch."""
@@ -517,7 +547,22 @@ class FusedStep:
         ev_fuse = self._mark()                                           # the fusion backward has read dE_u / dE_i
         m = self.m
         inv = 1.0 / (L + 1)
-        self._fork(self.s1)
+        # capture order at this fork (experiment knobs, profiles/experiments/r05_step_chain.md): LLMREC_BWD_MAIN_FIRST=1 captures the critical
+        # transposed side product BEFORE the two side branches; LLMREC_LOSS_STREAM=s3 puts the logged-scalar launch on its own stream
+        main_first = os.environ.get("LLMREC_BWD_MAIN_FIRST", "0") == "1" and self.multi_stream
+        loss_s3 = os.environ.get("LLMREC_LOSS_STREAM", "s2") == "s3" and self.multi_stream and side_work is not None
+        if main_first:
+            self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
+            if not self.preprop:
+                self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
+            self._fork_from(ev_fuse, self.s1)
+        else:
+            self._fork(self.s1)
+        if loss_s3:
+            self._fork_from(ev_rows, self.s3)
+            with self._on(self.s3):
+                side_work()
+            side_work = None
         with self._on(self.s1):
             # profile chain: prof_u = ui(prof_i), prof_i = iu(P_usr); user_trans' weight gradient joins the item-side ones below
             self._spmm(self.ui.bwd, self.dprof_u, self.dprof_i, accumulate=True, tag=1)
@@ -534,9 +579,12 @@ class FusedStep:
             # U^0 only enters the mean: the user table's gradient needs nothing else. It and the logged loss values go first: whatever
             # this stream still has queued when the weight-gradient GEMM takes every CU (about when the chain's last SpMM starts)
             # waits for the GEMM's blocks to retire and becomes the step's tail.
-            self._axpy(inv, self.dE_u, m.user_id_embedding.weight.grad, False)
-            if self.inline_adamw:                                                 # U^0 only enters the mean: the user table's gradient is final here
-                self.opt.step_params(self._emb_params[:1])
+            if self.fold:                                                         # AdamW reads inv * dE_u and stores it as the table's .grad
+                self.opt.step_params(self._emb_params[:1], sources={self._emb_params[0]: (self.dE_u, inv)})
+            else:
+                self._axpy(inv, self.dE_u, m.user_id_embedding.weight.grad, False)
+                if self.inline_adamw:                                             # U^0 only enters the mean: the user table's gradient is final here
+                    self.opt.step_params(self._emb_params[:1])
             if side_work is not None:
                 side_work()
             g = self.bufI
@@ -562,9 +610,14 @@ class FusedStep:
             # stamps needed a clean-up - makes the graph runtime start the WHOLE chain late: profiles/experiments/r03_wgrad.md, last table.)
             if ev_fuse is not None:
                 torch.cuda.current_stream().wait_event(ev_fuse)
-            _call("llmrec_bpr_multi_zero_rows_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid))
-            if self.inline_adamw:                                                 # the item table's gradient is final: update it here,
-                self.opt.step_params(self._emb_params[1:])                        # beside the weight-gradient GEMM
+            if self.fold and L > 0:                                               # clean-up + the item table's AdamW in ONE launch
+                jobs = [(users, self.dE_u), (pos, self.dE_i), (neg, self.dE_i), (users, self.sc_U), (pos, self.sc_I), (neg, self.sc_I),
+                        (users, self.sc_prof)]
+                self.opt.step_params(self._emb_params[1:], zero_rows=(jobs, B, n_valid))
+            else:
+                _call("llmrec_bpr_multi_zero_rows_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid))
+                if self.inline_adamw:                                             # the item table's gradient is final: update it here,
+                    self.opt.step_params(self._emb_params[1:])                    # beside the weight-gradient GEMM
 
         # the ID chain depends on the BPR rows only, not on the fusion backward: it starts beside it (captured after it, so that the
         # fusion backward stays the graph's same-queue successor of the BPR launch) and has most of its SpMMs behind it when the
@@ -574,9 +627,10 @@ class FusedStep:
         with self._on(self.s2):
             id_chain()
         # side chain: I_cat = iu(U_cat), U_cat = ui(P_cat) (or the pre-propagated projection); then the item-side weight gradients
-        self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
-        if not self.preprop:
-            self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
+        if not main_first:
+            self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
+            if not self.preprop:
+                self._spmm(self.ui.bwd, self.dU_cat, self.dP_cat)
         dY_cat = self.dU_cat if self.preprop else self.dP_cat
         targets = self.wgrad_targets(dY_cat, self.dP_usr)
         item_pairs, text_pairs, image_pairs = targets[0][0], targets[2][0], targets[3][0]
@@ -619,6 +673,8 @@ class FusedStep:
         if self.inline_adamw:                                            # whatever the reduction launch did not update (all four Linears on
             self.opt.step_params([p_ for p_ in self._lin_params if all(p_ is not q for q in updated)])   # the per-target fallback paths)
         self._join(self.s2)
+        if loss_s3:
+            self._join(self.s3)
 
     def _train_forward(self, sampler=None):
         """forward() of a training step: also advances AdamW's counters (and samples the batch) on a side stream."""

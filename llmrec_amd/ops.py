@@ -802,7 +802,13 @@ def sumsq(coef: float, Xs: Sequence[torch.Tensor]):
 # ---------------------------------------------------------------------------------------------
 class AdamwTensor(_c.Structure):
     """llmrec_adamw_tensor_t"""
-    _fields_ = [("p", _c.c_void_p), ("g", _c.c_void_p), ("m", _c.c_void_p), ("v", _c.c_void_p), ("n", _c.c_int64), ("g_scale", _c.c_float)]
+    _fields_ = [("p", _c.c_void_p), ("g", _c.c_void_p), ("m", _c.c_void_p), ("v", _c.c_void_p), ("n", _c.c_int64), ("g_scale", _c.c_float),
+                ("g_out", _c.c_void_p)]
+
+
+class ZeroRowsJob(_c.Structure):
+    """llmrec_zero_rows_job_t"""
+    _fields_ = [("ids", _c.c_void_p), ("dst", _c.c_void_p), ("ldd", _c.c_int64), ("d", _c.c_int32)]
 
 
 class FusedAdamW:
@@ -834,10 +840,13 @@ class FusedAdamW:
         _lib.call("llmrec_adamw_advance", _p(self.dev_state), self.lr, self.betas[0], self.betas[1], _stream())
 
     @torch.no_grad()
-    def step_params(self, params):
+    def step_params(self, params, sources=None, zero_rows=None):
         """The update of a SUBSET of the parameters (their gradients are final), the step counter having been advanced already
-        (advance()): a fused step updates its embedding tables while the weight-gradient GEMM of the Linears is still running."""
-        self._update([p for p in params if p.grad is not None])
+        (advance()): a fused step updates its embedding tables while the weight-gradient GEMM of the Linears is still running.
+        sources: {param: (G, scale)} - the gradient of that parameter is scale * G (another buffer); it is ALSO stored into param.grad by the
+        same launch (llmrec_adamw_tensor_t.g_out: no separate scaling pass). zero_rows: (jobs [(ids int64, dst [rows, width])], B_cap, n_valid_dev) -
+        the row-wise clean-up of the step's scatter targets rides in the same launch (llmrec_adamw_multi_zero_rows_f32)."""
+        self._update([p for p in params if p.grad is not None], sources=sources, zero_rows=zero_rows)
 
     @torch.no_grad()
     def step(self, advanced: bool = False):
@@ -857,14 +866,16 @@ class FusedAdamW:
             st = self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
         return st
 
-    def _update(self, live):
-        if not live:
+    def _update(self, live, sources=None, zero_rows=None):
+        if not live and zero_rows is None:
             return
         _need_gpu(*live)
         cap = CONST["LLMREC_ADAMW_MAX_TENSORS"]
-        for lo in range(0, len(live), cap):
+        if zero_rows is not None and len(live) > cap:
+            raise RuntimeError("FusedAdamW: the clean-up rides with at most %d tensors" % cap)
+        for lo in range(0, max(len(live), 1), cap):
             group = live[lo:lo + cap]
-            arr = (AdamwTensor * len(group))()
+            arr = (AdamwTensor * max(len(group), 1))()
             keep = []
             for i, p in enumerate(group):
                 st = self.state.get(p)
@@ -872,12 +883,31 @@ class FusedAdamW:
                     st = self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
                 if not p.is_contiguous():
                     raise RuntimeError("FusedAdamW: contiguous parameters expected")
-                g = p.grad.contiguous()
+                src = sources.get(p) if sources else None
+                if src is not None:
+                    g, scale = src
+                    if not g.is_contiguous() or g.numel() != p.numel() or not p.grad.is_contiguous():
+                        raise RuntimeError("FusedAdamW: a gradient source is a contiguous tensor of the parameter's size")
+                    arr[i].g_scale, arr[i].g_out = float(scale) * float(self.grad_scale.get(p, 1.0)), p.grad.data_ptr()
+                else:
+                    g = p.grad.contiguous()
+                    arr[i].g_scale, arr[i].g_out = float(self.grad_scale.get(p, 1.0)), None
                 keep.append(g)
                 arr[i].p, arr[i].g, arr[i].m, arr[i].v, arr[i].n = p.data_ptr(), g.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), p.numel()
-                arr[i].g_scale = float(self.grad_scale.get(p, 1.0))
-            _lib.call("llmrec_adamw_multi_f32", len(group), arr, _p(self.dev_state), self.lr, self.betas[0], self.betas[1],
-                      self.eps, self.wd, _stream())
+            if zero_rows is None:
+                _lib.call("llmrec_adamw_multi_f32", len(group), arr, _p(self.dev_state), self.lr, self.betas[0], self.betas[1],
+                          self.eps, self.wd, _stream())
+            else:
+                jobs, b_cap, n_valid = zero_rows
+                if len(jobs) > CONST["LLMREC_ZERO_ROWS_MAX_JOBS"]:
+                    raise RuntimeError("FusedAdamW: %d clean-up jobs exceed LLMREC_ZERO_ROWS_MAX_JOBS" % len(jobs))
+                jarr = (ZeroRowsJob * max(len(jobs), 1))()
+                for j, (ids, dst) in enumerate(jobs):
+                    jarr[j].ids, jarr[j].dst, jarr[j].ldd, jarr[j].d = ids.data_ptr(), dst.data_ptr(), _ld(dst), dst.shape[1]
+                if self.dev_state is None:
+                    raise RuntimeError("FusedAdamW: advance() first")
+                _lib.call("llmrec_adamw_multi_zero_rows_f32", len(group), arr, _p(self.dev_state), self.lr, self.betas[0], self.betas[1],
+                          self.eps, self.wd, len(jobs), jarr, int(b_cap), _p(n_valid), _stream())
 
 
 # ---------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ PAIRS = {
     "llmrec_wgrad_problem_t": ops.WgradProblem, "llmrec_bpr_problem_t": ops.BprProblem, "llmrec_adamw_tensor_t": ops.AdamwTensor,
     "llmrec_zero_tensor_t": ops.ZeroTensor, "llmrec_wgrad_target_t": ops.WgradTarget,
     "llmrec_fuse_fwd_problem_t": ops.FuseFwdProblem, "llmrec_fuse_bwd_problem_t": ops.FuseBwdProblem,
-    "llmrec_wgrad_update_t": ops.WgradUpdate,
+    "llmrec_wgrad_update_t": ops.WgradUpdate, "llmrec_zero_rows_job_t": ops.ZeroRowsJob,
 }
 
 

@@ -21,15 +21,17 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-@pytest.mark.parametrize("path", ["fused", "modular", "graph", "fused_f32", "fused_reference_order"])
+@pytest.mark.parametrize("path", ["fused", "modular", "graph", "fused_f32", "fused_reference_order", "fused_unfolded", "graph_unfolded"])
 def test_training_steps_and_eval_match_reference(golden, path, monkeypatch):
     """path: fused = hand-written backward over preallocated buffers (llmrec_amd/fused.py, the
     default: item-side operands pre-propagated, (A F) W^T), modular = torch.autograd over the per-op Functions, graph = fused +
     HIP graph replay, fused_f32 = fused with the bit-exact fp32-MFMA projection instead of the default 3-term bf16 split,
-    fused_reference_order = fused with projection then propagation, A (F W^T), as the reference orders them."""
+    fused_reference_order = fused with projection then propagation, A (F W^T), as the reference orders them; *_unfolded = LLMREC_FOLD=0, the
+    36-launch step of round 4 (separate sum-of-squares, AdamW-counter, loss-value, assembly, axpy and row clean-up launches)."""
     assert torch.cuda.is_available()
     monkeypatch.setenv("LLMREC_FUSED", "0" if path == "modular" else "1")
-    monkeypatch.setenv("LLMREC_GRAPH", "1" if path == "graph" else "0")
+    monkeypatch.setenv("LLMREC_GRAPH", "1" if path.startswith("graph") else "0")
+    monkeypatch.setenv("LLMREC_FOLD", "0" if path.endswith("_unfolded") else "1")
     monkeypatch.setenv("LLMREC_GEMM", "f32" if path == "fused_f32" else "bf16x3")
     monkeypatch.setenv("LLMREC_PREPROPAGATE", "0" if path == "fused_reference_order" else "1")
     m = load_dropin(golden_argv(golden))
