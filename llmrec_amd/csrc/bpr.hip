@@ -224,32 +224,67 @@ __global__ __launch_bounds__(BPR_THREADS) void bpr_reduce_kernel(int B_max, cons
 }
 
 // The logged scalars of a fused step in ONE single-block launch (llmrec_bpr_multi_losses_assemble_f32): the loss values of every
-// problem (bpr_reduce_kernel's trees: the same bits), the feature regulariser from the fusion launch's per-block partial sums
-// (thread t adds partial[t], partial[t + 1024], ...; then the pairwise tree), and the assembly of llmrec_loss_assemble_f32 mode 0.
+// problem, the feature regulariser from the fusion launch's per-block partial sums (thread t adds partial[t], partial[t + 1024], ...;
+// then the pairwise tree), and the assembly of llmrec_loss_assemble_f32 mode 0.
+// The problems are reduced SIDE BY SIDE: 128 threads per problem emulate bpr_reduce_kernel's 1024 threads (slot v = that launch's thread
+// v: the sum over b = v, v + 1024, ... in ascending order; then the same pairwise tree red[i] += red[i + off] over 1024 slots), one
+// column (kept values, three squared norms) at a time - the bits of out / saved are those of bpr_reduce_kernel, in 40 block barriers
+// instead of 8 x 40 (the first version ran the problems one after the other: 39 us on the ID chain's stream).
 struct LossW { float w[LLMREC_BPR_MAX_PROBLEMS]; };
+constexpr int LA_GROUP = BPR_THREADS / LLMREC_BPR_MAX_PROBLEMS;      // 128 threads per problem
 __global__ __launch_bounds__(BPR_THREADS) void bpr_losses_assemble_kernel(int n_prob, int B_max, const int32_t* __restrict__ n_valid_dev,
                                                                           double remember_rate, float decay, float bsz,
                                                                           float* __restrict__ out_all, float* __restrict__ saved_all, int saved_stride,
                                                                           LossW w, const float* __restrict__ partial, int n_partial, float reg_coef,
                                                                           float* __restrict__ scal, double* __restrict__ running) {
-    __shared__ float red[BPR_THREADS];
-    const BprGather none = {};
-    for (int p = 0; p < n_prob; ++p) {
-        bpr_reduce_problem(p, B_max, n_valid_dev, remember_rate, decay, bsz, out_all, saved_all, saved_stride, none, red);
+    __shared__ float red[LLMREC_BPR_MAX_PROBLEMS][BPR_THREADS];         // 32 KB
+    __shared__ float outs[LLMREC_BPR_MAX_PROBLEMS][2];
+    const int B = bpr_batch(n_valid_dev, B_max);
+    const int prob = threadIdx.x / LA_GROUP, t = threadIdx.x % LA_GROUP;
+    const bool live = prob < n_prob;
+    float* saved = saved_all + (int64_t)(live ? prob : 0) * saved_stride;
+    const float* sc = saved + B_max + 4;
+    float tot[4] = {0.f, 0.f, 0.f, 0.f};                               // kept, Su, Sp, Sq (valid in the group's thread 0)
+#pragma unroll
+    for (int col = 0; col < 4; ++col) {
+        const float* src = sc + (int64_t)(col + 1) * B_max;              // slots 1 (kept m_b), 2, 3, 4 (squared norms) of `saved`
+        if (live) {
+            for (int v = t; v < BPR_THREADS; v += LA_GROUP) {
+                float s_ = 0.f;
+                for (int b = v; b < B; b += BPR_THREADS) s_ += src[b];
+                red[prob][v] = s_;
+            }
+        }
         __syncthreads();
+        for (int off = BPR_THREADS / 2; off > 0; off >>= 1) {
+            if (live) for (int i = t; i < off; i += LA_GROUP) red[prob][i] += red[prob][i + off];
+            __syncthreads();
+        }
+        tot[col] = red[live ? prob : 0][0];
+        __syncthreads();
+    }
+    if (live && t == 0) {
+        const int k = (int)(remember_rate * (double)B);
+        const float mf = -(tot[0] / (float)k);                           // k == 0 -> nan, as torch's empty mean
+        const float reg = 1.0f / (2.0f * tot[1] + 1e-8f) + 1.0f / (2.0f * tot[2] + 1e-8f) + 1.0f / (2.0f * tot[3] + 1e-8f);
+        const float emb = decay * (reg / bsz);
+        out_all[prob * 2 + 0] = mf; out_all[prob * 2 + 1] = emb;
+        outs[prob][0] = mf; outs[prob][1] = emb;
+        saved[B_max + 0] = tot[1]; saved[B_max + 1] = tot[2]; saved[B_max + 2] = tot[3]; saved[B_max + 3] = (float)k;
     }
     float feat = scal[0];                                              // no partial sums: whatever llmrec_sumsq_f32 left there
     if (partial) {
-        float s = 0.f;
-        for (int i = threadIdx.x; i < n_partial; i += BPR_THREADS) s += partial[i];
-        feat = reg_coef * block_tree_sum(s, red);
+        float s_ = 0.f;
+        for (int i = threadIdx.x; i < n_partial; i += BPR_THREADS) s_ += partial[i];
+        feat = reg_coef * block_tree_sum(s_, red[0]);
     }
+    __syncthreads();                                                   // the groups' results (LDS) are visible to thread 0
     if (threadIdx.x != 0) return;
     float s = 0.f;
-    for (int p = 0; p < n_prob; ++p) s += out_all[2 * p] * w.w[p];     // (thread 0 wrote out_all itself: same-thread order)
+    for (int p = 0; p < n_prob; ++p) s += outs[p][0] * w.w[p];
     scal[0] = feat;
-    scal[2] = out_all[0]; scal[3] = out_all[1];
-    scal[1] = s + out_all[1] + feat;
+    scal[2] = outs[0][0]; scal[3] = outs[0][1];
+    scal[1] = s + outs[0][1] + feat;
     if (running) { running[0] += (double)scal[1]; running[1] += (double)scal[2]; running[2] += (double)scal[3]; }
 }
 

@@ -315,9 +315,12 @@ class FusedStep:
                 ([(self._side(dY_cat, 1), feats[1], roww)], m.text_trans.weight.grad, m.text_trans.bias.grad, False),
                 ([(self._side(dY_cat, 0), feats[0], roww)], m.image_trans.weight.grad, m.image_trans.bias.grad, False)]
 
-    def _project_all(self):
-        """All 8 projections in one grouped launch (d <= 64), else one by one."""
+    def _project_all(self, which: str = "all"):
+        """All 8 projections in one grouped launch (d <= 64), else one by one. which = "user" / "items": only user_trans' projection /
+        only the seven item-side ones (LLMREC_SPLIT_PROJ: two launches, so that the profile chain can start behind the first)."""
         jobs = self.projection_jobs()
+        if which != "all":
+            jobs = [j for j in jobs if (j[2] is self.P_usr) == (which == "user")]
         if self.d > 64 or len(jobs) > _lib.CONST["LLMREC_LINEAR_MAX_PROBLEMS"]:
             if self.preprop:
                 raise RuntimeError("FusedStep: the pre-propagated projection needs the grouped launch (d <= 64); set LLMREC_PREPROPAGATE=0")
@@ -383,16 +386,28 @@ class FusedStep:
                     self._spmm(self.iu.fwd, self.Ul[l], self.Il[l], tag=2)
                 i_prev = self.Il[l]
         self._stamp(1)
-        self._project_all()
+        split_proj = os.environ.get("LLMREC_SPLIT_PROJ", "0") == "1" and self.multi_stream and self.d <= 64
+        if split_proj:                                                   # user_trans first: the profile chain runs BESIDE the item-side projection
+            self._project_all("user")                                    # and is long done when the fusion joins it (no late second parent)
+            ev1 = self._mark()
+            self._fork_from(ev1, self.s1)
+            with self._on(self.s1):
+                self._spmm(self.iu.fwd, self.P_usr, self.prof_i, tag=1)
+                self._spmm(self.ui.fwd, self.prof_i, self.prof_u, tag=1)
+            self._project_all("items")
+        else:
+            self._project_all()
         self._stamp(2)
-        ev1 = self._mark()
+        if not split_proj:
+            ev1 = self._mark()
         if not self.preprop:
             self._spmm(self.ui.fwd, self.P_cat, self.U_cat)              # 7 streams, one adjacency pass
         self._spmm(self.iu.fwd, self.U_cat, self.I_cat)
-        self._fork_from(ev1, self.s1)
-        with self._on(self.s1):                                          # profile stream: items first
-            self._spmm(self.iu.fwd, self.P_usr, self.prof_i, tag=1)
-            self._spmm(self.ui.fwd, self.prof_i, self.prof_u, tag=1)
+        if not split_proj:
+            self._fork_from(ev1, self.s1)
+            with self._on(self.s1):                                      # profile stream: items first
+                self._spmm(self.iu.fwd, self.P_usr, self.prof_i, tag=1)
+                self._spmm(self.ui.fwd, self.prof_i, self.prof_u, tag=1)
         if self._zero_in_forward and not self.fold:                      # training: the feature regulariser's value needs only U_cat / I_cat -
             self._fork(self.s3)                                          # captured HERE it runs beside the fusion and the BPR launches (captured
             with self._on(self.s3):                                      # after the BPR backward, round 2, the graph ran it last: the step's tail)
@@ -549,8 +564,8 @@ class FusedStep:
         inv = 1.0 / (L + 1)
         # capture order at this fork (experiment knobs, profiles/experiments/r05_step_chain.md): LLMREC_BWD_MAIN_FIRST=1 captures the critical
         # transposed side product BEFORE the two side branches; LLMREC_LOSS_STREAM=s3 puts the logged-scalar launch on its own stream
-        main_first = os.environ.get("LLMREC_BWD_MAIN_FIRST", "0") == "1" and self.multi_stream
-        loss_s3 = os.environ.get("LLMREC_LOSS_STREAM", "s2") == "s3" and self.multi_stream and side_work is not None
+        main_first = os.environ.get("LLMREC_BWD_MAIN_FIRST", "1" if self.fold else "0") == "1" and self.multi_stream
+        loss_s3 = os.environ.get("LLMREC_LOSS_STREAM", "s3" if self.fold else "s2") == "s3" and self.multi_stream and side_work is not None
         if main_first:
             self._spmm(self.iu.bwd, self.dI_cat, self.dU_cat, accumulate=True)
             if not self.preprop:
@@ -641,14 +656,27 @@ class FusedStep:
             # per step, one launch 0.637 ms). user_trans' gradient is in the same launch since round 3: with the pre-propagated
             # operands nothing separates the two launches in time any more, and side by side each ran at half speed (the chip is
             # power-bound here: profiles/experiments/r03_wgrad.md). The bias gradients (row-weighted when pre-propagated) come out of it too.
-            self._join(self.s1)                                          # dP_usr (the profile chain is long done by now)
+            split_wgrad = os.environ.get("LLMREC_SPLIT_WGRAD", "0") == "1" and self.multi_stream and self.inline_adamw
+            if not split_wgrad:
+                self._join(self.s1)                                      # dP_usr (the profile chain is long done by now)
             if self.ws_wgrad_multi is None:
                 need = ops.linear_wgrad_multi_workspace(targets, self.wgrad_blocks)
                 self.ws_wgrad_multi = torch.empty(max(need, 0), dtype=torch.uint8, device=dY_cat.device) if need >= 0 else False
             if self.ws_wgrad_multi is not False:
                 self._stamp(3)
-                if self.inline_adamw:                                    # the four Linears' AdamW rides in the slab-reduction launch
-                    lins = (m.item_trans, m.user_trans, m.text_trans, m.image_trans)          # (wgrad_targets' order)
+                lins = (m.item_trans, m.user_trans, m.text_trans, m.image_trans)              # (wgrad_targets' order)
+                if split_wgrad:
+                    # the three item-side Linears first - their only late parent is the transposed side product on THIS stream - then,
+                    # behind the join with the profile chain, user_trans' own launch (two GEMM + two reduction launches instead of one + one)
+                    sel = [0, 2, 3]
+                    ops.linear_wgrad_multi([targets[i] for i in sel], self.ws_wgrad_multi, update=(self.opt, [(lins[i].weight, lins[i].bias) for i in sel]),
+                                           block_budget=self.wgrad_blocks)
+                    self._join(self.s1)
+                    if getattr(self, "ws_wgrad_user", None) is None:
+                        self.ws_wgrad_user = torch.empty(max(ops.linear_wgrad_multi_workspace(targets[1:2], self.wgrad_blocks), 16), dtype=torch.uint8, device=dY_cat.device)
+                    ops.linear_wgrad_multi(targets[1:2], self.ws_wgrad_user, update=(self.opt, [(lins[1].weight, lins[1].bias)]), block_budget=self.wgrad_blocks)
+                    updated = [p_ for l in lins for p_ in (l.weight, l.bias)]
+                elif self.inline_adamw:                                  # the four Linears' AdamW rides in the slab-reduction launch
                     ops.linear_wgrad_multi(targets, self.ws_wgrad_multi, update=(self.opt, [(l.weight, l.bias) for l in lins]), block_budget=self.wgrad_blocks)
                     updated = [p_ for l in lins for p_ in (l.weight, l.bias)]
                 else:
