@@ -61,6 +61,10 @@ struct TopkArgs {
     // the item table re-laid in FRAGMENT order by topk_pack_items_kernel (null: the sweep loads Ei itself):
     // packed[((tile * 2 + n) * DK + c) * 64 + lane] = the float4 lane `lane` feeds to column tile n, k chunk c of item tile `tile`
     const float4* packed;
+    // mode 1 (bf16 prefilter + exact rescoring): the item table as bf16 (hi, mid) fragments and max_i ||i||^2 (workspace)
+    int mode;
+    uint4* pk2;
+    uint32_t* max_norm2_bits;
 };
 
 template <int DK>
@@ -423,6 +427,289 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: bf16 PREFILTER + EXACT RESCORING. The sweep above spends 1024 matrix cycles per 16 users x 32 items
+// on the exact-fp32 MFMA although only ~4 % of the scores it forms ever reach a user's candidate buffer. Here the sweep runs on
+// v_mfma_f32_16x16x32_bf16 with both operands cut into two bf16 numbers (x = h + m + r, truncating splits: |r| < 2^-14 |x|):
+//     s' = <u_h, i_h> + <u_h, i_m> + <u_m, i_h>          (three MFMAs per 32 k: 192 matrix cycles per 16 x 32 tile at d = 64)
+//     |s - s'| <= (3 x 2^-14 + accumulation) sum_k |u_k| |i_k|  <=  2^-12 ||u|| ||i||      (Cauchy-Schwarz; the constant is 4 x 2^-14)
+// A score is APPENDED to the candidate buffer iff  s' >= thr_u - eps_u,  eps_u = 2^-12 ||u|| max_i ||i||  (thr_u = the user's exact K-th
+// score so far): a superset of what the exact sweep appends, since a true candidate has s >= thr_u. At every drain the buffered
+// candidates are RESCORED EXACTLY - one lane per candidate runs the k-ordered fp32 fma chain of v_mfma_f32_16x16x4_f32 (for c, for s,
+// for q: k = 16 c + 4 q + s; a VALU v_fma_f32 chain gives the MFMA's bits: tests/test_gpu_ops.py holds both to oracle.scores_fma_chain) on
+// the user's row (LDS) and the item's fp32 row (global, L2) - and sorted / merged exactly as above. The false positives have exact scores
+// below the K-th and never enter the top K: lists and scores are BIT-IDENTICAL to score_topk_kernel's (every top-K test runs both).
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef __bf16 tk_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 tk_mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tk_bf16x8, a), __builtin_bit_cast(tk_bf16x8, b), c, 0, 0, 0);
+}
+// two floats -> packed (hi, mid) bf16 pairs, truncating splits (the residual is exact in fp32)
+__device__ __forceinline__ void tk_split2(float x0, float x1, uint32_t& H, uint32_t& M) {
+    const uint32_t h0 = __float_as_uint(x0) & 0xffff0000u, h1 = __float_as_uint(x1) & 0xffff0000u;
+    const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
+    H = __builtin_amdgcn_perm(h1, h0, 0x07060302u);                      // high halves: e0 -> low 16 bits, e1 -> high 16 bits
+    M = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+}
+__device__ __forceinline__ void tk_split8(const float (&x)[8], uint4& H, uint4& M) {
+    tk_split2(x[0], x[1], H.x, M.x); tk_split2(x[2], x[3], H.y, M.y);
+    tk_split2(x[4], x[5], H.z, M.z); tk_split2(x[6], x[7], H.w, M.w);
+}
+constexpr float TK_PRE_SLACK = 0x1p-12f;                                 // eps_u = TK_PRE_SLACK ||u|| max ||i||
+
+// the item table as bf16 (hi, mid) MFMA fragments: pk2[(((tile * 2 + n) * DK32 + c) * 2 + hm) * 64 + lane], lane = 16 (k group) + item-in-tile;
+// one thread per (item, 8 consecutive k).
+__global__ __launch_bounds__(256) void topk_pack_items_bf16_kernel(TopkArgs a, int DK32, uint4* __restrict__ pk2) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.max_norm2_bits[0] = 0u;  // (topk_item_norm_kernel follows on the stream)
+    const int G = DK32 * 4;                                            // 8-float groups per (padded) row
+    const int64_t n_pad = (a.n_items + TK_TILE - 1) / TK_TILE * TK_TILE;
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n_pad * G) return;
+    const int64_t item_p = v / G;
+    const int g = (int)(v - item_p * G);
+    const int64_t item = item_p < a.n_items ? item_p : a.n_items - 1;  // the partial last tile repeats the last item (masked by the range check)
+    const float* row = a.Ei + item * a.ldi;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int k = 8 * g + j; x[j] = k < a.d ? row[k] : 0.f; }
+    uint4 H, M;
+    tk_split8(x, H, M);
+    const int64_t tile = item_p / TK_TILE;
+    const int within = (int)(item_p - tile * TK_TILE), n = within >> 4, li = within & 15;
+    const int c = g >> 2, lq = g & 3;
+    const int64_t base = (((tile * 2 + n) * DK32 + c) * 2) * 64 + (lq * 16 + li);
+    pk2[base] = H; pk2[base + 64] = M;
+}
+
+// max_i ||i||^2 as the bits of a non-negative float (atomicMax on uint32 is order-independent: deterministic). One 16-lane group per item.
+__global__ __launch_bounds__(256) void topk_item_norm_kernel(TopkArgs a, uint32_t* __restrict__ max_norm2_bits) {
+    const int gl = threadIdx.x & 15;
+    float mx = 0.f;
+    for (int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); item < a.n_items; item += (int64_t)gridDim.x * 16) {
+        const float* row = a.Ei + item * a.ldi;
+        float ss = 0.f;
+        for (int k = gl; k < a.d; k += 16) ss = fmaf(row[k], row[k], ss);
+        ss = group_sum<16>(ss);
+        mx = fmaxf(mx, ss);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(max_norm2_bits, __float_as_uint(mx));
+}
+
+template <int DK32>
+__global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kernel(TopkArgs a, const uint4* __restrict__ pk2, const uint32_t* __restrict__ max_norm2_bits) {
+    constexpr int DP = DK32 * 32;                                      // padded row width
+    __shared__ int32_t buf_i[4][16][TK_CAP];                           // candidate item ids (their approximate scores are not kept)
+    __shared__ int32_t cnt_s[4][16];
+    __shared__ float thr_s[16];                                        // exact K-th score so far
+    __shared__ float flt_s[16];                                        // the sweep's filter: thr - eps
+    __shared__ float eps_s[16];
+    __shared__ int32_t flag_s[2];
+    __shared__ __attribute__((aligned(16))) float u_lds[16][DP];       // the block's users, fp32, for the exact rescoring
+    __shared__ float list_s[16][64];                                   // the block's sorted lists (slot = lane): in LDS between drains - the
+    __shared__ int32_t list_i[16][64];                                 // sweep loop keeps its registers for the fragments
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    int tile = blockIdx.x, part = 0, n_parts = 1;
+    if ((int)blockIdx.x >= a.split_from) {
+        n_parts = a.n_parts;
+        tile = a.split_from + ((int)blockIdx.x - a.split_from) / n_parts;
+        part = ((int)blockIdx.x - a.split_from) % n_parts;
+    }
+    const int q0 = tile * 16;
+    if (q0 >= a.n_query) return;
+    if (threadIdx.x < 2) flag_s[threadIdx.x] = 0;
+
+    // A operand: row li of the block's users, k = 32 c + 8 lq + j -> (hi, mid) fragments; the fp32 row goes to LDS (wave 0 writes it)
+    int qa = q0 + li;
+    if (qa > a.n_query - 1) qa = a.n_query - 1;
+    const int64_t user_a = a.query_users[qa];
+    uint4 uH[DK32], uM[DK32];
+    float un2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < DK32; ++c) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int k = 32 * c + 8 * lq + j; x[j] = k < a.d ? a.Eu[user_a * a.ldu + k] : 0.f; un2 = fmaf(x[j], x[j], un2); }
+        tk_split8(x, uH[c], uM[c]);
+        if (w == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u_lds[li][32 * c + 8 * lq + j] = x[j];
+        }
+    }
+    un2 += __shfl_xor(un2, 16, 64); un2 += __shfl_xor(un2, 32, 64);    // ||u||^2 of row li in every lane with that li
+    if (threadIdx.x < 16) {
+        const float in2 = __uint_as_float(max_norm2_bits[0]);
+        eps_s[li] = TK_PRE_SLACK * sqrtf(un2) * sqrtf(in2) * 1.0001f;    // (the square roots round: a hair of extra slack)
+        thr_s[li] = -INFINITY; flt_s[li] = -INFINITY;
+    }
+    __syncthreads();
+
+    const int64_t tiles_all = (a.n_items + TK_TILE - 1) / TK_TILE;
+    const int64_t part_begin = tiles_all * part / n_parts, tiles_total = tiles_all * (part + 1) / n_parts;
+    const int64_t tiles_per_wave = (tiles_total - part_begin + 3) / 4;
+    const int64_t t_begin = part_begin + w * tiles_per_wave < tiles_total ? part_begin + w * tiles_per_wave : tiles_total;
+    const int64_t t_end = t_begin + tiles_per_wave < tiles_total ? t_begin + tiles_per_wave : tiles_total;
+
+    int32_t cur = 0, end = 0, nxt = INT_MAX;
+    if (lane < 16 && a.train_rowptr) {
+        cur = a.train_rowptr[user_a]; end = a.train_rowptr[user_a + 1];
+        const int64_t first = t_begin * TK_TILE;
+        int32_t lo = cur, hi = end;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (a.train_colidx[mid] < first) lo = mid + 1; else hi = mid;
+        }
+        cur = lo;
+        if (cur < end) nxt = a.train_colidx[cur];
+    }
+    int cntr[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) { list_s[4 * w + rr][lane] = -INFINITY; list_i[4 * w + rr][lane] = INT_MAX; }   // (only this wave touches its users' lists)
+
+    const int64_t my_rounds = t_end > t_begin ? t_end - t_begin : 0;
+    uint4 bH[2][DK32], bM[2][DK32];
+    const uint4* pk = pk2 + (t_begin * 2 * DK32 * 2) * 64 + lane;
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int c = 0; c < DK32; ++c) { bH[n][c] = pk[((n * DK32 + c) * 2) * 64]; bM[n][c] = pk[((n * DK32 + c) * 2 + 1) * 64]; }
+        pk += 2 * DK32 * 2 * 64;
+    };
+    if (my_rounds > 0) load_tile();
+    int64_t round = 0;
+    bool counted = false;
+    for (;;) {
+        const bool fin = round >= my_rounds;
+        const int fill = max(max(cntr[0], cntr[1]), max(cntr[2], cntr[3]));
+        bool drain = fin || __ballot(fill > TK_CAP - TK_TILE) != 0ull;
+        if (!drain) drain = __hip_atomic_load(&flag_s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+        if (drain) {
+            if (fin && !counted) { counted = true; if (lane == 0) atomicAdd(&flag_s[1], 1); }
+            if (!fin && lane == 0) __hip_atomic_store(&flag_s[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __syncthreads();
+            if (li == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cnt_s[w][lq * 4 + r] = cntr[r];
+            }
+            __syncthreads();
+            const int done_quarters = flag_s[1];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int u = 4 * w + rr;
+                const int p1 = cnt_s[0][u], p2 = p1 + cnt_s[1][u], p3 = p2 + cnt_s[2][u], total = p3 + cnt_s[3][u];
+                float l1[1] = {list_s[u][lane]}; int32_t i1[1] = {list_i[u][lane]};
+                for (int j0 = 0; j0 < total; j0 += 64) {
+                    const int j = j0 + lane;
+                    const int ww = (j >= p1) + (j >= p2) + (j >= p3);
+                    const int start = ww == 0 ? 0 : (ww == 1 ? p1 : (ww == 2 ? p2 : p3));
+                    float bs[1] = {-INFINITY}; int32_t bi[1] = {INT_MAX};
+                    if (j < total) {
+                        bi[0] = buf_i[ww][u][j - start];
+                        // EXACT score: the k-ordered fma chain of v_mfma_f32_16x16x4_f32 (c, then s, then q; k = 16 c + 4 q + s)
+                        const float* ir = a.Ei + (int64_t)bi[0] * a.ldi;
+                        float acc = 0.f;
+#pragma unroll 1
+                        for (int c = 0; c < DP / 16; ++c) {                     // (rolled: one chunk's 16 + 16 operand floats in registers at a time)
+                            if (16 * c < a.d) {
+                                float4 iv[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) iv[q] = ld4g(ir, 16 * c + 4 * q, a.d, a.vec_ok);
+                                const float* uc = &u_lds[u][16 * c];                // (wave-uniform address: LDS broadcast reads)
+#pragma unroll
+                                for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(uc[4 * q + s_], cmp4(iv[q], s_), acc);
+                            }
+                        }
+                        bs[0] = acc;
+                    }
+                    sort64<1>(bs, bi, lane);
+                    merge64<1>(l1, i1, bs, bi, lane);
+                }
+                list_s[u][lane] = l1[0]; list_i[u][lane] = i1[0];
+                if (total > 0) {
+                    const float nthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l1[0]), a.K - 1));
+                    if (lane == 0) { thr_s[u] = nthr; flt_s[u] = nthr - eps_s[u]; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cntr[r] = 0;
+            if (threadIdx.x == 0) flag_s[0] = 0;
+            __syncthreads();
+            if (done_quarters == 4) break;
+            // the tile prefetched before the drain is fetched AGAIN (L2) instead of being kept in 32 registers across the drain's
+            // sort / rescoring code: drains are ~6 per sweep, the registers decide whether four blocks fit a CU
+            if (!fin) { pk -= 2 * DK32 * 2 * 64; load_tile(); }
+            continue;
+        }
+        const int64_t base = (t_begin + round) * TK_TILE;
+        f32x4 acc[2];
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+#pragma unroll
+        for (int c = 0; c < DK32; ++c)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                acc[n] = tk_mfma_bf16(uM[c], bH[n][c], acc[n]);
+                acc[n] = tk_mfma_bf16(uH[c], bM[n][c], acc[n]);
+                acc[n] = tk_mfma_bf16(uH[c], bH[n][c], acc[n]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (round + 1 < my_rounds) load_tile();
+        __builtin_amdgcn_sched_barrier(0);
+
+        uint32_t m = 0;
+        while ((int64_t)nxt < base + TK_TILE) {
+            m |= 1u << (int)(nxt - base);
+            ++cur;
+            nxt = cur < end ? a.train_colidx[cur] : INT_MAX;
+        }
+        const unsigned long long any_train = __ballot(m != 0u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float rthr = (q0 + lq * 4 + r < a.n_query) ? flt_s[lq * 4 + r] : INFINITY;
+            uint32_t rm = 0;
+            if (any_train) rm = __shfl(m, lq * 4 + r, 64);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const float v = acc[n][r];
+                if (__ballot(v >= rthr) == 0ull) continue;
+                const int col = 16 * n + li;
+                const bool pass = (v >= rthr) && (base + col < a.n_items) && !((rm >> col) & 1u);
+                const unsigned long long bal = __ballot(pass);
+                if (bal == 0) continue;
+                const unsigned sub = (unsigned)(bal >> (16 * lq)) & 0xffffu;
+                if (pass) {
+                    const int off = cntr[r] + __popc(sub & ((1u << li) - 1u));
+                    buf_i[w][lq * 4 + r][off] = (int32_t)(base + col);
+                }
+                cntr[r] += __popc(sub);
+            }
+        }
+        ++round;
+    }
+    if (n_parts > 1) {
+        const int64_t base = ((int64_t)(tile - a.split_from) * n_parts + part) * 16;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            a.ws_idx[(base + 4 * w + rr) * 64 + lane] = list_i[4 * w + rr][lane];
+            a.ws_score[(base + 4 * w + rr) * 64 + lane] = list_s[4 * w + rr][lane];
+        }
+        return;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int q = q0 + 4 * w + rr;
+        if (q < a.n_query && lane < a.K) {
+            const int32_t id = list_i[4 * w + rr][lane];
+            a.out_idx[(int64_t)q * a.K + lane] = id == INT_MAX ? -1 : id;
+            a.out_score[(int64_t)q * a.K + lane] = list_s[4 * w + rr][lane];
+        }
+    }
+}
+
 // the lists of a split tile's parts -> the tile's top K (one wave per four users, as in the sweep)
 __global__ __launch_bounds__(256) void topk_merge_kernel(TopkArgs a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -519,6 +806,27 @@ static int launch_topk(const TopkArgs& a, hipStream_t stream) {
     const int n_tiles = (int)ceil_div(a.n_query, 16);
     const int grid = a.split_from + (n_tiles - a.split_from) * a.n_parts;
     const bool fast = a.vec_ok && a.d == 16 * DK;
+    if (SELECT && a.mode == 1) {
+        const int DK32 = (a.d + 31) / 32;
+        const int64_t n_thr = ceil_div(a.n_items, TK_TILE) * TK_TILE * DK32 * 4;
+        topk_pack_items_bf16_kernel<<<(unsigned)ceil_div(n_thr, 256), 256, 0, stream>>>(a, DK32, a.pk2);
+        LLMREC_LAUNCH_CHECK();
+        topk_item_norm_kernel<<<grid_for(a.n_items, 16), 256, 0, stream>>>(a, a.max_norm2_bits);
+        LLMREC_LAUNCH_CHECK();
+        switch (DK32) {
+            case 1: score_topk_pre_kernel<1><<<grid, 256, 0, stream>>>(a, a.pk2, a.max_norm2_bits); break;
+            case 2: score_topk_pre_kernel<2><<<grid, 256, 0, stream>>>(a, a.pk2, a.max_norm2_bits); break;
+            case 3: score_topk_pre_kernel<3><<<grid, 256, 0, stream>>>(a, a.pk2, a.max_norm2_bits); break;
+            case 4: score_topk_pre_kernel<4><<<grid, 256, 0, stream>>>(a, a.pk2, a.max_norm2_bits); break;
+            default: set_error("score_topk: d = %d > 128", a.d); return LLMREC_EUNSUPPORTED;
+        }
+        LLMREC_LAUNCH_CHECK();
+        if (a.n_parts > 1) {
+            topk_merge_kernel<<<n_tiles - a.split_from, 256, 0, stream>>>(a);
+            LLMREC_LAUNCH_CHECK();
+        }
+        return LLMREC_OK;
+    }
     if (SELECT && a.packed) {
         const int64_t n_vec = ceil_div(a.n_items, TK_TILE) * 2 * DK * 64;
         topk_pack_items_kernel<<<(unsigned)ceil_div(n_vec, 256), 256, 0, stream>>>(a, DK, const_cast<float4*>(a.packed), n_vec);
@@ -557,7 +865,9 @@ static int64_t topk_split_bytes(int32_t n_query, int64_t n_items) {
     return ((int64_t)ceil_div(n_query, 16) - split_from) * n_parts * 16 * 64 * 8;
 }
 static int64_t topk_packed_bytes(int64_t n_items, int32_t d) {
-    return ceil_div(n_items, TK_TILE) * 2 * ceil_div(d, 16) * 64 * 16;      // the item table in fragment order (rows padded to whole tiles, d to 16)
+    const int64_t exact = ceil_div(n_items, TK_TILE) * 2 * ceil_div(d, 16) * 64 * 16;      // fp32 fragments (rows padded to whole tiles, d to 16)
+    const int64_t pre = ceil_div(n_items, TK_TILE) * 2 * ceil_div(d, 32) * 2 * 64 * 16;   // bf16 (hi, mid) fragments (d padded to 32)
+    return (exact > pre ? exact : pre) + 256;                                              // + the slot of max ||i||^2 (mode 1)
 }
 
 int64_t llmrec_score_topk_workspace_bytes(int32_t n_query, int64_t n_items, int32_t d) {
@@ -580,7 +890,19 @@ int llmrec_score_topk_ws_f32(int32_t n_query, const int64_t* query_users,
                              const int32_t* train_rowptr, const int32_t* train_colidx,
                              int32_t K, int32_t* out_idx, float* out_score,
                              void* workspace, int64_t workspace_bytes, llmrec_stream_t stream_) {
+    return llmrec_score_topk_mode_f32(n_query, query_users, Eu, ldu, Ei, ldi, n_items, d, train_rowptr, train_colidx, K, out_idx, out_score,
+                                      workspace, workspace_bytes, LLMREC_TOPK_MODE_EXACT_SWEEP, stream_);
+}
+
+int llmrec_score_topk_mode_f32(int32_t n_query, const int64_t* query_users,
+                               const float* Eu, int64_t ldu, const float* Ei, int64_t ldi,
+                               int64_t n_items, int32_t d,
+                               const int32_t* train_rowptr, const int32_t* train_colidx,
+                               int32_t K, int32_t* out_idx, float* out_score,
+                               void* workspace, int64_t workspace_bytes, int32_t mode, llmrec_stream_t stream_) {
     LLMREC_CHECK_ARG(n_query >= 0 && n_items > 0 && d > 0 && K > 0 && K <= LLMREC_TOPK_MAX, "score_topk: bad sizes (K <= %d)", LLMREC_TOPK_MAX);
+    LLMREC_CHECK_ARG(mode == LLMREC_TOPK_MODE_EXACT_SWEEP || mode == LLMREC_TOPK_MODE_PREFILTER, "score_topk: unknown mode %d", mode);
+    LLMREC_CHECK_ARG(mode != LLMREC_TOPK_MODE_PREFILTER || workspace, "score_topk: the prefilter mode needs the workspace");
     if (n_query == 0) return LLMREC_OK;
     LLMREC_CHECK_ARG(query_users && Eu && Ei && out_idx && out_score && ldu >= d && ldi >= d, "score_topk: null pointer or ld < d");
     LLMREC_CHECK_ARG((train_rowptr == nullptr) == (train_colidx == nullptr) || train_rowptr, "score_topk: train CSR incomplete");
@@ -591,6 +913,7 @@ int llmrec_score_topk_ws_f32(int32_t n_query, const int64_t* query_users,
     a.out_idx = out_idx; a.out_score = out_score; a.S = nullptr; a.lds = 0;
     a.vec_ok = (ldu % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)Eu | (uintptr_t)Ei) % 16 == 0);
     a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
+    a.mode = mode; a.pk2 = nullptr; a.max_norm2_bits = nullptr;
     if (workspace) {                                           // without a workspace: one block per user tile, fragments straight from Ei
         const int64_t need = llmrec_score_topk_workspace_bytes(n_query, n_items, d), split = topk_split_bytes(n_query, n_items);
         LLMREC_CHECK_ARG(workspace_bytes >= need && (uintptr_t)workspace % 16 == 0, "score_topk: workspace of %lld bytes needed (16-byte aligned)", (long long)need);
@@ -599,7 +922,12 @@ int llmrec_score_topk_ws_f32(int32_t n_query, const int64_t* query_users,
             a.ws_score = (float*)workspace;
             a.ws_idx = (int32_t*)((char*)workspace + split / 2);
         }
-        a.packed = (const float4*)((char*)workspace + align_up(split, 256));
+        char* frag = (char*)workspace + align_up(split, 256);
+        a.packed = (const float4*)frag;
+        if (mode == LLMREC_TOPK_MODE_PREFILTER) {
+            a.max_norm2_bits = (uint32_t*)frag;                // (the first 256 bytes of the fragment area)
+            a.pk2 = (uint4*)(frag + 256);
+        }
     }
     return launch_topk<true>(a, (hipStream_t)stream_);
 }
@@ -616,6 +944,7 @@ int llmrec_scores_f32(int32_t n_query, const int64_t* query_users,
     a.out_idx = nullptr; a.out_score = nullptr; a.S = S; a.lds = lds;
     a.vec_ok = (ldu % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)Eu | (uintptr_t)Ei) % 16 == 0);
     a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
+    a.mode = 0; a.pk2 = nullptr; a.max_norm2_bits = nullptr;
     return launch_topk<false>(a, (hipStream_t)stream_);
 }
 

@@ -369,8 +369,12 @@ class FusedStep:
     def forward(self, sampler=None):
         m, d = self.m, self.d
         self._fork(self.s2)
+        # LLMREC_ID_FIRST=1 (experiment, profiles/experiments/r05_step_chain.md): the ID chain's SpMMs BEFORE the sampler and the row list on
+        # this stream - behind them (one-block kernels that wait 50 - 100 us for a CU beside the projection) the chain ended as late as
+        # the two other chains the fusion joins
+        id_first = os.environ.get("LLMREC_ID_FIRST", "0") == "1"
         with self._on(self.s2):                                          # ID chain: needs no projection
-            if sampler is not None and self.multi_stream:                # the batch is first read by the losses, after the join below:
+            if sampler is not None and self.multi_stream and not id_first:   # the batch is first read by the losses, after the join below:
                 sampler()                                                # sampling rides beside the projection instead of ahead of it
             if self._zero_in_forward and not self.fold:
                 self.opt.advance()                                       # AdamW's step counter / bias corrections, off the critical path
@@ -385,6 +389,8 @@ class FusedStep:
                     self._spmm(self.ui.fwd, i_prev, self.Ul[l], tag=2)
                     self._spmm(self.iu.fwd, self.Ul[l], self.Il[l], tag=2)
                 i_prev = self.Il[l]
+            if sampler is not None and self.multi_stream and id_first:
+                sampler()
         self._stamp(1)
         split_proj = os.environ.get("LLMREC_SPLIT_PROJ", "0") == "1" and self.multi_stream and self.d <= 64
         if split_proj:                                                   # user_trans first: the profile chain runs BESIDE the item-side projection
@@ -784,9 +790,9 @@ class FusedStep:
 
             def run():
                 self.forward()
-                _call("llmrec_score_topk_ws_f32", n, _p(q), _p(self.E_u), _ld(self.E_u), _p(self.E_i), _ld(self.E_i), self.I, self.d,
+                _call("llmrec_score_topk_mode_f32", n, _p(q), _p(self.E_u), _ld(self.E_u), _p(self.E_i), _ld(self.E_i), self.I, self.d,
                       _p(train.rowptr) if train is not None else None, _p(train.colidx) if train is not None else None,
-                      K, _p(idx), _p(sc), _p(ws), ws.numel() if ws is not None else 0)
+                      K, _p(idx), _p(sc), _p(ws), ws.numel() if ws is not None else 0, ops.topk_mode())
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):

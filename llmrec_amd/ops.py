@@ -8,6 +8,7 @@ torch math: if the HIP library is missing or a tensor is not on the GPU, it rais
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
@@ -913,7 +914,20 @@ class FusedAdamW:
 # ---------------------------------------------------------------------------------------------
 # R9/R10: scoring + top-K, R11: sampler
 # ---------------------------------------------------------------------------------------------
-def score_topk(Eu, Ei, query_users: torch.Tensor, train: Optional[Csr], K: int):
+TOPK_MODES = {"exact": 0, "prefilter": 1}
+
+
+def topk_mode(mode=None) -> int:
+    """llmrec_score_topk_mode_f32's mode: "exact" = every score by the exact-fp32 MFMA chain, "prefilter" = bf16 sweep + exact rescoring of
+    the candidates (bit-identical lists and scores). Default: LLMREC_TOPK_MODE, else "exact"."""
+    if mode is None:
+        mode = os.environ.get("LLMREC_TOPK_MODE", "exact")
+    if mode not in TOPK_MODES:
+        raise RuntimeError("top-K mode %r (exact | prefilter)" % (mode,))
+    return TOPK_MODES[mode]
+
+
+def score_topk(Eu, Ei, query_users: torch.Tensor, train: Optional[Csr], K: int, mode=None):
     """Masked top-K item ids (int32 [n_query, K], -1 = none) and scores for the listed users."""
     _need_gpu(Eu, Ei, query_users)
     Eu, Ei = _rowmajor(Eu.detach()), _rowmajor(Ei.detach())
@@ -922,9 +936,9 @@ def score_topk(Eu, Ei, query_users: torch.Tensor, train: Optional[Csr], K: int):
     idx = torch.empty(n, K, dtype=torch.int32, device=Eu.device)
     sc = torch.empty(n, K, dtype=torch.float32, device=Eu.device)
     ws = topk_workspace(n, Ei.shape[0], Eu.device, Eu.shape[1])
-    _lib.call("llmrec_score_topk_ws_f32", n, _p(q), _p(Eu), _ld(Eu), _p(Ei), _ld(Ei), Ei.shape[0], Eu.shape[1],
+    _lib.call("llmrec_score_topk_mode_f32", n, _p(q), _p(Eu), _ld(Eu), _p(Ei), _ld(Ei), Ei.shape[0], Eu.shape[1],
               _p(train.rowptr) if train is not None else None, _p(train.colidx) if train is not None else None,
-              K, _p(idx), _p(sc), _p(ws), ws.numel() if ws is not None else 0, _stream())
+              K, _p(idx), _p(sc), _p(ws), ws.numel() if ws is not None else 0, topk_mode(mode), _stream())
     return idx, sc
 
 

@@ -1,0 +1,118 @@
+"""llmrec_score_topk_mode_f32: the bf16-prefilter sweep with exact rescoring (LLMREC_TOPK_MODE_PREFILTER) must return the SAME BITS - item
+lists and scores - as the exact-fp32 sweep (LLMREC_TOPK_MODE_EXACT_SWEEP), which the other top-K tests hold to the oracle and to the
+reference's lists: random tables, score distributions that keep the filter loose (near-identical rows, softmax-shaped rows), exact ties
+(integer-valued embeddings: ordered by item id), orders that keep the threshold rising, fewer than K candidates, every supported width,
+the Netflix shape with its split user tiles, and 10^6 items."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from llmrec_amd import ops as _ops
+    return _ops
+
+
+def _train_csr(ops, U, I, rng, max_deg):
+    degs = rng.integers(0, max_deg + 1, size=U)
+    rows = np.repeat(np.arange(U), degs)
+    cols = np.concatenate([rng.choice(I, size=int(dg), replace=False) for dg in degs] + [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+    rp, ci, _ = ops.csr_from_coo(torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV), None, U, I)
+    return ops.Csr(U, I, rp, ci, None, None, None, ops.SpmmPlan())
+
+
+def _both(ops, Eu, Ei, q, train, K):
+    i0, s0 = ops.score_topk(Eu, Ei, q, train, K, mode="exact")
+    i1, s1 = ops.score_topk(Eu, Ei, q, train, K, mode="prefilter")
+    torch.cuda.synchronize()
+    return i0, s0, i1, s1
+
+
+def _assert_same(i0, s0, i1, s1, what):
+    same_i = torch.equal(i0, i1)
+    same_s = torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    if not (same_i and same_s):
+        bad = (i0 != i1).nonzero()
+        raise AssertionError("%s: lists differ at %d positions (first %s), scores equal: %s" % (what, bad.shape[0], bad[:3].tolist(), same_s))
+
+
+@pytest.mark.parametrize("U,I,d,K", [(150, 1000, 64, 50), (70, 130, 16, 50), (33, 64, 64, 20), (200, 777, 128, 64), (10, 45, 64, 50),
+                                     (300, 5000, 48, 50), (97, 3001, 80, 10), (130, 2500, 112, 50), (50, 4000, 32, 1), (2000, 9000, 64, 50)])
+def test_prefilter_equals_exact_on_random_tables(ops, U, I, d, K):
+    rng = np.random.default_rng(U * 7 + I + d)
+    Eu = torch.tensor((rng.standard_normal((U, d)) * 0.4).astype(np.float32)).to(DEV)
+    Ei = torch.tensor((rng.standard_normal((I, d)) * 0.4).astype(np.float32)).to(DEV)
+    train = _train_csr(ops, U, I, rng, min(40, I // 2))
+    q = torch.tensor(rng.permutation(U)).to(DEV)
+    _assert_same(*_both(ops, Eu, Ei, q, train, K), what="random")
+    _assert_same(*_both(ops, Eu, Ei, q, None, K), what="random, no mask")
+    _assert_same(*_both(ops, Eu, Ei, q[:7], train, K), what="7 queries")
+
+
+@pytest.mark.parametrize("kind", ["near_identical_rows", "softmax_rows", "tiny_spread", "huge_norm_outlier", "integers", "ascending", "few_candidates"])
+def test_prefilter_equals_exact_where_the_filter_is_loose_or_ties_abound(ops, kind):
+    rng = np.random.default_rng(abs(hash(kind)) % 1000)
+    U, I, d, K = 200, 6000, 64, 50
+    if kind == "near_identical_rows":        # scores within ~1e-4 relative of one another: the slack admits many false positives
+        base = rng.standard_normal(d).astype(np.float32)
+        Ei = base[None, :] + (rng.standard_normal((I, d)) * 1e-4).astype(np.float32)
+        Eu = np.abs(rng.standard_normal((U, d))).astype(np.float32)
+    elif kind == "softmax_rows":             # the trained shape: rows of a softmax layer output plus small normalised terms
+        z = rng.standard_normal((I, d)).astype(np.float32) * 0.05
+        Ei = (np.exp(z) / np.exp(z).sum(1, keepdims=True)).astype(np.float32)
+        zu = rng.standard_normal((U, d)).astype(np.float32) * 0.05
+        Eu = (np.exp(zu) / np.exp(zu).sum(1, keepdims=True)).astype(np.float32)
+    elif kind == "tiny_spread":              # every score equal up to the last bits
+        Ei = np.full((I, d), 0.125, dtype=np.float32); Ei += (rng.integers(0, 3, size=(I, d)) * 2.0 ** -24).astype(np.float32)
+        Eu = np.full((U, d), 0.5, dtype=np.float32)
+    elif kind == "huge_norm_outlier":        # one item with a norm 1e4 times the others': max ||i|| inflates every user's slack
+        Ei = (rng.standard_normal((I, d)) * 0.1).astype(np.float32); Ei[17] *= 1e4
+        Eu = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    elif kind == "integers":                 # exact arithmetic in every order: ties everywhere, ranked by item id
+        Ei = rng.integers(-2, 3, size=(I, d)).astype(np.float32)
+        Eu = rng.integers(-2, 3, size=(U, d)).astype(np.float32)
+    elif kind == "ascending":                # item scores grow with the id: the threshold rises all sweep long
+        Eu = np.abs(rng.standard_normal((U, d))).astype(np.float32)
+        Ei = (np.abs(rng.standard_normal((I, d))) * np.linspace(0.1, 2.0, I)[:, None]).astype(np.float32)
+    else:                                    # few_candidates: most items are train items
+        Ei = rng.standard_normal((I, d)).astype(np.float32); Eu = rng.standard_normal((U, d)).astype(np.float32)
+    Eu, Ei = torch.tensor(Eu).to(DEV), torch.tensor(Ei).to(DEV)
+    if kind == "few_candidates":
+        I = 90; Ei = Ei[:I].contiguous()
+        rows = np.repeat(np.arange(U), 60); cols = np.concatenate([rng.choice(I, size=60, replace=False) for _ in range(U)]).astype(np.int64)
+        rp, ci, _ = ops.csr_from_coo(torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV), None, U, I)
+        train = ops.Csr(U, I, rp, ci, None, None, None, ops.SpmmPlan())
+    else:
+        train = _train_csr(ops, U, I, rng, 30)
+    q = torch.arange(U, device=DEV)
+    i0, s0, i1, s1 = _both(ops, Eu, Ei, q, train, K)
+    _assert_same(i0, s0, i1, s1, what=kind)
+    if kind == "integers":                   # and the tie rule itself: (score desc, item id asc)
+        sc, ids = s1.cpu().numpy(), i1.cpu().numpy()
+        for r in range(0, U, 17):
+            pairs = [(-float(a), int(b)) for a, b in zip(sc[r], ids[r]) if b >= 0]
+            assert pairs == sorted(pairs)
+
+
+def test_prefilter_equals_exact_at_the_netflix_shape_and_at_a_million_items(ops):
+    rng = np.random.default_rng(1)
+    U, I, d, K = 13187, 17366, 64, 50
+    Eu = torch.tensor((rng.standard_normal((U, d)) * 0.2).astype(np.float32)).to(DEV)
+    Ei = torch.tensor((rng.standard_normal((I, d)) * 0.2).astype(np.float32)).to(DEV)
+    train = _train_csr(ops, U, I, rng, 12)
+    q = torch.arange(U, device=DEV)
+    _assert_same(*_both(ops, Eu, Ei, q, train, K), what="netflix shape")
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+    I2, U2 = 1_000_000, 600
+    Ei2 = torch.randn(I2, d, generator=g, device=DEV) * 0.3
+    Eu2 = torch.randn(U2, d, generator=g, device=DEV) * 0.3
+    _assert_same(*_both(ops, Eu2, Ei2, torch.arange(U2, device=DEV), None, K), what="10^6 items")
+    Ei3 = torch.randn(200_000, 128, generator=g, device=DEV) * 0.3
+    Eu3 = torch.randn(300, 128, generator=g, device=DEV) * 0.3
+    _assert_same(*_both(ops, Eu3, Ei3, torch.arange(300, device=DEV), None, 64), what="d = 128")

@@ -1,0 +1,55 @@
+"""A/B of llmrec_score_topk_mode_f32's two modes (exact-fp32 sweep vs bf16 prefilter + exact rescoring): time per call (HIP events) and
+bit-identity, on random tables and on trained-shape tables (softmax-layer outputs + normalised terms: scores close together).
+    python tools/topk_mode_ab.py [--json out.json]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from llmrec_amd import ops
+
+
+def tables(kind, U, I, d, g):
+    if kind == "random":
+        return torch.randn(U, d, generator=g, device="cuda") * 0.1, torch.randn(I, d, generator=g, device="cuda") * 0.1
+    sm = lambda n: torch.softmax(torch.randn(n, d, generator=g, device="cuda") * 0.05, dim=1)
+    nz = lambda n: torch.nn.functional.normalize(torch.randn(n, d, generator=g, device="cuda"), dim=1)
+    # the fused embeddings' shape (Models.py:185-197): mean of (table, layer, softmax layer) + rates x normalised side terms
+    mk = lambda n: (torch.randn(n, d, generator=g, device="cuda") * 0.1 + sm(n) + sm(n)) / 3 + 0.26 * (nz(n) + nz(n)) + 0.55 * nz(n) + 0.012 * nz(n)
+    return mk(U), mk(I)
+
+
+def main():
+    out_path = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    res = []
+    for kind in ("random", "trained_shape"):
+        for U, I, d, K, iters in ((13187, 17366, 64, 50, 20), (65536, 1_000_000, 64, 50, 2), (16384, 1_000_000, 128, 50, 2)):
+            Eu, Ei = tables(kind, U, I, d, g)
+            q = torch.arange(U, device="cuda")
+            rec = {"tables": kind, "U": U, "I": I, "d": d, "K": K}
+            outs = {}
+            for mode in ("exact", "prefilter"):
+                outs[mode] = ops.score_topk(Eu, Ei, q, None, K, mode=mode)
+                torch.cuda.synchronize()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(iters):
+                    ops.score_topk(Eu, Ei, q, None, K, mode=mode)
+                e.record(); torch.cuda.synchronize()
+                ms = s.elapsed_time(e) / iters
+                rec[mode + "_ms"] = ms
+                rec[mode + "_tflops_fp32_equivalent"] = 2.0 * U * I * d / ms / 1e9
+            rec["bit_identical"] = bool(torch.equal(outs["exact"][0], outs["prefilter"][0]) and
+                                        torch.equal(outs["exact"][1].view(torch.int32), outs["prefilter"][1].view(torch.int32)))
+            rec["speedup"] = rec["exact_ms"] / rec["prefilter_ms"]
+            res.append(rec)
+            print(json.dumps(rec), flush=True)
+            del Eu, Ei, outs
+    if out_path:
+        json.dump(res, open(out_path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
