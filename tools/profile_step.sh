@@ -1,6 +1,7 @@
 #!/bin/bash
-# rocprofv3 kernel summary + one-step timeline of the default bench workload, and the PMC passes over its step (round-4 evidence set)
-OUT=gpurun_out/r04prof; mkdir -p $OUT
+# The evidence set of a round for the default bench workload: rocprofv3 kernel summary (--kernel-trace --stats) + one-step timeline, then the
+# PMC passes over its step (tools/pmc_bench.sh). Usage: bash tools/profile_step.sh [out_dir]   (copy the results into profiles/rNN_*)
+OUT=${1:-gpurun_out/prof}; mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 rm -rf /tmp/prof_p

@@ -1,7 +1,8 @@
 #!/bin/bash
-# Round 5: the step's launch chain under rocprofv3 (--kernel-trace --stats), one run per variant of llmrec_amd/fused.py's knobs:
-#   a kernel summary (CSV), a one-step timeline, and the bench's own ms/step for each. Usage: bash tools/r05_chain.sh "<name>:<ENV=V ENV=V>" ...
-OUT=gpurun_out/r05chain; mkdir -p $OUT
+# The step's launch chain under rocprofv3 (--kernel-trace --stats), one run per variant of llmrec_amd/fused.py's knobs (LLMREC_FOLD,
+# LLMREC_BWD_MAIN_FIRST, LLMREC_LOSS_STREAM, LLMREC_SPLIT_PROJ, LLMREC_SPLIT_WGRAD, LLMREC_ID_FIRST ...): a kernel summary (CSV), a one-step
+# timeline, and the bench's own ms/step for each (same box). Usage: bash tools/step_variants.sh "<name>:<ENV=V ENV=V>" ...
+OUT=${STEP_VARIANTS_OUT:-gpurun_out/r05chain}; mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 ARGS="--steps 100 --warmup 20 --no-cpu-baseline --no-kernel-roofline --no-parity --no-row-sharded --no-end-to-end"
