@@ -103,6 +103,30 @@ __global__ void scatter_keys_kernel(int64_t n, const int64_t* __restrict__ ids, 
         keys[j] = ids[j] < 0 ? ~0ull : (((uint64_t)ids[j] << 32) | (uint64_t)(uint32_t)j);
 }
 
+// The per-step case (n <= 16 384: the gradient rows of every rank's batch, 2 B x world) sorts its keys in ONE block: bitonic network over
+// the keys in LDS (128 KB at most) - no vendor library on the per-step path of the row-sharded step; larger n goes
+// through rocPRIM's radix sort below. Keys are distinct ((id, j) pairs; ~0 for skipped / padded slots), so the result is THE sorted order.
+constexpr int SCATTER_SORT_MAX = 16384;
+__global__ __launch_bounds__(1024) void scatter_sort_block_kernel(int n, int n_pow2, const int64_t* __restrict__ ids, uint64_t* __restrict__ keys_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t* k = reinterpret_cast<uint64_t*>(smem_raw);
+    for (int i = threadIdx.x; i < n_pow2; i += 1024)
+        k[i] = (i < n && ids[i] >= 0) ? (((uint64_t)ids[i] << 32) | (uint64_t)(uint32_t)i) : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= n_pow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < (n_pow2 >> 1); t += 1024) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const bool up = (i & size) == 0;
+                const uint64_t a = k[i], b = k[j];
+                if ((a > b) == up) { k[i] = b; k[j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n; i += 1024) keys_out[i] = k[i];
+}
+
 // one 16-lane group per sorted position; the head of a run of equal ids adds the run's rows in ascending j
 __global__ __launch_bounds__(256) void scatter_runs_kernel(int64_t n, const uint64_t* __restrict__ keys, const float* __restrict__ rows,
                                                            int64_t ldr, int d, float alpha, float* __restrict__ dst, int64_t ldd) {
@@ -277,6 +301,22 @@ int llmrec_scatter_rows_f32(int64_t n, const int64_t* ids, const float* rows, in
     uint64_t* keys_b = (uint64_t*)(ws + align_up(8 * n, 256));
     void* temp = ws + 2 * align_up(8 * n, 256);
     size_t temp_avail = (size_t)align_up(n + (32ll << 20), 256), need = 0;
+    if (n <= SCATTER_SORT_MAX) {                               // the per-step case: one block, keys sorted in LDS, no library call
+        int n_pow2 = 2;
+        while (n_pow2 < n) n_pow2 <<= 1;
+        const size_t shmem = (size_t)n_pow2 * sizeof(uint64_t);
+        static bool attr_set = false;                          // (idempotent; a race between two first calls sets the same value twice)
+        if (!attr_set) {
+            LLMREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_sort_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           SCATTER_SORT_MAX * (int)sizeof(uint64_t)));
+            attr_set = true;
+        }
+        scatter_sort_block_kernel<<<1, 1024, shmem, stream>>>((int)n, n_pow2, ids, keys_a);
+        LLMREC_LAUNCH_CHECK();
+        scatter_runs_kernel<<<(unsigned)ceil_div(n, 16), 256, 0, stream>>>(n, keys_a, rows, ldr, d, alpha, dst, ldd);
+        LLMREC_LAUNCH_CHECK();
+        return LLMREC_OK;
+    }
     scatter_keys_kernel<<<grid_for(n, 256), 256, 0, stream>>>(n, ids, keys_a);
     LLMREC_LAUNCH_CHECK();
     hipcub::DoubleBuffer<uint64_t> kbuf(keys_a, keys_b);

@@ -64,7 +64,9 @@ struct TopkArgs {
     // mode 1 (bf16 prefilter + exact rescoring): the item table as bf16 (hi, mid) fragments and max_i ||i||^2 (workspace)
     int mode;
     uint4* pk2;
-    uint32_t* max_norm2_bits;
+    uint32_t* hdr;               // [0] bits of max_i ||i||^2, [1] user tiles flagged for the exact sweep (statistics)
+    uint32_t* fb_word;           // one word per user tile: != 0 = the verification failed, the exact sweep redoes the tile
+    const uint32_t* only_flagged; // exact sweep: blocks of tiles whose word is 0 exit at once (NULL: every tile)
 };
 
 template <int DK>
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     }
     const int q0 = tile * 16;
     if (q0 >= a.n_query) return;                               // block-uniform
+    if (a.only_flagged && a.only_flagged[tile] == 0u) return;  // (the second launch of the bf16 mode: only the tiles its verification flagged)
     if (threadIdx.x < 16) thr_s[threadIdx.x] = -INFINITY;
     if (threadIdx.x < 2) flag_s[threadIdx.x] = 0;             // [0] drain requested, [1] waves that finished their quarter
     __syncthreads();
@@ -428,17 +431,21 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Round 5: bf16 PREFILTER + EXACT RESCORING. The sweep above spends 1024 matrix cycles per 16 users x 32 items
-// on the exact-fp32 MFMA although only ~4 % of the scores it forms ever reach a user's candidate buffer. Here the sweep runs on
-// v_mfma_f32_16x16x32_bf16 with both operands cut into two bf16 numbers (x = h + m + r, truncating splits: |r| < 2^-14 |x|):
+// Round 5: bf16 SWEEP + EXACT VERIFICATION. The sweep above spends 1024 matrix cycles per 16 users x 32 items on
+// the exact-fp32 MFMA. Here the sweep runs on v_mfma_f32_16x16x32_bf16 with both operands cut into two bf16 numbers (x = h + m + r,
+// truncating splits: |r| < 2^-14 |x|):
 //     s' = <u_h, i_h> + <u_h, i_m> + <u_m, i_h>          (three MFMAs per 32 k: 192 matrix cycles per 16 x 32 tile at d = 64)
-//     |s - s'| <= (3 x 2^-14 + accumulation) sum_k |u_k| |i_k|  <=  2^-12 ||u|| ||i||      (Cauchy-Schwarz; the constant is 4 x 2^-14)
-// A score is APPENDED to the candidate buffer iff  s' >= thr_u - eps_u,  eps_u = 2^-12 ||u|| max_i ||i||  (thr_u = the user's exact K-th
-// score so far): a superset of what the exact sweep appends, since a true candidate has s >= thr_u. At every drain the buffered
-// candidates are RESCORED EXACTLY - one lane per candidate runs the k-ordered fp32 fma chain of v_mfma_f32_16x16x4_f32 (for c, for s,
-// for q: k = 16 c + 4 q + s; a VALU v_fma_f32 chain gives the MFMA's bits: tests/test_gpu_ops.py holds both to oracle.scores_fma_chain) on
-// the user's row (LDS) and the item's fp32 row (global, L2) - and sorted / merged exactly as above. The false positives have exact scores
-// below the K-th and never enter the top K: lists and scores are BIT-IDENTICAL to score_topk_kernel's (every top-K test runs both).
+//     |s - s'| <= (3 x 2^-14 + accumulation) sum_k |u_k| |i_k|  <=  eps_u := 2^-12 ||u|| max_i ||i||      (Cauchy-Schwarz)
+// and keeps, per user, the 64 best items BY s' (same buffers, drains, bitonic merges as the exact sweep; the filter is the list's 64th
+// s'). At the end the 64 kept items are scored EXACTLY - one lane per item runs the k-ordered fp32 fma chain of v_mfma_f32_16x16x4_f32
+// (for c, for s, for q: k = 16 c + 4 q + s; a VALU v_fma_f32 chain gives the MFMA's bits) - and re-ranked by (exact score desc, id asc).
+// VERIFICATION: every item outside the list has s' <= s'_64, hence s <= s'_64 + eps_u. If s'_64 + eps_u < e_K (the K-th exact score
+// of the list) no outside item can reach the top K: the list's top K IS the exact top K, bit for bit what score_topk_kernel returns.
+// Otherwise (more than 64 - K items within 2 eps of the boundary: near-identical rows, massive ties) the user tile is FLAGGED and the
+// exact sweep runs for the flagged tiles in a second launch (blocks of unflagged tiles exit at once). The first (wave-uniform) version
+// of this mode rescored every candidate at every drain: bit-identical too, but 5 - 20 % SLOWER than the exact sweep - the drains are a
+// block-wide critical section and the rescoring put 4 exposed L2 latencies into each of their ~190 iterations per block
+// (profiles/experiments/r05_topk.md).
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef __bf16 tk_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 tk_mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
@@ -457,13 +464,16 @@ __device__ __forceinline__ void tk_split8(const float (&x)[8], uint4& H, uint4& 
 }
 constexpr float TK_PRE_SLACK = 0x1p-12f;                                 // eps_u = TK_PRE_SLACK ||u|| max ||i||
 
+// workspace header of the mode (first 256 bytes of the fragment area): [0] bits of max_i ||i||^2, [1] user tiles flagged for the exact sweep
 // the item table as bf16 (hi, mid) MFMA fragments: pk2[(((tile * 2 + n) * DK32 + c) * 2 + hm) * 64 + lane], lane = 16 (k group) + item-in-tile;
-// one thread per (item, 8 consecutive k).
+// one thread per (item, 8 consecutive k). Also clears the header and the fallback flags (the norm kernel and the sweep follow on the stream).
 __global__ __launch_bounds__(256) void topk_pack_items_bf16_kernel(TopkArgs a, int DK32, uint4* __restrict__ pk2) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.max_norm2_bits[0] = 0u;  // (topk_item_norm_kernel follows on the stream)
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v < 2) a.hdr[v] = 0u;
+    const int n_tiles_u = (a.n_query + 15) / 16;
+    if (v < n_tiles_u) a.fb_word[v] = 0u;
     const int G = DK32 * 4;                                            // 8-float groups per (padded) row
     const int64_t n_pad = (a.n_items + TK_TILE - 1) / TK_TILE * TK_TILE;
-    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (v >= n_pad * G) return;
     const int64_t item_p = v / G;
     const int g = (int)(v - item_p * G);
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(256) void topk_pack_items_bf16_kernel(TopkArgs a, i
 }
 
 // max_i ||i||^2 as the bits of a non-negative float (atomicMax on uint32 is order-independent: deterministic). One 16-lane group per item.
-__global__ __launch_bounds__(256) void topk_item_norm_kernel(TopkArgs a, uint32_t* __restrict__ max_norm2_bits) {
+__global__ __launch_bounds__(256) void topk_item_norm_kernel(TopkArgs a) {
     const int gl = threadIdx.x & 15;
     float mx = 0.f;
     for (int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); item < a.n_items; item += (int64_t)gridDim.x * 16) {
@@ -494,21 +504,56 @@ __global__ __launch_bounds__(256) void topk_item_norm_kernel(TopkArgs a, uint32_
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(max_norm2_bits, __float_as_uint(mx));
+    if ((threadIdx.x & 63) == 0) atomicMax(&a.hdr[0], __float_as_uint(mx));
+}
+
+// One user's 64 kept items (lane = slot, sorted by approximate score; id INT_MAX = empty slot) -> the exact ranking, the verification, the
+// output. `urow` = the user's fp32 row (LDS or global). Wave-uniform control flow.
+__device__ __forceinline__ void tk_finalize_user(const TopkArgs& a, const float* urow, int q, int tile, float approx, int32_t id, int lane) {
+    const float s64 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(approx), 63));   // the outside bound (-inf: list not full)
+    float e = -INFINITY, un2 = 0.f;
+    {
+        const int64_t it = id == INT_MAX ? 0 : id;
+        const float* ir = a.Ei + it * a.ldi;
+        float acc = 0.f;
+        const int nc = (a.d + 15) / 16;
+#pragma unroll 1
+        for (int c = 0; c < nc; ++c) {                                   // the k-ordered chain: c, then s, then q; k = 16 c + 4 q + s
+            float4 iv[4], uv[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) { iv[qq] = ld4g(ir, 16 * c + 4 * qq, a.d, a.vec_ok); uv[qq] = ld4g(urow, 16 * c + 4 * qq, a.d, false); }
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float uu = cmp4(uv[qq], s_);
+                    acc = __builtin_fmaf(uu, cmp4(iv[qq], s_), acc);
+                    un2 = __builtin_fmaf(uu, uu, un2);
+                }
+        }
+        if (id != INT_MAX) e = acc;
+    }
+    float es[1] = {e}; int32_t ei[1] = {id};
+    sort64<1>(es, ei, lane);
+    const float eK = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(es[0]), a.K - 1));
+    const float eps = TK_PRE_SLACK * sqrtf(un2) * sqrtf(__uint_as_float(a.hdr[0])) * 1.0001f;
+    const bool ok = (s64 == -INFINITY) || (s64 + eps < eK);           // (NaN anywhere -> not ok -> the exact sweep decides)
+    if (q < a.n_query && lane < a.K) {
+        a.out_idx[(int64_t)q * a.K + lane] = ei[0] == INT_MAX ? -1 : ei[0];
+        a.out_score[(int64_t)q * a.K + lane] = es[0];
+    }
+    if (!ok && q < a.n_query && lane == 0) {
+        if (atomicExch(reinterpret_cast<unsigned int*>(&a.fb_word[tile]), 1u) == 0u) atomicAdd(&a.hdr[1], 1u);
+    }
 }
 
 template <int DK32>
-__global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kernel(TopkArgs a, const uint4* __restrict__ pk2, const uint32_t* __restrict__ max_norm2_bits) {
-    constexpr int DP = DK32 * 32;                                      // padded row width
-    __shared__ int32_t buf_i[4][16][TK_CAP];                           // candidate item ids (their approximate scores are not kept)
+__global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kernel(TopkArgs a, const uint4* __restrict__ pk2) {
+    __shared__ float buf_s[4][16][TK_CAP];                             // approximate scores of the buffered candidates
+    __shared__ int32_t buf_i[4][16][TK_CAP];
     __shared__ int32_t cnt_s[4][16];
-    __shared__ float thr_s[16];                                        // exact K-th score so far
-    __shared__ float flt_s[16];                                        // the sweep's filter: thr - eps
-    __shared__ float eps_s[16];
+    __shared__ float thr_s[16];                                        // the filter: the 64th approximate score of the user's list so far
     __shared__ int32_t flag_s[2];
-    __shared__ __attribute__((aligned(16))) float u_lds[16][DP];       // the block's users, fp32, for the exact rescoring
-    __shared__ float list_s[16][64];                                   // the block's sorted lists (slot = lane): in LDS between drains - the
-    __shared__ int32_t list_i[16][64];                                 // sweep loop keeps its registers for the fragments
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lq = lane >> 4;
     int tile = blockIdx.x, part = 0, n_parts = 1;
@@ -519,32 +564,22 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     }
     const int q0 = tile * 16;
     if (q0 >= a.n_query) return;
+    if (threadIdx.x < 16) thr_s[threadIdx.x] = -INFINITY;
     if (threadIdx.x < 2) flag_s[threadIdx.x] = 0;
+    __syncthreads();
 
-    // A operand: row li of the block's users, k = 32 c + 8 lq + j -> (hi, mid) fragments; the fp32 row goes to LDS (wave 0 writes it)
+    // A operand: row li of the block's users, k = 32 c + 8 lq + j -> (hi, mid) fragments
     int qa = q0 + li;
     if (qa > a.n_query - 1) qa = a.n_query - 1;
     const int64_t user_a = a.query_users[qa];
     uint4 uH[DK32], uM[DK32];
-    float un2 = 0.f;
 #pragma unroll
     for (int c = 0; c < DK32; ++c) {
         float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const int k = 32 * c + 8 * lq + j; x[j] = k < a.d ? a.Eu[user_a * a.ldu + k] : 0.f; un2 = fmaf(x[j], x[j], un2); }
+        for (int j = 0; j < 8; ++j) { const int k = 32 * c + 8 * lq + j; x[j] = k < a.d ? a.Eu[user_a * a.ldu + k] : 0.f; }
         tk_split8(x, uH[c], uM[c]);
-        if (w == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) u_lds[li][32 * c + 8 * lq + j] = x[j];
-        }
     }
-    un2 += __shfl_xor(un2, 16, 64); un2 += __shfl_xor(un2, 32, 64);    // ||u||^2 of row li in every lane with that li
-    if (threadIdx.x < 16) {
-        const float in2 = __uint_as_float(max_norm2_bits[0]);
-        eps_s[li] = TK_PRE_SLACK * sqrtf(un2) * sqrtf(in2) * 1.0001f;    // (the square roots round: a hair of extra slack)
-        thr_s[li] = -INFINITY; flt_s[li] = -INFINITY;
-    }
-    __syncthreads();
 
     const int64_t tiles_all = (a.n_items + TK_TILE - 1) / TK_TILE;
     const int64_t part_begin = tiles_all * part / n_parts, tiles_total = tiles_all * (part + 1) / n_parts;
@@ -565,8 +600,9 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
         if (cur < end) nxt = a.train_colidx[cur];
     }
     int cntr[4] = {0, 0, 0, 0};
+    float ls[4]; int32_t lid[4];                                       // the block's lists of users 4 w + rr by APPROXIMATE score, slot = lane
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) { list_s[4 * w + rr][lane] = -INFINITY; list_i[4 * w + rr][lane] = INT_MAX; }   // (only this wave touches its users' lists)
+    for (int rr = 0; rr < 4; ++rr) { ls[rr] = -INFINITY; lid[rr] = INT_MAX; }
 
     const int64_t my_rounds = t_end > t_begin ? t_end - t_begin : 0;
     uint4 bH[2][DK32], bM[2][DK32];
@@ -600,39 +636,20 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
             for (int rr = 0; rr < 4; ++rr) {
                 const int u = 4 * w + rr;
                 const int p1 = cnt_s[0][u], p2 = p1 + cnt_s[1][u], p3 = p2 + cnt_s[2][u], total = p3 + cnt_s[3][u];
-                float l1[1] = {list_s[u][lane]}; int32_t i1[1] = {list_i[u][lane]};
+                float l1[1] = {ls[rr]}; int32_t i1[1] = {lid[rr]};
                 for (int j0 = 0; j0 < total; j0 += 64) {
                     const int j = j0 + lane;
                     const int ww = (j >= p1) + (j >= p2) + (j >= p3);
                     const int start = ww == 0 ? 0 : (ww == 1 ? p1 : (ww == 2 ? p2 : p3));
                     float bs[1] = {-INFINITY}; int32_t bi[1] = {INT_MAX};
-                    if (j < total) {
-                        bi[0] = buf_i[ww][u][j - start];
-                        // EXACT score: the k-ordered fma chain of v_mfma_f32_16x16x4_f32 (c, then s, then q; k = 16 c + 4 q + s)
-                        const float* ir = a.Ei + (int64_t)bi[0] * a.ldi;
-                        float acc = 0.f;
-#pragma unroll 1
-                        for (int c = 0; c < DP / 16; ++c) {                     // (rolled: one chunk's 16 + 16 operand floats in registers at a time)
-                            if (16 * c < a.d) {
-                                float4 iv[4];
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) iv[q] = ld4g(ir, 16 * c + 4 * q, a.d, a.vec_ok);
-                                const float* uc = &u_lds[u][16 * c];                // (wave-uniform address: LDS broadcast reads)
-#pragma unroll
-                                for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(uc[4 * q + s_], cmp4(iv[q], s_), acc);
-                            }
-                        }
-                        bs[0] = acc;
-                    }
+                    if (j < total) { bs[0] = buf_s[ww][u][j - start]; bi[0] = buf_i[ww][u][j - start]; }
                     sort64<1>(bs, bi, lane);
                     merge64<1>(l1, i1, bs, bi, lane);
                 }
-                list_s[u][lane] = l1[0]; list_i[u][lane] = i1[0];
+                ls[rr] = l1[0]; lid[rr] = i1[0];
                 if (total > 0) {
-                    const float nthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l1[0]), a.K - 1));
-                    if (lane == 0) { thr_s[u] = nthr; flt_s[u] = nthr - eps_s[u]; }
+                    const float nthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ls[rr]), 63));   // the 64th: the whole list is exact-by-s'
+                    if (lane == 0) thr_s[u] = nthr;
                 }
             }
 #pragma unroll
@@ -640,9 +657,6 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
             if (threadIdx.x == 0) flag_s[0] = 0;
             __syncthreads();
             if (done_quarters == 4) break;
-            // the tile prefetched before the drain is fetched AGAIN (L2) instead of being kept in 32 registers across the drain's
-            // sort / rescoring code: drains are ~6 per sweep, the registers decide whether four blocks fit a CU
-            if (!fin) { pk -= 2 * DK32 * 2 * 64; load_tile(); }
             continue;
         }
         const int64_t base = (t_begin + round) * TK_TILE;
@@ -669,7 +683,7 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
         const unsigned long long any_train = __ballot(m != 0u);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float rthr = (q0 + lq * 4 + r < a.n_query) ? flt_s[lq * 4 + r] : INFINITY;
+            const float rthr = (q0 + lq * 4 + r < a.n_query) ? thr_s[lq * 4 + r] : INFINITY;
             uint32_t rm = 0;
             if (any_train) rm = __shfl(m, lq * 4 + r, 64);
 #pragma unroll
@@ -683,6 +697,7 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
                 const unsigned sub = (unsigned)(bal >> (16 * lq)) & 0xffffu;
                 if (pass) {
                     const int off = cntr[r] + __popc(sub & ((1u << li) - 1u));
+                    buf_s[w][lq * 4 + r][off] = v;
                     buf_i[w][lq * 4 + r][off] = (int32_t)(base + col);
                 }
                 cntr[r] += __popc(sub);
@@ -690,23 +705,38 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
         }
         ++round;
     }
-    if (n_parts > 1) {
+    if (n_parts > 1) {                                         // a part's lists (approximate scores): merged and finalised by topk_merge_pre_kernel
         const int64_t base = ((int64_t)(tile - a.split_from) * n_parts + part) * 16;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            a.ws_idx[(base + 4 * w + rr) * 64 + lane] = list_i[4 * w + rr][lane];
-            a.ws_score[(base + 4 * w + rr) * 64 + lane] = list_s[4 * w + rr][lane];
+            a.ws_idx[(base + 4 * w + rr) * 64 + lane] = lid[rr];
+            a.ws_score[(base + 4 * w + rr) * 64 + lane] = ls[rr];
         }
         return;
     }
-#pragma unroll
+#pragma unroll 1
     for (int rr = 0; rr < 4; ++rr) {
         const int q = q0 + 4 * w + rr;
-        if (q < a.n_query && lane < a.K) {
-            const int32_t id = list_i[4 * w + rr][lane];
-            a.out_idx[(int64_t)q * a.K + lane] = id == INT_MAX ? -1 : id;
-            a.out_score[(int64_t)q * a.K + lane] = list_s[4 * w + rr][lane];
+        if (q >= a.n_query) continue;                          // wave-uniform
+        tk_finalize_user(a, a.Eu + a.query_users[q] * a.ldu, q, tile, ls[rr], lid[rr], lane);
+    }
+}
+
+// the lists of a split tile's parts (by approximate score) -> the tile's 64 best by approximate score -> exact ranking + verification
+__global__ __launch_bounds__(256) void topk_merge_pre_kernel(TopkArgs a) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int tile = a.split_from + blockIdx.x;
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+        const int q = tile * 16 + 4 * w + rr;
+        if (q >= a.n_query) continue;                          // wave-uniform
+        float l1[1] = {-INFINITY}; int32_t i1[1] = {INT_MAX};
+        for (int p = 0; p < a.n_parts; ++p) {
+            const int64_t row = ((int64_t)blockIdx.x * a.n_parts + p) * 16 + 4 * w + rr;
+            const float bs[1] = {a.ws_score[row * 64 + lane]}; const int32_t bi[1] = {a.ws_idx[row * 64 + lane]};
+            merge64<1>(l1, i1, bs, bi, lane);
         }
+        tk_finalize_user(a, a.Eu + a.query_users[q] * a.ldu, q, tile, l1[0], i1[0], lane);
     }
 }
 
@@ -808,23 +838,39 @@ static int launch_topk(const TopkArgs& a, hipStream_t stream) {
     const bool fast = a.vec_ok && a.d == 16 * DK;
     if (SELECT && a.mode == 1) {
         const int DK32 = (a.d + 31) / 32;
-        const int64_t n_thr = ceil_div(a.n_items, TK_TILE) * TK_TILE * DK32 * 4;
+        int64_t n_thr = ceil_div(a.n_items, TK_TILE) * TK_TILE * DK32 * 4;
+        if (n_thr < n_tiles) n_thr = n_tiles;                  // (the pack launch also clears one flag word per user tile)
         topk_pack_items_bf16_kernel<<<(unsigned)ceil_div(n_thr, 256), 256, 0, stream>>>(a, DK32, a.pk2);
         LLMREC_LAUNCH_CHECK();
-        topk_item_norm_kernel<<<grid_for(a.n_items, 16), 256, 0, stream>>>(a, a.max_norm2_bits);
+        topk_item_norm_kernel<<<grid_for(a.n_items, 16), 256, 0, stream>>>(a);
         LLMREC_LAUNCH_CHECK();
         switch (DK32) {
-            case 1: score_topk_pre_kernel<1><<<grid, 256, 0, stream>>>(a, a.pk2, a.max_norm2_bits); break;
-            case 2: score_topk_pre_kernel<2><<<grid, 256, 0, stream>>>(a, a.pk2, a.max_norm2_bits); break;
-            case 3: score_topk_pre_kernel<3><<<grid, 256, 0, stream>>>(a, a.pk2, a.max_norm2_bits); break;
-            case 4: score_topk_pre_kernel<4><<<grid, 256, 0, stream>>>(a, a.pk2, a.max_norm2_bits); break;
+            case 1: score_topk_pre_kernel<1><<<grid, 256, 0, stream>>>(a, a.pk2); break;
+            case 2: score_topk_pre_kernel<2><<<grid, 256, 0, stream>>>(a, a.pk2); break;
+            case 3: score_topk_pre_kernel<3><<<grid, 256, 0, stream>>>(a, a.pk2); break;
+            case 4: score_topk_pre_kernel<4><<<grid, 256, 0, stream>>>(a, a.pk2); break;
             default: set_error("score_topk: d = %d > 128", a.d); return LLMREC_EUNSUPPORTED;
         }
         LLMREC_LAUNCH_CHECK();
         if (a.n_parts > 1) {
-            topk_merge_kernel<<<n_tiles - a.split_from, 256, 0, stream>>>(a);
+            topk_merge_pre_kernel<<<n_tiles - a.split_from, 256, 0, stream>>>(a);
             LLMREC_LAUNCH_CHECK();
         }
+        // second launch: the exact sweep for the tiles whose verification failed (every other block exits at once); unsplit, fragments
+        // straight from Ei (the workspace's fragment area holds the bf16 table)
+        TopkArgs e = a;
+        e.mode = 0; e.only_flagged = a.fb_word; e.split_from = n_tiles; e.n_parts = 1; e.packed = nullptr;
+#define LLMREC_TOPK_FB(D) case D: \
+        if (fast) score_topk_kernel<D, true, false><<<n_tiles, 256, 0, stream>>>(e); \
+        else score_topk_kernel<D, false, false><<<n_tiles, 256, 0, stream>>>(e); \
+        break;
+        switch (DK) {
+            LLMREC_TOPK_FB(1) LLMREC_TOPK_FB(2) LLMREC_TOPK_FB(3) LLMREC_TOPK_FB(4)
+            LLMREC_TOPK_FB(5) LLMREC_TOPK_FB(6) LLMREC_TOPK_FB(7) LLMREC_TOPK_FB(8)
+            default: set_error("score_topk: d = %d > 128", a.d); return LLMREC_EUNSUPPORTED;
+        }
+#undef LLMREC_TOPK_FB
+        LLMREC_LAUNCH_CHECK();
         return LLMREC_OK;
     }
     if (SELECT && a.packed) {
@@ -867,12 +913,18 @@ static int64_t topk_split_bytes(int32_t n_query, int64_t n_items) {
 static int64_t topk_packed_bytes(int64_t n_items, int32_t d) {
     const int64_t exact = ceil_div(n_items, TK_TILE) * 2 * ceil_div(d, 16) * 64 * 16;      // fp32 fragments (rows padded to whole tiles, d to 16)
     const int64_t pre = ceil_div(n_items, TK_TILE) * 2 * ceil_div(d, 32) * 2 * 64 * 16;   // bf16 (hi, mid) fragments (d padded to 32)
-    return (exact > pre ? exact : pre) + 256;                                              // + the slot of max ||i||^2 (mode 1)
+    return (exact > pre ? exact : pre) + 256;                                              // + the header of the bf16 mode
 }
+static int64_t topk_flag_bytes(int32_t n_query) { return align_up(4 * ceil_div(n_query, 16), 256); }   // one word per user tile (bf16 mode)
 
 int64_t llmrec_score_topk_workspace_bytes(int32_t n_query, int64_t n_items, int32_t d) {
     if (n_query < 0 || n_items <= 0 || d <= 0) return -1;
-    return align_up(topk_split_bytes(n_query, n_items), 256) + topk_packed_bytes(n_items, d);
+    return align_up(topk_split_bytes(n_query, n_items), 256) + topk_packed_bytes(n_items, d) + topk_flag_bytes(n_query);
+}
+
+int64_t llmrec_score_topk_stats_offset(int32_t n_query, int64_t n_items) {
+    if (n_query < 0 || n_items <= 0) return -1;
+    return align_up(topk_split_bytes(n_query, n_items), 256);
 }
 
 int llmrec_score_topk_f32(int32_t n_query, const int64_t* query_users,
@@ -913,7 +965,8 @@ int llmrec_score_topk_mode_f32(int32_t n_query, const int64_t* query_users,
     a.out_idx = out_idx; a.out_score = out_score; a.S = nullptr; a.lds = 0;
     a.vec_ok = (ldu % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)Eu | (uintptr_t)Ei) % 16 == 0);
     a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
-    a.mode = mode; a.pk2 = nullptr; a.max_norm2_bits = nullptr;
+    if (mode == LLMREC_TOPK_MODE_PREFILTER && K > LLMREC_TOPK_PREFILTER_MAX_K) mode = LLMREC_TOPK_MODE_EXACT_SWEEP;   // (no room to verify in 64 slots)
+    a.mode = mode; a.pk2 = nullptr; a.hdr = nullptr; a.fb_word = nullptr; a.only_flagged = nullptr;
     if (workspace) {                                           // without a workspace: one block per user tile, fragments straight from Ei
         const int64_t need = llmrec_score_topk_workspace_bytes(n_query, n_items, d), split = topk_split_bytes(n_query, n_items);
         LLMREC_CHECK_ARG(workspace_bytes >= need && (uintptr_t)workspace % 16 == 0, "score_topk: workspace of %lld bytes needed (16-byte aligned)", (long long)need);
@@ -925,8 +978,9 @@ int llmrec_score_topk_mode_f32(int32_t n_query, const int64_t* query_users,
         char* frag = (char*)workspace + align_up(split, 256);
         a.packed = (const float4*)frag;
         if (mode == LLMREC_TOPK_MODE_PREFILTER) {
-            a.max_norm2_bits = (uint32_t*)frag;                // (the first 256 bytes of the fragment area)
+            a.hdr = (uint32_t*)frag;                           // (the first 256 bytes of the fragment area)
             a.pk2 = (uint4*)(frag + 256);
+            a.fb_word = (uint32_t*)(frag + topk_packed_bytes(n_items, d));
         }
     }
     return launch_topk<true>(a, (hipStream_t)stream_);
@@ -944,7 +998,7 @@ int llmrec_scores_f32(int32_t n_query, const int64_t* query_users,
     a.out_idx = nullptr; a.out_score = nullptr; a.S = S; a.lds = lds;
     a.vec_ok = (ldu % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)Eu | (uintptr_t)Ei) % 16 == 0);
     a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
-    a.mode = 0; a.pk2 = nullptr; a.max_norm2_bits = nullptr;
+    a.mode = 0; a.pk2 = nullptr; a.hdr = nullptr; a.fb_word = nullptr; a.only_flagged = nullptr;
     return launch_topk<false>(a, (hipStream_t)stream_);
 }
 

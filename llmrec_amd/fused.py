@@ -768,6 +768,23 @@ class FusedStep:
         need = ops.linear_wgrad_multi_workspace(self.wgrad_targets(self.dU_cat if self.preprop else self.dP_cat, self.dP_usr), self.wgrad_blocks)
         self.ws_wgrad_multi = torch.empty(max(need, 0), dtype=torch.uint8, device=self.dP_usr.device) if need >= 0 else False
 
+    def check_wgrad_geometry(self, factor: float = 1.5) -> bool:
+        """the row-listed weight gradient's launch geometry is laid out for the list length of the FIRST step (+ 10 %) and frozen
+        into the captured graph; the kernel re-cuts its slabs for the actual length, so results never depend on it, but a workload whose
+        batches later reach many more (or far fewer) rows would run in a badly balanced launch with no signal. Call this where the host
+        synchronises anyway (main.py: once per epoch, behind the epoch sums): ONE read-back of the last step's list length; when it left
+        [expected / factor, expected * factor] the launch is laid out again and the step graph RE-captured (no warm-up step: nothing is
+        trained here). Returns whether it re-captured."""
+        if not self.wgrad_rows or self.act_expected is None or torch.cuda.is_current_stream_capturing():
+            return False
+        want = max(64, min(self.U, int(int(self.act_n.item()) * 1.10) + 32))
+        if self.act_expected / factor <= want <= self.act_expected * factor:
+            return False
+        self._size_wgrad_for_rows()
+        if self.graph_exec is not None and getattr(self, "_capture_args", None) is not None:
+            self.capture(warm=False, **self._capture_args)
+        return True
+
     def flush(self):
         """Nothing is deferred in the single-graph step (DataParallelStep defers its AdamW)."""
 
@@ -822,27 +839,31 @@ class FusedStep:
         self.static = {"users": blk[0:b], "pos": blk[b:2 * b], "neg": blk[2 * b:3 * b], "n_valid": blk[3 * b:3 * b + 1].view(torch.int32)[:1]}
         return self.static
 
-    def capture(self, warm_users=None, warm_pos=None, warm_neg=None, warm_n_valid=None, batcher=None, unroll: int = 1):
+    def capture(self, warm_users=None, warm_pos=None, warm_neg=None, warm_n_valid=None, batcher=None, unroll: int = 1, warm: bool = True):
         """Capture one step (fixed batch capacity b_max, actual size on the device in n_valid).
         With `batcher` (engine.DeviceBatcher, capacity == b_max) the sampler is part of the graph: a
-        training step is then ``step()`` with no arguments = one graph replay, nothing else on the stream."""
-        st = self._make_static()
+        training step is then ``step()`` with no arguments = one graph replay, nothing else on the stream.
+        warm=False (a RE-capture, check_wgrad_geometry): no warm-up step is run - it would be an extra optimiser step - and the static
+        batch buffers are kept."""
+        st = self._make_static() if (warm or self.static is None) else self.static
         self.batcher = batcher
+        self._capture_args = {"batcher": batcher, "unroll": unroll}
         if batcher is not None:
             if batcher.capacity != self.b_max:
                 raise RuntimeError("FusedStep.capture: batcher capacity %d != b_max %d" % (batcher.capacity, self.b_max))
-        else:
+        elif warm:
             self._load(warm_users, warm_pos, warm_neg, warm_n_valid)
 
         def one_step():
             fill = (lambda: batcher.fill(st["users"], st["pos"], st["neg"], st["n_valid"])) if batcher is not None else None
             self.step_eager(st["users"], st["pos"], st["neg"], st["n_valid"], sampler=fill)
         self.reset_scatter_targets()                           # (re)capture starts from the invariant, whatever ran before
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):                             # warm-up on a side stream (allocations, plan caches)
-            one_step()
-        torch.cuda.current_stream().wait_stream(s)
+        if warm:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):                         # warm-up on a side stream (allocations, plan caches)
+                one_step()
+            torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with _capture_without_gc(g):

@@ -927,8 +927,9 @@ def topk_mode(mode=None) -> int:
     return TOPK_MODES[mode]
 
 
-def score_topk(Eu, Ei, query_users: torch.Tensor, train: Optional[Csr], K: int, mode=None):
-    """Masked top-K item ids (int32 [n_query, K], -1 = none) and scores for the listed users."""
+def score_topk(Eu, Ei, query_users: torch.Tensor, train: Optional[Csr], K: int, mode=None, stats: Optional[dict] = None):
+    """Masked top-K item ids (int32 [n_query, K], -1 = none) and scores for the listed users. stats (a dict; synchronises): receives
+    "fallback_tiles" / "tiles" - the user tiles the bf16 mode's verification sent to the exact sweep."""
     _need_gpu(Eu, Ei, query_users)
     Eu, Ei = _rowmajor(Eu.detach()), _rowmajor(Ei.detach())
     q = query_users.to(torch.int64).contiguous()
@@ -939,6 +940,10 @@ def score_topk(Eu, Ei, query_users: torch.Tensor, train: Optional[Csr], K: int, 
     _lib.call("llmrec_score_topk_mode_f32", n, _p(q), _p(Eu), _ld(Eu), _p(Ei), _ld(Ei), Ei.shape[0], Eu.shape[1],
               _p(train.rowptr) if train is not None else None, _p(train.colidx) if train is not None else None,
               K, _p(idx), _p(sc), _p(ws), ws.numel() if ws is not None else 0, topk_mode(mode), _stream())
+    if stats is not None:
+        off = _lib.query("llmrec_score_topk_stats_offset", n, Ei.shape[0])
+        stats["tiles"] = (n + 15) // 16
+        stats["fallback_tiles"] = int(ws[off + 4:off + 8].view(torch.int32).item()) if (topk_mode(mode) == 1 and K <= CONST["LLMREC_TOPK_PREFILTER_MAX_K"]) else 0
     return idx, sc
 
 

@@ -440,6 +440,9 @@ class Trainer(object):
                     sums = fused.epoch_sums
             self.sample_time = sample_time                               # host seconds of this epoch spent in Data.sample() + the aug triples
             loss, mf_loss, emb_loss = (float(x) for x in sums.cpu())     # one sync per epoch
+            fused_ = self._fused_step()
+            if fused_ and hasattr(fused_, "check_wgrad_geometry"):       # (the host is synchronised here anyway: one more scalar read-back)
+                fused_.check_wgrad_geometry()
             reg_loss, contrastive_loss = 0., 0.
 
             if math.isnan(loss):

@@ -251,6 +251,32 @@ def test_scatter_rows_is_deterministic_and_matches_index_add():
     assert torch.equal(big_dst[:, :d].cpu(), outs[0]) and float(big_dst[:, d:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 1000, 16383, 16384, 16385, 40000])
+def test_scatter_rows_sorts_in_one_block_up_to_16384_rows_and_through_the_radix_sort_beyond(n):
+    """llmrec_scatter_rows_f32: n <= 16 384 (the per-step case: 2 B x world gradient rows) orders its (id, j) keys with a one-block bitonic
+    network in LDS - no vendor library on the row-sharded step's path -, larger n with rocPRIM's radix sort; the keys are
+    distinct, so both give THE order: the same bits as a sequential accumulation in ascending j, run to run."""
+    from llmrec_amd import dist as ld
+    be = ld.HipBackend()
+    rng = np.random.default_rng(n)
+    rows_dst, d = 257, 64
+    ids = rng.integers(0, rows_dst, size=n)
+    if n > 10:
+        ids[: n // 7] = 5; ids[rng.integers(0, n, size=n // 20 + 1)] = -1
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    base = rng.standard_normal((rows_dst, d)).astype(np.float32)
+    outs = []
+    for _ in range(2):
+        dst = torch.tensor(base).cuda()
+        be.scatter_rows(torch.tensor(ids).cuda(), torch.tensor(rows).cuda(), dst, 0.5)
+        outs.append(dst.cpu())
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.tensor(base).double()
+    keep = ids >= 0
+    ref.index_add_(0, torch.tensor(ids[keep]), 0.5 * torch.tensor(rows[keep]).double())
+    assert float((outs[0].double() - ref).abs().max() / ref.abs().max()) < 3e-6
+
+
 def test_bpr_gradient_rows_match_the_scatter_form():
     """llmrec_bpr_prune_bwd_rows_f32 = the same per-sample gradients llmrec_bpr_prune_bwd_f32 scatters."""
     from llmrec_amd import dist as ld

@@ -340,3 +340,40 @@ def test_device_state_is_built_once_per_device(golden):
     fused = tr._fused_step()
     if fused:
         assert len(fused._eval_graphs) == 1                       # one captured evaluation, replayed
+
+
+def test_weight_gradient_geometry_is_relaid_and_the_graph_recaptured_without_an_extra_step(golden, monkeypatch):
+    """FusedStep.check_wgrad_geometry: when the row list's length has left the range the captured launch was laid out for, the
+    launch is laid out again and the step graph RE-captured with no warm-up step - the trajectory goes on exactly where it was: every later
+    step's 8 (mf, emb) pairs and the final parameters still match the reference's golden vectors."""
+    monkeypatch.setenv("LLMREC_FUSED", "1"); monkeypatch.setenv("LLMREC_GRAPH", "1")
+    m = load_dropin(golden_argv(golden))
+    m.set_seed(golden.args["seed"])
+    tr = m.Trainer(data_config={})
+    bpr_log = []
+    tr._on_bpr = lambda mf, emb: bpr_log.append((mf.detach(), emb.detach()))
+    recaptured = 0
+    for s in range(golden.n_steps):
+        users, pos, neg = (torch.tensor(golden.z["step%d/%s" % (s, n)]).cuda() for n in ("users", "pos", "neg"))
+        bpr_log.clear()
+        tr.train_step(users, pos, neg)
+        got = np.array([[float(a), float(b)] for a, b in bpr_log])
+        gold = golden.z["step%d/bpr" % s]
+        assert np.abs(got - gold).max() <= RTOL * np.abs(gold).max(), (s, recaptured)
+        f = tr._fused_step()
+        if s == 1 and f.wgrad_rows:
+            assert f.graph_exec is not None and f.act_expected is not None
+            assert f.check_wgrad_geometry() is False                     # the list length is what the launch was laid out for
+            old_graph = f.graph_exec
+            f.act_expected = f.act_expected * 4 + 1000                   # pretend the launch had been laid out for a far longer list
+            assert f.check_wgrad_geometry() is True
+            assert f.graph_exec is not old_graph and f.act_expected < 4 * f.U
+            recaptured += 1
+    params = dict(tr.model_mm.named_parameters())
+    last = max(golden.detail_steps())
+    if last == golden.n_steps - 1:
+        for nm in TRAINABLE:
+            e = rel(params[nm].detach().cpu().numpy(), golden.z["step%d/param/%s" % (last, nm)])
+            assert e < RTOL, (nm, e)
+    if tr._fused_step().wgrad_rows:
+        assert recaptured == 1

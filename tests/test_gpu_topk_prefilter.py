@@ -1,6 +1,6 @@
-"""llmrec_score_topk_mode_f32: the bf16-prefilter sweep with exact rescoring (LLMREC_TOPK_MODE_PREFILTER) must return the SAME BITS - item
-lists and scores - as the exact-fp32 sweep (LLMREC_TOPK_MODE_EXACT_SWEEP), which the other top-K tests hold to the oracle and to the
-reference's lists: random tables, score distributions that keep the filter loose (near-identical rows, softmax-shaped rows), exact ties
+"""llmrec_score_topk_mode_f32: the bf16 sweep with exact re-ranking and verification (LLMREC_TOPK_MODE_PREFILTER; user tiles whose
+verification fails are redone by the exact sweep) must return the SAME BITS - item lists and scores - as the exact-fp32 sweep
+(LLMREC_TOPK_MODE_EXACT_SWEEP), which the other top-K tests hold to the oracle and to the reference's lists: random tables, score distributions that keep the filter loose (near-identical rows, softmax-shaped rows), exact ties
 (integer-valued embeddings: ordered by item id), orders that keep the threshold rising, fewer than K candidates, every supported width,
 the Netflix shape with its split user tiles, and 10^6 items."""
 import numpy as np
@@ -27,9 +27,13 @@ def _train_csr(ops, U, I, rng, max_deg):
     return ops.Csr(U, I, rp, ci, None, None, None, ops.SpmmPlan())
 
 
+LAST = {}
+
+
 def _both(ops, Eu, Ei, q, train, K):
     i0, s0 = ops.score_topk(Eu, Ei, q, train, K, mode="exact")
-    i1, s1 = ops.score_topk(Eu, Ei, q, train, K, mode="prefilter")
+    LAST.clear()
+    i1, s1 = ops.score_topk(Eu, Ei, q, train, K, mode="prefilter", stats=LAST)
     torch.cuda.synchronize()
     return i0, s0, i1, s1
 
@@ -51,6 +55,8 @@ def test_prefilter_equals_exact_on_random_tables(ops, U, I, d, K):
     train = _train_csr(ops, U, I, rng, min(40, I // 2))
     q = torch.tensor(rng.permutation(U)).to(DEV)
     _assert_same(*_both(ops, Eu, Ei, q, train, K), what="random")
+    if K <= 50 and I >= 1000:
+        assert LAST["fallback_tiles"] == 0, LAST                   # well-separated scores: the verification holds everywhere
     _assert_same(*_both(ops, Eu, Ei, q, None, K), what="random, no mask")
     _assert_same(*_both(ops, Eu, Ei, q[:7], train, K), what="7 queries")
 
@@ -93,6 +99,9 @@ def test_prefilter_equals_exact_where_the_filter_is_loose_or_ties_abound(ops, ki
     q = torch.arange(U, device=DEV)
     i0, s0, i1, s1 = _both(ops, Eu, Ei, q, train, K)
     _assert_same(i0, s0, i1, s1, what=kind)
+    if kind in ("near_identical_rows", "tiny_spread", "integers"):   # more than 14 items within the slack of the boundary: the exact sweep
+        assert LAST["fallback_tiles"] > 0, (kind, LAST)              # must have redone tiles (the path is exercised, not just present)
+    print(kind, LAST)
     if kind == "integers":                   # and the tie rule itself: (score desc, item id asc)
         sc, ids = s1.cpu().numpy(), i1.cpu().numpy()
         for r in range(0, U, 17):

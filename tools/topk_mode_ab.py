@@ -31,8 +31,11 @@ def main():
             rec = {"tables": kind, "U": U, "I": I, "d": d, "K": K}
             outs = {}
             for mode in ("exact", "prefilter"):
-                outs[mode] = ops.score_topk(Eu, Ei, q, None, K, mode=mode)
+                st = {}
+                outs[mode] = ops.score_topk(Eu, Ei, q, None, K, mode=mode, stats=st)
                 torch.cuda.synchronize()
+                if mode == "prefilter":
+                    rec["fallback_tiles"], rec["tiles"] = st["fallback_tiles"], st["tiles"]
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 for _ in range(iters):
