@@ -809,7 +809,7 @@ class FusedStep:
                 self.forward()
                 _call("llmrec_score_topk_mode_f32", n, _p(q), _p(self.E_u), _ld(self.E_u), _p(self.E_i), _ld(self.E_i), self.I, self.d,
                       _p(train.rowptr) if train is not None else None, _p(train.colidx) if train is not None else None,
-                      K, _p(idx), _p(sc), _p(ws), ws.numel() if ws is not None else 0, ops.topk_mode())
+                      K, _p(idx), _p(sc), _p(ws), ws.numel() if ws is not None else 0, ops.topk_mode(None, self.I, self.d, K))
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):

@@ -915,15 +915,23 @@ class FusedAdamW:
 # R9/R10: scoring + top-K, R11: sampler
 # ---------------------------------------------------------------------------------------------
 TOPK_MODES = {"exact": 0, "prefilter": 1}
+TOPK_PREFILTER_MAX_TABLE_BYTES = 1 << 27      # 128 MB: where the bf16 sweep stops paying (profiles/experiments/r05_topk.md)
 
 
-def topk_mode(mode=None) -> int:
-    """llmrec_score_topk_mode_f32's mode: "exact" = every score by the exact-fp32 MFMA chain, "prefilter" = bf16 sweep + exact rescoring of
-    the candidates (bit-identical lists and scores). Default: LLMREC_TOPK_MODE, else "exact"."""
+def topk_mode(mode=None, n_items: int = 0, d: int = 64, K: int = 50) -> int:
+    """llmrec_score_topk_mode_f32's mode: "exact" = every score by the exact-fp32 MFMA chain; "prefilter" = bf16 sweep keeping the 64 best
+    by approximate score, exact re-ranking + verification, exact sweep for the tiles that fail it (bit-identical lists and scores);
+    "auto" (default; LLMREC_TOPK_MODE overrides) = prefilter while the fp32 item table (n_items x d x 4 bytes) stays within
+    TOPK_PREFILTER_MAX_TABLE_BYTES and K leaves room to verify - measured on MI355X at 16 384 users, d = 64: 1.22 x (10 K items), 1.6 x (33 K),
+    1.8 x (66 K - 131 K), 1.4 x (262 K), 1.08 x (524 K = 134 MB), 0.84 x at 10^6 items, where every 16-user tile streams a 256 MB table past the
+    Infinity Cache and the sweep is bound by that stream, not by the matrix cores."""
     if mode is None:
-        mode = os.environ.get("LLMREC_TOPK_MODE", "exact")
+        mode = os.environ.get("LLMREC_TOPK_MODE", "auto")
+    if mode == "auto":
+        ok = K <= CONST["LLMREC_TOPK_PREFILTER_MAX_K"] and 0 < n_items * max(d, 1) * 4 <= TOPK_PREFILTER_MAX_TABLE_BYTES
+        mode = "prefilter" if ok else "exact"
     if mode not in TOPK_MODES:
-        raise RuntimeError("top-K mode %r (exact | prefilter)" % (mode,))
+        raise RuntimeError("top-K mode %r (auto | exact | prefilter)" % (mode,))
     return TOPK_MODES[mode]
 
 
@@ -939,11 +947,11 @@ def score_topk(Eu, Ei, query_users: torch.Tensor, train: Optional[Csr], K: int, 
     ws = topk_workspace(n, Ei.shape[0], Eu.device, Eu.shape[1])
     _lib.call("llmrec_score_topk_mode_f32", n, _p(q), _p(Eu), _ld(Eu), _p(Ei), _ld(Ei), Ei.shape[0], Eu.shape[1],
               _p(train.rowptr) if train is not None else None, _p(train.colidx) if train is not None else None,
-              K, _p(idx), _p(sc), _p(ws), ws.numel() if ws is not None else 0, topk_mode(mode), _stream())
+              K, _p(idx), _p(sc), _p(ws), ws.numel() if ws is not None else 0, topk_mode(mode, Ei.shape[0], Eu.shape[1], K), _stream())
     if stats is not None:
         off = _lib.query("llmrec_score_topk_stats_offset", n, Ei.shape[0])
         stats["tiles"] = (n + 15) // 16
-        stats["fallback_tiles"] = int(ws[off + 4:off + 8].view(torch.int32).item()) if (topk_mode(mode) == 1 and K <= CONST["LLMREC_TOPK_PREFILTER_MAX_K"]) else 0
+        stats["fallback_tiles"] = int(ws[off + 4:off + 8].view(torch.int32).item()) if (topk_mode(mode, Ei.shape[0], Eu.shape[1], K) == 1 and K <= CONST["LLMREC_TOPK_PREFILTER_MAX_K"]) else 0
     return idx, sc
 
 

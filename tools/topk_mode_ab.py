@@ -25,7 +25,10 @@ def main():
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     res = []
     for kind in ("random", "trained_shape"):
-        for U, I, d, K, iters in ((13187, 17366, 64, 50, 20), (65536, 1_000_000, 64, 50, 2), (16384, 1_000_000, 128, 50, 2)):
+        shapes = ((13187, 17366, 64, 50, 20), (65536, 1_000_000, 64, 50, 2), (16384, 1_000_000, 128, 50, 2))
+        if "--crossover" in sys.argv:                          # where does the bf16 mode stop paying? (item table: I x d x 4 bytes)
+            shapes = tuple((16384, I, 64, 50, 5) for I in (10_322, 32_768, 65_536, 131_072, 262_144, 524_288)) if kind == "random" else ()
+        for U, I, d, K, iters in shapes:
             Eu, Ei = tables(kind, U, I, d, g)
             q = torch.arange(U, device="cuda")
             rec = {"tables": kind, "U": U, "I": I, "d": d, "K": K}
