@@ -598,13 +598,14 @@ int llmrec_score_topk_ws_f32(int32_t n_query, const int64_t* query_users,
 /* debug / test entry: the full score block with the same MFMA arithmetic as above */
 /* The same call with the sweep's arithmetic chosen explicitly (round 5). Lists and scores are BIT-IDENTICAL in both modes:
  *   LLMREC_TOPK_MODE_EXACT_SWEEP  every score by the exact-fp32 MFMA chain (what llmrec_score_topk_ws_f32 runs);
- *   LLMREC_TOPK_MODE_PREFILTER    the sweep on bf16 MFMAs (both operands as two bf16 terms, three products: |s - s'| <= eps_u = 2^-12 ||u|| max ||i||)
- *                                 keeps each user's 64 best items by the approximate score s'; those 64 are then scored with the exact fp32
- *                                 fma chain, re-ranked, and VERIFIED: (64th s') + eps_u < (K-th exact score) proves that no other item can
- *                                 be in the top K. User tiles that fail the proof are swept again by the exact kernel (second launch; the
- *                                 other tiles' blocks exit at once). Needs the workspace; K <= LLMREC_TOPK_PREFILTER_MAX_K (else the exact
- *                                 sweep runs). llmrec_score_topk_stats_offset: byte offset inside the workspace of two uint32 words the mode
- *                                 leaves behind - [0] the bits of max ||i||^2, [1] the number of user tiles the exact sweep had to redo. */
+ *   LLMREC_TOPK_MODE_PREFILTER    the sweep on bf16 MFMAs (both operands as two round-to-nearest bf16 terms, three products:
+ *                                 |s - s'| <= 2^-14 ||u|| ||i||) keeps each user's 64 best items by the UPPER BOUND ub = s' + 2^-14 ||u|| ||i||;
+ *                                 those 64 are then scored with the exact fp32 fma chain, re-ranked, and VERIFIED: (64th ub) < (K-th exact
+ *                                 score) proves that no other item can be in the top K. User tiles that fail the proof are swept again by the
+ *                                 exact kernel (second launch; the other tiles' blocks exit at once). Needs the workspace;
+ *                                 K <= LLMREC_TOPK_PREFILTER_MAX_K (else the exact sweep runs). llmrec_score_topk_stats_offset: byte offset inside
+ *                                 the workspace of two uint32 words the mode leaves behind - [1] = the number of user tiles the exact sweep
+ *                                 had to redo. */
 #define LLMREC_TOPK_PREFILTER_MAX_K 56
 #define LLMREC_TOPK_MODE_EXACT_SWEEP 0
 #define LLMREC_TOPK_MODE_PREFILTER 1

@@ -64,7 +64,8 @@ struct TopkArgs {
     // mode 1 (bf16 prefilter + exact rescoring): the item table as bf16 (hi, mid) fragments and max_i ||i||^2 (workspace)
     int mode;
     uint4* pk2;
-    uint32_t* hdr;               // [0] bits of max_i ||i||^2, [1] user tiles flagged for the exact sweep (statistics)
+    uint32_t* hdr;               // [1] user tiles flagged for the exact sweep (statistics)
+    float* cn;                   // per item: 2^-14 ||item|| rounded up (the item's factor of the score's upper bound)
     uint32_t* fb_word;           // one word per user tile: != 0 = the verification failed, the exact sweep redoes the tile
     const uint32_t* only_flagged; // exact sweep: blocks of tiles whose word is 0 exit at once (NULL: every tile)
 };
@@ -433,38 +434,47 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
 // ---------------------------------------------------------------------------------------------------------------------------
 // Round 5: bf16 SWEEP + EXACT VERIFICATION. The sweep above spends 1024 matrix cycles per 16 users x 32 items on
 // the exact-fp32 MFMA. Here the sweep runs on v_mfma_f32_16x16x32_bf16 with both operands cut into two bf16 numbers (x = h + m + r,
-// truncating splits: |r| < 2^-14 |x|):
+// round-to-nearest splits: |r| <= 2^-16 |x|):
 //     s' = <u_h, i_h> + <u_h, i_m> + <u_m, i_h>          (three MFMAs per 32 k: 192 matrix cycles per 16 x 32 tile at d = 64)
-//     |s - s'| <= (3 x 2^-14 + accumulation) sum_k |u_k| |i_k|  <=  eps_u := 2^-12 ||u|| max_i ||i||      (Cauchy-Schwarz)
-// and keeps, per user, the 64 best items BY s' (same buffers, drains, bitonic merges as the exact sweep; the filter is the list's 64th
-// s'). At the end the 64 kept items are scored EXACTLY - one lane per item runs the k-ordered fp32 fma chain of v_mfma_f32_16x16x4_f32
-// (for c, for s, for q: k = 16 c + 4 q + s; a VALU v_fma_f32 chain gives the MFMA's bits) - and re-ranked by (exact score desc, id asc).
-// VERIFICATION: every item outside the list has s' <= s'_64, hence s <= s'_64 + eps_u. If s'_64 + eps_u < e_K (the K-th exact score
-// of the list) no outside item can reach the top K: the list's top K IS the exact top K, bit for bit what score_topk_kernel returns.
-// Otherwise (more than 64 - K items within 2 eps of the boundary: near-identical rows, massive ties) the user tile is FLAGGED and the
-// exact sweep runs for the flagged tiles in a second launch (blocks of unflagged tiles exit at once). The first (wave-uniform) version
-// of this mode rescored every candidate at every drain: bit-identical too, but 5 - 20 % SLOWER than the exact sweep - the drains are a
-// block-wide critical section and the rescoring put 4 exposed L2 latencies into each of their ~190 iterations per block
-// (profiles/experiments/r05_topk.md).
+//     s - s' = <u_h, i_r> + <u_m, i_m> + <u_m, i_r> + <u_r, i>   =>   |s - s'| <= (3.02 x 2^-16 + fp32 accumulation of 192 terms) sum_k |u_k| |i_k|
+//                                                                            <=  2^-14 ||u|| ||i||                     (Cauchy-Schwarz)
+// so  ub(u, i) := s' + 2^-14 ||u|| ||i||  is an UPPER BOUND of the exact score, item by item (a cold item with a tiny embedding gets a tiny
+// slack: thousands of near-identical cold rows do not blur the boundary the way one max-norm slack for all items did - the first form of the
+// verification sent 34 % of the Netflix-shaped bench's user tiles to the exact sweep for exactly that reason).
+// The sweep keeps, per user, the 64 best items BY ub (the exact kernel's buffers, drains, bitonic merges; the filter is the list's 64th ub).
+// At the end the 64 kept items are scored EXACTLY - one lane per item runs the k-ordered fp32 fma chain of v_mfma_f32_16x16x4_f32 (for c, for
+// s, for q: k = 16 c + 4 q + s; a VALU v_fma_f32 chain gives the MFMA's bits) - and re-ranked by (exact score desc, id asc).
+// VERIFICATION: every item x outside the list has s(x) <= ub(x) <= ub_64. If ub_64 < e_K (the K-th exact score of the list) no outside item
+// can reach the top K: the list's top K IS the exact top K, bit for bit what score_topk_kernel returns. Otherwise (more than 64 - K items
+// within the slack of the boundary: massive exact ties) the user tile is FLAGGED and the exact sweep runs for the flagged tiles in a second
+// launch (blocks of unflagged tiles exit at once). The first version of the mode rescored every candidate at every drain: bit-identical too,
+// but 5 - 20 % SLOWER than the exact sweep (profiles/experiments/r05_topk.md).
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef __bf16 tk_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 tk_mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tk_bf16x8, a), __builtin_bit_cast(tk_bf16x8, b), c, 0, 0, 0);
 }
-// two floats -> packed (hi, mid) bf16 pairs, truncating splits (the residual is exact in fp32)
+// round-to-nearest-even bf16 of a finite float, as a float (low 16 bits zero)
+__device__ __forceinline__ uint32_t tk_rn_bf16_bits(float x) {
+    const uint32_t b = __float_as_uint(x);
+    return (b + 0x7fffu + ((b >> 16) & 1u)) & 0xffff0000u;
+}
+// two floats -> packed (hi, mid) bf16 pairs, round-to-nearest splits (h = RN(x); the residual x - h is exact in fp32; m = RN(x - h))
 __device__ __forceinline__ void tk_split2(float x0, float x1, uint32_t& H, uint32_t& M) {
-    const uint32_t h0 = __float_as_uint(x0) & 0xffff0000u, h1 = __float_as_uint(x1) & 0xffff0000u;
+    const uint32_t h0 = tk_rn_bf16_bits(x0), h1 = tk_rn_bf16_bits(x1);
     const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
+    const uint32_t m0 = tk_rn_bf16_bits(r0), m1 = tk_rn_bf16_bits(r1);
     H = __builtin_amdgcn_perm(h1, h0, 0x07060302u);                      // high halves: e0 -> low 16 bits, e1 -> high 16 bits
-    M = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+    M = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
 }
 __device__ __forceinline__ void tk_split8(const float (&x)[8], uint4& H, uint4& M) {
     tk_split2(x[0], x[1], H.x, M.x); tk_split2(x[2], x[3], H.y, M.y);
     tk_split2(x[4], x[5], H.z, M.z); tk_split2(x[6], x[7], H.w, M.w);
 }
-constexpr float TK_PRE_SLACK = 0x1p-12f;                                 // eps_u = TK_PRE_SLACK ||u|| max ||i||
+constexpr float TK_PRE_SLACK = 0x1p-14f;                                 // ub = s' + TK_PRE_SLACK ||u|| ||i||  (both norms rounded UP by 2^-10)
+constexpr float TK_NORM_UP = 1.0f + 0x1p-10f;
 
-// workspace header of the mode (first 256 bytes of the fragment area): [0] bits of max_i ||i||^2, [1] user tiles flagged for the exact sweep
+// workspace header of the mode (first 256 bytes of the fragment area): [0] unused, [1] user tiles flagged for the exact sweep
 // the item table as bf16 (hi, mid) MFMA fragments: pk2[(((tile * 2 + n) * DK32 + c) * 2 + hm) * 64 + lane], lane = 16 (k group) + item-in-tile;
 // one thread per (item, 8 consecutive k). Also clears the header and the fallback flags (the norm kernel and the sweep follow on the stream).
 __global__ __launch_bounds__(256) void topk_pack_items_bf16_kernel(TopkArgs a, int DK32, uint4* __restrict__ pk2) {
@@ -491,27 +501,25 @@ __global__ __launch_bounds__(256) void topk_pack_items_bf16_kernel(TopkArgs a, i
     pk2[base] = H; pk2[base + 64] = M;
 }
 
-// max_i ||i||^2 as the bits of a non-negative float (atomicMax on uint32 is order-independent: deterministic). One 16-lane group per item.
-__global__ __launch_bounds__(256) void topk_item_norm_kernel(TopkArgs a) {
+// cn[item] = TK_PRE_SLACK * ||item|| rounded up: the item's factor of the score's upper bound. One 16-lane group per item; padded slots get 0.
+__global__ __launch_bounds__(256) void topk_item_norm_kernel(TopkArgs a, float* __restrict__ cn, int64_t n_pad) {
     const int gl = threadIdx.x & 15;
-    float mx = 0.f;
-    for (int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); item < a.n_items; item += (int64_t)gridDim.x * 16) {
-        const float* row = a.Ei + item * a.ldi;
+    for (int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); item < n_pad; item += (int64_t)gridDim.x * 16) {
         float ss = 0.f;
-        for (int k = gl; k < a.d; k += 16) ss = fmaf(row[k], row[k], ss);
+        if (item < a.n_items) {
+            const float* row = a.Ei + item * a.ldi;
+            for (int k = gl; k < a.d; k += 16) ss = fmaf(row[k], row[k], ss);
+        }
         ss = group_sum<16>(ss);
-        mx = fmaxf(mx, ss);
+        if (gl == 0) cn[item] = TK_PRE_SLACK * (sqrtf(ss) * TK_NORM_UP);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(&a.hdr[0], __float_as_uint(mx));
 }
 
 // One user's 64 kept items (lane = slot, sorted by approximate score; id INT_MAX = empty slot) -> the exact ranking, the verification, the
 // output. `urow` = the user's fp32 row (LDS or global). Wave-uniform control flow.
-__device__ __forceinline__ void tk_finalize_user(const TopkArgs& a, const float* urow, int q, int tile, float approx, int32_t id, int lane) {
-    const float s64 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(approx), 63));   // the outside bound (-inf: list not full)
-    float e = -INFINITY, un2 = 0.f;
+__device__ __forceinline__ void tk_finalize_user(const TopkArgs& a, const float* urow, int q, int tile, float ub, int32_t id, int lane) {
+    const float ub64 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ub), 63));   // bounds every item outside the list (-inf: list not full)
+    float e = -INFINITY;
     {
         const int64_t it = id == INT_MAX ? 0 : id;
         const float* ir = a.Ei + it * a.ldi;
@@ -525,19 +533,14 @@ __device__ __forceinline__ void tk_finalize_user(const TopkArgs& a, const float*
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const float uu = cmp4(uv[qq], s_);
-                    acc = __builtin_fmaf(uu, cmp4(iv[qq], s_), acc);
-                    un2 = __builtin_fmaf(uu, uu, un2);
-                }
+                for (int qq = 0; qq < 4; ++qq) acc = __builtin_fmaf(cmp4(uv[qq], s_), cmp4(iv[qq], s_), acc);
         }
         if (id != INT_MAX) e = acc;
     }
     float es[1] = {e}; int32_t ei[1] = {id};
     sort64<1>(es, ei, lane);
     const float eK = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(es[0]), a.K - 1));
-    const float eps = TK_PRE_SLACK * sqrtf(un2) * sqrtf(__uint_as_float(a.hdr[0])) * 1.0001f;
-    const bool ok = (s64 == -INFINITY) || (s64 + eps < eK);           // (NaN anywhere -> not ok -> the exact sweep decides)
+    const bool ok = (ub64 == -INFINITY) || (ub64 < eK);               // (NaN anywhere -> not ok -> the exact sweep decides)
     if (q < a.n_query && lane < a.K) {
         a.out_idx[(int64_t)q * a.K + lane] = ei[0] == INT_MAX ? -1 : ei[0];
         a.out_score[(int64_t)q * a.K + lane] = es[0];
@@ -548,11 +551,11 @@ __device__ __forceinline__ void tk_finalize_user(const TopkArgs& a, const float*
 }
 
 template <int DK32>
-__global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kernel(TopkArgs a, const uint4* __restrict__ pk2) {
-    __shared__ float buf_s[4][16][TK_CAP];                             // approximate scores of the buffered candidates
+__global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kernel(TopkArgs a, const uint4* __restrict__ pk2, const float* __restrict__ cn) {
+    __shared__ float buf_s[4][16][TK_CAP];                             // upper bounds ub of the buffered candidates
     __shared__ int32_t buf_i[4][16][TK_CAP];
     __shared__ int32_t cnt_s[4][16];
-    __shared__ float thr_s[16];                                        // the filter: the 64th approximate score of the user's list so far
+    __shared__ float thr_s[16];                                        // the filter: the 64th ub of the user's list so far
     __shared__ int32_t flag_s[2];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lq = lane >> 4;
@@ -573,13 +576,19 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     if (qa > a.n_query - 1) qa = a.n_query - 1;
     const int64_t user_a = a.query_users[qa];
     uint4 uH[DK32], uM[DK32];
+    float un2 = 0.f;
 #pragma unroll
     for (int c = 0; c < DK32; ++c) {
         float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const int k = 32 * c + 8 * lq + j; x[j] = k < a.d ? a.Eu[user_a * a.ldu + k] : 0.f; }
+        for (int j = 0; j < 8; ++j) { const int k = 32 * c + 8 * lq + j; x[j] = k < a.d ? a.Eu[user_a * a.ldu + k] : 0.f; un2 = fmaf(x[j], x[j], un2); }
         tk_split8(x, uH[c], uM[c]);
     }
+    un2 += __shfl_xor(un2, 16, 64); un2 += __shfl_xor(un2, 32, 64);    // ||u||^2 of row li, in every lane with that li
+    const float un_row = sqrtf(un2) * TK_NORM_UP;
+    float unr[4];                                                      // ||u|| (rounded up) of the four rows this lane's accumulators belong to
+#pragma unroll
+    for (int r = 0; r < 4; ++r) unr[r] = __shfl(un_row, lq * 4 + r, 64);
 
     const int64_t tiles_all = (a.n_items + TK_TILE - 1) / TK_TILE;
     const int64_t part_begin = tiles_all * part / n_parts, tiles_total = tiles_all * (part + 1) / n_parts;
@@ -606,13 +615,16 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
 
     const int64_t my_rounds = t_end > t_begin ? t_end - t_begin : 0;
     uint4 bH[2][DK32], bM[2][DK32];
+    float cnv[2];                                                      // the slack factors of this lane's two items of the tile
     const uint4* pk = pk2 + (t_begin * 2 * DK32 * 2) * 64 + lane;
+    const float* cnp = cn + t_begin * TK_TILE + li;
     auto load_tile = [&]() {
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int c = 0; c < DK32; ++c) { bH[n][c] = pk[((n * DK32 + c) * 2) * 64]; bM[n][c] = pk[((n * DK32 + c) * 2 + 1) * 64]; }
-        pk += 2 * DK32 * 2 * 64;
+        cnv[0] = cnp[0]; cnv[1] = cnp[16];
+        pk += 2 * DK32 * 2 * 64; cnp += TK_TILE;
     };
     if (my_rounds > 0) load_tile();
     int64_t round = 0;
@@ -648,7 +660,7 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
                 }
                 ls[rr] = l1[0]; lid[rr] = i1[0];
                 if (total > 0) {
-                    const float nthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ls[rr]), 63));   // the 64th: the whole list is exact-by-s'
+                    const float nthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ls[rr]), 63));   // the 64th: the whole list is exact-by-ub
                     if (lane == 0) thr_s[u] = nthr;
                 }
             }
@@ -670,6 +682,7 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
                 acc[n] = tk_mfma_bf16(uH[c], bM[n][c], acc[n]);
                 acc[n] = tk_mfma_bf16(uH[c], bH[n][c], acc[n]);
             }
+        const float cn_now[2] = {cnv[0], cnv[1]};                       // (this tile's factors: the prefetch below overwrites cnv)
         __builtin_amdgcn_sched_barrier(0);
         if (round + 1 < my_rounds) load_tile();
         __builtin_amdgcn_sched_barrier(0);
@@ -688,7 +701,7 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
             if (any_train) rm = __shfl(m, lq * 4 + r, 64);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const float v = acc[n][r];
+                const float v = fmaf(unr[r], cn_now[n], acc[n][r]);        // ub = s' + 2^-14 ||u|| ||i||
                 if (__ballot(v >= rthr) == 0ull) continue;
                 const int col = 16 * n + li;
                 const bool pass = (v >= rthr) && (base + col < a.n_items) && !((rm >> col) & 1u);
@@ -722,7 +735,7 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     }
 }
 
-// the lists of a split tile's parts (by approximate score) -> the tile's 64 best by approximate score -> exact ranking + verification
+// the lists of a split tile's parts (by upper bound) -> the tile's 64 best by upper bound -> exact ranking + verification
 __global__ __launch_bounds__(256) void topk_merge_pre_kernel(TopkArgs a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int tile = a.split_from + blockIdx.x;
@@ -842,13 +855,14 @@ static int launch_topk(const TopkArgs& a, hipStream_t stream) {
         if (n_thr < n_tiles) n_thr = n_tiles;                  // (the pack launch also clears one flag word per user tile)
         topk_pack_items_bf16_kernel<<<(unsigned)ceil_div(n_thr, 256), 256, 0, stream>>>(a, DK32, a.pk2);
         LLMREC_LAUNCH_CHECK();
-        topk_item_norm_kernel<<<grid_for(a.n_items, 16), 256, 0, stream>>>(a);
+        const int64_t n_pad = ceil_div(a.n_items, TK_TILE) * TK_TILE;
+        topk_item_norm_kernel<<<grid_for(n_pad, 16), 256, 0, stream>>>(a, a.cn, n_pad);
         LLMREC_LAUNCH_CHECK();
         switch (DK32) {
-            case 1: score_topk_pre_kernel<1><<<grid, 256, 0, stream>>>(a, a.pk2); break;
-            case 2: score_topk_pre_kernel<2><<<grid, 256, 0, stream>>>(a, a.pk2); break;
-            case 3: score_topk_pre_kernel<3><<<grid, 256, 0, stream>>>(a, a.pk2); break;
-            case 4: score_topk_pre_kernel<4><<<grid, 256, 0, stream>>>(a, a.pk2); break;
+            case 1: score_topk_pre_kernel<1><<<grid, 256, 0, stream>>>(a, a.pk2, a.cn); break;
+            case 2: score_topk_pre_kernel<2><<<grid, 256, 0, stream>>>(a, a.pk2, a.cn); break;
+            case 3: score_topk_pre_kernel<3><<<grid, 256, 0, stream>>>(a, a.pk2, a.cn); break;
+            case 4: score_topk_pre_kernel<4><<<grid, 256, 0, stream>>>(a, a.pk2, a.cn); break;
             default: set_error("score_topk: d = %d > 128", a.d); return LLMREC_EUNSUPPORTED;
         }
         LLMREC_LAUNCH_CHECK();
@@ -913,7 +927,7 @@ static int64_t topk_split_bytes(int32_t n_query, int64_t n_items) {
 static int64_t topk_packed_bytes(int64_t n_items, int32_t d) {
     const int64_t exact = ceil_div(n_items, TK_TILE) * 2 * ceil_div(d, 16) * 64 * 16;      // fp32 fragments (rows padded to whole tiles, d to 16)
     const int64_t pre = ceil_div(n_items, TK_TILE) * 2 * ceil_div(d, 32) * 2 * 64 * 16;   // bf16 (hi, mid) fragments (d padded to 32)
-    return (exact > pre ? exact : pre) + 256;                                              // + the header of the bf16 mode
+    return (exact > pre ? exact : pre) + 256 + align_up(4 * ceil_div(n_items, TK_TILE) * TK_TILE, 256);   // + the bf16 mode's header and per-item factors
 }
 static int64_t topk_flag_bytes(int32_t n_query) { return align_up(4 * ceil_div(n_query, 16), 256); }   // one word per user tile (bf16 mode)
 
@@ -966,7 +980,7 @@ int llmrec_score_topk_mode_f32(int32_t n_query, const int64_t* query_users,
     a.vec_ok = (ldu % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)Eu | (uintptr_t)Ei) % 16 == 0);
     a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
     if (mode == LLMREC_TOPK_MODE_PREFILTER && K > LLMREC_TOPK_PREFILTER_MAX_K) mode = LLMREC_TOPK_MODE_EXACT_SWEEP;   // (no room to verify in 64 slots)
-    a.mode = mode; a.pk2 = nullptr; a.hdr = nullptr; a.fb_word = nullptr; a.only_flagged = nullptr;
+    a.mode = mode; a.pk2 = nullptr; a.hdr = nullptr; a.cn = nullptr; a.fb_word = nullptr; a.only_flagged = nullptr;
     if (workspace) {                                           // without a workspace: one block per user tile, fragments straight from Ei
         const int64_t need = llmrec_score_topk_workspace_bytes(n_query, n_items, d), split = topk_split_bytes(n_query, n_items);
         LLMREC_CHECK_ARG(workspace_bytes >= need && (uintptr_t)workspace % 16 == 0, "score_topk: workspace of %lld bytes needed (16-byte aligned)", (long long)need);
@@ -980,6 +994,7 @@ int llmrec_score_topk_mode_f32(int32_t n_query, const int64_t* query_users,
         if (mode == LLMREC_TOPK_MODE_PREFILTER) {
             a.hdr = (uint32_t*)frag;                           // (the first 256 bytes of the fragment area)
             a.pk2 = (uint4*)(frag + 256);
+            a.cn = (float*)(frag + topk_packed_bytes(n_items, d) - align_up(4 * ceil_div(n_items, TK_TILE) * TK_TILE, 256));
             a.fb_word = (uint32_t*)(frag + topk_packed_bytes(n_items, d));
         }
     }
@@ -998,7 +1013,7 @@ int llmrec_scores_f32(int32_t n_query, const int64_t* query_users,
     a.out_idx = nullptr; a.out_score = nullptr; a.S = S; a.lds = lds;
     a.vec_ok = (ldu % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)Eu | (uintptr_t)Ei) % 16 == 0);
     a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
-    a.mode = 0; a.pk2 = nullptr; a.hdr = nullptr; a.fb_word = nullptr; a.only_flagged = nullptr;
+    a.mode = 0; a.pk2 = nullptr; a.hdr = nullptr; a.cn = nullptr; a.fb_word = nullptr; a.only_flagged = nullptr;
     return launch_topk<false>(a, (hipStream_t)stream_);
 }
 

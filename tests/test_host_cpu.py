@@ -29,11 +29,13 @@ def test_workspace_queries_run_without_gpu():
     assert _lib.query("llmrec_sumsq_workspace_bytes", 10, 10) > 0
     # top-K: 825 user tiles on 256 compute units (the default when no device answers) leave 57 tiles, cut in 4 parts each
     # the item table in fragment order: fp32 fragments (exact sweep) or bf16 (hi, mid) fragments with d padded to 32 (prefilter sweep),
-    # whichever is larger, + 256 bytes (the slot of max ||i||^2)
-    packed = lambda n_items, d: max(-(-n_items // 32) * 2 * -(-d // 16) * 64 * 16, -(-n_items // 32) * 2 * -(-d // 32) * 2 * 64 * 16) + 256
-    assert _lib.query("llmrec_score_topk_workspace_bytes", 13187, 17366, 64) == 57 * 4 * 16 * 64 * 8 + packed(17366, 64)
-    assert _lib.query("llmrec_score_topk_workspace_bytes", 4096 * 16, 1_000_000, 64) == packed(1_000_000, 64)      # whole rounds: nothing is split
-    assert _lib.query("llmrec_score_topk_workspace_bytes", 100, 500, 20) == packed(500, 20)                        # too few items to cut
+    # whichever is larger, + the bf16 mode's 256-byte header, per-item factors (4 bytes per padded item) and one flag word per user tile
+    up = lambda x: -(-x // 256) * 256
+    frag = lambda n_items, d: max(-(-n_items // 32) * 2 * -(-d // 16) * 64 * 16, -(-n_items // 32) * 2 * -(-d // 32) * 2 * 64 * 16) + 256 + up(4 * -(-n_items // 32) * 32)
+    packed = lambda n_items, d, n_query=None: frag(n_items, d) + (up(4 * -(-n_query // 16)) if n_query is not None else 0)
+    assert _lib.query("llmrec_score_topk_workspace_bytes", 13187, 17366, 64) == 57 * 4 * 16 * 64 * 8 + packed(17366, 64, 13187)
+    assert _lib.query("llmrec_score_topk_workspace_bytes", 4096 * 16, 1_000_000, 64) == packed(1_000_000, 64, 4096 * 16)      # whole rounds: nothing is split
+    assert _lib.query("llmrec_score_topk_workspace_bytes", 100, 500, 20) == packed(500, 20, 100)                        # too few items to cut
     assert _lib.query("llmrec_score_topk_workspace_bytes", -1, 10, 64) == -1
 
 
