@@ -1109,7 +1109,7 @@ def compact_line(line: dict) -> dict:
         keys = ("ok", "forward_max_rel", "bpr_max_rel", "loss_rel", "grad_max_rel", "adamw_given_gpu_grads_max_rel", "embeddings_after_steps_max_rel",
                 "param_l2_rel_max", "adam_moments_max_rel", "topk_lists_checked", "topk_lists_equal", "topk_lists_equal_oracle_embeddings",
                 "topk_mismatch_max_gap_ulps", "metrics_max_abs",
-                "rows_checked", "max_rel", "tolerance_rel")           # (the row-sharded workloads' sampled-row gate)
+                "rows_per_spmm", "spmm_checked", "max_rel_err_vs_fp64", "tolerance_rel")           # (the row-sharded workloads' sampled-row gate)
         out["parity"] = _pick(par, keys, 3)
     if isinstance(line.get("eval"), dict):
         out["eval"] = _pick(line["eval"], ("value", "ms", "n_users", "topk_mode", "topk_tiles", "topk_tiles_redone_exact"), 6)
@@ -1145,11 +1145,17 @@ def compact_line(line: dict) -> dict:
                     o[k]["vs_prev"] = str(rs[k]["vs_prev"])[:100]
         out["row_sharded"] = o
     # row-sharded workloads (--workload cfg4 / cfg5, and N > 1)
-    for k in ("propagated_edges_per_step", "spmm_algorithmic_bytes_per_step_per_gpu", "speedup_vs_single_gpu", "peak_memory_gb"):
+    if isinstance(line.get("propagated_edges_per_sec"), (int, float)):
+        out["propagated_edges_per_sec"] = _r(line["propagated_edges_per_sec"])
+    if isinstance(line.get("ingest"), dict):
+        out["ingest"] = _pick(line["ingest"], ("generate_s", "csr_build_and_plans_s", "hbm_peak_gb"), 4)
+    if isinstance(line.get("eval_sample"), dict):
+        out["eval_sample"] = _pick(line["eval_sample"], ("users", "items", "ms", "users_per_s", "tflops", "frac_mfma_f32"), 5)
+    for k in ("propagated_edges_per_step", "spmm_algorithmic_bytes_per_step_per_gpu", "speedup_vs_single_gpu", "peak_memory_gb", "loss"):
         if k in line:
             out[k] = _r(line[k])
     if isinstance(line.get("messages"), dict):
-        out["messages"] = _pick(line["messages"], ("exchange", "n_chunks", "bytes_per_step", "bytes_per_message", "messages_per_step"), 5)
+        out["messages"] = _pick(line["messages"], ("exchange", "allreduce_I_x_d_bytes", "exchanged_bytes_last_step", "allreduce_messages"), 5)
     for k in ("single_gpu_reference", "netflix_replicas", "row_restricted_forward"):
         if isinstance(line.get(k), dict):
             out[k] = _pick(line[k], ("ms_per_step", "value", "error"), 6)
