@@ -282,7 +282,8 @@ class NetflixShaped:
             return None
         us = lambda ticks: ticks / n / rate * 1e6
         f.capture(batcher=self.batcher, unroll=self.UNROLL)     # back to the uninstrumented graphs
-        return {"projection_us": us(acc[0]), "wgrad_us": us(acc[1]) if acc[1] > 0 else None, "span_us": us(acc[2]), "rate_hz": rate, "replays": n,
+        return {"projection_us": us(acc[0]), "wgrad_us": us(acc[1]) if acc[1] > 0 else None, "rate_hz": rate, "replays": n,
+                "instrumented_span_us": us(acc[2]),           # (of the INSTRUMENTED single-step graph: not the step's span - that is in profiles/r*_step_timeline.txt)
                 "how": "llmrec_timestamp launches inside the re-captured step graph (FusedStep.stamps), averaged over the replays"}
 
     # ---- per-kernel roofline (dominant kernels of this workload, timed in isolation) -------------
@@ -1160,7 +1161,7 @@ def compact_line(line: dict) -> dict:
         if isinstance(line.get(k), dict):
             out[k] = _pick(line[k], ("ms_per_step", "value", "error"), 6)
     if isinstance(line.get("step_in_graph"), dict):
-        out["step_in_graph"] = _pick(line["step_in_graph"], ("span_us", "entry_point_calls", "projection_us", "wgrad_us"), 5)
+        out["step_in_graph"] = _pick(line["step_in_graph"], ("entry_point_calls", "projection_us", "wgrad_us"), 5)
     out["detail"] = line.get("detail_file", "bench_detail.json")
     text = json.dumps(out, allow_nan=False)
     # a last guard: drop optional blocks, least important first, until the line fits
@@ -1386,14 +1387,14 @@ def main():
             # 25 % of the step) ahead of the single grouped-projection launch; both are reported, the dominant one first
             gemms = [k for k in ks if "algorithmic_bytes_per_launch" in k]
             def dur(k):                                      # the dominant kernel by its in-step duration (rocprof summary, else isolated events)
-                rp = rocprof_avg_us(k["pmc"])
+                rp = rocprof_avg_us(k["pmc"]) if workload == "nf" else None
                 return rp["avg_us"] if rp else k["ms"] * 1e3
             dom = max(gemms, key=dur)
             other = min(gemms, key=dur)
 
             def roof(k):
                 hbm = k.get("bound") == "hbm"
-                traffic, src = pmc_traffic_bytes(k["pmc"])
+                traffic, tsrc = pmc_traffic_bytes(k["pmc"]) if workload == "nf" else (None, None)
                 n = k.get("launches", 1)
                 # `achieved` / `frac`: the launch's duration INSIDE the replayed step graph. Live: a pair of device timestamps around the launch
                 # in a re-captured graph (in_graph_durations) - an UPPER bound, it includes the dispatch gaps between the stamp launches and
@@ -1403,12 +1404,15 @@ def main():
                 # `frac_isolated`: HIP events around 20 launches back to back on the launch's stream
                 iso = k["frac_hbm"] if hbm else k["frac_mfma_f32"]
                 us = None if ig is None else ig.get("projection_us" if "linear_fwd" in k["kernel"] else "wgrad_us")
-                rp = rocprof_avg_us(k["pmc"])
+                rp = rocprof_avg_us(k["pmc"]) if workload == "nf" else None     # (the committed summary is of the Netflix-shaped command)
                 rp_us = rp["avg_us"] if rp else None
+                iso_us = k["ms"] / n * 1e3
                 src = "device timestamps inside the replayed step graph"
                 use = us
                 if rp_us and (not us or us > 1.15 * rp_us):
                     use, src = rp_us, "rocprofv3 average of the committed summary (the live timestamp bracket is loose for this launch: %s us)" % (None if not us else round(us, 1))
+                elif not rp_us and us and us > 1.15 * iso_us:
+                    use, src = iso_us, "HIP events, isolated launches (the live timestamp bracket is loose for this launch: %s us)" % round(us, 1)
                 if use:
                     ach = (k["algorithmic_bytes_per_launch"] / use / 1e3) if hbm else (k["algorithmic_flop_per_launch"] / use / 1e6)
                 else:
@@ -1418,8 +1422,8 @@ def main():
                         "achieved": ach, "peak": peak,
                         "unit": "GB/s" if hbm else "TFLOP/s", "frac": ach / peak, "frac_isolated": iso, "in_step_us": us, "isolated_us": k["ms"] / n * 1e3,
                         "frac_source": src, "in_step_us_used": use,
-                        "traffic": None if traffic is None else traffic / n, "traffic_source": src,
-                        "launches_per_step": n, "ms_per_launch": k["ms"] / n, "ms_per_step": k["ms"], "in_step_us_rocprof": rocprof_avg_us(k["pmc"]),
+                        "traffic": None if traffic is None else traffic / n, "traffic_source": tsrc,
+                        "launches_per_step": n, "ms_per_launch": k["ms"] / n, "ms_per_step": k["ms"], "in_step_us_rocprof": rp,
                         "algorithmic_flop_per_launch": k["algorithmic_flop_per_launch"],
                         "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"],
                         "timing": k.get("timing", "HIP events around the launch on its stream, in isolation"),

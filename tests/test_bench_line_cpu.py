@@ -57,7 +57,7 @@ def test_compact_line_carries_the_round5_blocks_and_drops_nonfinite():
     full["propagated_edges_per_sec"] = {"executed": 1.9e9, "executed_per_step": 9.1e5, "reference_equivalent": 4.6e9, "reference_equivalent_per_step": 2205840,
                                         "definition": "x" * 500}
     full["end_to_end"]["default"]["vs_reference"] = {"ok": True, "epochs": 2, "loss_rel": 3e-6, "metric_max_abs": 0.0, "recall20": [0.1, 0.2], "note": "y" * 900}
-    full["step_in_graph"] = {"span_us": 431.0, "entry_point_calls": 31, "projection_us": 135.2, "wgrad_us": 118.0, "how": "z" * 300}
+    full["step_in_graph"] = {"entry_point_calls": 31, "projection_us": 135.2, "wgrad_us": 118.0, "how": "z" * 300}
     full["row_sharded"]["strong"]["vs_prev"] = "r03 51.0 ms was the row-restricted forward"
     out = bench.compact_line(full)
     text = json.dumps(out, allow_nan=False)
