@@ -85,3 +85,37 @@ def test_round_helper():
     assert bench._r(True) is True and bench._r(3) == 3 and bench._r("x") == "x" and bench._r(None) is None
     assert bench._r(0.123456789, 4) == 0.1235 and bench._r(2139167.692349985, 7) == 2139168.0
     assert math.isclose(bench._r(5.681170173345285e-07, 3), 5.68e-07)
+
+
+def test_headline_vs_reference_comparison_is_a_pure_function_of_the_two_records():
+    """tools/e2e_main.vs_reference: the drop-in's epochs against profiles/r05_reference_cpu.json (the unmodified reference at the headline shape) -
+    north_star's tolerances (loss 1e-4 relative, every metric +-0.002), and the dataset must be the same bytes."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_main
+    ref = e2e_main.reference_record()
+    assert ref is not None and ref["file"].startswith("r05_") and len(ref["epochs"]) == 2 and len(ref["digests"]) == 9
+    assert ref["n_test_users"] == 13187 and ref["n_batch"] == 42 and ref["seed"] == 2022
+    same = [{"loss": e["loss"], "mf_loss": e["mf_loss"], "emb_loss": 1e-7, "metrics": e["metrics"]} for e in ref["epochs"]]
+    v = e2e_main.vs_reference(same, ref, ref["digests"])
+    assert v["ok"] and v["loss_rel"] == 0.0 and v["metric_max_abs"] == 0.0 and v["epochs"] == 2
+    # a drifted loss, a drifted metric, other bytes: each alone fails the gate
+    bad = json.loads(json.dumps(same)); bad[1]["loss"] *= 1.0 + 2e-4
+    assert not e2e_main.vs_reference(bad, ref, ref["digests"])["ok"]
+    bad = json.loads(json.dumps(same)); bad[0]["metrics"]["recall"][1] += 0.0021
+    w = e2e_main.vs_reference(bad, ref, ref["digests"])
+    assert not w["ok"] and w["metric_worst"] == "epoch0/recall[1]"
+    other = dict(ref["digests"], **{"train.json": "0" * 64})
+    assert not e2e_main.vs_reference(same, ref, other)["ok"]
+
+
+def test_topk_mode_policy():
+    """ops.topk_mode: "auto" = the bf16 sweep while the fp32 item table fits 128 MB and K leaves room for the verification."""
+    from llmrec_amd import ops
+    assert ops.topk_mode("auto", 17366, 64, 50) == 1 and ops.topk_mode("auto", 10322, 64, 50) == 1
+    assert ops.topk_mode("auto", 524288, 64, 50) == 1 and ops.topk_mode("auto", 524289, 64, 50) == 0      # 128 MB
+    assert ops.topk_mode("auto", 1_000_000, 64, 50) == 0 and ops.topk_mode("auto", 200_000, 128, 50) == 1
+    assert ops.topk_mode("auto", 17366, 64, 57) == 0 and ops.topk_mode("auto", 17366, 64, 56) == 1       # K <= LLMREC_TOPK_PREFILTER_MAX_K
+    assert ops.topk_mode("exact", 17366, 64, 50) == 0 and ops.topk_mode("prefilter", 10**7, 64, 50) == 1
+    with pytest.raises(RuntimeError):
+        ops.topk_mode("fast")
