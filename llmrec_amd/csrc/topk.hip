@@ -735,22 +735,21 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     }
 }
 
-// the lists of a split tile's parts (by upper bound) -> the tile's 64 best by upper bound -> exact ranking + verification
-__global__ __launch_bounds__(256) void topk_merge_pre_kernel(TopkArgs a) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// the lists of a split tile's parts (by upper bound) -> the tile's 64 best by upper bound -> exact ranking + verification.
+// 16 wavefronts per block, ONE user each: the exact re-ranking is a chain of dependent L2 round trips per user, and this launch runs alone
+// behind the sweep (four users per wave in sequence made it 33 us for 57 tiles).
+__global__ __launch_bounds__(1024) void topk_merge_pre_kernel(TopkArgs a) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;     // w = the user's slot in the tile (0..15)
     const int tile = a.split_from + blockIdx.x;
-#pragma unroll 1
-    for (int rr = 0; rr < 4; ++rr) {
-        const int q = tile * 16 + 4 * w + rr;
-        if (q >= a.n_query) continue;                          // wave-uniform
-        float l1[1] = {-INFINITY}; int32_t i1[1] = {INT_MAX};
-        for (int p = 0; p < a.n_parts; ++p) {
-            const int64_t row = ((int64_t)blockIdx.x * a.n_parts + p) * 16 + 4 * w + rr;
-            const float bs[1] = {a.ws_score[row * 64 + lane]}; const int32_t bi[1] = {a.ws_idx[row * 64 + lane]};
-            merge64<1>(l1, i1, bs, bi, lane);
-        }
-        tk_finalize_user(a, a.Eu + a.query_users[q] * a.ldu, q, tile, l1[0], i1[0], lane);
+    const int q = tile * 16 + w;
+    if (q >= a.n_query) return;                                // wave-uniform
+    float l1[1] = {-INFINITY}; int32_t i1[1] = {INT_MAX};
+    for (int p = 0; p < a.n_parts; ++p) {
+        const int64_t row = ((int64_t)blockIdx.x * a.n_parts + p) * 16 + w;
+        const float bs[1] = {a.ws_score[row * 64 + lane]}; const int32_t bi[1] = {a.ws_idx[row * 64 + lane]};
+        merge64<1>(l1, i1, bs, bi, lane);
     }
+    tk_finalize_user(a, a.Eu + a.query_users[q] * a.ldu, q, tile, l1[0], i1[0], lane);
 }
 
 // the lists of a split tile's parts -> the tile's top K (one wave per four users, as in the sweep)
@@ -867,7 +866,7 @@ static int launch_topk(const TopkArgs& a, hipStream_t stream) {
         }
         LLMREC_LAUNCH_CHECK();
         if (a.n_parts > 1) {
-            topk_merge_pre_kernel<<<n_tiles - a.split_from, 256, 0, stream>>>(a);
+            topk_merge_pre_kernel<<<n_tiles - a.split_from, 1024, 0, stream>>>(a);
             LLMREC_LAUNCH_CHECK();
         }
         // second launch: the exact sweep for the tiles whose verification failed (every other block exits at once); unsplit, fragments
