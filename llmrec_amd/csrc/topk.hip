@@ -490,8 +490,13 @@ __global__ __launch_bounds__(256) void topk_pack_items_bf16_kernel(TopkArgs a, i
     const int64_t item = item_p < a.n_items ? item_p : a.n_items - 1;  // the partial last tile repeats the last item (masked by the range check)
     const float* row = a.Ei + item * a.ldi;
     float x[8];
+    float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const int k = 8 * g + j; x[j] = k < a.d ? row[k] : 0.f; }
+    for (int j = 0; j < 8; ++j) { const int k = 8 * g + j; x[j] = k < a.d ? row[k] : 0.f; ss = fmaf(x[j], x[j], ss); }
+    if (a.cn && (G & (G - 1)) == 0) {                                  // G = 4, 8, 16: an item's threads are G aligned neighbouring lanes - its
+        for (int off = G >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);   // squared norm by a butterfly (fixed tree); G = 12: topk_item_norm_kernel
+        if (g == 0) a.cn[item_p] = item_p < a.n_items ? TK_PRE_SLACK * (sqrtf(ss) * TK_NORM_UP) : 0.f;
+    }
     uint4 H, M;
     tk_split8(x, H, M);
     const int64_t tile = item_p / TK_TILE;
@@ -854,9 +859,11 @@ static int launch_topk(const TopkArgs& a, hipStream_t stream) {
         if (n_thr < n_tiles) n_thr = n_tiles;                  // (the pack launch also clears one flag word per user tile)
         topk_pack_items_bf16_kernel<<<(unsigned)ceil_div(n_thr, 256), 256, 0, stream>>>(a, DK32, a.pk2);
         LLMREC_LAUNCH_CHECK();
-        const int64_t n_pad = ceil_div(a.n_items, TK_TILE) * TK_TILE;
-        topk_item_norm_kernel<<<grid_for(n_pad, 16), 256, 0, stream>>>(a, a.cn, n_pad);
-        LLMREC_LAUNCH_CHECK();
+        if ((DK32 * 4) & (DK32 * 4 - 1)) {                     // d in (64, 96]: 12 threads per item in the pack launch - the norms get their own
+            const int64_t n_pad = ceil_div(a.n_items, TK_TILE) * TK_TILE;
+            topk_item_norm_kernel<<<grid_for(n_pad, 16), 256, 0, stream>>>(a, a.cn, n_pad);
+            LLMREC_LAUNCH_CHECK();
+        }
         switch (DK32) {
             case 1: score_topk_pre_kernel<1><<<grid, 256, 0, stream>>>(a, a.pk2, a.cn); break;
             case 2: score_topk_pre_kernel<2><<<grid, 256, 0, stream>>>(a, a.pk2, a.cn); break;
