@@ -141,6 +141,24 @@ typedef struct {
      * bit-identical. Pattern-only, unmasked products; ignored otherwise. 0 = off. */
     int32_t x_nt_from_row;
 } llmrec_spmm_epilogue_t;
+/* Round 5 - "these rows of A X" with the row list AND its length in device memory (the row-restricted forward of the row-sharded step,
+ * without a host read-back: llmrec_amd/dist_fused.py). Pattern-only operands (A = diag(row_scale) P).
+ *   llmrec_sort_unique_ids_i32   list[0 .. *n_out) = the distinct ids >= 0 among ids[0 .. n), ascending (n <= LLMREC_SORT_UNIQUE_MAX: one block,
+ *                                bitonic network over 32-bit keys in LDS); list holds n entries.
+ *   llmrec_spmm_rows_compact_f32 out[j] = row_scale[r_j] * sum_{c in row r_j} X[c] for j < *n_list_dev, r_j = row_list[j]; out[j] = 0 for
+ *                                *n_list_dev <= j < capacity (a fixed-size message for the exchange that follows). Long rows are cut into up to
+ *                                LLMREC_SPMM_COMPACT_PARTS pieces (one block each, partial sums added in piece order by a second launch:
+ *                                deterministic). workspace: llmrec_spmm_rows_compact_workspace_bytes(capacity, d).
+ *   llmrec_scatter_set_rows_f32  dst[row_list[j]] = src[j] for j < *n_list_dev. */
+#define LLMREC_SORT_UNIQUE_MAX 32768
+#define LLMREC_SPMM_COMPACT_PARTS 8
+int llmrec_sort_unique_ids_i32(int64_t n, const int64_t* ids, int32_t* list, int32_t* n_out, llmrec_stream_t stream);
+int64_t llmrec_spmm_rows_compact_workspace_bytes(int64_t capacity, int32_t d);
+int llmrec_spmm_rows_compact_f32(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, const int32_t* colidx, const float* row_scale,
+                                 const float* X, int64_t ldx, int32_t d, const int32_t* row_list, const int32_t* n_list_dev, int32_t capacity,
+                                 float* out, int64_t ldo, void* workspace, int64_t workspace_bytes, llmrec_stream_t stream);
+int llmrec_scatter_set_rows_f32(int32_t capacity, const int32_t* row_list, const int32_t* n_list_dev, int32_t d, const float* src, int64_t lds,
+                                float* dst, int64_t ldd, llmrec_stream_t stream);
 /* flags[ids[j]] = value for j < n (ids[j] < 0 skipped): marks the rows a batch touches (x_row_mask / z_row_flag above) */
 int llmrec_mark_rows_u8(int64_t n, const int64_t* ids, int32_t value, uint8_t* flags, llmrec_stream_t stream);
 /* flags[c] = value for every column c of the CSR rows ids[j], j < n (ids[j] < 0 skipped): the rows of the transposed operand that have

@@ -127,6 +127,50 @@ __global__ __launch_bounds__(1024) void scatter_sort_block_kernel(int n, int n_p
     for (int i = threadIdx.x; i < n; i += 1024) keys_out[i] = k[i];
 }
 
+// distinct ids >= 0, ascending, in one block (llmrec_sort_unique_ids_i32): bitonic network over 32-bit keys in LDS (skipped / padded slots
+// = 0xffffffff sort to the end), heads of runs counted per thread chunk, block-wide exclusive scan, ordered write
+__global__ __launch_bounds__(1024) void sort_unique_block_kernel(int n, int n_pow2, const int64_t* __restrict__ ids, int32_t* __restrict__ list,
+                                                                int32_t* __restrict__ n_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t* k = reinterpret_cast<uint32_t*>(smem_raw);
+    __shared__ int32_t wave_total[16];
+    for (int i = threadIdx.x; i < n_pow2; i += 1024)
+        k[i] = (i < n && ids[i] >= 0 && ids[i] < 0xffffffffll) ? (uint32_t)ids[i] : 0xffffffffu;
+    __syncthreads();
+    for (int size = 2; size <= n_pow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < (n_pow2 >> 1); t += 1024) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const bool up = (i & size) == 0;
+                const uint32_t a = k[i], b = k[j];
+                if ((a > b) == up) { k[i] = b; k[j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const int per = (n_pow2 + 1023) / 1024;                              // contiguous chunk per thread
+    const int i0 = threadIdx.x * per, i1 = min(i0 + per, n_pow2);
+    int32_t c = 0;
+    for (int i = i0; i < i1; ++i) c += k[i] != 0xffffffffu && (i == 0 || k[i - 1] != k[i]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    int32_t base = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 16; ++w2) { const int32_t t = wave_total[w2]; if (w2 < wave) base += t; total += t; }
+    int32_t o = base + incl - c;
+    for (int i = i0; i < i1; ++i)
+        if (k[i] != 0xffffffffu && (i == 0 || k[i - 1] != k[i])) list[o++] = (int32_t)k[i];
+    for (int i = total + threadIdx.x; i < n; i += 1024) list[i] = 0;     // the unused tail: defined values
+    if (threadIdx.x == 0) *n_out = total;
+}
+
 // one 16-lane group per sorted position; the head of a run of equal ids adds the run's rows in ascending j
 __global__ __launch_bounds__(256) void scatter_runs_kernel(int64_t n, const uint64_t* __restrict__ keys, const float* __restrict__ rows,
                                                            int64_t ldr, int d, float alpha, float* __restrict__ dst, int64_t ldd) {
@@ -278,6 +322,22 @@ int llmrec_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, int32_t t_wave,
                                                                     split_seg_begin, seg_split);
         LLMREC_LAUNCH_CHECK();
     }
+    return LLMREC_OK;
+}
+
+int llmrec_sort_unique_ids_i32(int64_t n, const int64_t* ids, int32_t* list, int32_t* n_out, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n >= 0 && n <= LLMREC_SORT_UNIQUE_MAX && n_out, "sort_unique_ids: 0 <= n <= %d", LLMREC_SORT_UNIQUE_MAX);
+    LLMREC_CHECK_ARG(n == 0 || (ids && list), "sort_unique_ids: null pointer");
+    int n_pow2 = 2;
+    while (n_pow2 < n) n_pow2 <<= 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LLMREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_unique_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       LLMREC_SORT_UNIQUE_MAX * (int)sizeof(uint32_t)));
+        attr_set = true;
+    }
+    sort_unique_block_kernel<<<1, 1024, (size_t)n_pow2 * sizeof(uint32_t), (hipStream_t)stream_>>>((int)n, n_pow2, ids, list, n_out);
+    LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }
 

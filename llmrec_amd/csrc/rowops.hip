@@ -563,6 +563,17 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(int64_t n, const int64_t
     for (int c = gl; c < d; c += 16) p[c] = 0.f;
 }
 
+// dst[list[j]] = src[j] for j < *n (llmrec_scatter_set_rows_f32): one 16-lane group per slot
+__global__ __launch_bounds__(256) void scatter_set_rows_kernel(int capacity, const int32_t* __restrict__ list, const int32_t* __restrict__ n_dev, int d,
+                                                               const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd) {
+    const int gl = threadIdx.x & 15;
+    const int j = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (j >= capacity || j >= n_dev[0]) return;
+    const float* s_ = src + (int64_t)j * lds_;
+    float* o = dst + (int64_t)list[j] * ldd;
+    for (int c = gl; c < d; c += 16) o[c] = s_[c];
+}
+
 __global__ __launch_bounds__(256) void mark_rows_kernel(int64_t n, const int64_t* __restrict__ ids, uint8_t value, uint8_t* __restrict__ flags) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
@@ -1077,6 +1088,16 @@ int llmrec_loss_assemble_f32(int32_t mode, int32_t n_problems, const float* bpr_
     LossWeights w = {};
     if (w_mf_host) for (int i = 0; i < n_problems; ++i) w.w[i] = w_mf_host[i];
     loss_assemble_kernel<<<1, 64, 0, (hipStream_t)stream_>>>(mode, n_problems, bpr_out, w, scal4, tail, inv_world, running_sums3);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_scatter_set_rows_f32(int32_t capacity, const int32_t* row_list, const int32_t* n_list_dev, int32_t d, const float* src, int64_t lds_,
+                                float* dst, int64_t ldd, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(capacity >= 0 && d > 0, "scatter_set_rows: bad sizes");
+    if (capacity == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(row_list && n_list_dev && src && dst && lds_ >= d && ldd >= d, "scatter_set_rows: null pointer or ld < d");
+    scatter_set_rows_kernel<<<(unsigned)ceil_div(capacity, 16), 256, 0, (hipStream_t)stream_>>>(capacity, row_list, n_list_dev, d, src, lds_, dst, ldd);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

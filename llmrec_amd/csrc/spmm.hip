@@ -461,6 +461,80 @@ __global__ __launch_bounds__(256) void spmm_finalize_kernel(SpmmArgs a) {
     finish_row<LPR, NCHUNK, VEC>(a, (int64_t)slice * a.d, row, gl, acc);
 }
 
+// "These rows of A X" with the list and its length on the device (llmrec_spmm_rows_compact_f32): block (j, p) sums piece p of listed row j
+// (block_range: 8 waves, LDS reduction in wave order) into partial[j][p]; rows up to COMPACT_MIN_PIECE nnz are one piece.
+constexpr int COMPACT_MIN_PIECE = 2048;
+__device__ __forceinline__ void compact_pieces(int32_t deg, int32_t& per, int32_t& n_pieces) {
+    per = (deg + LLMREC_SPMM_COMPACT_PARTS - 1) / LLMREC_SPMM_COMPACT_PARTS;
+    per = (per + 511) / 512 * 512;                                    // (whole 64-index chunks per wave)
+    if (per < COMPACT_MIN_PIECE) per = COMPACT_MIN_PIECE;
+    n_pieces = deg > 0 ? (deg + per - 1) / per : 0;
+}
+template <int LPR, int NCHUNK, int VEC>
+__global__ __launch_bounds__(TPB) void spmm_rows_compact_kernel(SpmmArgs a, const int32_t* __restrict__ row_list, const int32_t* __restrict__ n_list,
+                                                                float* __restrict__ partial) {
+    constexpr int ROWW = NCHUNK * LPR * VEC;
+    __shared__ __attribute__((aligned(16))) float red_lds[(TPB / 64 - 1) * ROWW];
+    const int j = blockIdx.x, p = blockIdx.y;
+    if (j >= n_list[0]) return;                                         // block-uniform
+    const int32_t row = row_list[j];
+    const int32_t s = a.rowptr[row], e = a.rowptr[row + 1];
+    int32_t per, n_pieces;
+    compact_pieces(e - s, per, n_pieces);
+    if (p >= n_pieces) return;
+    Vec<VEC> acc[NCHUNK];
+    if (block_range<LPR, NCHUNK, VEC, false, false, false>(a, 0, s + p * per, min(s + (p + 1) * per, e), red_lds, acc)) {
+        float* pr = partial + ((int64_t)j * LLMREC_SPMM_COMPACT_PARTS + p) * a.d;
+#pragma unroll
+        for (int k = 0; k < NCHUNK; ++k) {
+            const int col = (k * LPR + (int)threadIdx.x) * VEC;
+            if (col < a.d) acc[k].store(pr + col);
+        }
+    }
+}
+// one lane group per slot j < capacity: the pieces of row j in piece order, the row scale; zeros past the list's end
+template <int LPR, int NCHUNK, int VEC>
+__global__ __launch_bounds__(256) void spmm_rows_compact_finish_kernel(SpmmArgs a, const int32_t* __restrict__ row_list, const int32_t* __restrict__ n_list,
+                                                                       int capacity, const float* __restrict__ partial, float* __restrict__ out, int64_t ldo) {
+    const int gl = threadIdx.x & (LPR - 1);
+    const int j = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    if (j >= capacity) return;
+    Vec<VEC> acc[NCHUNK];
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
+    float rs = 0.f;
+    if (j < n_list[0]) {
+        const int32_t row = row_list[j];
+        int32_t per, n_pieces;
+        compact_pieces(a.rowptr[row + 1] - a.rowptr[row], per, n_pieces);
+        for (int p = 0; p < n_pieces; ++p) {
+            const float* pr = partial + ((int64_t)j * LLMREC_SPMM_COMPACT_PARTS + p) * a.d;
+#pragma unroll
+            for (int k = 0; k < NCHUNK; ++k) {
+                const int col = (k * LPR + gl) * VEC;
+                if (col < a.d) { Vec<VEC> v; v.load(pr + col); acc[k].add(v); }
+            }
+        }
+        rs = a.row_scale ? a.row_scale[row] : 1.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < NCHUNK; ++k) {
+        const int col = (k * LPR + gl) * VEC;
+        acc[k].scale(rs);
+        if (col < a.d) acc[k].store(out + (int64_t)j * ldo + col);
+    }
+}
+
+template <int LPR, int NCHUNK, int VEC>
+static int launch_rows_compact(SpmmArgs& a, const int32_t* row_list, const int32_t* n_list, int capacity, float* out, int64_t ldo, float* partial,
+                               hipStream_t stream) {
+    spmm_rows_compact_kernel<LPR, NCHUNK, VEC><<<dim3((unsigned)capacity, LLMREC_SPMM_COMPACT_PARTS), TPB, 0, stream>>>(a, row_list, n_list, partial);
+    LLMREC_LAUNCH_CHECK();
+    spmm_rows_compact_finish_kernel<LPR, NCHUNK, VEC><<<(unsigned)ceil_div(capacity, 256 / LPR), 256, 0, stream>>>(a, row_list, n_list, capacity, partial, out, ldo);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
 template <int LPR, int NCHUNK, int VEC>
 static int launch_spmm(SpmmArgs& a, hipStream_t stream) {
     const bool weighted = a.val != nullptr || a.col_scale != nullptr;
@@ -565,5 +639,41 @@ extern "C" int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
         if (dd <= 256) return launch_spmm<64, 4, 1>(a, stream);
     }
     set_error("spmm: d = %d outside the compiled kernel family (vec4 = %d)", dd, (int)vec4);
+    return LLMREC_EUNSUPPORTED;
+}
+
+extern "C" int64_t llmrec_spmm_rows_compact_workspace_bytes(int64_t capacity, int32_t d) {
+    if (capacity < 0 || d <= 0) return -1;
+    return align_up(capacity * LLMREC_SPMM_COMPACT_PARTS * (int64_t)d * 4, 256);
+}
+
+extern "C" int llmrec_spmm_rows_compact_f32(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, const int32_t* colidx, const float* row_scale,
+                                            const float* X, int64_t ldx, int32_t d, const int32_t* row_list, const int32_t* n_list_dev,
+                                            int32_t capacity, float* out, int64_t ldo, void* workspace, int64_t workspace_bytes,
+                                            llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && d > 0 && capacity >= 0, "spmm_rows_compact: bad sizes");
+    if (capacity == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(rowptr && colidx && X && row_list && n_list_dev && out && ldx >= d && ldo >= d, "spmm_rows_compact: null pointer or ld < d");
+    LLMREC_CHECK_ARG(capacity <= 65535 * 16, "spmm_rows_compact: capacity too large for one launch");
+    if (!workspace || workspace_bytes < llmrec_spmm_rows_compact_workspace_bytes(capacity, d)) {
+        set_error("spmm_rows_compact: workspace %lld < %lld", (long long)workspace_bytes, (long long)llmrec_spmm_rows_compact_workspace_bytes(capacity, d));
+        return LLMREC_EWORKSPACE;
+    }
+    SpmmArgs a = {};
+    a.n_rows = n_rows; a.rowptr = rowptr; a.colidx = colidx; a.row_scale = row_scale; a.X = X; a.ldx = ldx; a.d = d; a.n_slices = 1;
+    hipStream_t stream = (hipStream_t)stream_;
+    float* partial = (float*)workspace;
+    const bool vec4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)X | (uintptr_t)out | (uintptr_t)partial) % 16 == 0);
+    if (vec4) {
+        if (d <= 16) return launch_rows_compact<4, 1, 4>(a, row_list, n_list_dev, capacity, out, ldo, partial, stream);
+        if (d <= 32) return launch_rows_compact<8, 1, 4>(a, row_list, n_list_dev, capacity, out, ldo, partial, stream);
+        if (d <= 64) return launch_rows_compact<16, 1, 4>(a, row_list, n_list_dev, capacity, out, ldo, partial, stream);
+        if (d <= 128) return launch_rows_compact<32, 1, 4>(a, row_list, n_list_dev, capacity, out, ldo, partial, stream);
+        if (d <= 256) return launch_rows_compact<64, 1, 4>(a, row_list, n_list_dev, capacity, out, ldo, partial, stream);
+    } else {
+        if (d <= 16) return launch_rows_compact<16, 1, 1>(a, row_list, n_list_dev, capacity, out, ldo, partial, stream);
+        if (d <= 64) return launch_rows_compact<64, 1, 1>(a, row_list, n_list_dev, capacity, out, ldo, partial, stream);
+    }
+    set_error("spmm_rows_compact: d = %d outside the compiled kernel family (vec4 = %d)", d, (int)vec4);
     return LLMREC_EUNSUPPORTED;
 }

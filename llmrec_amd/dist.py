@@ -120,6 +120,21 @@ class HipBackend:
         """out[r] = (A X)[r] for the listed distinct rows only (ops.spmm_listed); other rows of out keep their contents."""
         return self.ops.spmm_listed(csr, X, rows, out)
 
+    # -- "these rows of A X" with the list and its length on the device (round 5: the restricted forward without host read-backs) --
+    def sort_unique_ids(self, ids, out_list, out_n):
+        self.ops.sort_unique_ids(ids, out_list, out_n)
+
+    def spmm_rows_compact(self, csr, X, row_list, n_list, out):
+        """out[j] = (A X)[row_list[j]] for j < n_list[0], zero rows behind (one workspace per output block, kept)."""
+        key = ("_rows_compact_ws", tuple(out.shape))
+        ws = csr.plans.get(key) if hasattr(csr, "plans") and isinstance(csr.plans, dict) else None
+        ws = self.ops.spmm_rows_compact(csr, X, row_list, n_list, out, ws)
+        if hasattr(csr, "plans") and isinstance(csr.plans, dict):
+            csr.plans[key] = ws
+
+    def scatter_set_rows(self, row_list, n_list, src, dst):
+        self.ops.scatter_set_rows(row_list, n_list, src, dst)
+
     def mark_rows(self, ids, value: int, flags):
         """flags[ids] = value (ids < 0 skipped): llmrec_mark_rows_u8."""
         o = self.ops

@@ -177,6 +177,11 @@ class ShardedFusedID:
         # nothing is ever cleared): those two SpMMs skip the gathers of all-zero rows - 2 of the step's 4 L products.
         self.sparse_backward = sparse_backward
         self.sparse_forward = sparse_backward and sparse_forward
+        if self.sparse_forward:                                # the restricted last layer's row list (device) and its fixed-size message block
+            cap = comm.world * 2 * batch_local
+            self.need_rows = torch.zeros(cap, dtype=torch.int32, device=dev)
+            self.need_n = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.need_part = torch.zeros(cap, d, dtype=torch.float32, device=dev)
         self.graph_items_to_users = graph.ui_bwd                 # rows = items, columns = this rank's users (the pattern is what matters)
         self.flag_u = torch.zeros(U, dtype=torch.uint8, device=dev)
         self.flag_i = torch.zeros(I, dtype=torch.uint8, device=dev)
@@ -254,15 +259,17 @@ class ShardedFusedID:
         for l in range(L):
             last = l == L - 1
             if last and needed is not None:
-                stamp, rows = needed
+                # no host read-back anywhere (round 5): the list of item rows and its length stay on the device, the message is the
+                # fixed-size block [2 B world, d] whose slots past the list's end are zeros
+                stamp, rows, n_rows = needed
                 be.spmm(self.g.ui_fwd, i_prev, out=self.Ul[l], epilogue={"op": "softmax", "y_row_needed": self.flag_u, "x_mask_active": stamp})
-                be.spmm_listed(self.g.iu_fwd, self.Ul[l], rows, self.Il[l])          # this rank's share of the listed rows
-                part = self.Il[l][rows]                                              # compact [n_rows, d]: the layer's message
+                part = self.need_part
+                be.spmm_rows_compact(self.g.iu_fwd, self.Ul[l], rows, n_rows, part)   # this rank's share of the listed rows
                 self.allreduce_bytes += part.numel() * 4
                 if self.comm.dist is not None and (self.comm.world > 1 or self.comm.force):
                     self.comm.all_reduce_(part)
                 be.softmax_rows_into(part, part)
-                self.Il[l][rows] = part
+                be.scatter_set_rows(rows, n_rows, part, self.Il[l])
                 break
             be.spmm(self.g.ui_fwd, i_prev, out=self.Ul[l], epilogue={"op": "softmax"} if last else None)      # local users
             self._reduced_spmm(self.iu_fwd_chunks, self.Ul[l], self.Il[l],
@@ -303,9 +310,9 @@ class ShardedFusedID:
             # ... and the local users those items reach: the only rows of A_iu^T g that can be non-zero (a sweep over the adjacency of
             # <= 2 B world items instead of a look at every user's index list)
             be.mark_neighbours(self.gat_ids.view(-1), self.graph_items_to_users, stamp, self.flag_u)
-            if self.sparse_forward:
-                ids = self.gat_ids.view(-1)
-                needed = (stamp, torch.unique(ids[ids >= 0]))             # (sorted, identical on every rank; padded ids < 0 are skipped as everywhere else)
+            if self.sparse_forward:                                # the distinct item rows of every rank's batch, ascending: identical on every
+                be.sort_unique_ids(self.gat_ids.view(-1), self.need_rows, self.need_n)   # rank; built on the device (padded ids < 0 skipped)
+                needed = (stamp, self.need_rows, self.need_n)
         self.forward(dense_users=False, dense_items=False, needed=needed)
         # BPR + prune over the global batch (reference main.py:158-165,330-342): two passes around an all-gather of B floats;
         # the user side of the loss is the B x d block of layer-mean rows, indexed 0..B-1
@@ -396,7 +403,7 @@ class ShardedFusedID:
     # -- accounting for bench.py -------------------------------------------------------------------------
     def message_bytes_per_step(self) -> dict:
         return {"exchange": self.exchange, "allreduce_I_x_d_bytes": 4 * self.I * self.d * (2 * self.L - (1 if self.sparse_forward else 0)),
-                "last_forward_message": "the rows of the batches' items only (<= 2 B world rows)" if self.sparse_forward else "I x d",
+                "last_forward_message": "a fixed block of 2 B world rows (the batches' item rows, zeros behind the list's end)" if self.sparse_forward else "I x d",
                 "exchanged_bytes_last_step": int(self.allreduce_bytes),
                 "allreduce_messages": (2 * self.L - (1 if self.sparse_forward else 0)) * len(self.chunks) + (1 if self.sparse_forward else 0),
                 "bpr_rows_allgather_bytes_per_rank": 2 * self.B * (4 * self.d + 8), "prune_allgather_bytes_per_rank": 4 * self.B}

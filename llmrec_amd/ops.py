@@ -352,6 +352,38 @@ def spmm_listed(a: Csr, X: torch.Tensor, rows: torch.Tensor, out: torch.Tensor, 
     return spmm_raw(a, X, out=out, epilogue=epilogue, partials=part, plan=pl)
 
 
+def sort_unique_ids(ids: torch.Tensor, out_list: torch.Tensor, out_n: torch.Tensor):
+    """out_list[0 .. out_n[0]) = the distinct ids >= 0 of `ids`, ascending (int32), entirely on the device (llmrec_sort_unique_ids_i32:
+    one block, <= 32 768 ids): the host never learns the count."""
+    _need_gpu(ids, out_list, out_n)
+    n = ids.numel()
+    if out_list.dtype != torch.int32 or out_n.dtype != torch.int32 or out_list.numel() < n or ids.dtype != torch.int64 or not ids.is_contiguous():
+        raise RuntimeError("sort_unique_ids: ids int64 contiguous, out_list int32 with room for every id, out_n int32[1]")
+    _lib.call("llmrec_sort_unique_ids_i32", n, _p(ids), _p(out_list), _p(out_n), _stream())
+
+
+def spmm_rows_compact(a: Csr, X: torch.Tensor, row_list: torch.Tensor, n_list: torch.Tensor, out: torch.Tensor, ws: Optional[torch.Tensor] = None):
+    """out[j] = (A X)[row_list[j]] for j < n_list[0] (device count), zeros for the other slots of out [capacity, d]: "these rows of A X" as a
+    fixed-size compact block, no host read-back (llmrec_spmm_rows_compact_f32; pattern-only operands)."""
+    _need_gpu(X, out, row_list, n_list)
+    if a.val is not None or a.col_scale is not None:
+        raise RuntimeError("spmm_rows_compact: pattern-only operands (A = diag(row_scale) P)")
+    X = _rowmajor(X)
+    cap, d = out.shape
+    need = _lib.query("llmrec_spmm_rows_compact_workspace_bytes", cap, d)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=X.device)
+    _lib.call("llmrec_spmm_rows_compact_f32", a.n_rows, a.n_cols, _p(a.rowptr), _p(a.colidx), _p(a.row_scale), _p(X), _ld(X), d, _p(row_list),
+              _p(n_list), cap, _p(out), _ld(out), _p(ws), ws.numel(), _stream())
+    return ws
+
+
+def scatter_set_rows(row_list: torch.Tensor, n_list: torch.Tensor, src: torch.Tensor, dst: torch.Tensor):
+    """dst[row_list[j]] = src[j] for j < n_list[0] (llmrec_scatter_set_rows_f32)."""
+    _need_gpu(src, dst, row_list, n_list)
+    _lib.call("llmrec_scatter_set_rows_f32", src.shape[0], _p(row_list), _p(n_list), src.shape[1], _p(src), _ld(src), _p(dst), _ld(dst), _stream())
+
+
 def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False, epilogue=None,
              partials: Optional[torch.Tensor] = None, plan: Optional[SpmmPlan] = None) -> torch.Tensor:
     """Y = epilogue(A X) through llmrec_spmm_f32. accumulate: Y += A X (epilogue Z = Y, alpha = 1). partials: scratch of

@@ -69,6 +69,20 @@ class CpuBackend:
         out[rows] = Y[rows]
         return out
 
+    def sort_unique_ids(self, ids, out_list, out_n):
+        u = torch.unique(ids[ids >= 0]).to(torch.int32)
+        out_list.zero_(); out_list[:u.numel()] = u; out_n[0] = u.numel()
+
+    def spmm_rows_compact(self, p, X, row_list, n_list, out):
+        n = int(n_list[0])
+        Y = self.spmm(p, X)
+        out.zero_()                                                         # slots past the list's end are zeros (a fixed-size message)
+        out[:n] = Y[row_list[:n].long()]
+
+    def scatter_set_rows(self, row_list, n_list, src, dst):
+        n = int(n_list[0])
+        dst[row_list[:n].long()] = src[:n]
+
     def mark_rows(self, ids, value, flags):
         flags[ids[ids >= 0]] = value
 

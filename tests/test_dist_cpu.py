@@ -160,8 +160,9 @@ def test_two_rank_fused_sharded_step_matches_single_process_oracle(tmp_path, exc
     assert np.allclose(r0["losses"], ref_losses, rtol=1e-5) and np.allclose(r1["losses"], ref_losses, rtol=1e-5)
     assert np.abs(got_u - ref_u).max() <= 1e-4 * np.abs(ref_u).max()
     assert np.abs(r0["items"] - ref_i).max() <= 1e-4 * np.abs(ref_i).max()
-    # one message per layer and direction: I x d, except the last layer's forward message = the rows of the two batches' items only
-    assert 4 * I * D * (2 * L - 1) < int(r0["msg"][0]) < 4 * I * D * 2 * L
+    # one message per layer and direction: I x d, except the last layer's forward message = the FIXED-SIZE block of the two batches' item rows
+    # (world x 2 x batch_local slots, zeros behind the list's end: its length never reaches the host - round 5)
+    assert int(r0["msg"][0]) == 4 * I * D * (2 * L - 1) + 4 * (2 * 2 * (B_LOCAL + n_aug)) * D
 
 
 def test_user_block_partition_covers_all_users():

@@ -216,6 +216,77 @@ def test_sharded_step_with_the_dense_forward_never_synchronises_the_host():
     assert np.isfinite(float(loss)) and np.isfinite(float(loss2))
 
 
+def test_sharded_step_with_the_restricted_forward_never_synchronises_the_host_either():
+    """the row-restricted-forward VARIANT builds its row list on the device (llmrec_sort_unique_ids_i32), forms the listed
+    rows of the last product as a fixed-size compact block with a device-side count (llmrec_spmm_rows_compact_f32) and writes them back
+    (llmrec_scatter_set_rows_f32): no torch.unique, no boolean indexing, no plan read-back - a step under torch's sync debug mode."""
+    st, _ = _run_rank_variant(0, 1, 3, 64, 0, "all_reduce", sparse_forward=True)
+    assert st.sparse_forward
+    rows, cols, u_tab, i_tab, batches = _problem(1, 64, 0)
+    us, ps, ns = batches[0][0]
+    triples = (torch.tensor(us).cuda(), torch.tensor(ps).cuda(), torch.tensor(ns).cuda())
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        loss, parts = st.step(triples)
+        loss2, _ = st.step()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert np.isfinite(float(loss)) and np.isfinite(float(loss2))
+
+
+@pytest.mark.parametrize("d", [64, 128, 20])
+def test_listed_rows_of_a_product_with_the_list_on_the_device(d):
+    """llmrec_sort_unique_ids_i32 + llmrec_spmm_rows_compact_f32 + llmrec_scatter_set_rows_f32 against torch: distinct ids ascending (negatives
+    skipped, duplicates once), the listed rows of diag(s) P X incl. empty rows, rows around the 2 048-edge piece size and hubs cut into 8
+    pieces, zeros behind the list's end, deterministic; the scatter writes exactly the listed rows."""
+    from llmrec_amd import ops
+    rng = np.random.default_rng(40 + d)
+    n_rows, n_cols = 400, 30000
+    degs = rng.integers(0, 30, size=n_rows)
+    for k, dg in enumerate([0, 1, 2047, 2048, 2049, 4096, 9000, 16384, 20000, 29000]):
+        degs[(k * 17 + 3) % n_rows] = dg
+    r = np.repeat(np.arange(n_rows), degs)
+    c = np.concatenate([rng.choice(n_cols, size=int(x), replace=False) for x in degs]).astype(np.int64)
+    rp, ci, _ = ops.csr_from_coo(torch.tensor(r).cuda(), torch.tensor(c).cuda(), None, n_rows, n_cols)
+    s = torch.tensor(rng.random(n_rows).astype(np.float32) + 0.5).cuda()
+    a = ops.Csr(n_rows, n_cols, rp, ci, None, s, None, {})
+    X = torch.tensor(rng.standard_normal((n_cols, d)).astype(np.float32)).cuda()
+    ids = rng.integers(0, n_rows, size=300); ids[::7] = -1; ids[:12] = [(k * 17 + 3) % n_rows for k in range(10)] + [5, 5]
+    ids_t = torch.tensor(ids).cuda()
+    cap = ids.size
+    lst, n = torch.full((cap,), -7, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.sort_unique_ids(ids_t, lst, n)
+    want_ids = np.unique(ids[ids >= 0])
+    assert int(n[0]) == want_ids.size and np.array_equal(lst[:want_ids.size].cpu().numpy(), want_ids) and int(lst[want_ids.size:].abs().max()) == 0
+    out = torch.full((cap, d), float("nan"), device="cuda")
+    ops.spmm_rows_compact(a, X, lst, n, out)
+    out2 = torch.full((cap, d), float("nan"), device="cuda")
+    ops.spmm_rows_compact(a, X, lst, n, out2)
+    assert torch.equal(out, out2)                                               # fixed piece order: deterministic
+    A = torch.sparse_csr_tensor(rp.long(), ci.long(), torch.ones(ci.numel(), device="cuda", dtype=torch.float64), (n_rows, n_cols))
+    ref = (A @ X.double()) * s.double()[:, None]
+    got = out[:want_ids.size].double()
+    assert float((got - ref[want_ids]).abs().max() / ref.abs().max()) < 2e-6
+    assert float(out[want_ids.size:].abs().max()) == 0.0                        # zeros behind the list's end
+    dst = torch.full((n_rows, d), 3.0, device="cuda")
+    ops.scatter_set_rows(lst, n, out, dst)
+    want = torch.full((n_rows, d), 3.0, device="cuda"); want[want_ids] = out[:want_ids.size]
+    assert torch.equal(dst, want)
+    # an empty list: nothing computed, everything zero
+    n.zero_()
+    ops.spmm_rows_compact(a, X, lst, n, out)
+    assert float(out.abs().max()) == 0.0
+    # sort_unique at its limit and beyond
+    big = torch.randint(0, 5_000_000, (32768,), device="cuda")
+    l2, n2 = torch.zeros(32768, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.sort_unique_ids(big, l2, n2)
+    u = torch.unique(big)
+    assert int(n2[0]) == u.numel() and torch.equal(l2[:u.numel()].long(), u)
+    with pytest.raises(RuntimeError):
+        ops.sort_unique_ids(torch.zeros(32769, dtype=torch.int64, device="cuda"), torch.zeros(32769, dtype=torch.int32, device="cuda"), n2)
+
+
 def test_zero_rows_clears_exactly_the_listed_rows():
     from llmrec_amd import dist as ld
     be = ld.HipBackend()
