@@ -186,17 +186,23 @@ class Trainer(object):
                 # forward + scoring + masked top-K as ONE graph replay per evaluation
                 # the query tensor is cached on the CONTENT of the user list (a different list of the same length
                 # must not reuse it); the evaluation graph is keyed on that tensor
-                users_np = np.asarray(users_to_test, dtype=np.int64)
-                users_key = users_np.tobytes()                  # (the list's content as one bytes object: hashed and compared in ~30 us for 13 k users)
-                cache = getattr(self, "_eval_queries", None)
-                if cache is None:
-                    cache = self._eval_queries = {}
-                if users_key not in cache:
-                    if len(cache) >= 4:                        # bound the number of live evaluation graphs: drop the oldest query
-                        old_q = cache.pop(next(iter(cache)))   # AND the graph / lists / workspace FusedStep keeps for it
-                        fused.drop_eval_graph(old_q)
-                    cache[users_key] = torch.from_numpy(users_np.copy()).to(device)
-                q = cache[users_key]
+                own = getattr(self, "_eval_own", None)          # the list train() itself built once and hands in every epoch: trusted by identity
+                if own is not None and own[0] is users_to_test and own[1] == len(users_to_test):
+                    q = own[2]                                  # (converting 13 k python ints per evaluation cost 0.4 ms of a 1.1 ms evaluation)
+                else:
+                    users_np = np.asarray(users_to_test, dtype=np.int64)
+                    users_key = users_np.tobytes()              # (the list's content as one bytes object: hashed and compared in ~30 us for 13 k users)
+                    cache = getattr(self, "_eval_queries", None)
+                    if cache is None:
+                        cache = self._eval_queries = {}
+                    if users_key not in cache:
+                        if len(cache) >= 4:                    # bound the number of live evaluation graphs: drop the oldest query
+                            old_q = cache.pop(next(iter(cache)))   # AND the graph / lists / workspace FusedStep keeps for it
+                            fused.drop_eval_graph(old_q)
+                        cache[users_key] = torch.from_numpy(users_np.copy()).to(device)
+                    q = cache[users_key]
+                    if getattr(self, "_eval_own_list", None) is users_to_test:
+                        self._eval_own = (users_to_test, len(users_to_test), q)
                 st = data_generator.device_state(device)
                 idx, _ = fused.eval_topk(q, st["train"], max(eval(args.Ks)), use_graph=True)
                 return test_torch(fused.E_u, fused.E_i, users_to_test, is_val, topk=(q, idx))
@@ -412,6 +418,10 @@ class Trainer(object):
         best_recall = 0
         test_ret = None
         in_graph_sampler = bool(self._device_sampler and USE_GRAPH() and self._fused_step())
+        # the reference rebuilds this list every epoch (main.py:297); the test set does not change during training, so it is built once and the
+        # evaluation recognises the object (its device query tensor is converted once, not 13 k python ints per epoch)
+        users_to_test = list(data_generator.test_set.keys())
+        self._eval_own_list, self._eval_own = users_to_test, None
         for epoch in range(args.epoch):
             t1 = time()
             n_batch = data_generator.n_train // args.batch_size + 1
@@ -456,7 +466,6 @@ class Trainer(object):
                 self.logger.logging(perf_str)
 
             t2 = time()
-            users_to_test = list(data_generator.test_set.keys())
             ret = self.test(users_to_test, is_val=False)
             training_time_list.append(t2 - t1)
             t3 = time()

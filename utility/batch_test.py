@@ -70,10 +70,10 @@ def test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val, drop_flag=Fa
     (the graph-captured evaluation of llmrec_amd.fused.FusedStep.eval_topk)."""
     result = {'precision': np.zeros(len(Ks)), 'recall': np.zeros(len(Ks)), 'ndcg': np.zeros(len(Ks)),
               'hit_ratio': np.zeros(len(Ks)), 'auc': 0.}
-    test_users = list(users_to_test)
-    n_test_users = len(test_users)
+    n_test_users = len(users_to_test)
     if n_test_users == 0:
         return result
+    test_users = users_to_test if topk is not None else list(users_to_test)     # (with device lists in hand the host copy is not needed)
     from llmrec_amd import ops
     held = data_generator.val_set if is_val else data_generator.test_set
     if args.test_flag == 'part':
