@@ -1,19 +1,21 @@
-"""Fused training step: the whole Stage-2 step - sampler included - as a fixed sequence of ~80 HIP launches
+"""Fused training step: the whole Stage-2 step - sampler included - as a fixed sequence of 28 HIP launches (36 with LLMREC_FOLD=0)
 over preallocated buffers, with the backward pass written out by hand (no autograd graph), captured into one
 HIP graph; likewise an evaluation (forward + scoring + masked top-K).
 
 Same arithmetic as the modular path (Models.MM_Model.forward + llmrec_amd.engine.train_step,
 i.e. reference Models.py:127-199 + main.py:228-278); what changes is the organisation:
   * the seven item-side streams (image, text, 5 attributes) travel as ONE [rows, 7d] operand, so
-    the 16 side-feature SpMMs of the reference (Models.py:152-167) become 4 (+4 in backward) and the
-    adjacency indices are read once per direction instead of seven times;
-  * the 8 BPR + prune losses (main.py:232-254) are three launches (llmrec_bpr_multi_fwd_f32: scores, rank
-    selection, reduction) and their backward one (llmrec_bpr_multi_bwd_f32), scattering straight into the
-    gradient buffers;
+    the 16 side-feature SpMMs of the reference (Models.py:152-167) become 4 (+4 in backward) - 2 + 2 when the constant
+    products A_ui F_k are pre-propagated at set-up - and the adjacency indices are read once per direction instead of seven times;
+  * the 8 BPR + prune losses (main.py:232-254) are two launches on the critical path (scores - which also begin the step on the device:
+    row stamp, AdamW's counter - and selection + gradient rows) and one beside it (the loss values, the feature regulariser from the
+    fusion launch's partial sums, the logged scalars);
   * projections and weight gradients of the constant feature matrices are grouped launches (8 projections in
-    one; item_trans' five streams in one) in split-precision bf16x3 arithmetic (LLMREC_GEMM=f32: exact fp32);
-  * independent chains run on five HIP streams (fork/join = graph edges);
-  * gradients are written into preallocated .grad tensors; AdamW reads them in place;
+    one; all four Linears' gradients, row-listed, in one, with their AdamW in the reduction launch) in split-precision bf16x3
+    arithmetic (LLMREC_GEMM=f32: exact fp32);
+  * independent chains run on four HIP streams (fork/join = graph edges);
+  * the embedding tables' AdamW reads its gradient where it is formed (the user table's is inv * dE_u) and the row-wise clean-up of the
+    scatter targets rides in the item table's AdamW launch;
   * nothing allocates or synchronises, so the step can be replayed from a HIP graph
     (``capture()``), removing the per-launch host cost that dominates at Netflix scale.
 Falls outside its scope (use the modular path): dropout > 0 and the --mask branch.
