@@ -66,5 +66,6 @@ if which in ("topk", "all"):
     rp, ci, _ = ops.csr_from_coo(torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev), None, U, I)
     tr = ops.Csr(U, I, rp, ci, None, None, None, ops.SpmmPlan())
     q = torch.arange(U, device=dev)
-    ms = timeit(lambda: ops.score_topk(Eu, Ei, q, tr, 50))
-    print("score_topk ms %.4f TF %.2f users/s %.0f" % (ms, 2.0 * U * I * d / ms / 1e9, U / ms * 1e3))
+    for mode in ("exact", "prefilter"):                      # both sweeps (bit-identical lists): profiles/experiments/r05_topk.md
+        ms = timeit(lambda: ops.score_topk(Eu, Ei, q, tr, 50, mode=mode))
+        print("score_topk[%s] ms %.4f TF %.2f users/s %.0f" % (mode, ms, 2.0 * U * I * d / ms / 1e9, U / ms * 1e3))
