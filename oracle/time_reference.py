@@ -2,7 +2,7 @@
 drop-in on. Runs in the build container only (needs /root/reference); the GPU box never sees the reference,
 so the result travels as a committed record:
 
-    python oracle/time_reference.py [--epochs 2] [--out profiles/r04_reference_cpu.json]
+    python oracle/time_reference.py [--epochs 6] [--out profiles/r05_reference_cpu.json] [--note "..."]
 
 The reference is imported through oracle/ref_loader.py (import shims only; its evaluation pool becomes an in-process map - the
 reference would use Pool(cpu_count() // 5) = one worker on this 8-core host, utility/batch_test.py:11,115) and its own
@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_reference_cpu.json"))
     ap.add_argument("--data", default="/tmp/llmrec_e2e")
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--note", default=None, help="free text stored as timing_note (e.g. the state of the host during the run)")
     a = ap.parse_args()
     if a.child:
         return child(a.data, a.epochs)
@@ -100,6 +101,8 @@ def main():
            "epochs": c["epochs"], "n_batch": c["n_batch"], "batch_size": c["batch_size"], "n_test_users": c["n_test_users"],
            "train_s": best["train_s"], "eval_s": best["eval_s"],
            "edges_per_s": c["n_batch"] * c["batch_size"] / best["train_s"], "users_per_s": c["n_test_users"] / best["eval_s"], "init_s": c["init_s"]}
+    if a.note:
+        out["timing_note"] = a.note
     json.dump(out, open(a.out, "w"), indent=1)
     print(json.dumps(out))
 

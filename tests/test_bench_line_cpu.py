@@ -94,11 +94,11 @@ def test_headline_vs_reference_comparison_is_a_pure_function_of_the_two_records(
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import e2e_main
     ref = e2e_main.reference_record()
-    assert ref is not None and ref["file"].startswith("r05_") and len(ref["epochs"]) == 2 and len(ref["digests"]) == 9
+    assert ref is not None and ref["file"].startswith("r05_") and len(ref["epochs"]) >= 2 and len(ref["digests"]) == 9
     assert ref["n_test_users"] == 13187 and ref["n_batch"] == 42 and ref["seed"] == 2022
     same = [{"loss": e["loss"], "mf_loss": e["mf_loss"], "emb_loss": 1e-7, "metrics": e["metrics"]} for e in ref["epochs"]]
     v = e2e_main.vs_reference(same, ref, ref["digests"])
-    assert v["ok"] and v["loss_rel"] == 0.0 and v["metric_max_abs"] == 0.0 and v["epochs"] == 2
+    assert v["ok"] and v["loss_rel"] == 0.0 and v["metric_max_abs"] == 0.0 and v["epochs"] == len(ref["epochs"])
     # a drifted loss, a drifted metric, other bytes: each alone fails the gate
     bad = json.loads(json.dumps(same)); bad[1]["loss"] *= 1.0 + 2e-4
     assert not e2e_main.vs_reference(bad, ref, ref["digests"])["ok"]
