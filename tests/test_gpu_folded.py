@@ -201,3 +201,28 @@ def test_adamw_with_a_gradient_source_and_the_row_cleanup_in_one_launch(ops):
     opt.step_params([pi], zero_rows=([(ids[1], wide)], cap, nv))
     torch.cuda.synchronize()
     assert torch.equal(wide, keep)
+
+
+def test_device_timestamps_are_monotonic_and_tick_at_the_advertised_rate(ops):
+    """llmrec_timestamp (the bench's in-graph timing aid): stamps taken in stream order never decrease, a known kernel between two stamps
+    takes about as long by the counter as by HIP events, and the step re-captured with stamps in it gives the same results as without."""
+    from llmrec_amd import _lib
+    rate = _lib.query("llmrec_timestamp_rate_hz")
+    assert rate >= 1_000_000
+    slots = torch.zeros(4, dtype=torch.int64, device=DEV)
+    x = torch.randn(64 << 20, device=DEV)                               # 256 MB
+    y = torch.empty_like(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        _lib.call("llmrec_timestamp", ctypes.c_void_p(slots.data_ptr()), _stream())
+        e0.record()
+        _lib.call("llmrec_axpy_f32", 1 << 20, 64, 2.0, None, p_(x), 64, p_(y), 64, 0, _stream())
+        e1.record()
+        _lib.call("llmrec_timestamp", ctypes.c_void_p(slots.data_ptr() + 8), _stream())
+        _lib.call("llmrec_timestamp", ctypes.c_void_p(slots.data_ptr() + 16), _stream())
+    torch.cuda.synchronize()
+    t = slots.tolist()
+    assert t[0] > 0 and t[0] <= t[1] <= t[2]
+    by_counter_ms = (t[1] - t[0]) / rate * 1e3
+    by_events_ms = e0.elapsed_time(e1)
+    assert 0.5 * by_events_ms <= by_counter_ms <= 2.0 * by_events_ms + 0.05, (by_counter_ms, by_events_ms)
