@@ -91,14 +91,14 @@ __device__ __forceinline__ bool pair_better(float s, int i, float t, int j) { re
 // value of lane (lane ^ J): DPP inside a 16-lane row (no LDS round trip), ds_swizzle for 16, ds_bpermute for 32
 template <int J>
 __device__ __forceinline__ int xor_lane_i(int x, int lane) {
-    if (J == 1) return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);          // quad_perm [1,0,3,2]
-    if (J == 2) return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);          // quad_perm [2,3,0,1]
+    if (J == 1) return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);           // quad_perm [1,0,3,2]
+    if (J == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);           // quad_perm [2,3,0,1]
     if (J == 4) {
-        const int up = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0xf, false);         // row_shl:4  lane i <- i + 4
-        const int dn = __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xf, false);         // row_shr:4  lane i <- i - 4
+        const int up = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0xf, true);          // row_shl:4  lane i <- i + 4
+        const int dn = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);          // row_shr:4  lane i <- i - 4
         return (lane & 4) ? dn : up;
     }
-    if (J == 8) return __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false);          // row_ror:8
+    if (J == 8) return __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, true);           // row_ror:8
     if (J == 16) return __builtin_amdgcn_ds_swizzle(x, 0x401F);                            // bit mode: and 0x1f, xor 0x10
     return __shfl_xor(x, J, 64);
 }
@@ -154,6 +154,56 @@ __device__ __forceinline__ void sort64(float (&s)[NV], int (&i)[NV], int lane) {
     bitonic_net<16, NV>(s, i, lane, 32);
     bitonic_net<32, NV>(s, i, lane, 0);
 }
+
+// ---- the same networks on ONE 64-bit key per entry (the bf16 sweep's lists) ----
+// key = (order-preserving bits of the upper bound) << 32 | ~item: a larger key is the better entry (higher bound, then the smaller item id;
+// the empty slot (-inf, INT_MAX) is the smallest key a list can hold). One 64-bit compare per stage instead of three 32-bit ones: the drains
+// are ~45 % of the bf16 sweep's vector instructions at the Netflix width. The order among equal bounds cannot change the output (the lists
+// are re-ranked by the exact score and verified), it only has to be a strict total order so that a compare-exchange never duplicates an entry.
+__device__ __forceinline__ uint32_t tk_ord(float x) {
+    const uint32_t b = __float_as_uint(x);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float tk_unord(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+
+__device__ __forceinline__ uint64_t tk_key(float ub, int32_t id) { return ((uint64_t)tk_ord(ub) << 32) | (uint32_t)~id; }
+__device__ __forceinline__ float tk_key_ub(uint64_t k) { return tk_unord((uint32_t)(k >> 32)); }
+__device__ __forceinline__ int32_t tk_key_id(uint64_t k) { return (int32_t)~(uint32_t)k; }
+template <int J>
+__device__ __forceinline__ uint64_t xor_lane_k(uint64_t k, int lane) {
+    const uint32_t ol = (uint32_t)xor_lane_i<J>((int)(uint32_t)k, lane), oh = (uint32_t)xor_lane_i<J>((int)(uint32_t)(k >> 32), lane);
+    return ((uint64_t)oh << 32) | ol;
+}
+template <int J>
+__device__ __forceinline__ void cmpxk(uint64_t& k, int lane, bool keep_better) {
+    const uint64_t o = xor_lane_k<J>(k, lane);
+    k = (keep_better == (o > k)) ? o : k;
+}
+template <int FROM>
+__device__ __forceinline__ void bitonic_netk(uint64_t& k, int lane, int dirbit) {
+    const bool up = (lane & dirbit) == 0;
+    if (FROM >= 32) cmpxk<32>(k, lane, ((lane & 32) == 0) == up);
+    if (FROM >= 16) cmpxk<16>(k, lane, ((lane & 16) == 0) == up);
+    if (FROM >= 8) cmpxk<8>(k, lane, ((lane & 8) == 0) == up);
+    if (FROM >= 4) cmpxk<4>(k, lane, ((lane & 4) == 0) == up);
+    if (FROM >= 2) cmpxk<2>(k, lane, ((lane & 2) == 0) == up);
+    cmpxk<1>(k, lane, ((lane & 1) == 0) == up);
+}
+__device__ __forceinline__ void merge64k(uint64_t& k, uint64_t b, int lane) {
+    const uint32_t rl = (uint32_t)__shfl((int)(uint32_t)b, 63 - lane, 64), rh = (uint32_t)__shfl((int)(uint32_t)(b >> 32), 63 - lane, 64);
+    const uint64_t r = ((uint64_t)rh << 32) | rl;
+    k = r > k ? r : k;
+    bitonic_netk<32>(k, lane, 0);
+}
+__device__ __forceinline__ void sort64k(uint64_t& k, int lane) {
+    bitonic_netk<1>(k, lane, 2);
+    bitonic_netk<2>(k, lane, 4);
+    bitonic_netk<4>(k, lane, 8);
+    bitonic_netk<8>(k, lane, 16);
+    bitonic_netk<16>(k, lane, 32);
+    bitonic_netk<32>(k, lane, 0);
+}
+constexpr uint64_t TK_KEY_EMPTY = 0x007FFFFF80000000ull;   // tk_key(-inf, INT_MAX)
 
 // (The cycle accounting and the one-part-removed ablation builds of round 2 - profiles/r02_topk_ablation.txt - were tools-only
 // variants of this kernel; they are no longer part of the source.)
@@ -223,7 +273,7 @@ template <int DK, bool FAST, bool PACKED>
 __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(TopkArgs a) {
     __shared__ float buf_s[4][16][TK_CAP];
     __shared__ int32_t buf_i[4][16][TK_CAP];
-    __shared__ int32_t cnt_s[4][16];
+    __shared__ __attribute__((aligned(16))) int32_t cnt_s[4][16];     // fill of buffer (wave, user): LDS atomics (the appends are lane-local)
     __shared__ float thr_s[16];
     __shared__ int32_t flag_s[2];
     // readfirstlane: tells the compiler the wave index is uniform, so the per-wave round counters and
@@ -240,6 +290,7 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     if (q0 >= a.n_query) return;                               // block-uniform
     if (a.only_flagged && a.only_flagged[tile] == 0u) return;  // (the second launch of the bf16 mode: only the tiles its verification flagged)
     if (threadIdx.x < 16) thr_s[threadIdx.x] = -INFINITY;
+    if (threadIdx.x < 64) (&cnt_s[0][0])[threadIdx.x] = 0;
     if (threadIdx.x < 2) flag_s[threadIdx.x] = 0;             // [0] drain requested, [1] waves that finished their quarter
     __syncthreads();
 
@@ -275,10 +326,9 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
         cur = lo;
         if (cur < end) nxt = a.train_colidx[cur];
     }
-    int cntr[4] = {0, 0, 0, 0};                                // fill of this wave's buffers of users 4 lq + r (replicated in the lane group)
-    float ls[4]; int32_t lid[4];                               // the block's lists of users 4 w + rr, slot = lane
+    uint64_t lk[4];                                            // the block's lists of users 4 w + rr as 64-bit keys (score, ~item), slot = lane
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) { ls[rr] = -INFINITY; lid[rr] = INT_MAX; }
+    for (int rr = 0; rr < 4; ++rr) lk[rr] = TK_KEY_EMPTY;
 
     // The waves of a block run decoupled: a wave that needs a drain (or has finished its quarter) raises
     // the flag / waits at the rendezvous, the others join at their next round boundary.
@@ -316,8 +366,9 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     bool counted = false;
     for (;;) {
         const bool fin = round >= my_rounds;
-        const int fill = max(max(cntr[0], cntr[1]), max(cntr[2], cntr[3]));
-        // a buffer must keep room for the next round's TK_TILE candidates
+        // a buffer must keep room for the next round's TK_TILE candidates: this wave's four counters of the lane's user group, straight from LDS
+        const int4 c4 = *reinterpret_cast<const int4*>(&cnt_s[w][lq * 4]);
+        const int fill = max(max(c4.x, c4.y), max(c4.z, c4.w));
         bool drain = fin || __ballot(fill > TK_CAP - TK_TILE) != 0ull;
         // (an atomic load, not a volatile one: volatile accesses to LDS are compiled as FLAT loads with a vmcnt(0)
         //  wait, which would also wait for the prefetched tile)
@@ -325,12 +376,7 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
         if (drain) {                                           // wave-uniform; every wave of the block gets here
             if (fin && !counted) { counted = true; if (lane == 0) atomicAdd(&flag_s[1], 1); }
             if (!fin && lane == 0) __hip_atomic_store(&flag_s[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __syncthreads();
-            if (li == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cnt_s[w][lq * 4 + r] = cntr[r];
-            }
-            __syncthreads();
+            __syncthreads();                                   // (every wave's appends - LDS atomics and stores - are complete and visible)
             // snapshot of the finished-quarter count, taken BETWEEN the drain's barriers: every increment of this cycle
             // happened before the first barrier and the next cycle's cannot happen before the last one - reading it after
             // the last barrier would race with a faster wave that has already finished its final round
@@ -339,24 +385,24 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
             for (int rr = 0; rr < 4; ++rr) {
                 const int u = 4 * w + rr;
                 const int p1 = cnt_s[0][u], p2 = p1 + cnt_s[1][u], p3 = p2 + cnt_s[2][u], total = p3 + cnt_s[3][u];
-                float l1[1] = {ls[rr]}; int32_t i1[1] = {lid[rr]};
+                uint64_t k1 = lk[rr];
                 for (int j0 = 0; j0 < total; j0 += 64) {       // wave-uniform
                     const int j = j0 + lane;
                     const int ww = (j >= p1) + (j >= p2) + (j >= p3);
                     const int start = ww == 0 ? 0 : (ww == 1 ? p1 : (ww == 2 ? p2 : p3));
-                    float bs[1] = {-INFINITY}; int32_t bi[1] = {INT_MAX};
-                    if (j < total) { bs[0] = buf_s[ww][u][j - start]; bi[0] = buf_i[ww][u][j - start]; }
-                    sort64<1>(bs, bi, lane);
-                    merge64<1>(l1, i1, bs, bi, lane);
+                    uint64_t bk = TK_KEY_EMPTY;
+                    if (j < total) bk = tk_key(buf_s[ww][u][j - start], buf_i[ww][u][j - start]);
+                    sort64k(bk, lane);
+                    merge64k(k1, bk, lane);
                 }
-                ls[rr] = l1[0]; lid[rr] = i1[0];
+                lk[rr] = k1;
                 if (total > 0) {
-                    const float nthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ls[rr]), a.K - 1));
+                    const float nthr = tk_unord((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k1 >> 32), a.K - 1));
                     if (lane == 0) thr_s[u] = nthr;
                 }
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cntr[r] = 0;
+            __syncthreads();                                   // (every owner has read the counters)
+            if (threadIdx.x < 64) (&cnt_s[0][0])[threadIdx.x] = 0;
             if (threadIdx.x == 0) flag_s[0] = 0;
             __syncthreads();
             if (done_quarters == 4) break;    // all four quarters swept and drained
@@ -399,15 +445,11 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
                 if (__ballot(v >= rthr) == 0ull) continue;
                 const int col = 16 * n + li;
                 const bool pass = (v >= rthr) && (base + col < a.n_items) && !((rm >> col) & 1u);
-                const unsigned long long bal = __ballot(pass);
-                if (bal == 0) continue;
-                const unsigned sub = (unsigned)(bal >> (16 * lq)) & 0xffffu;   // my lane group = my user
-                if (pass) {
-                    const int off = cntr[r] + __popc(sub & ((1u << li) - 1u));
+                if (pass) {                                    // lane-local append: a slot from the buffer's LDS counter (the order inside a
+                    const int off = atomicAdd(&cnt_s[w][lq * 4 + r], 1);   // buffer is irrelevant: the drain sorts it by (score, item))
                     buf_s[w][lq * 4 + r][off] = v;
                     buf_i[w][lq * 4 + r][off] = (int32_t)(base + col);
                 }
-                cntr[r] += __popc(sub);
             }
         }
         ++round;
@@ -416,8 +458,8 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
         const int64_t base = ((int64_t)(tile - a.split_from) * n_parts + part) * 16;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            a.ws_idx[(base + 4 * w + rr) * 64 + lane] = lid[rr];
-            a.ws_score[(base + 4 * w + rr) * 64 + lane] = ls[rr];
+            a.ws_idx[(base + 4 * w + rr) * 64 + lane] = tk_key_id(lk[rr]);
+            a.ws_score[(base + 4 * w + rr) * 64 + lane] = tk_key_ub(lk[rr]);
         }
         return;
     }
@@ -425,8 +467,9 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     for (int rr = 0; rr < 4; ++rr) {
         const int q = q0 + 4 * w + rr;
         if (q < a.n_query && lane < a.K) {
-            a.out_idx[(int64_t)q * a.K + lane] = lid[rr] == INT_MAX ? -1 : lid[rr];
-            a.out_score[(int64_t)q * a.K + lane] = ls[rr];
+            const int32_t id = tk_key_id(lk[rr]);
+            a.out_idx[(int64_t)q * a.K + lane] = id == INT_MAX ? -1 : id;
+            a.out_score[(int64_t)q * a.K + lane] = tk_key_ub(lk[rr]);
         }
     }
 }
@@ -559,7 +602,7 @@ template <int DK32>
 __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kernel(TopkArgs a, const uint4* __restrict__ pk2, const float* __restrict__ cn) {
     __shared__ float buf_s[4][16][TK_CAP];                             // upper bounds ub of the buffered candidates
     __shared__ int32_t buf_i[4][16][TK_CAP];
-    __shared__ int32_t cnt_s[4][16];
+    __shared__ __attribute__((aligned(16))) int32_t cnt_s[4][16];     // fill of buffer (wave, user): LDS atomics (the appends are lane-local)
     __shared__ float thr_s[16];                                        // the filter: the 64th ub of the user's list so far
     __shared__ int32_t flag_s[2];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -573,6 +616,7 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     const int q0 = tile * 16;
     if (q0 >= a.n_query) return;
     if (threadIdx.x < 16) thr_s[threadIdx.x] = -INFINITY;
+    if (threadIdx.x < 64) (&cnt_s[0][0])[threadIdx.x] = 0;
     if (threadIdx.x < 2) flag_s[threadIdx.x] = 0;
     __syncthreads();
 
@@ -613,10 +657,9 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
         cur = lo;
         if (cur < end) nxt = a.train_colidx[cur];
     }
-    int cntr[4] = {0, 0, 0, 0};
-    float ls[4]; int32_t lid[4];                                       // the block's lists of users 4 w + rr by APPROXIMATE score, slot = lane
+    uint64_t lk[4];                                                    // the block's lists of users 4 w + rr by upper bound, as 64-bit keys, slot = lane
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) { ls[rr] = -INFINITY; lid[rr] = INT_MAX; }
+    for (int rr = 0; rr < 4; ++rr) lk[rr] = TK_KEY_EMPTY;
 
     const int64_t my_rounds = t_end > t_begin ? t_end - t_begin : 0;
     uint4 bH[2][DK32], bM[2][DK32];
@@ -636,41 +679,38 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     bool counted = false;
     for (;;) {
         const bool fin = round >= my_rounds;
-        const int fill = max(max(cntr[0], cntr[1]), max(cntr[2], cntr[3]));
+        // a buffer must keep room for the next round's TK_TILE candidates: this wave's four counters of the lane's user group, straight from LDS
+        const int4 c4 = *reinterpret_cast<const int4*>(&cnt_s[w][lq * 4]);
+        const int fill = max(max(c4.x, c4.y), max(c4.z, c4.w));
         bool drain = fin || __ballot(fill > TK_CAP - TK_TILE) != 0ull;
         if (!drain) drain = __hip_atomic_load(&flag_s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
         if (drain) {
             if (fin && !counted) { counted = true; if (lane == 0) atomicAdd(&flag_s[1], 1); }
             if (!fin && lane == 0) __hip_atomic_store(&flag_s[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __syncthreads();
-            if (li == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cnt_s[w][lq * 4 + r] = cntr[r];
-            }
-            __syncthreads();
+            __syncthreads();                                   // (every wave's appends - LDS atomics and stores - are complete and visible)
             const int done_quarters = flag_s[1];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int u = 4 * w + rr;
                 const int p1 = cnt_s[0][u], p2 = p1 + cnt_s[1][u], p3 = p2 + cnt_s[2][u], total = p3 + cnt_s[3][u];
-                float l1[1] = {ls[rr]}; int32_t i1[1] = {lid[rr]};
+                uint64_t k1 = lk[rr];
                 for (int j0 = 0; j0 < total; j0 += 64) {
                     const int j = j0 + lane;
                     const int ww = (j >= p1) + (j >= p2) + (j >= p3);
                     const int start = ww == 0 ? 0 : (ww == 1 ? p1 : (ww == 2 ? p2 : p3));
-                    float bs[1] = {-INFINITY}; int32_t bi[1] = {INT_MAX};
-                    if (j < total) { bs[0] = buf_s[ww][u][j - start]; bi[0] = buf_i[ww][u][j - start]; }
-                    sort64<1>(bs, bi, lane);
-                    merge64<1>(l1, i1, bs, bi, lane);
+                    uint64_t bk = TK_KEY_EMPTY;
+                    if (j < total) bk = tk_key(buf_s[ww][u][j - start], buf_i[ww][u][j - start]);
+                    sort64k(bk, lane);
+                    merge64k(k1, bk, lane);
                 }
-                ls[rr] = l1[0]; lid[rr] = i1[0];
+                lk[rr] = k1;
                 if (total > 0) {
-                    const float nthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ls[rr]), 63));   // the 64th: the whole list is exact-by-ub
+                    const float nthr = tk_unord((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k1 >> 32), 63));   // the 64th: the whole list is exact-by-ub
                     if (lane == 0) thr_s[u] = nthr;
                 }
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cntr[r] = 0;
+            __syncthreads();                                   // (every owner has read the counters)
+            if (threadIdx.x < 64) (&cnt_s[0][0])[threadIdx.x] = 0;
             if (threadIdx.x == 0) flag_s[0] = 0;
             __syncthreads();
             if (done_quarters == 4) break;
@@ -710,15 +750,11 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
                 if (__ballot(v >= rthr) == 0ull) continue;
                 const int col = 16 * n + li;
                 const bool pass = (v >= rthr) && (base + col < a.n_items) && !((rm >> col) & 1u);
-                const unsigned long long bal = __ballot(pass);
-                if (bal == 0) continue;
-                const unsigned sub = (unsigned)(bal >> (16 * lq)) & 0xffffu;
-                if (pass) {
-                    const int off = cntr[r] + __popc(sub & ((1u << li) - 1u));
+                if (pass) {                                    // lane-local append: a slot from the buffer's LDS counter (the order inside a
+                    const int off = atomicAdd(&cnt_s[w][lq * 4 + r], 1);   // buffer is irrelevant: it is sorted by (ub, id) at the drain)
                     buf_s[w][lq * 4 + r][off] = v;
                     buf_i[w][lq * 4 + r][off] = (int32_t)(base + col);
                 }
-                cntr[r] += __popc(sub);
             }
         }
         ++round;
@@ -727,8 +763,8 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
         const int64_t base = ((int64_t)(tile - a.split_from) * n_parts + part) * 16;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            a.ws_idx[(base + 4 * w + rr) * 64 + lane] = lid[rr];
-            a.ws_score[(base + 4 * w + rr) * 64 + lane] = ls[rr];
+            a.ws_idx[(base + 4 * w + rr) * 64 + lane] = tk_key_id(lk[rr]);
+            a.ws_score[(base + 4 * w + rr) * 64 + lane] = tk_key_ub(lk[rr]);
         }
         return;
     }
@@ -736,7 +772,7 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     for (int rr = 0; rr < 4; ++rr) {
         const int q = q0 + 4 * w + rr;
         if (q >= a.n_query) continue;                          // wave-uniform
-        tk_finalize_user(a, a.Eu + a.query_users[q] * a.ldu, q, tile, ls[rr], lid[rr], lane);
+        tk_finalize_user(a, a.Eu + a.query_users[q] * a.ldu, q, tile, tk_key_ub(lk[rr]), tk_key_id(lk[rr]), lane);
     }
 }
 
@@ -748,13 +784,12 @@ __global__ __launch_bounds__(1024) void topk_merge_pre_kernel(TopkArgs a) {
     const int tile = a.split_from + blockIdx.x;
     const int q = tile * 16 + w;
     if (q >= a.n_query) return;                                // wave-uniform
-    float l1[1] = {-INFINITY}; int32_t i1[1] = {INT_MAX};
+    uint64_t k1 = TK_KEY_EMPTY;
     for (int p = 0; p < a.n_parts; ++p) {
         const int64_t row = ((int64_t)blockIdx.x * a.n_parts + p) * 16 + w;
-        const float bs[1] = {a.ws_score[row * 64 + lane]}; const int32_t bi[1] = {a.ws_idx[row * 64 + lane]};
-        merge64<1>(l1, i1, bs, bi, lane);
+        merge64k(k1, tk_key(a.ws_score[row * 64 + lane], a.ws_idx[row * 64 + lane]), lane);
     }
-    tk_finalize_user(a, a.Eu + a.query_users[q] * a.ldu, q, tile, l1[0], i1[0], lane);
+    tk_finalize_user(a, a.Eu + a.query_users[q] * a.ldu, q, tile, tk_key_ub(k1), tk_key_id(k1), lane);
 }
 
 // the lists of a split tile's parts -> the tile's top K (one wave per four users, as in the sweep)
@@ -765,15 +800,15 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(TopkArgs a) {
     for (int rr = 0; rr < 4; ++rr) {
         const int q = tile * 16 + 4 * w + rr;
         if (q >= a.n_query) continue;                          // wave-uniform
-        float l1[1] = {-INFINITY}; int32_t i1[1] = {INT_MAX};
+        uint64_t k1 = TK_KEY_EMPTY;
         for (int p = 0; p < a.n_parts; ++p) {
             const int64_t row = ((int64_t)blockIdx.x * a.n_parts + p) * 16 + 4 * w + rr;
-            const float bs[1] = {a.ws_score[row * 64 + lane]}; const int32_t bi[1] = {a.ws_idx[row * 64 + lane]};
-            merge64<1>(l1, i1, bs, bi, lane);
+            merge64k(k1, tk_key(a.ws_score[row * 64 + lane], a.ws_idx[row * 64 + lane]), lane);
         }
         if (lane < a.K) {
-            a.out_idx[(int64_t)q * a.K + lane] = i1[0] == INT_MAX ? -1 : i1[0];
-            a.out_score[(int64_t)q * a.K + lane] = l1[0];
+            const int32_t id = tk_key_id(k1);
+            a.out_idx[(int64_t)q * a.K + lane] = id == INT_MAX ? -1 : id;
+            a.out_score[(int64_t)q * a.K + lane] = tk_key_ub(k1);
         }
     }
 }
