@@ -209,6 +209,37 @@ constexpr uint64_t TK_KEY_EMPTY = 0x007FFFFF80000000ull;   // tk_key(-inf, INT_M
 // variants of this kernel; they are no longer part of the source.)
 
 constexpr int TK_TILE = 32;   // items per wave per round
+constexpr int TK_TRAIN_STAGE = 16;   // train items staged in LDS per (wave, user): the sweep's rounds never wait for a train-row load
+// the train items [cur, cur + TK_TRAIN_STAGE) of one user's row -> this lane's LDS slots (INT_MAX past the row's end). The loads are issued
+// four at a time (clamped index, no branch around them) and waited for HERE: at the start of the sweep, and again only when a (wave, user)
+// pair has consumed all TK_TRAIN_STAGE staged items. (A load per consumed item inside the sweep stalled the wave for a memory latency
+// at every train item - vmcnt counts loads in order, the next tile's fragments queue behind it: 0.07 ms of 0.37 at the Netflix shape.)
+__device__ __forceinline__ void tk_train_stage(const int32_t* __restrict__ colidx, int32_t cur, int32_t end, int32_t* slot) {
+    if (cur >= end) {
+#pragma unroll
+        for (int j = 0; j < TK_TRAIN_STAGE; ++j) slot[j] = INT_MAX;
+        return;
+    }
+#pragma unroll 1
+    for (int j0 = 0; j0 < TK_TRAIN_STAGE; j0 += 4) {           // four loads in flight at a time (rolled: the sweep has no registers to spare)
+        int32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = colidx[cur + j0 + j < end ? cur + j0 + j : end - 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) slot[j0 + j] = cur + j0 + j < end ? v[j] : INT_MAX;
+    }
+}
+// inside the sweep: the users in `need` (bit = row-owner lane) have consumed their staged window; their next TK_TRAIN_STAGE items are loaded by
+// the wave's first lanes, one coalesced load per user (scalar row bounds: no registers beyond one value per lane)
+__device__ __forceinline__ void tk_train_refill(const int32_t* __restrict__ colidx, unsigned need, int32_t cur, int32_t end,
+                                                int32_t (*rows)[TK_TRAIN_STAGE], int lane) {
+    while (need) {                                             // wave-uniform
+        const int u = __builtin_ctz(need);
+        need &= need - 1u;
+        const int32_t cu = __builtin_amdgcn_readlane(cur, u), eu = __builtin_amdgcn_readlane(end, u);   // cu: a multiple of TK_TRAIN_STAGE
+        if (lane < TK_TRAIN_STAGE) rows[u][lane] = cu + lane < eu ? colidx[cu + lane] : INT_MAX;
+    }
+}
 constexpr int TK_CAP = 64;    // buffer slots per (wave, user): drained before a round could overflow it
 
 // scores only (llmrec_scores_f32): S[q][item], same MFMA chain as the selection kernel
@@ -276,6 +307,8 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     __shared__ __attribute__((aligned(16))) int32_t cnt_s[4][16];     // fill of buffer (wave, user): LDS atomics (the appends are lane-local)
     __shared__ float thr_s[16];
     __shared__ int32_t flag_s[2];
+    __shared__ int32_t train_s[4][16][TK_TRAIN_STAGE];
+    __shared__ __attribute__((aligned(16))) uint32_t mask_s[4][16];   // train masks of an event round (zero between rounds)
     // readfirstlane: tells the compiler the wave index is uniform, so the per-wave round counters and
     // branches live in SGPRs / scalar branches instead of 64-bit VGPR arithmetic under exec masks
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -290,7 +323,7 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     if (q0 >= a.n_query) return;                               // block-uniform
     if (a.only_flagged && a.only_flagged[tile] == 0u) return;  // (the second launch of the bf16 mode: only the tiles its verification flagged)
     if (threadIdx.x < 16) thr_s[threadIdx.x] = -INFINITY;
-    if (threadIdx.x < 64) (&cnt_s[0][0])[threadIdx.x] = 0;
+    if (threadIdx.x < 64) { (&cnt_s[0][0])[threadIdx.x] = 0; (&mask_s[0][0])[threadIdx.x] = 0u; }
     if (threadIdx.x < 2) flag_s[threadIdx.x] = 0;             // [0] drain requested, [1] waves that finished their quarter
     __syncthreads();
 
@@ -314,7 +347,7 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     // wave's quarter (binary search) and that item's id in a register - a round touches memory only when
     // it consumes a train item (a per-round peek would put a dependent global load, and a vmcnt(0) that
     // also waits for the prefetched tile, on every round's critical path).
-    int32_t cur = 0, end = 0, nxt = INT_MAX;
+    int32_t cur = 0, end = 0, nxt = INT_MAX;                           // cur: nxt's position in colidx; its LDS slot is cur % TK_TRAIN_STAGE
     if (lane < 16 && a.train_rowptr) {
         cur = a.train_rowptr[user_a]; end = a.train_rowptr[user_a + 1];
         const int64_t first = t_begin * TK_TILE;
@@ -324,7 +357,8 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
             if (a.train_colidx[mid] < first) lo = mid + 1; else hi = mid;
         }
         cur = lo;
-        if (cur < end) nxt = a.train_colidx[cur];
+        tk_train_stage(a.train_colidx, cur & ~(TK_TRAIN_STAGE - 1), end, &train_s[w][lane][0]);   // (the window is aligned in colidx positions:
+        nxt = train_s[w][lane][cur & (TK_TRAIN_STAGE - 1)];                                       //  slots before cur are never read)
     }
     uint64_t lk[4];                                            // the block's lists of users 4 w + rr as 64-bit keys (score, ~item), slot = lane
 #pragma unroll
@@ -418,27 +452,44 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(cmp4(ua[c], s), cmp4(b[n][c], s), acc[n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // 32-bit mask of this tile's train items, by the row-owner lanes; the items come from the LDS stage (tk_train_stage)
+        uint32_t m = 0;
+        for (;;) {
+            const int32_t base32 = (int32_t)base;
+            bool need = false;
+            while ((uint32_t)(nxt - base32) < (uint32_t)TK_TILE) {      // lanes >= 16 hold INT_MAX; nxt >= base (sorted rows)
+                m |= 1u << (nxt - base32);
+                if ((++cur & (TK_TRAIN_STAGE - 1)) == 0) { need = true; break; }    // window consumed
+                nxt = train_s[w][lane & 15][cur & (TK_TRAIN_STAGE - 1)];
+            }
+            const unsigned nb = (unsigned)__ballot(need);
+            if (nb == 0u) break;                                       // (wave-uniform; the usual case)
+            tk_train_refill(a.train_colidx, nb, cur, end, train_s[w], lane);
+            if (need) nxt = train_s[w][lane & 15][0];
+        }
         // the next tile's operands go into the registers the MFMAs have just read: the loads fly during the selection
         __builtin_amdgcn_sched_barrier(0);
         if (round + 1 < my_rounds) load_tile(t_begin + round + 1);
         __builtin_amdgcn_sched_barrier(0);
 
-        // 32-bit mask of this tile's train items and the current filter, by the row-owner lanes
-        uint32_t m = 0;
-        while ((int64_t)nxt < base + TK_TILE) {                     // lanes >= 16 hold INT_MAX
-            m |= 1u << (int)(nxt - base);
-            ++cur;
-            nxt = cur < end ? a.train_colidx[cur] : INT_MAX;
-        }
         // first level: one compare per score against the user's filter (the compare's lane mask IS the ballot);
         // range / train-mask checks only for the few (row, column-tile) pairs that have a candidate at all.
         // Rows past n_query carry a +inf filter.
-        const unsigned long long any_train = __ballot(m != 0u);
+        // event rounds only (wave-uniform): the owners' masks go through LDS - one 16-byte read gives a lane the masks of its four rows
+        uint32_t rm4[4] = {0u, 0u, 0u, 0u};
+        if (__ballot(m != 0u) != 0ull) {
+            if (m != 0u) mask_s[w][lane & 15] = m;
+            __builtin_amdgcn_wave_barrier();
+            const uint4 t = *reinterpret_cast<const uint4*>(&mask_s[w][lq * 4]);
+            rm4[0] = t.x; rm4[1] = t.y; rm4[2] = t.z; rm4[3] = t.w;
+            __builtin_amdgcn_wave_barrier();
+            if (m != 0u) mask_s[w][lane & 15] = 0u;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float rthr = (q0 + lq * 4 + r < a.n_query) ? thr_s[lq * 4 + r] : INFINITY;
-            uint32_t rm = 0;
-            if (any_train) rm = __shfl(m, lq * 4 + r, 64);       // wave-uniform branch
+            const uint32_t rm = rm4[r];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const float v = acc[n][r];
@@ -605,6 +656,8 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     __shared__ __attribute__((aligned(16))) int32_t cnt_s[4][16];     // fill of buffer (wave, user): LDS atomics (the appends are lane-local)
     __shared__ float thr_s[16];                                        // the filter: the 64th ub of the user's list so far
     __shared__ int32_t flag_s[2];
+    __shared__ int32_t train_s[4][16][TK_TRAIN_STAGE];
+    __shared__ __attribute__((aligned(16))) uint32_t mask_s[4][16];   // train masks of an event round (zero between rounds)
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lq = lane >> 4;
     int tile = blockIdx.x, part = 0, n_parts = 1;
@@ -616,7 +669,7 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     const int q0 = tile * 16;
     if (q0 >= a.n_query) return;
     if (threadIdx.x < 16) thr_s[threadIdx.x] = -INFINITY;
-    if (threadIdx.x < 64) (&cnt_s[0][0])[threadIdx.x] = 0;
+    if (threadIdx.x < 64) { (&cnt_s[0][0])[threadIdx.x] = 0; (&mask_s[0][0])[threadIdx.x] = 0u; }
     if (threadIdx.x < 2) flag_s[threadIdx.x] = 0;
     __syncthreads();
 
@@ -645,7 +698,7 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     const int64_t t_begin = part_begin + w * tiles_per_wave < tiles_total ? part_begin + w * tiles_per_wave : tiles_total;
     const int64_t t_end = t_begin + tiles_per_wave < tiles_total ? t_begin + tiles_per_wave : tiles_total;
 
-    int32_t cur = 0, end = 0, nxt = INT_MAX;
+    int32_t cur = 0, end = 0, nxt = INT_MAX;                           // cur: nxt's position in colidx; its LDS slot is cur % TK_TRAIN_STAGE
     if (lane < 16 && a.train_rowptr) {
         cur = a.train_rowptr[user_a]; end = a.train_rowptr[user_a + 1];
         const int64_t first = t_begin * TK_TILE;
@@ -655,7 +708,8 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
             if (a.train_colidx[mid] < first) lo = mid + 1; else hi = mid;
         }
         cur = lo;
-        if (cur < end) nxt = a.train_colidx[cur];
+        tk_train_stage(a.train_colidx, cur & ~(TK_TRAIN_STAGE - 1), end, &train_s[w][lane][0]);   // (the window is aligned in colidx positions:
+        nxt = train_s[w][lane][cur & (TK_TRAIN_STAGE - 1)];                                       //  slots before cur are never read)
     }
     uint64_t lk[4];                                                    // the block's lists of users 4 w + rr by upper bound, as 64-bit keys, slot = lane
 #pragma unroll
@@ -729,21 +783,39 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
             }
         const float cn_now[2] = {cnv[0], cnv[1]};                       // (this tile's factors: the prefetch below overwrites cnv)
         __builtin_amdgcn_sched_barrier(0);
+        // 32-bit mask of this tile's train items, by the row-owner lanes; the items come from the LDS stage (tk_train_stage)
+        uint32_t m = 0;
+        for (;;) {
+            const int32_t base32 = (int32_t)base;
+            bool need = false;
+            while ((uint32_t)(nxt - base32) < (uint32_t)TK_TILE) {      // lanes >= 16 hold INT_MAX; nxt >= base (sorted rows)
+                m |= 1u << (nxt - base32);
+                if ((++cur & (TK_TRAIN_STAGE - 1)) == 0) { need = true; break; }    // window consumed
+                nxt = train_s[w][lane & 15][cur & (TK_TRAIN_STAGE - 1)];
+            }
+            const unsigned nb = (unsigned)__ballot(need);
+            if (nb == 0u) break;                                       // (wave-uniform; the usual case)
+            tk_train_refill(a.train_colidx, nb, cur, end, train_s[w], lane);
+            if (need) nxt = train_s[w][lane & 15][0];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (round + 1 < my_rounds) load_tile();
         __builtin_amdgcn_sched_barrier(0);
 
-        uint32_t m = 0;
-        while ((int64_t)nxt < base + TK_TILE) {
-            m |= 1u << (int)(nxt - base);
-            ++cur;
-            nxt = cur < end ? a.train_colidx[cur] : INT_MAX;
+        // event rounds only (wave-uniform): the owners' masks go through LDS - one 16-byte read gives a lane the masks of its four rows
+        uint32_t rm4[4] = {0u, 0u, 0u, 0u};
+        if (__ballot(m != 0u) != 0ull) {
+            if (m != 0u) mask_s[w][lane & 15] = m;
+            __builtin_amdgcn_wave_barrier();
+            const uint4 t = *reinterpret_cast<const uint4*>(&mask_s[w][lq * 4]);
+            rm4[0] = t.x; rm4[1] = t.y; rm4[2] = t.z; rm4[3] = t.w;
+            __builtin_amdgcn_wave_barrier();
+            if (m != 0u) mask_s[w][lane & 15] = 0u;
         }
-        const unsigned long long any_train = __ballot(m != 0u);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float rthr = (q0 + lq * 4 + r < a.n_query) ? thr_s[lq * 4 + r] : INFINITY;
-            uint32_t rm = 0;
-            if (any_train) rm = __shfl(m, lq * 4 + r, 64);
+            const uint32_t rm = rm4[r];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const float v = fmaf(unr[r], cn_now[n], acc[n][r]);        // ub = s' + 2^-14 ||u|| ||i||

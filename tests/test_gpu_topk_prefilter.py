@@ -125,3 +125,36 @@ def test_prefilter_equals_exact_at_the_netflix_shape_and_at_a_million_items(ops)
     Ei3 = torch.randn(200_000, 128, generator=g, device=DEV) * 0.3
     Eu3 = torch.randn(300, 128, generator=g, device=DEV) * 0.3
     _assert_same(*_both(ops, Eu3, Ei3, torch.arange(300, device=DEV), None, 64), what="d = 128")
+
+
+@pytest.mark.parametrize("I,d", [(3000, 64), (520, 32), (20000, 64)])
+def test_dense_train_rows_cross_the_staged_window(ops, I, d):
+    """Train rows of 0, 1, 15, 16, 17, 33, hundreds and ALL items: the sweep stages 16 train items per (wavefront, user) in LDS and
+    refills the window from inside the sweep; both modes against torch's masked top-K (values bit-exact against one another, lists
+    against the fp32 reference: well-separated random scores)."""
+    rng = np.random.default_rng(I + d)
+    degs = np.array([0, 1, 15, 16, 17, 33, 64, 65, 200, min(1500, I - 60), I - 55, I, 2, 31, 32, 48, 100, 3] * 3)
+    U, K = len(degs), 50
+    rows = np.repeat(np.arange(U), degs)
+    cols = np.concatenate([np.sort(rng.choice(I, size=int(dg), replace=False)) for dg in degs]).astype(np.int64)
+    # a contiguous run of train items inside one item tile and across a window boundary
+    run_user = 1
+    rows = np.concatenate([rows, np.full(40, run_user)]); cols = np.concatenate([cols, np.arange(100, 140)])
+    keep = np.unique(rows * I + cols); rows, cols = keep // I, keep % I
+    rp, ci, _ = ops.csr_from_coo(torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV), None, U, I)
+    train = ops.Csr(U, I, rp, ci, None, None, None, ops.SpmmPlan())
+    Eu = torch.tensor(rng.standard_normal((U, d)).astype(np.float32)).to(DEV)
+    Ei = torch.tensor(rng.standard_normal((I, d)).astype(np.float32)).to(DEV)
+    q = torch.arange(U, device=DEV)
+    i0, s0, i1, s1 = _both(ops, Eu, Ei, q, train, K)
+    _assert_same(i0, s0, i1, s1, what="dense train rows")
+    S = (Eu.double() @ Ei.double().T)
+    S[torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV)] = -float("inf")
+    ref_s, ref_i = torch.topk(S, K, dim=1)
+    for u in range(U):
+        n_free = I - int((rows == u).sum())
+        n = min(K, n_free)
+        assert i0[u, :n].tolist() == ref_i[u, :n].tolist(), (u, int(degs[u % len(degs)]))
+        assert (i0[u, n:] == -1).all(), (u, n_free)
+        tr_u = set(cols[rows == u].tolist())
+        assert not (set(i0[u, :n].tolist()) & tr_u)
