@@ -604,7 +604,9 @@ int llmrec_score_topk_f32(int32_t n_query, const int64_t* query_users,
  *   - the item table is first re-laid in MFMA fragment order (one pass over Ei, written into the workspace), so that every load of
  *     the sweep is one contiguous KB instead of 64 row pieces;
  *   - the user tiles left over after the last full round of one 16-user tile per compute unit are each swept by several
- *     blocks (parts of the item range) whose 64-slot lists are merged by a second launch, spreading the left-over blocks over the device.
+ *     blocks (parts of the item range) whose 64-slot lists are merged by a second launch, spreading the left-over blocks over the device;
+ *   - with a train CSR and at most 131 072 items: a block turns the rows of up to two of its users with more than 48 train items into
+ *     bitmaps (one word per 32-item tile, in its own slice of the workspace) and reads one word per round instead of walking the row.
  * The lists and scores are the same, bit for bit. workspace == NULL behaves like llmrec_score_topk_f32. */
 int64_t llmrec_score_topk_workspace_bytes(int32_t n_query, int64_t n_items, int32_t d);
 int llmrec_score_topk_ws_f32(int32_t n_query, const int64_t* query_users,

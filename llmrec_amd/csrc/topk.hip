@@ -68,6 +68,9 @@ struct TopkArgs {
     float* cn;                   // per item: 2^-14 ||item|| rounded up (the item's factor of the score's upper bound)
     uint32_t* fb_word;           // one word per user tile: != 0 = the verification failed, the exact sweep redoes the tile
     const uint32_t* only_flagged; // exact sweep: blocks of tiles whose word is 0 exit at once (NULL: every tile)
+    // users with long train rows: a block builds bitmaps (one word per item tile) of up to TK_HEAVY_PER_BLOCK of its users in its own
+    // slice of this area and reads one word per round instead of walking the row (NULL: every row is walked)
+    uint32_t* heavy_bm; int heavy_words;
 };
 
 template <int DK>
@@ -240,6 +243,42 @@ __device__ __forceinline__ void tk_train_refill(const int32_t* __restrict__ coli
         if (lane < TK_TRAIN_STAGE) rows[u][lane] = cu + lane < eu ? colidx[cu + lane] : INT_MAX;
     }
 }
+// ---- long train rows ----
+// The row walk above costs an LDS round trip per train item and a memory latency per TK_TRAIN_STAGE of them, in ONE wavefront: the bench's
+// heaviest user (2 012 train items) kept its block sweeping 35 us after every other block had finished. A block therefore turns the rows of
+// up to TK_HEAVY_PER_BLOCK of its users with more than TK_HEAVY_DEG train items into bitmaps - one 32-bit word per item tile, in the
+// block's own slice of the workspace: no allocation, no cross-block traffic - and those users' row-owner lanes read one word per round (with
+// the tile prefetch) instead. Further long rows of the same block are walked. Called by all 256 threads (every wave holds the same 16 rows
+// in its lanes 0..15); returns this lane's word offset inside the block's slice, -1: walk the row.
+constexpr int TK_HEAVY_PER_BLOCK = 2, TK_HEAVY_DEG = 48;
+__device__ __forceinline__ int tk_heavy_setup(const TopkArgs& a, int lane, bool row_valid, int32_t row_begin, int32_t row_end) {
+    if (!a.heavy_bm) return -1;                                // uniform
+    unsigned hb = (unsigned)__ballot(lane < 16 && row_valid && row_end - row_begin > TK_HEAVY_DEG) & 0xffffu;
+    if (hb == 0u) return -1;                                   // block-uniform: every wave sees the same rows
+    uint32_t* const slice = a.heavy_bm + (size_t)blockIdx.x * TK_HEAVY_PER_BLOCK * a.heavy_words;
+    int mine = -1;
+    for (int s = 0; s < TK_HEAVY_PER_BLOCK && hb != 0u; ++s) {
+        const int u = __builtin_ctz(hb);
+        hb &= hb - 1u;
+        const int32_t rb = __builtin_amdgcn_readlane(row_begin, u), re = __builtin_amdgcn_readlane(row_end, u);
+        uint32_t* const row = slice + (size_t)s * a.heavy_words;
+        for (int i = threadIdx.x; i < a.heavy_words; i += 256) row[i] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the slice is this block's own: no agent-scope fence - an L2 write-back - needed)
+        __syncthreads();
+        for (int e = rb + (int)threadIdx.x; e < re; e += 256) {
+            const int32_t it = a.train_colidx[e];
+            atomicOr(&row[it >> 5], 1u << (it & 31));
+        }
+        if (lane == u) mine = s * a.heavy_words;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    return mine;
+}
+// (an agent-scope atomic load: served by the L2, where the atomics above landed)
+__device__ __forceinline__ uint32_t tk_heavy_word(const TopkArgs& a, int off, int64_t tile) {
+    return __hip_atomic_load(a.heavy_bm + (size_t)blockIdx.x * TK_HEAVY_PER_BLOCK * a.heavy_words + off + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 constexpr int TK_CAP = 64;    // buffer slots per (wave, user): drained before a round could overflow it
 
 // scores only (llmrec_scores_f32): S[q][item], same MFMA chain as the selection kernel
@@ -348,8 +387,10 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     // it consumes a train item (a per-round peek would put a dependent global load, and a vmcnt(0) that
     // also waits for the prefetched tile, on every round's critical path).
     int32_t cur = 0, end = 0, nxt = INT_MAX;                           // cur: nxt's position in colidx; its LDS slot is cur % TK_TRAIN_STAGE
+    int32_t row_begin = 0;
     if (lane < 16 && a.train_rowptr) {
         cur = a.train_rowptr[user_a]; end = a.train_rowptr[user_a + 1];
+        row_begin = cur;
         const int64_t first = t_begin * TK_TILE;
         int32_t lo = cur, hi = end;
         while (lo < hi) {
@@ -360,6 +401,9 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
         tk_train_stage(a.train_colidx, cur & ~(TK_TRAIN_STAGE - 1), end, &train_s[w][lane][0]);   // (the window is aligned in colidx positions:
         nxt = train_s[w][lane][cur & (TK_TRAIN_STAGE - 1)];                                       //  slots before cur are never read)
     }
+    const int hoff = tk_heavy_setup(a, lane, q0 + lane < a.n_query, row_begin, end);               // >= 0: this lane's row is a bitmap
+    if (hoff >= 0) nxt = INT_MAX;
+    uint32_t hm = 0u;                                                                              // the bitmap word of the round's tile
     uint64_t lk[4];                                            // the block's lists of users 4 w + rr as 64-bit keys (score, ~item), slot = lane
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) lk[rr] = TK_KEY_EMPTY;
@@ -395,7 +439,7 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
         }
         row0 += tile_stride; row1 += tile_stride;
     };
-    if (my_rounds > 0) load_tile(t_begin);
+    if (my_rounds > 0) { load_tile(t_begin); if (hoff >= 0) hm = tk_heavy_word(a, hoff, t_begin); }
     int64_t round = 0;
     bool counted = false;
     for (;;) {
@@ -452,9 +496,14 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(cmp4(ua[c], s), cmp4(b[n][c], s), acc[n], 0, 0, 0);
+        const uint32_t hm_now = hm;                                    // (this tile's bitmap word: the prefetch below overwrites hm)
+        // the next tile's operands go into the registers the MFMAs have just read: the loads fly during the selection (the train-mask
+        // code below touches LDS only - a refill of the staged window, once per 16 items of a walked row, is the one wait)
+        __builtin_amdgcn_sched_barrier(0);
+        if (round + 1 < my_rounds) { load_tile(t_begin + round + 1); if (hoff >= 0) hm = tk_heavy_word(a, hoff, t_begin + round + 1); }
         __builtin_amdgcn_sched_barrier(0);
         // 32-bit mask of this tile's train items, by the row-owner lanes; the items come from the LDS stage (tk_train_stage)
-        uint32_t m = 0;
+        uint32_t m = hm_now;
         for (;;) {
             const int32_t base32 = (int32_t)base;
             bool need = false;
@@ -468,10 +517,6 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
             tk_train_refill(a.train_colidx, nb, cur, end, train_s[w], lane);
             if (need) nxt = train_s[w][lane & 15][0];
         }
-        // the next tile's operands go into the registers the MFMAs have just read: the loads fly during the selection
-        __builtin_amdgcn_sched_barrier(0);
-        if (round + 1 < my_rounds) load_tile(t_begin + round + 1);
-        __builtin_amdgcn_sched_barrier(0);
 
         // first level: one compare per score against the user's filter (the compare's lane mask IS the ballot);
         // range / train-mask checks only for the few (row, column-tile) pairs that have a candidate at all.
@@ -699,8 +744,10 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     const int64_t t_end = t_begin + tiles_per_wave < tiles_total ? t_begin + tiles_per_wave : tiles_total;
 
     int32_t cur = 0, end = 0, nxt = INT_MAX;                           // cur: nxt's position in colidx; its LDS slot is cur % TK_TRAIN_STAGE
+    int32_t row_begin = 0;
     if (lane < 16 && a.train_rowptr) {
         cur = a.train_rowptr[user_a]; end = a.train_rowptr[user_a + 1];
+        row_begin = cur;
         const int64_t first = t_begin * TK_TILE;
         int32_t lo = cur, hi = end;
         while (lo < hi) {
@@ -711,6 +758,9 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
         tk_train_stage(a.train_colidx, cur & ~(TK_TRAIN_STAGE - 1), end, &train_s[w][lane][0]);   // (the window is aligned in colidx positions:
         nxt = train_s[w][lane][cur & (TK_TRAIN_STAGE - 1)];                                       //  slots before cur are never read)
     }
+    const int hoff = tk_heavy_setup(a, lane, q0 + lane < a.n_query, row_begin, end);               // >= 0: this lane's row is a bitmap
+    if (hoff >= 0) nxt = INT_MAX;
+    uint32_t hm = 0u;                                                                              // the bitmap word of the round's tile
     uint64_t lk[4];                                                    // the block's lists of users 4 w + rr by upper bound, as 64-bit keys, slot = lane
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) lk[rr] = TK_KEY_EMPTY;
@@ -728,7 +778,7 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
         cnv[0] = cnp[0]; cnv[1] = cnp[16];
         pk += 2 * DK32 * 2 * 64; cnp += TK_TILE;
     };
-    if (my_rounds > 0) load_tile();
+    if (my_rounds > 0) { load_tile(); if (hoff >= 0) hm = tk_heavy_word(a, hoff, t_begin); }
     int64_t round = 0;
     bool counted = false;
     for (;;) {
@@ -782,9 +832,12 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
                 acc[n] = tk_mfma_bf16(uH[c], bH[n][c], acc[n]);
             }
         const float cn_now[2] = {cnv[0], cnv[1]};                       // (this tile's factors: the prefetch below overwrites cnv)
+        const uint32_t hm_now = hm;
+        __builtin_amdgcn_sched_barrier(0);
+        if (round + 1 < my_rounds) { load_tile(); if (hoff >= 0) hm = tk_heavy_word(a, hoff, t_begin + round + 1); }
         __builtin_amdgcn_sched_barrier(0);
         // 32-bit mask of this tile's train items, by the row-owner lanes; the items come from the LDS stage (tk_train_stage)
-        uint32_t m = 0;
+        uint32_t m = hm_now;
         for (;;) {
             const int32_t base32 = (int32_t)base;
             bool need = false;
@@ -798,9 +851,6 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
             tk_train_refill(a.train_colidx, nb, cur, end, train_s[w], lane);
             if (need) nxt = train_s[w][lane & 15][0];
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (round + 1 < my_rounds) load_tile();
-        __builtin_amdgcn_sched_barrier(0);
 
         // event rounds only (wave-uniform): the owners' masks go through LDS - one 16-byte read gives a lane the masks of its four rows
         uint32_t rm4[4] = {0u, 0u, 0u, 0u};
@@ -1043,10 +1093,20 @@ static int64_t topk_packed_bytes(int64_t n_items, int32_t d) {
     return (exact > pre ? exact : pre) + 256 + align_up(4 * ceil_div(n_items, TK_TILE) * TK_TILE, 256);   // + the bf16 mode's header and per-item factors
 }
 static int64_t topk_flag_bytes(int32_t n_query) { return align_up(4 * ceil_div(n_query, 16), 256); }   // one word per user tile (bf16 mode)
+// bitmaps of long train rows: TK_HEAVY_PER_BLOCK rows of one word per item tile for every block of the sweep; 0 = off (item tables beyond
+// 131 072 items, or more than 64 MB of slices)
+static int64_t topk_heavy_bytes(int32_t n_query, int64_t n_items) {
+    const int64_t words = ceil_div(n_items, TK_TILE);
+    int split_from = 0, n_parts = 1;
+    plan_split(n_query, n_items, &split_from, &n_parts);
+    const int64_t n_tiles = ceil_div(n_query, 16), grid = split_from + (n_tiles - split_from) * n_parts;
+    const int64_t bytes = grid * TK_HEAVY_PER_BLOCK * words * 4;
+    return (words > 4096 || bytes > (64ll << 20)) ? 0 : align_up(bytes, 256);
+}
 
 int64_t llmrec_score_topk_workspace_bytes(int32_t n_query, int64_t n_items, int32_t d) {
     if (n_query < 0 || n_items <= 0 || d <= 0) return -1;
-    return align_up(topk_split_bytes(n_query, n_items), 256) + topk_packed_bytes(n_items, d) + topk_flag_bytes(n_query);
+    return align_up(topk_split_bytes(n_query, n_items), 256) + topk_packed_bytes(n_items, d) + topk_flag_bytes(n_query) + topk_heavy_bytes(n_query, n_items);
 }
 
 int64_t llmrec_score_topk_stats_offset(int32_t n_query, int64_t n_items) {
@@ -1094,6 +1154,7 @@ int llmrec_score_topk_mode_f32(int32_t n_query, const int64_t* query_users,
     a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
     if (mode == LLMREC_TOPK_MODE_PREFILTER && K > LLMREC_TOPK_PREFILTER_MAX_K) mode = LLMREC_TOPK_MODE_EXACT_SWEEP;   // (no room to verify in 64 slots)
     a.mode = mode; a.pk2 = nullptr; a.hdr = nullptr; a.cn = nullptr; a.fb_word = nullptr; a.only_flagged = nullptr;
+    a.heavy_bm = nullptr; a.heavy_words = 0;
     if (workspace) {                                           // without a workspace: one block per user tile, fragments straight from Ei
         const int64_t need = llmrec_score_topk_workspace_bytes(n_query, n_items, d), split = topk_split_bytes(n_query, n_items);
         LLMREC_CHECK_ARG(workspace_bytes >= need && (uintptr_t)workspace % 16 == 0, "score_topk: workspace of %lld bytes needed (16-byte aligned)", (long long)need);
@@ -1104,6 +1165,10 @@ int llmrec_score_topk_mode_f32(int32_t n_query, const int64_t* query_users,
         }
         char* frag = (char*)workspace + align_up(split, 256);
         a.packed = (const float4*)frag;
+        if (train_rowptr && topk_heavy_bytes(n_query, n_items) > 0) {
+            a.heavy_bm = (uint32_t*)(frag + topk_packed_bytes(n_items, d) + topk_flag_bytes(n_query));
+            a.heavy_words = (int)ceil_div(n_items, TK_TILE);
+        }
         if (mode == LLMREC_TOPK_MODE_PREFILTER) {
             a.hdr = (uint32_t*)frag;                           // (the first 256 bytes of the fragment area)
             a.pk2 = (uint4*)(frag + 256);
@@ -1127,6 +1192,7 @@ int llmrec_scores_f32(int32_t n_query, const int64_t* query_users,
     a.vec_ok = (ldu % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)Eu | (uintptr_t)Ei) % 16 == 0);
     a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
     a.mode = 0; a.pk2 = nullptr; a.hdr = nullptr; a.cn = nullptr; a.fb_word = nullptr; a.only_flagged = nullptr;
+    a.heavy_bm = nullptr; a.heavy_words = 0;
     return launch_topk<false>(a, (hipStream_t)stream_);
 }
 
