@@ -85,12 +85,6 @@ __device__ __forceinline__ void load_items(const TopkArgs& a, int64_t base, int 
     }
 }
 
-__device__ __forceinline__ float wave_shr1(float x) {     // lane i <- lane i-1 (lane 0 keeps its value)
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138, 0xf, 0xf, false));
-}
-__device__ __forceinline__ int wave_shr1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ bool pair_better(float s, int i, float t, int j) { return (s > t) || (s == t && i < j); }
-
 // value of lane (lane ^ J): DPP inside a 16-lane row (no LDS round trip), ds_swizzle for 16, ds_bpermute for 32
 template <int J>
 __device__ __forceinline__ int xor_lane_i(int x, int lane) {
@@ -105,64 +99,14 @@ __device__ __forceinline__ int xor_lane_i(int x, int lane) {
     if (J == 16) return __builtin_amdgcn_ds_swizzle(x, 0x401F);                            // bit mode: and 0x1f, xor 0x10
     return __shfl_xor(x, J, 64);
 }
-template <int J> __device__ __forceinline__ float xor_lane_f(float x, int lane) { return __int_as_float(xor_lane_i<J>(__float_as_int(x), lane)); }
-
-// compare-exchange with lane ^ J for NV independent vectors at once: the chains of one vector are
-// latency-bound (DPP / LDS crossbar -> compare -> select), NV of them interleave in the instruction stream
-template <int J, int NV>
-__device__ __forceinline__ void cmpx(float (&s)[NV], int (&i)[NV], int lane, bool keep_better) {
-    float os[NV]; int oi[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) { os[v] = xor_lane_f<J>(s[v], lane); oi[v] = xor_lane_i<J>(i[v], lane); }
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const bool other_better = pair_better(os[v], oi[v], s[v], i[v]);
-        if (keep_better == other_better) { s[v] = os[v]; i[v] = oi[v]; }
-    }
-}
-
-// one bitonic merge network over 64 lanes: strides FROM ... 1; blocks of size 2*FROM alternate
-// direction with bit `dirbit` of the lane (0 = best first everywhere)
-template <int FROM, int NV>
-__device__ __forceinline__ void bitonic_net(float (&s)[NV], int (&i)[NV], int lane, int dirbit) {
-    const bool up = (lane & dirbit) == 0;
-    if (FROM >= 32) cmpx<32, NV>(s, i, lane, ((lane & 32) == 0) == up);
-    if (FROM >= 16) cmpx<16, NV>(s, i, lane, ((lane & 16) == 0) == up);
-    if (FROM >= 8) cmpx<8, NV>(s, i, lane, ((lane & 8) == 0) == up);
-    if (FROM >= 4) cmpx<4, NV>(s, i, lane, ((lane & 4) == 0) == up);
-    if (FROM >= 2) cmpx<2, NV>(s, i, lane, ((lane & 2) == 0) == up);
-    cmpx<1, NV>(s, i, lane, ((lane & 1) == 0) == up);
-}
-
-// top-64 of the union of two descending 64-lists held one entry per lane: elementwise best of A and
-// reversed B is bitonic and holds the 64 best; six compare-exchange stages sort it (best first).
-template <int NV>
-__device__ __forceinline__ void merge64(float (&s)[NV], int (&i)[NV], const float (&bs)[NV], const int (&bi)[NV], int lane) {
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const float rs = __shfl(bs[v], 63 - lane, 64);
-        const int ri = __shfl(bi[v], 63 - lane, 64);
-        if (pair_better(rs, ri, s[v], i[v])) { s[v] = rs; i[v] = ri; }
-    }
-    bitonic_net<32, NV>(s, i, lane, 0);
-}
-
-// bitonic sort of 64 (score, item) pairs, one per lane, best first
-template <int NV>
-__device__ __forceinline__ void sort64(float (&s)[NV], int (&i)[NV], int lane) {
-    bitonic_net<1, NV>(s, i, lane, 2);
-    bitonic_net<2, NV>(s, i, lane, 4);
-    bitonic_net<4, NV>(s, i, lane, 8);
-    bitonic_net<8, NV>(s, i, lane, 16);
-    bitonic_net<16, NV>(s, i, lane, 32);
-    bitonic_net<32, NV>(s, i, lane, 0);
-}
-
-// ---- the same networks on ONE 64-bit key per entry (the bf16 sweep's lists) ----
-// key = (order-preserving bits of the upper bound) << 32 | ~item: a larger key is the better entry (higher bound, then the smaller item id;
-// the empty slot (-inf, INT_MAX) is the smallest key a list can hold). One 64-bit compare per stage instead of three 32-bit ones: the drains
-// are ~45 % of the bf16 sweep's vector instructions at the Netflix width. The order among equal bounds cannot change the output (the lists
-// are re-ranked by the exact score and verified), it only has to be a strict total order so that a compare-exchange never duplicates an entry.
+// ---- bitonic networks over 64 lanes on ONE 64-bit key per entry ----
+// key = (order-preserving bits of the score) << 32 | ~item: a larger key is the better entry - higher score, then the smaller item id: the
+// reference's rank rule (heapq.nlargest over (score, item) pairs, utility/batch_test.py:21-36, ties by item id asc) -; the empty slot
+// (-inf, INT_MAX) is the smallest key a list can hold. One 64-bit compare per stage instead of three 32-bit ones (score >, score ==, id <):
+// a stage is 2 DPP moves + 1 compare + 2 selects - the drains were ~45 % of the bf16 sweep's vector instructions at the Netflix width with the
+// two-register form. A strict total order: a compare-exchange never duplicates or loses an entry (NaN scores never reach a list: the filter
+// compare rejects them). The exact sweep's lists, the bf16 sweep's lists (by upper bound: there the order among equal bounds cannot change the
+// output - the lists are re-ranked by the exact score and verified) and the final exact re-ranking all use it.
 __device__ __forceinline__ uint32_t tk_ord(float x) {
     const uint32_t b = __float_as_uint(x);
     return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
@@ -684,13 +628,15 @@ __device__ __forceinline__ void tk_finalize_user(const TopkArgs& a, const float*
         }
         if (id != INT_MAX) e = acc;
     }
-    float es[1] = {e}; int32_t ei[1] = {id};
-    sort64<1>(es, ei, lane);
-    const float eK = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(es[0]), a.K - 1));
+    uint64_t ek = tk_key(e, id);                                      // (exact score desc, item id asc): the exact sweep's order
+    sort64k(ek, lane);
+    const float es = tk_key_ub(ek);
+    const int32_t ei = tk_key_id(ek);
+    const float eK = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(es), a.K - 1));
     const bool ok = (ub64 == -INFINITY) || (ub64 < eK);               // (NaN anywhere -> not ok -> the exact sweep decides)
     if (q < a.n_query && lane < a.K) {
-        a.out_idx[(int64_t)q * a.K + lane] = ei[0] == INT_MAX ? -1 : ei[0];
-        a.out_score[(int64_t)q * a.K + lane] = es[0];
+        a.out_idx[(int64_t)q * a.K + lane] = ei == INT_MAX ? -1 : ei;
+        a.out_score[(int64_t)q * a.K + lane] = es;
     }
     if (!ok && q < a.n_query && lane == 0) {
         if (atomicExch(reinterpret_cast<unsigned int*>(&a.fb_word[tile]), 1u) == 0u) atomicAdd(&a.hdr[1], 1u);
