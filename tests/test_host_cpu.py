@@ -343,3 +343,34 @@ def test_queue_work_around_decision_is_loud():
             del os.environ["LLMREC_UNSAFE_GRAPH"]
     finally:
         llmrec_amd._graph_safe, llmrec_amd._message = saved
+
+
+def test_topk_key_order_is_the_reference_rank_rule():
+    """csrc/topk.hip sorts its lists as one 64-bit key per entry, key = tk_ord(score) << 32 | ~item (tk_key): restated here in numpy, a larger
+    key must mean (score desc, item id asc) - the reference's rank rule (utility/batch_test.py:21-36) - for every float incl. +-0 / +-inf /
+    denormals, the empty slot (-inf, INT_MAX) must be the smallest key a list can hold, and the mapping must be a bijection on the score bits."""
+    rng = np.random.default_rng(0)
+    bits = np.concatenate([rng.integers(0, 2 ** 32, size=20000, dtype=np.uint64).astype(np.uint32),
+                           np.array([0x00000000, 0x80000000, 0x7f800000, 0xff800000, 0x00000001, 0x80000001, 0x007fffff, 0x3f800000, 0xbf800000], dtype=np.uint32)])
+    x = bits.view(np.float32)
+    keep = ~np.isnan(x)                                        # (NaN scores never reach a list: the filter compare rejects them)
+    bits, x = bits[keep], x[keep]
+    sign = (bits.view(np.int32) >> 31).view(np.uint32)
+    ordv = bits ^ (sign | np.uint32(0x80000000))               # tk_ord
+    unord = np.where(ordv & np.uint32(0x80000000), ordv ^ np.uint32(0x80000000), ~ordv)
+    assert np.array_equal(unord, bits)                         # tk_unord(tk_ord(x)) == x, bit for bit
+    a, b = rng.integers(0, len(x), size=(2, 50000))
+    lt = x[a] < x[b]
+    assert np.all(ordv[a][lt] < ordv[b][lt])
+    eq = x[a] == x[b]                                          # only -0 / +0 compare equal with different bits: -0 orders below +0 (never produced by the sweeps' fma chains)
+    assert np.all((ordv[a][eq] == ordv[b][eq]) | ((x[a][eq] == 0) & (x[b][eq] == 0)))
+    ids = rng.integers(0, 2 ** 31 - 1, size=len(x), dtype=np.int64)
+    key = (ordv.astype(np.uint64) << np.uint64(32)) | (~ids.astype(np.uint32)).astype(np.uint64)
+    same = x[a] == x[a]                                        # same score, different ids: the smaller id is the better (larger) key
+    k1 = (ordv[a].astype(np.uint64) << np.uint64(32)) | (~ids[a].astype(np.uint32)).astype(np.uint64)
+    k2 = (ordv[a].astype(np.uint64) << np.uint64(32)) | (~ids[b].astype(np.uint32)).astype(np.uint64)
+    d = ids[a] != ids[b]
+    assert np.all((k1[d] > k2[d]) == (ids[a][d] < ids[b][d])) and same.all()
+    empty = (np.uint64(0x007FFFFF) << np.uint64(32)) | np.uint64(0x80000000)        # TK_KEY_EMPTY = tk_key(-inf, INT_MAX)
+    ninf = np.array([0xff800000], dtype=np.uint32)
+    assert int(ninf ^ np.uint32(0xffffffff)) == 0x007FFFFF and np.all(key >= empty)
