@@ -373,4 +373,4 @@ def test_topk_key_order_is_the_reference_rank_rule():
     assert np.all((k1[d] > k2[d]) == (ids[a][d] < ids[b][d])) and same.all()
     empty = (np.uint64(0x007FFFFF) << np.uint64(32)) | np.uint64(0x80000000)        # TK_KEY_EMPTY = tk_key(-inf, INT_MAX)
     ninf = np.array([0xff800000], dtype=np.uint32)
-    assert int(ninf ^ np.uint32(0xffffffff)) == 0x007FFFFF and np.all(key >= empty)
+    assert int((ninf ^ np.uint32(0xffffffff))[0]) == 0x007FFFFF and np.all(key >= empty)
