@@ -217,6 +217,7 @@ __device__ __forceinline__ int tk_heavy_setup(const TopkArgs& a, int lane, bool 
             if ((uint32_t)it < (uint32_t)a.n_items) atomicOr(&row[it >> 5], 1u << (it & 31));   // (an id outside the table never matches in the walk either)
         }
         if (lane == u) mine = s * a.heavy_words;
+        if (a.hdr && threadIdx.x == 0) atomicAdd(&a.hdr[2], 1u);      // (statistics: train rows swept as bitmaps, counted per block)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the atomics are performed at the L2 before any wave reads a word back)
     __syncthreads();
@@ -560,12 +561,12 @@ __device__ __forceinline__ void tk_split8(const float (&x)[8], uint4& H, uint4& 
 constexpr float TK_PRE_SLACK = 0x1p-14f;                                 // ub = s' + TK_PRE_SLACK ||u|| ||i||  (both norms rounded UP by 2^-10)
 constexpr float TK_NORM_UP = 1.0f + 0x1p-10f;
 
-// workspace header of the mode (first 256 bytes of the fragment area): [0] unused, [1] user tiles flagged for the exact sweep
+// workspace header of the mode (first 256 bytes of the fragment area): [0] unused, [1] user tiles flagged for the exact sweep, [2] train rows swept as bitmaps
 // the item table as bf16 (hi, mid) MFMA fragments: pk2[(((tile * 2 + n) * DK32 + c) * 2 + hm) * 64 + lane], lane = 16 (k group) + item-in-tile;
 // one thread per (item, 8 consecutive k). Also clears the header and the fallback flags (the norm kernel and the sweep follow on the stream).
 __global__ __launch_bounds__(256) void topk_pack_items_bf16_kernel(TopkArgs a, int DK32, uint4* __restrict__ pk2) {
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (v < 2) a.hdr[v] = 0u;
+    if (v < 3) a.hdr[v] = 0u;
     const int n_tiles_u = (a.n_query + 15) / 16;
     if (v < n_tiles_u) a.fb_word[v] = 0u;
     const int G = DK32 * 4;                                            // 8-float groups per (padded) row

@@ -57,6 +57,7 @@ def test_prefilter_equals_exact_on_random_tables(ops, U, I, d, K):
     _assert_same(*_both(ops, Eu, Ei, q, train, K), what="random")
     if K <= 50 and I >= 1000:
         assert LAST["fallback_tiles"] == 0, LAST                   # well-separated scores: the verification holds everywhere
+        assert LAST["bitmap_rows"] == 0, LAST                      # rows of at most 40 train items are walked
     _assert_same(*_both(ops, Eu, Ei, q, None, K), what="random, no mask")
     _assert_same(*_both(ops, Eu, Ei, q[:7], train, K), what="7 queries")
 
@@ -148,6 +149,9 @@ def test_dense_train_rows_cross_the_staged_window(ops, I, d):
     q = torch.arange(U, device=DEV)
     i0, s0, i1, s1 = _both(ops, Eu, Ei, q, train, K)
     _assert_same(i0, s0, i1, s1, what="dense train rows")
+    # the long rows went through the bitmap path (up to two per block - the others of a block are walked; 54 users = 4 user tiles, each
+    # swept by one block or, at 20 000 items, by eight blocks of an item range each)
+    assert LAST["bitmap_rows"] >= 4, LAST
     S = (Eu.double() @ Ei.double().T)
     S[torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV)] = -float("inf")
     ref_s, ref_i = torch.topk(S, K, dim=1)
