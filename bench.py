@@ -1113,7 +1113,7 @@ def compact_line(line: dict) -> dict:
                 "rows_per_spmm", "spmm_checked", "max_rel_err_vs_fp64", "tolerance_rel")           # (the row-sharded workloads' sampled-row gate)
         out["parity"] = _pick(par, keys, 3)
     if isinstance(line.get("eval"), dict):
-        out["eval"] = _pick(line["eval"], ("value", "ms", "n_users", "topk_mode", "topk_tiles", "topk_tiles_redone_exact"), 6)
+        out["eval"] = _pick(line["eval"], ("value", "ms", "n_users", "topk_mode", "topk_tiles", "topk_tiles_redone_exact", "topk_train_rows_as_bitmaps"), 6)
         out["eval"]["unit"] = "users/s"
     for k in ("exact_f32", "reference_order", "pre_propagated_order"):
         if isinstance(line.get(k), dict):
@@ -1369,6 +1369,7 @@ def main():
                 off = _l.query("llmrec_score_topk_stats_offset", evs[0][3].numel(), w.sh.n_items)
                 tk["topk_tiles"] = (evs[0][3].numel() + 15) // 16
                 tk["topk_tiles_redone_exact"] = int(evs[0][5][off + 4:off + 8].view(torch.int32).item())
+                tk["topk_train_rows_as_bitmaps"] = int(evs[0][5][off + 8:off + 12].view(torch.int32).item())
         except Exception as e:                                # pragma: no cover
             tk = {"topk_stats_error": str(e)[:100]}
         line["eval"] = {"metric": "full_rank_eval_users_per_sec", "value": w.sh.n_users / te, "ms": te * 1e3, **tk,
