@@ -64,7 +64,10 @@ def test_prefilter_equals_exact_on_random_tables(ops, U, I, d, K):
 
 @pytest.mark.parametrize("kind", ["near_identical_rows", "softmax_rows", "tiny_spread", "huge_norm_outlier", "integers", "ascending", "few_candidates"])
 def test_prefilter_equals_exact_where_the_filter_is_loose_or_ties_abound(ops, kind):
-    rng = np.random.default_rng(abs(hash(kind)) % 1000)
+    # fixed seeds (hash(str) changes from process to process; 35 of the 1000 seeds it produced leave the "integers" case without a single
+    # tile for the exact sweep - all 1000 give bit-identical, reference-equal lists in both modes, swept on the GPU)
+    rng = np.random.default_rng({"near_identical_rows": 101, "softmax_rows": 102, "tiny_spread": 103, "huge_norm_outlier": 104, "integers": 105,
+                                 "ascending": 106, "few_candidates": 107}[kind])
     U, I, d, K = 200, 6000, 64, 50
     if kind == "near_identical_rows":        # scores within ~1e-4 relative of one another: the slack admits many false positives
         base = rng.standard_normal(d).astype(np.float32)
