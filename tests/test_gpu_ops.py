@@ -1007,6 +1007,7 @@ def test_spmm_operand_row_mask_and_output_flags(ops, d, weighted):
     byte values count as not active. All row buckets (hub rows past the split threshold), the softmax-backward epilogue included."""
     import scipy.sparse as sp
     rng = np.random.default_rng(41)
+    torch.manual_seed(41)                                      # (the torch.rand / randn operands below: the same data whatever ran before)
     n_rows, n_cols, stamp = 3000, 2500, 77
     degs = rng.integers(0, 30, size=n_rows); degs[5] = 2400; degs[6] = 0; degs[7] = 700; degs[8] = 150
     rows, cols = rand_graph(rng, n_rows, n_cols, degs)
@@ -1113,6 +1114,7 @@ def test_spmm_of_listed_rows_and_of_needed_rows(ops):
     wavefront / block rows and a hub past the split threshold - equal to the full product's rows to summation-order rounding; y_row_needed: the short-row
     range skips the rows that are not marked (their previous contents stay), the forward softmax epilogue included."""
     rng = np.random.default_rng(47)
+    torch.manual_seed(47)
     n_rows, n_cols, d = 4000, 3000, 64
     degs = rng.integers(0, 30, size=n_rows); degs[5] = 2900; degs[6] = 0; degs[7] = 900; degs[8] = 200; degs[9] = 40
     rows, cols = rand_graph(rng, n_rows, n_cols, degs)
