@@ -1,4 +1,4 @@
-"""CPU, gloo, world_size 2: the user-sharded path of llmrec_amd/dist.py (partitioning, global
+"""CPU, gloo, world_size 2 (and 3 with an uneven user partition): the user-sharded path of llmrec_amd/dist.py (partitioning, global
 item degrees, one all-reduce per layer forward/backward, sharded BPR + prune over the global
 batch) reproduces the single-process oracle after optimiser steps. The local kernels are the
 torch stand-ins of tests/_cpu_backend.py; the HIP kernels themselves are checked on the GPU."""
@@ -16,32 +16,35 @@ U, I, D, L, B_LOCAL, STEPS = 60, 45, 16, 2, 12, 3
 DROP, DECAY, LR = 0.71, 1e-5, 1e-2
 
 
-def _problem():
+def _problem(world=2, n_users=U):
+    """world = 2, n_users = U: the problem of the two-rank tests (same random stream as ever). Other values: the users are cut into the
+    contiguous blocks of llmrec_amd.dist.user_block (the last one shorter when world does not divide n_users)."""
+    from llmrec_amd.dist import user_block
     rng = np.random.default_rng(0)
-    rows = np.repeat(np.arange(U), rng.integers(1, 9, size=U))
+    rows = np.repeat(np.arange(n_users), rng.integers(1, 9, size=n_users))
     cols = np.concatenate([rng.choice(I, size=c, replace=False) for c in np.bincount(rows)])
-    u_tab = (rng.standard_normal((U, D)) * 0.1).astype(np.float32)
+    u_tab = (rng.standard_normal((n_users, D)) * 0.1).astype(np.float32)
     i_tab = (rng.standard_normal((I, D)) * 0.1).astype(np.float32)
     batches = []
     for s in range(STEPS):
         per_rank = []
-        for r in range(2):
-            u0, u1 = r * (U // 2), (r + 1) * (U // 2)
+        for r in range(world):
+            u0, u1 = user_block(n_users, r, world)
             us = rng.integers(u0, u1, size=B_LOCAL)
             per_rank.append((us, rng.integers(0, I, size=B_LOCAL), rng.integers(0, I, size=B_LOCAL)))
         batches.append(per_rank)
     return rows, cols, u_tab, i_tab, batches
 
 
-def _oracle_run(n_aug=0):
+def _oracle_run(n_aug=0, world=2, n_users=U):
     import scipy.sparse as sp
-    rows, cols, u_tab, i_tab, batches = _problem()
+    rows, cols, u_tab, i_tab, batches = _problem(world, n_users)
     batches = _with_aug(batches, n_aug)
-    R = sp.csr_matrix((np.ones(rows.size, dtype=np.float32), (rows, cols)), shape=(U, I))
+    R = sp.csr_matrix((np.ones(rows.size, dtype=np.float32), (rows, cols)), shape=(n_users, I))
     a_ui, a_iu = O.normalized_graphs(R)
     pu = torch.tensor(u_tab, requires_grad=True); pi = torch.tensor(i_tab, requires_grad=True)
     opt = torch.optim.AdamW([{"params": [pu, pi]}], lr=LR)
-    cfg = O.Config(batch_size=2 * B_LOCAL, decay=DECAY, prune_loss_drop_rate=DROP)
+    cfg = O.Config(batch_size=world * B_LOCAL, decay=DECAY, prune_loss_drop_rate=DROP)
     losses = []
     for per_rank in batches:
         us = np.concatenate([b[0] for b in per_rank]); ps = np.concatenate([b[1] for b in per_rank]); ns = np.concatenate([b[2] for b in per_rank])
@@ -105,7 +108,7 @@ def test_two_rank_sharded_training_matches_single_process_oracle(tmp_path):
     assert np.abs(r0["items"] - ref_i).max() <= 1e-4 * np.abs(ref_i).max()
 
 
-def _fused_worker(rank, world, port, out_dir, exchange, n_aug):
+def _fused_worker(rank, world, port, out_dir, exchange, n_aug, n_users=U):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -113,16 +116,16 @@ def _fused_worker(rank, world, port, out_dir, exchange, n_aug):
     from llmrec_amd import dist as ld
     from llmrec_amd.dist_fused import ShardedFusedID
     from tests._cpu_backend import CpuBackend
-    rows, cols, u_tab, i_tab, batches = _problem()
+    rows, cols, u_tab, i_tab, batches = _problem(world, n_users)
     comm, be = ld.Comm(), CpuBackend()
-    u0, u1 = ld.user_block(U, rank, world)
+    u0, u1 = ld.user_block(n_users, rank, world)
     sel = (rows >= u0) & (rows < u1)
     g = ld.ShardedGraph.build(torch.tensor(rows[sel] - u0), torch.tensor(cols[sel]), u1 - u0, I, u0, comm, be)
-    st = ShardedFusedID(g, comm, be, D, L, U, seed=1, lr=LR, batch_local=B_LOCAL + n_aug, drop_rate=DROP, decay=DECAY, n_chunks=3,
+    st = ShardedFusedID(g, comm, be, D, L, n_users, seed=1, lr=LR, batch_local=B_LOCAL + n_aug, drop_rate=DROP, decay=DECAY, n_chunks=3,
                         user_init=torch.tensor(u_tab[u0:u1]), item_init=torch.tensor(i_tab),
                         batch_size_flag=float(world * B_LOCAL), exchange=exchange)
     assert len(st.chunks) == 3
-    if exchange == "rs_ag":                                    # 45 items: chunks of 16 rows split over the two ranks, the last (13 rows) does not
+    if exchange == "rs_ag" and world == 2:                     # 45 items: chunks of 16 rows split over the two ranks, the last (13 rows) does not
         assert [s_ is not None for s_ in st.shards] == [True, True, False]
     losses = []
     for per_rank in _with_aug(batches, n_aug):
@@ -165,6 +168,25 @@ def test_two_rank_fused_sharded_step_matches_single_process_oracle(tmp_path, exc
     assert int(r0["msg"][0]) == 4 * I * D * (2 * L - 1) + 4 * (2 * 2 * (B_LOCAL + n_aug)) * D
 
 
+@pytest.mark.parametrize("exchange", ["all_reduce", "rs_ag"])
+def test_three_rank_fused_sharded_step_with_an_uneven_user_partition(tmp_path, exchange):
+    """The same step on THREE gloo ranks with 61 users (blocks of 21, 21 and 19: the last rank's shard is shorter, its graph block and user table
+    too; the BPR rows of three ranks are gathered, the prune threshold covers 3 x 12 samples): the sharded result equals the single-process
+    oracle's after 3 optimiser steps, the item replicas stay bit-identical on all three ranks."""
+    world, n_users = 3, 61
+    ref_u, ref_i, ref_losses = _oracle_run(0, world, n_users)
+    mp.spawn(_fused_worker, args=(world, _free_port(), str(tmp_path), exchange, 0, n_users), nprocs=world, join=True)
+    rs = [np.load(tmp_path / ("f%d.npz" % r)) for r in range(world)]
+    assert [r["users"].shape[0] for r in rs] == [21, 21, 19]
+    got_u = np.concatenate([r["users"] for r in rs])
+    assert np.array_equal(rs[0]["items"], rs[1]["items"]) and np.array_equal(rs[0]["items"], rs[2]["items"])
+    for r in rs:
+        assert np.allclose(r["losses"], ref_losses, rtol=1e-5)
+    assert np.abs(got_u - ref_u).max() <= 1e-4 * np.abs(ref_u).max()
+    assert np.abs(rs[0]["items"] - ref_i).max() <= 1e-4 * np.abs(ref_i).max()
+    assert int(rs[0]["msg"][0]) == 4 * I * D * (2 * L - 1) + 4 * (world * 2 * B_LOCAL) * D
+
+
 def test_user_block_partition_covers_all_users():
     from llmrec_amd.dist import user_block
     for n, w in ((10, 3), (8, 8), (5, 8), (1000003, 8)):
@@ -179,11 +201,11 @@ def test_user_block_partition_covers_all_users():
 MM_KEYS = ("year", "title", "director", "country", "language")
 
 
-def _mm_problem():
+def _mm_problem(world=2, n_users=U):
     rng = np.random.default_rng(5)
-    rows, cols, u_tab, i_tab, batches = _problem()
+    rows, cols, u_tab, i_tab, batches = _problem(world, n_users)
     feats = {"image": rng.standard_normal((I, 12)).astype(np.float32), "text": rng.standard_normal((I, 20)).astype(np.float32),
-             "user": rng.standard_normal((U, 28)).astype(np.float32)}
+             "user": rng.standard_normal((n_users, 28)).astype(np.float32)}
     for k in MM_KEYS:
         feats["attr/" + k] = rng.standard_normal((I, 28)).astype(np.float32)
     lin = {}
@@ -193,16 +215,16 @@ def _mm_problem():
     return rows, cols, u_tab, i_tab, batches, feats, lin
 
 
-def _mm_cfg():
-    return O.Config(embed_size=D, n_layers=L, batch_size=2 * B_LOCAL, decay=DECAY, prune_loss_drop_rate=DROP, lr=LR, keys=MM_KEYS)
+def _mm_cfg(world=2):
+    return O.Config(embed_size=D, n_layers=L, batch_size=world * B_LOCAL, decay=DECAY, prune_loss_drop_rate=DROP, lr=LR, keys=MM_KEYS)
 
 
-def _mm_oracle_run():
+def _mm_oracle_run(world=2, n_users=U):
     import scipy.sparse as sp
-    rows, cols, u_tab, i_tab, batches, feats, lin = _mm_problem()
-    R = sp.csr_matrix((np.ones(rows.size, dtype=np.float32), (rows, cols)), shape=(U, I))
+    rows, cols, u_tab, i_tab, batches, feats, lin = _mm_problem(world, n_users)
+    R = sp.csr_matrix((np.ones(rows.size, dtype=np.float32), (rows, cols)), shape=(n_users, I))
     a_ui, a_iu = O.normalized_graphs(R)
-    cfg = _mm_cfg()
+    cfg = _mm_cfg(world)
     params = {k: torch.tensor(v, requires_grad=True) for k, v in lin.items()}
     params["user_id_embedding.weight"] = torch.tensor(u_tab, requires_grad=True)
     params["item_id_embedding.weight"] = torch.tensor(i_tab, requires_grad=True)
@@ -220,7 +242,7 @@ def _mm_oracle_run():
     return {k: v.detach().numpy() for k, v in params.items()}, losses, fw["E_u"].numpy(), fw["E_i"].numpy(), rows, cols
 
 
-def _mm_worker(rank, world, port, out_dir):
+def _mm_worker(rank, world, port, out_dir, n_users=U):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -228,19 +250,19 @@ def _mm_worker(rank, world, port, out_dir):
     from llmrec_amd import dist as ld
     from llmrec_amd.engine import Hyper
     from tests._cpu_backend import CpuBackend
-    rows, cols, u_tab, i_tab, batches, feats, lin = _mm_problem()
+    rows, cols, u_tab, i_tab, batches, feats, lin = _mm_problem(world, n_users)
     comm, be = ld.Comm(), CpuBackend()
-    u0, u1 = ld.user_block(U, rank, world)
+    u0, u1 = ld.user_block(n_users, rank, world)
     sel = (rows >= u0) & (rows < u1)
     g = ld.ShardedGraph.build(torch.tensor(rows[sel] - u0), torch.tensor(cols[sel]), u1 - u0, I, u0, comm, be)
     item_feats = {k: torch.tensor(v) for k, v in feats.items() if k != "user"}
-    model = ld.ShardedMMModel(g, comm, be, D, L, U, item_feats, torch.tensor(feats["user"][u0:u1]), MM_KEYS, (0.02, 2.8, 0.005), seed=3)
+    model = ld.ShardedMMModel(g, comm, be, D, L, n_users, item_feats, torch.tensor(feats["user"][u0:u1]), MM_KEYS, (0.02, 2.8, 0.005), seed=3)
     with torch.no_grad():
         for name, v in lin.items():
             mod, attr = name.split(".")
             getattr(getattr(model, mod), attr).copy_(torch.tensor(v))
         model.user_id_embedding.copy_(torch.tensor(u_tab[u0:u1])); model.item_id_embedding.copy_(torch.tensor(i_tab))
-    hp = Hyper(batch_size=2 * B_LOCAL, decay=DECAY, prune_loss_drop_rate=DROP); hp.lr = LR
+    hp = Hyper(batch_size=world * B_LOCAL, decay=DECAY, prune_loss_drop_rate=DROP); hp.lr = LR
     tr = ld.ShardedMMTrainer(model, hp, B_LOCAL, I)
     losses = []
     for per_rank in batches:
@@ -271,6 +293,27 @@ def test_two_rank_full_model_matches_single_process_oracle(tmp_path):
     assert rel(got_u, ref_params["user_id_embedding.weight"]) < 1e-4
     assert rel(np.concatenate([r0["E_u"], r1["E_u"]]), ref_eu) < 1e-4
     assert rel(r0["E_i"], ref_ei) < 1e-4
+
+
+def test_three_rank_full_model_with_an_uneven_user_partition(tmp_path):
+    """The full multi-modal model on THREE gloo ranks, 61 users (21 + 21 + 19): parameters, losses and fused embeddings against the
+    single-process oracle; the replicated parameters stay bit-identical on all three ranks."""
+    world, n_users = 3, 61
+    ref_params, ref_losses, ref_eu, ref_ei, rows, cols = _mm_oracle_run(world, n_users)
+    mp.spawn(_mm_worker, args=(world, _free_port(), str(tmp_path), n_users), nprocs=world, join=True)
+    rs = [np.load(tmp_path / ("mm%d.npz" % r)) for r in range(world)]
+    rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    for r in rs:
+        assert np.allclose(r["losses"], ref_losses, rtol=2e-5)
+    for name in ("image_trans.weight", "image_trans.bias", "text_trans.weight", "user_trans.weight", "user_trans.bias",
+                 "item_trans.weight", "item_trans.bias"):
+        assert np.array_equal(rs[0]["p/" + name], rs[1]["p/" + name]) and np.array_equal(rs[0]["p/" + name], rs[2]["p/" + name]), name
+        assert rel(rs[0]["p/" + name], ref_params[name]) < 1e-4, name
+    assert rel(rs[0]["p/item_id_embedding"], ref_params["item_id_embedding.weight"]) < 1e-4
+    assert [r["p/user_id_embedding"].shape[0] for r in rs] == [21, 21, 19]
+    assert rel(np.concatenate([r["p/user_id_embedding"] for r in rs]), ref_params["user_id_embedding.weight"]) < 1e-4
+    assert rel(np.concatenate([r["E_u"] for r in rs]), ref_eu) < 1e-4
+    assert rel(rs[0]["E_i"], ref_ei) < 1e-4
 
 
 # ---------------------------------------------------------------------------------------------
