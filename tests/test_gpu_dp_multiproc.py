@@ -87,16 +87,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_two_process_replicas_match_single_process_global_batch(tmp_path, use_graph):
+@pytest.mark.parametrize("use_graph,world", [(False, 2), (True, 2), (True, 4)])
+def test_two_process_replicas_match_single_process_global_batch(tmp_path, use_graph, world):
+    """world = 4: four replicas on the one GPU (the exchange buffers hold four slices, the prune threshold covers four local batches)."""
     case = GOLDEN_CASES[0]
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path), use_graph), nprocs=world, join=True)
     r = [np.load(tmp_path / ("r%d.npz" % k)) for k in range(world)]
     for k in NAMES:                                            # replicas bit-identical
-        assert np.array_equal(r[0][k.replace(".", "_")], r[1][k.replace(".", "_")]), k
-    assert np.allclose(r[0]["losses"], r[1]["losses"], rtol=0, atol=0)
-    # single process, global batch = the two slices concatenated (valid entries of rank 0, then of rank 1)
+        for j in range(1, world):
+            assert np.array_equal(r[0][k.replace(".", "_")], r[j][k.replace(".", "_")]), (k, j)
+    for j in range(1, world):
+        assert np.allclose(r[0]["losses"], r[j]["losses"], rtol=0, atol=0)
+    # single process, global batch = the ranks' slices concatenated (valid entries of rank 0, then of rank 1, ...)
     from llmrec_amd.fused import FusedStep
     B = 64
     cap = B + int(B * 0.25)
