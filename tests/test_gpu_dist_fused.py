@@ -126,15 +126,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("D,n_aug,exchange", [(64, 0, "all_reduce"), (128, 6, "all_reduce"), (128, 6, "rs_ag")])
-def test_fused_sharded_step_two_processes_one_gpu_match_oracle(tmp_path, D, n_aug, exchange):
-    world = 2
+@pytest.mark.parametrize("D,n_aug,exchange,world", [(64, 0, "all_reduce", 2), (128, 6, "all_reduce", 2), (128, 6, "rs_ag", 2),
+                                                    (64, 0, "rs_ag", 4), (128, 6, "all_reduce", 3)])
+def test_fused_sharded_step_two_processes_one_gpu_match_oracle(tmp_path, D, n_aug, exchange, world):
+    """world = 3 / 4: more user blocks (the last one shorter when the world does not divide the users), chunk shards cut four ways."""
     ref_u, ref_i, ref_losses = _oracle_run(world, D, n_aug)
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), D, n_aug, exchange), nprocs=world, join=True)
     r = [np.load(tmp_path / ("g%d.npz" % k)) for k in range(world)]
-    assert np.array_equal(r[0]["items"], r[1]["items"])                                   # replicas bit-identical (deterministic scatter)
-    assert np.allclose(r[0]["losses"], ref_losses, rtol=2e-5) and np.allclose(r[1]["losses"], ref_losses, rtol=2e-5)
-    got_u = np.concatenate([r[0]["users"], r[1]["users"]])
+    for j in range(1, world):
+        assert np.array_equal(r[0]["items"], r[j]["items"])                               # replicas bit-identical (deterministic scatter)
+    for j in range(world):
+        assert np.allclose(r[j]["losses"], ref_losses, rtol=2e-5)
+    got_u = np.concatenate([r[j]["users"] for j in range(world)])
     assert np.abs(got_u - ref_u).max() <= 1e-4 * np.abs(ref_u).max()
     assert np.abs(r[0]["items"] - ref_i).max() <= 1e-4 * np.abs(ref_i).max()
 
