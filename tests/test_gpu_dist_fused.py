@@ -129,7 +129,8 @@ def _free_port():
 @pytest.mark.parametrize("D,n_aug,exchange,world", [(64, 0, "all_reduce", 2), (128, 6, "all_reduce", 2), (128, 6, "rs_ag", 2),
                                                     (64, 0, "rs_ag", 4), (128, 6, "all_reduce", 3)])
 def test_fused_sharded_step_two_processes_one_gpu_match_oracle(tmp_path, D, n_aug, exchange, world):
-    """world = 3 / 4: more user blocks (the last one shorter when the world does not divide the users), chunk shards cut four ways."""
+    """world = 3 / 4: three / four user blocks of 300 / 225 users, chunk shards cut three / four ways (a world that does not divide the users:
+    tests/test_dist_cpu.py, 61 users on three gloo ranks)."""
     ref_u, ref_i, ref_losses = _oracle_run(world, D, n_aug)
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), D, n_aug, exchange), nprocs=world, join=True)
     r = [np.load(tmp_path / ("g%d.npz" % k)) for k in range(world)]
