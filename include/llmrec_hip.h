@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LLMREC_ABI_VERSION 5
+#define LLMREC_ABI_VERSION 6
 
 enum {
     LLMREC_OK = 0,
@@ -398,7 +398,7 @@ int llmrec_bpr_prune_fwd_sharded_f32(const float* Eu, int64_t ldu, const float* 
 /* Several (user table, item table) pairs over ONE batch in two launches - the reference computes
  * 8 such losses per step (main.py:232-254). out: [n_problems][2], saved: n_problems blocks of
  * LLMREC_BPR_SAVED_FLOATS(B_max). The backward takes the loss weights from the (host) problem
- * table (g_mf, g_emb) and scatter-adds into dEu / dEi, which the caller zero-initialises. */
+ * table (g_mf, g_emb) and scatter-adds (deterministically, see llmrec_bpr_scatter_plan) into dEu / dEi, which the caller zero-initialises. */
 typedef struct {
     const float* Eu; int64_t ldu; const float* Ei; int64_t ldi;
     float* dEu; int64_t lddu; float* dEi; int64_t lddi;
@@ -426,20 +426,34 @@ int llmrec_bpr_multi_fwd_sharded_f32(int32_t n_problems, const llmrec_bpr_proble
                                      float batch_size_flag, int32_t phase, float* gather_block,
                                      const float* gathered, int32_t n_ranks, int64_t rank_stride, int32_t my_rank,
                                      float* out, float* saved, llmrec_stream_t stream);
+/* DETERMINISTIC gradient scatter (ABI 6). The reference's backward is index_put(accumulate) on CPU - the rows several samples share
+ * are added in one fixed order and same-seed runs agree (main.py:232-254,330-342). Every backward entry point below therefore takes a
+ * SCATTER PLAN of the batch instead of adding rows with float atomics:
+ *   llmrec_bpr_scatter_plan   plan[0 .. B_max)        = the keys  users[b] << 32 | b                          sorted ascending
+ *                             plan[B_max .. 3 B_max)  = the keys  pos[b] << 32 | b  and  neg[b] << 32 | (B_max + b), sorted ascending
+ *                             (samples b >= n_valid: id 0xffffffff, at the end), then as int32 runlen[3 B_max]: at the first position of a
+ *                             run of equal ids the run's length, 0 elsewhere. One launch (rank counting in LDS, ceil(3 B_max / 16) blocks);
+ *                             it depends on the batch only, so a step builds it right behind its sampler, off the critical path.
+ * In the backward launch the head of every run of equal ids owns the destination row and adds the run's contributions in ascending
+ * problem index, then ascending slot. Problems whose dEu (or dEi) POINTERS are equal share one target (the five attribute problems of a
+ * step all scatter into d prof_u): the first of them sums the others' shares; targets must otherwise be disjoint. */
+#define LLMREC_BPR_PLAN_WORDS(B) (5 * (B))         /* 64-bit words of `plan`: 3 B keys + 3 B int32 run lengths */
+int llmrec_bpr_scatter_plan(const int64_t* users, const int64_t* pos, const int64_t* neg, int32_t B_max, const int32_t* n_valid_dev,
+                            uint64_t* plan, llmrec_stream_t stream);
 int llmrec_bpr_multi_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
                              const int64_t* users, const int64_t* pos, const int64_t* neg,
                              int32_t B_max, const int32_t* n_valid_dev, float decay, float batch_size_flag,
-                             const float* saved, llmrec_stream_t stream);
-/* The same step of one LOCAL batch (no gathered layout) with the selection and the backward in ONE launch - the fused training
- * step's critical path is scores -> [rank + backward rows] instead of scores -> rank -> reduce -> backward:
+                             const float* saved, const uint64_t* plan, llmrec_stream_t stream);
+/* The same step of one LOCAL batch (no gathered layout) with the loss VALUES off the critical path - the fused training step's
+ * critical path is scores -> selection -> backward rows instead of scores -> rank -> reduce -> backward:
  *   llmrec_bpr_multi_scores_f32       launch 1: m_b, sigmoid(-x_b) and the per-sample squared norms into `saved`
- *   llmrec_bpr_multi_select_bwd_f32   launch 2: every block re-sums the batch's squared norms (the summation tree of the loss launch
- *                                     below, so the bits agree), ranks its 16 samples against the batch in LDS, writes the kept
- *                                     coefficients / values into `saved` and scatter-adds the gradient rows (as llmrec_bpr_multi_bwd_f32)
+ *   llmrec_bpr_multi_select_bwd_f32   launch 2 (selection): ranks every sample against the batch in LDS and writes the kept coefficients /
+ *                                     values into `saved`; one more block per problem sums the batch's squared norms with the summation
+ *                                     tree of the loss launch below (so the bits agree) into saved[B_max .. B_max + 2];
+ *                                     launch 3 (backward rows): the deterministic scatter of llmrec_bpr_multi_bwd_f32 through `plan`
  *   llmrec_bpr_multi_losses_f32       any time after launch 2, on any stream: out[p] = {mf_p, emb_p} and the norm / k slots of `saved`
  *                                     (only the logged loss values depend on it)
- * Results: `out`, `saved` bit-identical to llmrec_bpr_multi_fwd_f32, gradient rows identical to llmrec_bpr_multi_bwd_f32 up to the
- * order of the atomic adds on rows several samples share. */
+ * Results: `out`, `saved` and the gradient rows bit-identical to llmrec_bpr_multi_fwd_f32 + llmrec_bpr_multi_bwd_f32. */
 /* Row stamps: the rows a batch touches are marked in byte arrays with the value LLMREC_ROW_STAMP(counter) of a device counter that
  * the scores launch advances once per step; consumers (llmrec_fuse_bwd_problem_t.row_flags) treat a
  * row as touched iff its byte equals the current stamp. Nothing ever has to be cleared - a stale byte differs from the current stamp for
@@ -455,6 +469,7 @@ int llmrec_bpr_multi_select_bwd_f32(int32_t n_problems, const llmrec_bpr_problem
                                     float batch_size_flag, float* saved,
                                     uint8_t* user_row_flags, uint8_t* item_row_flags,   /* optional: [u_b] / [p_b], [q_b] := stamp for b < n_valid */
                                     const int32_t* row_stamp,                           /* optional device counter (NULL: stamp = 1) */
+                                    const uint64_t* plan,                               /* llmrec_bpr_scatter_plan of this batch */
                                     llmrec_stream_t stream);
 int llmrec_bpr_multi_losses_f32(int32_t n_problems, int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
                                 float batch_size_flag, float* out, float* saved, llmrec_stream_t stream);
@@ -478,15 +493,15 @@ int llmrec_bpr_multi_losses_assemble_f32(int32_t n_problems, int32_t B_max, cons
 int llmrec_bpr_multi_zero_rows_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
                                    const int64_t* users, const int64_t* pos, const int64_t* neg,
                                    int32_t B_max, const int32_t* n_valid_dev, llmrec_stream_t stream);
-/* dEu[u_b] += g_mf * ds_b * (Ei[p_b] - Ei[q_b]) + g_emb * c_u * Eu[u_b]   (atomic scatter-add)
+/* dEu[u_b] += g_mf * ds_b * (Ei[p_b] - Ei[q_b]) + g_emb * c_u * Eu[u_b]   (deterministic scatter-add through `plan`, see above)
  * dEi[p_b] += g_mf * ds_b * Eu[u_b] + g_emb * c_p * Ei[p_b] ; dEi[q_b] likewise with -ds_b, c_q
- * g_mf / g_emb are upstream gradients read from device memory (grads2[0], grads2[1]). */
+ * g_mf / g_emb are upstream gradients read from device memory (grads2[0], grads2[1]). dEu and dEi are distinct buffers. */
 int llmrec_bpr_prune_bwd_f32(const float* Eu, int64_t ldu, const float* Ei, int64_t ldi, int32_t d,
                              const int64_t* users, const int64_t* pos, const int64_t* neg,
                              int32_t B_max, const int32_t* n_valid_dev,
                              float decay, float batch_size_flag,
                              const float* saved, const float* grads2,
-                             float* dEu, int64_t lddu, float* dEi, int64_t lddi, llmrec_stream_t stream);
+                             float* dEu, int64_t lddu, float* dEi, int64_t lddi, const uint64_t* plan, llmrec_stream_t stream);
 
 /* The same gradient as COMPACT rows instead of a scatter (row-sharded step): rows3 = [3][B_max][d],
  * block 0 = d/dEu[u_b], block 1 = d/dEi[p_b], block 2 = d/dEi[q_b]; rows of samples b >= B are zero. The item rows are

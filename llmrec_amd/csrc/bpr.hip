@@ -308,73 +308,268 @@ __global__ __launch_bounds__(256) void bpr_pack_kernel(int n_prob, int B_max, co
     }
 }
 
-// backward for several problems with HOST loss weights (fused step): grid.y = problem
-__global__ __launch_bounds__(256) void bpr_bwd_multi_kernel(BprTables t, int d, const int64_t* __restrict__ users,
-                                                            const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
-                                                            int B_max, const int32_t* __restrict__ n_valid_dev, float decay, float bsz,
-                                                            const float* __restrict__ saved_all, int saved_stride) {
+// ---------------------------------------------------------------------------------------------
+// DETERMINISTIC gradient scatter (round 6). The reference's backward is index_put(accumulate) on CPU: given the seed it adds the
+// rows several samples share in one fixed order (main.py:232-254,330-342), and same-seed runs agree. Rounds 1 - 5 added the rows
+// with fp32 atomicAdd, so two runs of one seed drifted apart (1.0e-3 vs 3.6e-3 in the final E_i of one trajectory on two boxes).
+// Now every destination row has ONE owner that adds the row's contributions in a fixed order, without atomics:
+//   bpr_plan_kernel      depends on (users, pos, neg, n_valid) only - the fused step runs it right behind the sampler, off the
+//                        critical path. Keys  id << 32 | slot  (distinct), sorted by RANK COUNTING: every block stages its side's keys in
+//                        LDS, each 16-lane group counts the keys below its own -> the key's sorted position (no serial sorting network:
+//                        one round of LDS reads, ceil(3 B / 16) blocks):
+//                          plan[0 .. B_max)          user side, slot b          (id = users[b])
+//                          plan[B_max .. 3 B_max)    item side, slot b          (id = pos[b])  /  B_max + b  (id = neg[b])
+//                        slots of samples b >= n_valid carry the id 0xffffffff and sort to the end. Behind the keys, as int32:
+//                          runlen[3 B_max]           at a run's first position: the number of keys with that id; 0 elsewhere (and for id 0xffffffff)
+//   bpr_bwd_runs_kernel  one 16-lane group per sorted position and problem; the HEAD of a run of equal ids owns the destination row
+//                        and adds, in ascending problem index (problems whose target POINTER is the same - the five attribute problems
+//                        of a step share d prof_u - are summed by the first of them) and ascending slot, what bpr_bwd_multi_kernel's
+//                        atomics added; a dropped sample (coefficient 0) of a problem without a regulariser share is skipped, its
+//                        contribution being exactly zero. The (problem, member) pairs of a run are taken 16 at a time: lane l fetches
+//                        pair l's slot, coefficient and row ids (ONE round of dependent loads for 16 pairs), the pairs that contribute are
+//                        compacted into LDS records, and the group then streams the records' rows four at a time.
+// Targets of different problems must be identical (same pointer, same leading dimension) or disjoint.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t PLAN_NO_ID = 0xffffffffu;
+__global__ __launch_bounds__(256) void bpr_plan_kernel(const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
+                                                       const int64_t* __restrict__ neg, int B_max,
+                                                       const int32_t* __restrict__ n_valid_dev, uint64_t* __restrict__ plan) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* k = reinterpret_cast<uint64_t*>(smem);
     const int B = bpr_batch(n_valid_dev, B_max);
-    const int prob = blockIdx.y;
-    const float* saved = saved_all + (int64_t)prob * saved_stride;
-    const float g_mf = t.g_mf[prob], g_emb = t.g_emb[prob];
-    const float Su = saved[B_max], Sp = saved[B_max + 1], Sq = saved[B_max + 2];
-    const float base = -4.0f * decay / bsz * g_emb;
-    const float du_ = 2.0f * Su + 1e-8f, dp_ = 2.0f * Sp + 1e-8f, dq_ = 2.0f * Sq + 1e-8f;
-    const float cu = base / (du_ * du_), cp = base / (dp_ * dp_), cq = base / (dq_ * dq_);
+    const int nbu = (B_max + 15) / 16;
+    const bool items = (int)blockIdx.x >= nbu;
+    const int n = items ? 2 * B_max : B_max;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int b = (items && i >= B_max) ? i - B_max : i;
+        uint64_t id = PLAN_NO_ID;
+        if (b < B) id = (uint64_t)(items ? (i >= B_max ? neg[b] : pos[b]) : users[b]);
+        k[i] = (id << 32) | (uint64_t)(uint32_t)i;
+    }
+    __syncthreads();
     const int gl = threadIdx.x & 15;
-    const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (b >= B) return;
-    const int64_t ui = users[b], pi = pos[b], qi = neg[b];
-    const float ds = g_mf * saved[b];
-    const float* u = t.Eu[prob] + ui * t.ldu[prob];
-    const float* p = t.Ei[prob] + pi * t.ldi[prob];
-    const float* q = t.Ei[prob] + qi * t.ldi[prob];
-    float* du = t.dEu[prob] + ui * t.lddu[prob];
-    float* dpp = t.dEi[prob] + pi * t.lddi[prob];
-    float* dqq = t.dEi[prob] + qi * t.lddi[prob];
-    for (int c = gl; c < d; c += 16) {
-        const float uu = u[c], pp = p[c], qq = q[c];
-        atomicAdd(du + c, fmaf(ds, pp - qq, cu * uu));
-        atomicAdd(dpp + c, fmaf(ds, uu, cp * pp));
-        atomicAdd(dqq + c, fmaf(-ds, uu, cq * qq));
+    const int i = ((int)blockIdx.x - (items ? nbu : 0)) * 16 + (threadIdx.x >> 4);
+    if (i >= n) return;
+    const uint64_t me = k[i];
+    const uint32_t id = (uint32_t)(me >> 32);
+    int below = 0, lower_id = 0, same_id = 0;
+    for (int j = gl; j < n; j += 16) {
+        const uint64_t kj = k[j];
+        const uint32_t idj = (uint32_t)(kj >> 32);
+        below += kj < me; lower_id += idj < id; same_id += idj == id;
+    }
+    below = (int)group_sum<16>((float)below); lower_id = (int)group_sum<16>((float)lower_id); same_id = (int)group_sum<16>((float)same_id);   // < 2^24: exact
+    if (gl == 0) {
+        const int base = items ? B_max : 0;
+        plan[base + below] = me;
+        int32_t* runlen = reinterpret_cast<int32_t*>(plan + 3 * (int64_t)B_max);
+        runlen[base + below] = (below == lower_id && id != PLAN_NO_ID) ? same_id : 0;
     }
 }
 
-// selection + backward of a LOCAL batch in one launch (llmrec_bpr_multi_select_bwd_f32): grid = (ceil(B_max / 16), problems).
-// Every block (1) re-sums the batch's three squared-norm columns with the summation tree of bpr_reduce_kernel - thread t of that
-// 1024-thread launch is emulated by the four slots t, t + 256, ... of this block's threads, then the same pairwise tree over 1024 LDS
-// slots - so Su, Sp, Sq carry the bits the loss launch writes; (2) stages the batch's log-sigmoids in LDS and ranks its 16 samples as
-// bpr_rank_kernel does; (3) adds the gradient rows of its samples as bpr_bwd_multi_kernel does.
-__global__ __launch_bounds__(256) void bpr_select_bwd_multi_kernel(BprTables t, int d, const int64_t* __restrict__ users,
-                                                                   const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
-                                                                   int B_max, const int32_t* __restrict__ n_valid_dev, double remember_rate,
-                                                                   float decay, float bsz, float* __restrict__ saved_all, int saved_stride,
-                                                                   uint8_t* __restrict__ flag_u, uint8_t* __restrict__ flag_i,
-                                                                   const int32_t* __restrict__ row_stamp) {
+constexpr int RUN_MAX_SHARE = LLMREC_BPR_MAX_PROBLEMS;
+struct RunShare {                                                      // the problems that scatter into this block's target (LDS)
+    const float* Eu[RUN_MAX_SHARE]; const float* Ei[RUN_MAX_SHARE]; const float* saved[RUN_MAX_SHARE];
+    int64_t ldu[RUN_MAX_SHARE], ldi[RUN_MAX_SHARE];
+    float g_mf[RUN_MAX_SHARE], cu[RUN_MAX_SHARE], cp[RUN_MAX_SHARE], cq[RUN_MAX_SHARE];
+    int n, any_reg;
+};
+struct RunRec { const float* a; const float* b; const float* self; float ds, cr; };   // user row: ds (a - b) + cr self ; item row: ds a + cr self
+
+template <int NV, bool VEC> struct RunAcc;
+template <int NV> struct RunAcc<NV, true> {                            // lane gl: float4 chunks gl, gl + 16, ... of a 64 NV-column pass
+    float4 v[NV];
+    __device__ __forceinline__ void load(const float* row, int c0, int d, int gl) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int c = c0 + 4 * (gl + 16 * i); v[i] = c < d ? *reinterpret_cast<const float4*>(row + c) : float4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    __device__ __forceinline__ void store(float* row, int c0, int d, int gl) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int c = c0 + 4 * (gl + 16 * i); if (c < d) *reinterpret_cast<float4*>(row + c) = v[i]; }
+    }
+};
+template <int NV> struct RunAcc<NV, false> {                           // lane gl: columns gl, gl + 16, ... of a 64 NV-column pass
+    float v[4 * NV];
+    __device__ __forceinline__ void load(const float* row, int c0, int d, int gl) {
+#pragma unroll
+        for (int i = 0; i < 4 * NV; ++i) { const int c = c0 + gl + 16 * i; v[i] = c < d ? row[c] : 0.f; }
+    }
+    __device__ __forceinline__ void store(float* row, int c0, int d, int gl) const {
+#pragma unroll
+        for (int i = 0; i < 4 * NV; ++i) { const int c = c0 + gl + 16 * i; if (c < d) row[c] = v[i]; }
+    }
+};
+template <int NV, bool VEC, bool ITEM, bool REG>
+__device__ __forceinline__ void run_add(RunAcc<NV, VEC>& acc, const RunAcc<NV, VEC>& a, const RunAcc<NV, VEC>& b, const RunAcc<NV, VEC>& self,
+                                        float ds, float cr) {
+    if constexpr (VEC) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float4 x = a.v[i], y = ITEM ? float4{0.f, 0.f, 0.f, 0.f} : b.v[i], z = REG ? self.v[i] : float4{0.f, 0.f, 0.f, 0.f};
+            acc.v[i].x += fmaf(ds, ITEM ? x.x : x.x - y.x, cr * z.x); acc.v[i].y += fmaf(ds, ITEM ? x.y : x.y - y.y, cr * z.y);
+            acc.v[i].z += fmaf(ds, ITEM ? x.z : x.z - y.z, cr * z.z); acc.v[i].w += fmaf(ds, ITEM ? x.w : x.w - y.w, cr * z.w);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4 * NV; ++i)
+            acc.v[i] += fmaf(ds, ITEM ? a.v[i] : a.v[i] - b.v[i], cr * (REG ? self.v[i] : 0.f));
+    }
+}
+
+// the records [0, n) of one group, four at a time (their row loads are independent: up to 12 rows in flight per group)
+template <int NV, bool VEC, bool ITEM, bool REG>
+__device__ __forceinline__ void run_stream(RunAcc<NV, VEC>& acc, const RunRec* __restrict__ recs, int n, int c0, int d, int gl) {
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        RunAcc<NV, VEC> a[4], b[4], z[4];
+        float ds[4], cr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const RunRec r = recs[i + u];
+            ds[u] = r.ds; cr[u] = r.cr;
+            a[u].load(r.a, c0, d, gl);
+            if (!ITEM) b[u].load(r.b, c0, d, gl);
+            if (REG) z[u].load(r.self, c0, d, gl);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) run_add<NV, VEC, ITEM, REG>(acc, a[u], b[u], z[u], ds[u], cr[u]);
+    }
+    for (; i < n; ++i) {
+        const RunRec r = recs[i];
+        RunAcc<NV, VEC> a, b, z;
+        a.load(r.a, c0, d, gl);
+        if (!ITEM) b.load(r.b, c0, d, gl);
+        if (REG) z.load(r.self, c0, d, gl);
+        run_add<NV, VEC, ITEM, REG>(acc, a, b, z, r.ds, r.cr);
+    }
+}
+
+// grid = (ceil(B_max / 16) + ceil(2 B_max / 16), problems): a block works on ONE side (its 16 positions are all user-side or all item-side)
+template <bool VEC, int NV>                                             // NV: 64-column units per pass (1 when d <= 64)
+__global__ __launch_bounds__(256) void bpr_bwd_runs_kernel(BprTables t, int n_prob, int d, const int64_t* __restrict__ users,
+                                                           const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
+                                                           int B_max, float decay, float bsz, const float* __restrict__ saved_all,
+                                                           int saved_stride, const uint64_t* __restrict__ plan,
+                                                           const float* __restrict__ grads2_dev) {
+    __shared__ RunShare sh;
+    __shared__ RunRec recs_s[16][16];
+    const int prob = blockIdx.y;
+    const int nbu = (B_max + 15) / 16;
+    const bool item = (int)blockIdx.x >= nbu;
+    float* const dst0 = item ? t.dEi[prob] : t.dEu[prob];
+    for (int q = 0; q < prob; ++q)
+        if ((item ? t.dEi[q] : t.dEu[q]) == dst0) return;             // an earlier problem owns this target (and sums this one's share): block-uniform
+    if (threadIdx.x == 0) {
+        int n = 0, any_reg = 0;
+        for (int pp = prob; pp < n_prob; ++pp) {
+            if ((item ? t.dEi[pp] : t.dEu[pp]) != dst0) continue;
+            const float* saved = saved_all + (int64_t)pp * saved_stride;
+            const float g_emb = grads2_dev ? grads2_dev[1] : t.g_emb[pp];
+            // d emb / d X = decay / bsz * (-1 / (2 S + 1e-8)^2) * 4 X
+            const float base = -4.0f * decay / bsz * g_emb;
+            const float du_ = 2.0f * saved[B_max] + 1e-8f, dp_ = 2.0f * saved[B_max + 1] + 1e-8f, dq_ = 2.0f * saved[B_max + 2] + 1e-8f;
+            sh.Eu[n] = t.Eu[pp]; sh.Ei[n] = t.Ei[pp]; sh.saved[n] = saved; sh.ldu[n] = t.ldu[pp]; sh.ldi[n] = t.ldi[pp];
+            sh.g_mf[n] = grads2_dev ? grads2_dev[0] : t.g_mf[pp];
+            sh.cu[n] = base / (du_ * du_); sh.cp[n] = base / (dp_ * dp_); sh.cq[n] = base / (dq_ * dq_);
+            any_reg |= base != 0.f;
+            ++n;
+        }
+        sh.n = n; sh.any_reg = any_reg;
+    }
+    __syncthreads();
+    const int gl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int side_n = item ? 2 * B_max : B_max, side_base = item ? B_max : 0;
+    const int j0 = ((int)blockIdx.x - (item ? nbu : 0)) * 16 + grp;   // position within the side
+    if (j0 >= side_n) return;
+    const int32_t* runlen = reinterpret_cast<const int32_t*>(plan + 3 * (int64_t)B_max);
+    const int len = runlen[side_base + j0];
+    if (len <= 0) return;                                              // not the head of a run (or the run of the unused slots)
+    const uint64_t* keys = plan + side_base + j0;
+    const uint32_t id = (uint32_t)(keys[0] >> 32);
+    float* const out = dst0 + (int64_t)id * (item ? t.lddi[prob] : t.lddu[prob]);
+    const int total = sh.n * len;
+    const bool reg = sh.any_reg != 0;
+    RunRec* recs = recs_s[grp];
+    const int shift = 16 * (grp & 3);                                  // this group's 16 bits of the wave's ballot
+    for (int c0 = 0; c0 < d; c0 += 64 * NV) {
+        RunAcc<NV, VEC> acc;
+        acc.load(out, c0, d, gl);
+        for (int t0 = 0; t0 < total; t0 += 16) {
+            const int tt = t0 + gl;
+            bool act = false;
+            RunRec r = {};
+            if (tt < total) {
+                const int s_ = tt / len, m_ = tt - s_ * len;
+                const uint32_t slot = (uint32_t)keys[m_];
+                const bool is_neg = slot >= (uint32_t)B_max;
+                const int b = (int)(is_neg ? slot - (uint32_t)B_max : slot);
+                const float ds = sh.g_mf[s_] * sh.saved[s_][b];
+                if (item) {                                                // d/dEi[p_b] = ds u + cp p ; d/dEi[q_b] = -ds u + cq q
+                    r.ds = is_neg ? -ds : ds; r.cr = is_neg ? sh.cq[s_] : sh.cp[s_];
+                    act = !(ds == 0.f && r.cr == 0.f);
+                    if (act) { r.a = sh.Eu[s_] + users[b] * sh.ldu[s_]; r.b = r.a; r.self = sh.Ei[s_] + (int64_t)id * sh.ldi[s_]; }
+                } else {                                                   // d/dEu[u_b] = ds (p - q) + cu u
+                    r.ds = ds; r.cr = sh.cu[s_];
+                    act = !(ds == 0.f && r.cr == 0.f);
+                    if (act) { r.a = sh.Ei[s_] + pos[b] * sh.ldi[s_]; r.b = sh.Ei[s_] + neg[b] * sh.ldi[s_]; r.self = sh.Eu[s_] + (int64_t)id * sh.ldu[s_]; }
+                }
+            }
+            const uint32_t bits = (uint32_t)(__ballot(act) >> shift) & 0xffffu;
+            const int n_act = __popc(bits);
+            if (act) recs[__popc(bits & ((1u << gl) - 1u))] = r;
+            __builtin_amdgcn_wave_barrier();                           // (one wave: its LDS writes and reads execute in order)
+            if (item) {
+                if (reg) run_stream<NV, VEC, true, true>(acc, recs, n_act, c0, d, gl);
+                else run_stream<NV, VEC, true, false>(acc, recs, n_act, c0, d, gl);
+            } else {
+                if (reg) run_stream<NV, VEC, false, true>(acc, recs, n_act, c0, d, gl);
+                else run_stream<NV, VEC, false, false>(acc, recs, n_act, c0, d, gl);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        acc.store(out, c0, d, gl);
+    }
+}
+
+// selection of a LOCAL batch (first launch of llmrec_bpr_multi_select_bwd_f32): grid = (ceil(B_max / 16) + 1, problems).
+// Blocks [0, ceil(B_max / 16)): stage the batch's log-sigmoids in LDS and rank their 16 samples as bpr_rank_kernel does (kept
+// coefficient -> saved[b], kept value -> slot 1), stamp the rows the batch touches. The LAST block of a problem sums the three
+// squared-norm columns with the summation tree of bpr_reduce_kernel - thread t of that 1024-thread launch is emulated by the four
+// slots t, t + 256, ... of this block's threads, then the same pairwise tree over 1024 LDS slots - so saved[B_max .. B_max + 2] carry
+// the bits the loss launch writes later (the backward launch reads them).
+__global__ __launch_bounds__(256) void bpr_select_kernel(const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
+                                                         const int64_t* __restrict__ neg, int B_max,
+                                                         const int32_t* __restrict__ n_valid_dev, double remember_rate,
+                                                         float* __restrict__ saved_all, int saved_stride,
+                                                         uint8_t* __restrict__ flag_u, uint8_t* __restrict__ flag_i,
+                                                         const int32_t* __restrict__ row_stamp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* m_s = reinterpret_cast<float*>(smem);                      // [B]
-    __shared__ float red[3][BPR_THREADS];
+    float* m_s = reinterpret_cast<float*>(smem);                      // [B] (rank blocks) / [3][1024] (the norm block)
     const int B = bpr_batch(n_valid_dev, B_max);
     const int prob = blockIdx.y;
     float* saved = saved_all + (int64_t)prob * saved_stride;
     float* sc = saved + B_max + 4;
-    for (int v = threadIdx.x; v < BPR_THREADS; v += 256) {            // the partial sums of bpr_reduce_kernel's thread v
-        float su = 0.f, sp = 0.f, sq = 0.f;
-        for (int b = v; b < B; b += BPR_THREADS) {
-            m_s[b] = sc[b];
-            su += sc[2 * B_max + b]; sp += sc[3 * B_max + b]; sq += sc[4 * B_max + b];
-        }
-        red[0][v] = su; red[1][v] = sp; red[2][v] = sq;
-    }
-    __syncthreads();
-    for (int off = BPR_THREADS / 2; off > 0; off >>= 1) {             // block_tree_sum's tree, three columns at once
-        for (int i = threadIdx.x; i < off; i += 256) {
-            red[0][i] += red[0][i + off]; red[1][i] += red[1][i + off]; red[2][i] += red[2][i + off];
+    const int k = (int)(remember_rate * (double)B);
+    if (blockIdx.x == gridDim.x - 1) {
+        float (*red)[BPR_THREADS] = reinterpret_cast<float (*)[BPR_THREADS]>(smem);
+        for (int v = threadIdx.x; v < BPR_THREADS; v += 256) {        // the partial sums of bpr_reduce_kernel's thread v
+            float su = 0.f, sp = 0.f, sq = 0.f;
+            for (int b = v; b < B; b += BPR_THREADS) { su += sc[2 * B_max + b]; sp += sc[3 * B_max + b]; sq += sc[4 * B_max + b]; }
+            red[0][v] = su; red[1][v] = sp; red[2][v] = sq;
         }
         __syncthreads();
+        for (int off = BPR_THREADS / 2; off > 0; off >>= 1) {         // block_tree_sum's tree, three columns at once
+            for (int i = threadIdx.x; i < off; i += 256) {
+                red[0][i] += red[0][i + off]; red[1][i] += red[1][i + off]; red[2][i] += red[2][i + off];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x < 3) saved[B_max + threadIdx.x] = red[threadIdx.x][0];
+        if (threadIdx.x == 3) saved[B_max + 3] = (float)k;
+        return;
     }
-    const float Su = red[0][0], Sp = red[1][0], Sq = red[2][0];
-    const int k = (int)(remember_rate * (double)B);
+    for (int j = threadIdx.x; j < B; j += 256) m_s[j] = sc[j];
+    __syncthreads();
     const int gl = threadIdx.x & 15;
     const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (b >= B_max) return;
@@ -392,29 +587,13 @@ __global__ __launch_bounds__(256) void bpr_select_bwd_multi_kernel(BprTables t, 
     }
     const float coef = keep ? (-1.0f / (float)k) * sc[B_max + b] : 0.f;   // every lane of the group reads slot 1 before lane 0 rewrites it
     __builtin_amdgcn_wave_barrier();
-    if (gl == 0) { saved[b] = coef; sc[B_max + b] = keep ? mb : 0.f; }
-    const float g_mf = t.g_mf[prob], g_emb = t.g_emb[prob];
-    const float base = -4.0f * decay / bsz * g_emb;
-    const float du_ = 2.0f * Su + 1e-8f, dp_ = 2.0f * Sp + 1e-8f, dq_ = 2.0f * Sq + 1e-8f;
-    const float cu = base / (du_ * du_), cp = base / (dp_ * dp_), cq = base / (dq_ * dq_);
-    const int64_t ui = users[b], pi = pos[b], qi = neg[b];
-    if (prob == 0 && gl == 0) {                                       // rows this batch touches (same rows for every problem)
-        const uint8_t stamp = row_stamp ? LLMREC_ROW_STAMP(row_stamp[0]) : (uint8_t)1;
-        if (flag_u) flag_u[ui] = stamp;
-        if (flag_i) { flag_i[pi] = stamp; flag_i[qi] = stamp; }
-    }
-    const float ds = g_mf * coef;
-    const float* u = t.Eu[prob] + ui * t.ldu[prob];
-    const float* p = t.Ei[prob] + pi * t.ldi[prob];
-    const float* q = t.Ei[prob] + qi * t.ldi[prob];
-    float* du = t.dEu[prob] + ui * t.lddu[prob];
-    float* dpp = t.dEi[prob] + pi * t.lddi[prob];
-    float* dqq = t.dEi[prob] + qi * t.lddi[prob];
-    for (int c = gl; c < d; c += 16) {
-        const float uu = u[c], pp = p[c], qq = q[c];
-        atomicAdd(du + c, fmaf(ds, pp - qq, cu * uu));
-        atomicAdd(dpp + c, fmaf(ds, uu, cp * pp));
-        atomicAdd(dqq + c, fmaf(-ds, uu, cq * qq));
+    if (gl == 0) {
+        saved[b] = coef; sc[B_max + b] = keep ? mb : 0.f;
+        if (prob == 0) {                                              // rows this batch touches (same rows for every problem)
+            const uint8_t stamp = row_stamp ? LLMREC_ROW_STAMP(row_stamp[0]) : (uint8_t)1;
+            if (flag_u) flag_u[users[b]] = stamp;
+            if (flag_i) { flag_i[pos[b]] = stamp; flag_i[neg[b]] = stamp; }
+        }
     }
 }
 
@@ -432,38 +611,6 @@ __global__ __launch_bounds__(256) void bpr_zero_rows_kernel(BprTables t, int d, 
     float* dpp = t.dEi[prob] + pos[b] * t.lddi[prob];
     float* dqq = t.dEi[prob] + neg[b] * t.lddi[prob];
     for (int c = gl; c < d; c += 16) { du[c] = 0.f; dpp[c] = 0.f; dqq[c] = 0.f; }
-}
-
-__global__ __launch_bounds__(256) void bpr_bwd_kernel(const float* __restrict__ Eu, int64_t ldu,
-                                                      const float* __restrict__ Ei, int64_t ldi, int d,
-                                                      const int64_t* __restrict__ users, const int64_t* __restrict__ pos,
-                                                      const int64_t* __restrict__ neg, int B_max,
-                                                      const int32_t* __restrict__ n_valid_dev, float decay, float bsz,
-                                                      const float* __restrict__ saved, const float* __restrict__ grads2,
-                                                      float* __restrict__ dEu, int64_t lddu, float* __restrict__ dEi, int64_t lddi) {
-    int B = n_valid_dev ? n_valid_dev[0] : B_max;
-    if (B > B_max) B = B_max;
-    const float g_mf = grads2[0], g_emb = grads2[1];
-    const float Su = saved[B_max], Sp = saved[B_max + 1], Sq = saved[B_max + 2];
-    // d emb / d X = decay / bsz * (-1 / (2 S + 1e-8)^2) * 4 X
-    const float base = -4.0f * decay / bsz * g_emb;
-    const float du_ = 2.0f * Su + 1e-8f, dp_ = 2.0f * Sp + 1e-8f, dq_ = 2.0f * Sq + 1e-8f;
-    const float cu = base / (du_ * du_), cp = base / (dp_ * dp_), cq = base / (dq_ * dq_);
-    const int gl = threadIdx.x & 15;
-    const int groups = gridDim.x * (blockDim.x >> 4);
-    for (int b = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); b < B; b += groups) {
-        const int64_t ui = users[b], pi = pos[b], qi = neg[b];
-        const float ds = g_mf * saved[b];
-        const float* u = Eu + ui * ldu;
-        const float* p = Ei + pi * ldi;
-        const float* q = Ei + qi * ldi;
-        for (int c = gl; c < d; c += 16) {
-            const float uu = u[c], pp = p[c], qq = q[c];
-            atomicAdd(dEu + ui * lddu + c, fmaf(ds, pp - qq, cu * uu));
-            atomicAdd(dEi + pi * lddi + c, fmaf(ds, uu, cp * pp));
-            atomicAdd(dEi + qi * lddi + c, fmaf(-ds, uu, cq * qq));
-        }
-    }
 }
 
 // the same gradient as compact rows (row-sharded step): rows3[0][b] = d/dEu[u_b], rows3[1][b] = d/dEi[p_b], rows3[2][b] = d/dEi[q_b]
@@ -768,21 +915,46 @@ int llmrec_bpr_multi_fwd_sharded_f32(int32_t n_problems, const llmrec_bpr_proble
                           ga, false, true, nullptr, (hipStream_t)stream_);
 }
 
+int llmrec_bpr_scatter_plan(const int64_t* users, const int64_t* pos, const int64_t* neg, int32_t B_max, const int32_t* n_valid_dev,
+                            uint64_t* plan, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(B_max >= 0, "bpr_scatter_plan: bad argument");
+    if (B_max > LLMREC_BPR_MAX_B) { set_error("bpr_scatter_plan: B_max %d > %d", B_max, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
+    if (B_max == 0) return LLMREC_OK;
+    LLMREC_CHECK_ARG(users && pos && neg && plan, "bpr_scatter_plan: null pointer");
+    const unsigned blocks = (unsigned)(ceil_div(B_max, 16) + ceil_div(2 * (int64_t)B_max, 16));
+    bpr_plan_kernel<<<blocks, 256, sizeof(uint64_t) * 2 * (size_t)B_max, (hipStream_t)stream_>>>(users, pos, neg, B_max, n_valid_dev, plan);   // <= 64 KB of LDS
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+static int launch_bwd_runs(const BprTables& t, int n_prob, int d, const int64_t* users, const int64_t* pos, const int64_t* neg, int B_max,
+                           float decay, float bsz, const float* saved, const uint64_t* plan, const float* grads2_dev, hipStream_t stream) {
+    dim3 grid((unsigned)(ceil_div(B_max, 16) + ceil_div(2 * (int64_t)B_max, 16)), (unsigned)n_prob);
+    bool vec = d % 4 == 0;                                             // float4 rows: every row pointer 16-byte aligned
+    for (int i = 0; i < n_prob && vec; ++i)
+        vec = t.ldu[i] % 4 == 0 && t.ldi[i] % 4 == 0 && t.lddu[i] % 4 == 0 && t.lddi[i] % 4 == 0 &&
+              ((uintptr_t)t.Eu[i] | (uintptr_t)t.Ei[i] | (uintptr_t)t.dEu[i] | (uintptr_t)t.dEi[i]) % 16 == 0;
+    const int stride = LLMREC_BPR_SAVED_FLOATS(B_max);
+#define RUNS_LAUNCH(V, N) bpr_bwd_runs_kernel<V, N><<<grid, 256, 0, stream>>>(t, n_prob, d, users, pos, neg, B_max, decay, bsz, saved, stride, plan, grads2_dev)
+    if (vec) { if (d <= 64) RUNS_LAUNCH(true, 1); else RUNS_LAUNCH(true, 2); }
+    else { if (d <= 64) RUNS_LAUNCH(false, 1); else RUNS_LAUNCH(false, 2); }
+#undef RUNS_LAUNCH
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
 int llmrec_bpr_multi_bwd_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
                              const int64_t* users, const int64_t* pos, const int64_t* neg,
                              int32_t B_max, const int32_t* n_valid_dev, float decay, float batch_size_flag,
-                             const float* saved, llmrec_stream_t stream_) {
+                             const float* saved, const uint64_t* plan, llmrec_stream_t stream_) {
+    (void)n_valid_dev;                                                  // (the plan carries it: slots beyond n_valid are not listed)
     LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && problems_host && d > 0 && saved,
                      "bpr_multi_bwd: bad argument");
     if (B_max == 0) return LLMREC_OK;
-    LLMREC_CHECK_ARG(users && pos && neg, "bpr_multi_bwd: null index pointer");
+    LLMREC_CHECK_ARG(users && pos && neg && plan, "bpr_multi_bwd: null index pointer or no scatter plan (llmrec_bpr_scatter_plan)");
     BprTables t = {};
     LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, true), "bpr_multi_bwd: bad problem table");
-    dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_problems);
-    bpr_bwd_multi_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(t, d, users, pos, neg, B_max, n_valid_dev, decay, batch_size_flag,
-                                                                saved, LLMREC_BPR_SAVED_FLOATS(B_max));
-    LLMREC_LAUNCH_CHECK();
-    return LLMREC_OK;
+    return launch_bwd_runs(t, n_problems, d, users, pos, neg, B_max, decay, batch_size_flag, saved, plan, nullptr, (hipStream_t)stream_);
 }
 
 int llmrec_bpr_multi_scores_f32(int32_t n_problems, const llmrec_bpr_problem_t* problems_host, int32_t d,
@@ -818,19 +990,19 @@ int llmrec_bpr_multi_select_bwd_f32(int32_t n_problems, const llmrec_bpr_problem
                                     const int64_t* users, const int64_t* pos, const int64_t* neg,
                                     int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
                                     float batch_size_flag, float* saved, uint8_t* user_row_flags, uint8_t* item_row_flags,
-                                    const int32_t* row_stamp, llmrec_stream_t stream_) {
+                                    const int32_t* row_stamp, const uint64_t* plan, llmrec_stream_t stream_) {
     LLMREC_CHECK_ARG(n_problems >= 1 && n_problems <= LLMREC_BPR_MAX_PROBLEMS && problems_host && d > 0 && saved, "bpr_multi_select_bwd: bad argument");
     if (B_max > LLMREC_BPR_MAX_B) { set_error("bpr_multi_select_bwd: B_max %d > %d", B_max, LLMREC_BPR_MAX_B); return LLMREC_EUNSUPPORTED; }
     if (B_max == 0) return LLMREC_OK;
-    LLMREC_CHECK_ARG(users && pos && neg, "bpr_multi_select_bwd: null index pointer");
+    LLMREC_CHECK_ARG(users && pos && neg && plan, "bpr_multi_select_bwd: null index pointer or no scatter plan (llmrec_bpr_scatter_plan)");
     BprTables t = {};
     LLMREC_CHECK_ARG(!fill_tables(t, n_problems, problems_host, d, true), "bpr_multi_select_bwd: bad problem table");
-    dim3 grid((unsigned)ceil_div(B_max, 16), (unsigned)n_problems);
-    bpr_select_bwd_multi_kernel<<<grid, 256, sizeof(float) * (size_t)B_max, (hipStream_t)stream_>>>(
-        t, d, users, pos, neg, B_max, n_valid_dev, remember_rate, decay, batch_size_flag, saved, LLMREC_BPR_SAVED_FLOATS(B_max), user_row_flags,
-        item_row_flags, row_stamp);
+    dim3 grid((unsigned)ceil_div(B_max, 16) + 1u, (unsigned)n_problems);
+    const size_t shmem = sizeof(float) * (size_t)(B_max > 3 * BPR_THREADS ? B_max : 3 * BPR_THREADS);
+    bpr_select_kernel<<<grid, 256, shmem, (hipStream_t)stream_>>>(users, pos, neg, B_max, n_valid_dev, remember_rate, saved,
+                                                                 LLMREC_BPR_SAVED_FLOATS(B_max), user_row_flags, item_row_flags, row_stamp);
     LLMREC_LAUNCH_CHECK();
-    return LLMREC_OK;
+    return launch_bwd_runs(t, n_problems, d, users, pos, neg, B_max, decay, batch_size_flag, saved, plan, nullptr, (hipStream_t)stream_);
 }
 
 int llmrec_bpr_multi_losses_f32(int32_t n_problems, int32_t B_max, const int32_t* n_valid_dev, double remember_rate, float decay,
@@ -878,16 +1050,18 @@ int llmrec_bpr_prune_bwd_f32(const float* Eu, int64_t ldu, const float* Ei, int6
                              const int64_t* users, const int64_t* pos, const int64_t* neg,
                              int32_t B_max, const int32_t* n_valid_dev, float decay, float batch_size_flag,
                              const float* saved, const float* grads2,
-                             float* dEu, int64_t lddu, float* dEi, int64_t lddi, llmrec_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+                             float* dEu, int64_t lddu, float* dEi, int64_t lddi, const uint64_t* plan, llmrec_stream_t stream_) {
+    (void)n_valid_dev;
     LLMREC_CHECK_ARG(B_max >= 0 && d > 0 && saved && grads2, "bpr_bwd: bad argument");
     if (B_max == 0) return LLMREC_OK;
     LLMREC_CHECK_ARG(Eu && Ei && users && pos && neg && dEu && dEi && ldu >= d && ldi >= d && lddu >= d && lddi >= d,
                      "bpr_bwd: null pointer or ld < d");
-    bpr_bwd_kernel<<<grid_for(B_max, 16), 256, 0, stream>>>(Eu, ldu, Ei, ldi, d, users, pos, neg, B_max, n_valid_dev, decay,
-                                                            batch_size_flag, saved, grads2, dEu, lddu, dEi, lddi);
-    LLMREC_LAUNCH_CHECK();
-    return LLMREC_OK;
+    LLMREC_CHECK_ARG(plan, "bpr_bwd: no scatter plan (llmrec_bpr_scatter_plan)");
+    LLMREC_CHECK_ARG(dEu != dEi, "bpr_bwd: dEu and dEi must be distinct buffers");
+    BprTables t = {};
+    t.Eu[0] = Eu; t.Ei[0] = Ei; t.ldu[0] = ldu; t.ldi[0] = ldi;
+    t.dEu[0] = dEu; t.dEi[0] = dEi; t.lddu[0] = lddu; t.lddi[0] = lddi;
+    return launch_bwd_runs(t, 1, d, users, pos, neg, B_max, decay, batch_size_flag, saved, plan, grads2, (hipStream_t)stream_);
 }
 
 int llmrec_bpr_prune_bwd_rows_f32(const float* Eu, int64_t ldu, const float* Ei, int64_t ldi, int32_t d,

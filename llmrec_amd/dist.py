@@ -285,9 +285,10 @@ class HipBackend:
         o = self.ops
         Eu, Ei = o._rowmajor(Eu), o._rowmajor(Ei)
         dEu, dEi = torch.zeros_like(Eu), torch.zeros_like(Ei)
+        plan = o.bpr_scatter_plan(u, p, n)
         o._lib.call("llmrec_bpr_prune_bwd_f32", o._p(Eu), o._ld(Eu), o._p(Ei), o._ld(Ei), Eu.shape[1], o._p(u), o._p(p), o._p(n),
                     u.numel(), None, float(decay), float(bsz), o._p(saved), o._p(grads2.contiguous()), o._p(dEu), o._ld(dEu),
-                    o._p(dEi), o._ld(dEi), o._stream())
+                    o._p(dEi), o._ld(dEi), o._p(plan), o._stream())
         return dEu, dEi
 
     def sample(self, seed, step, exist_users, n_items, by_user, B):

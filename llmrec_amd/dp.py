@@ -94,6 +94,7 @@ class DataParallelStep(FusedStep):
             raise RuntimeError("DataParallelStep: every rank passes exactly b_max = %d slots (n_valid marks the used ones)" % self.b_max)
         if sampler is not None:
             sampler()
+        self.build_scatter_plan(users, pos, neg, n_valid)                # the deterministic scatter of phase_b's backward (fused.py)
         self._train_forward()                                            # (also starts the feature regulariser's value on s3)
         self._bpr_phase(1, users, pos, neg, n_valid)
         self._join(self.s3)

@@ -111,6 +111,9 @@ class FusedStep:
         self.flag_u = torch.zeros(U, dtype=torch.uint8, device=dev)
         self.flag_i = torch.zeros(I, dtype=torch.uint8, device=dev)
         self.row_stamp = torch.zeros(1, dtype=torch.int32, device=dev)     # advanced by the scores launch (LLMREC_ROW_STAMP)
+        # the batch's deterministic scatter plan (llmrec_bpr_scatter_plan: sorted (id, slot) keys + run lengths), built right behind the
+        # sampler: the loss backward adds the rows several samples share in one fixed order - no float atomics, same-seed runs agree bit for bit
+        self.bpr_plan = torch.zeros(max(ops.bpr_plan_words(b_max), 1), dtype=torch.int64, device=dev)
         # running sums (double) of the logged scalars [loss, mf, emb] over the steps since the caller last cleared them: the epoch line of
         # reference main.py:280-283 without any host-side arithmetic between graph replays
         self.epoch_sums = torch.zeros(3, dtype=torch.float64, device=dev)
@@ -368,7 +371,8 @@ class FusedStep:
         return (_c.c_float * len(r))(*r)
 
     # -- forward ----------------------------------------------------------------------------------
-    def forward(self, sampler=None):
+    def forward(self, sampler=None, after_chain=None):
+        """sampler / after_chain: launches for the ID chain's stream, ahead of / behind its SpMMs (the batch and what is derived from it)."""
         m, d = self.m, self.d
         self._fork(self.s2)
         # LLMREC_ID_FIRST=1 (experiment, profiles/experiments/r05_step_chain.md): the ID chain's SpMMs BEFORE the sampler and the row list on
@@ -393,6 +397,8 @@ class FusedStep:
                 i_prev = self.Il[l]
             if sampler is not None and self.multi_stream and id_first:
                 sampler()
+            if after_chain is not None:
+                after_chain()
         self._stamp(1)
         split_proj = os.environ.get("LLMREC_SPLIT_PROJ", "0") == "1" and self.multi_stream and self.d <= 64
         if split_proj:                                                   # user_trans first: the profile chain runs BESIDE the item-side projection
@@ -487,7 +493,7 @@ class FusedStep:
             _call("llmrec_bpr_multi_scores_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), _p(self.saved),
                   _p(self.row_stamp))
         _call("llmrec_bpr_multi_select_bwd_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), remember,
-              float(hp.decay), float(hp.batch_size), _p(self.saved), _p(self.flag_u), _p(self.flag_i), _p(self.row_stamp))
+              float(hp.decay), float(hp.batch_size), _p(self.saved), _p(self.flag_u), _p(self.flag_i), _p(self.row_stamp), _p(self.bpr_plan))
 
         def side():                              # (runs on the ID chain's stream, _backward places it)
             if self.fold:                        # loss values + regulariser (the fusion launch's partial sums) + assembly: one launch
@@ -536,7 +542,7 @@ class FusedStep:
         if not bpr_bwd_done:
             self._check_scatter_targets()
             _call("llmrec_bpr_multi_bwd_f32", self.n_prob, probs, d, _p(users), _p(pos), _p(neg), B, _p(n_valid), float(hp.decay),
-                  float(hp.batch_size), _p(self.saved))
+                  float(hp.batch_size), _p(self.saved), _p(self.bpr_plan))
         ev_rows = self._mark()                                           # dE_u / dE_i hold the scattered rows: all the ID chain needs
         if after_first is not None:
             after_first()
@@ -712,13 +718,21 @@ class FusedStep:
         if loss_s3:
             self._join(self.s3)
 
-    def _train_forward(self, sampler=None):
+    def _train_forward(self, sampler=None, after_chain=None):
         """forward() of a training step: also advances AdamW's counters (and samples the batch) on a side stream."""
         self._zero_in_forward = True
         try:
-            self.forward(sampler)
+            self.forward(sampler, after_chain)
         finally:
             self._zero_in_forward = False
+
+    def build_scatter_plan(self, users, pos, neg, n_valid=None):
+        """llmrec_bpr_scatter_plan of this batch into the step's plan buffer (one launch; step_eager does it behind the sampler - callers
+        that drive forward() / loss_backward() themselves call it once per batch, any time before the loss backward)."""
+        B = users.numel()
+        if B > self.b_max:
+            raise RuntimeError("FusedStep: batch of %d exceeds b_max %d" % (B, self.b_max))
+        _call("llmrec_bpr_scatter_plan", _p(users), _p(pos), _p(neg), B, _p(n_valid), _p(self.bpr_plan))
 
     def reset_scatter_targets(self):
         """Dense clear of the buffers the sparse-zero scheme keeps all-zero between steps (set-up, (re)capture, and after a
@@ -732,19 +746,29 @@ class FusedStep:
         side = self.multi_stream                                 # the sampler rides beside the projection (forward())
         # (Built on the regulariser's stream instead - forked from the main stream, waiting for the sampler's event of the ID chain's stream,
         #  its own event awaited by the weight gradient - hipGraphInstantiate of this image recursed until the stack ran out: not kept.)
-        if self.wgrad_rows:                                      # the row list right behind the sampler, on the ID chain's stream (needed by the
-            fill = sampler                                       # weight gradient only, at the far end of the step)
-            def sampler():
-                if fill is not None:
-                    fill()
+        # right behind the sampler, on the ID chain's stream: the scatter plan of the loss backward (needed ~200 us later) and the row list
+        # (needed by the weight gradient only, at the far end of the step). Measured on one box, 300 steps each, twice (round 6):
+        # here 0.452 / 0.455 ms per step; LLMREC_PLAN_STREAM=late (behind the chain's SpMMs, where the launch takes 16 us instead of the
+        # ~60 us its blocks wait for LDS beside the projection) 0.463 / 0.463; on a branch of its own forked from the sampler and joined
+        # ahead of the loss launches 0.534 / 0.534 - the graph runtime then runs the PROJECTION behind the ID chain (not kept).
+        fill = sampler
+        late = self.multi_stream and os.environ.get("LLMREC_PLAN_STREAM", "early") == "late"
+
+        def sampler():
+            if fill is not None:
+                fill()
+            if not late:
+                self.build_scatter_plan(users, pos, neg, n_valid)
+            if self.wgrad_rows:
                 ops.batch_reach_rows(users, pos, neg, n_valid, self.iu.fwd, self.act_flags, self.act_rows, self.act_n)
+        late = (lambda: self.build_scatter_plan(users, pos, neg, n_valid)) if late else None
         self.spmm_edge_units = 0.0
         calls0 = _lib.n_calls
         try:
             self._stamp(0)
             if sampler is not None and not side:
                 sampler()
-            self._train_forward(sampler if side else None)
+            self._train_forward(sampler if side else None, late)
             self.loss_backward(users, pos, neg, n_valid)
             if not self.inline_adamw:
                 self.opt.step(advanced=True)

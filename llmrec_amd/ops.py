@@ -595,6 +595,25 @@ def bpr_saved_floats(B: int) -> int:
     return 6 * B + 8
 
 
+def bpr_plan_words(B: int) -> int:
+    """LLMREC_BPR_PLAN_WORDS(B): 3 B sorted keys + 3 B int32 run lengths."""
+    return 5 * B
+
+
+def bpr_scatter_plan(users, pos, neg, n_valid=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The deterministic scatter plan of one batch (llmrec_bpr_scatter_plan): sorted (id, slot) keys of the user side and of the item
+    side + the run lengths, LLMREC_BPR_PLAN_WORDS(B) 64-bit words. Every BPR backward entry point takes it - rows that several samples share are added in one fixed order,
+    as the reference's CPU index_put does (main.py:232-254), never with float atomics."""
+    _need_gpu(users, pos, neg)
+    B = users.numel()
+    if out is None:
+        out = torch.empty(max(bpr_plan_words(B), 1), dtype=torch.int64, device=users.device)
+    elif out.numel() < bpr_plan_words(B) or out.dtype != torch.int64:
+        raise RuntimeError("bpr_scatter_plan: plan buffer needs %d int64 words" % bpr_plan_words(B))
+    _lib.call("llmrec_bpr_scatter_plan", _p(users), _p(pos), _p(neg), B, _p(n_valid), _p(out), _stream())
+    return out
+
+
 class BprProblem(_c.Structure):
     """llmrec_bpr_problem_t"""
     _fields_ = [("Eu", _c.c_void_p), ("ldu", _c.c_int64), ("Ei", _c.c_void_p), ("ldi", _c.c_int64),
@@ -780,8 +799,9 @@ class _BprPrune(torch.autograd.Function):
         Eu, Ei, users, pos, neg, saved = ctx.saved_tensors
         g = g.contiguous()
         dEu, dEi = torch.zeros_like(Eu), torch.zeros_like(Ei)
+        plan = bpr_scatter_plan(users, pos, neg, ctx.n_valid)
         _lib.call("llmrec_bpr_prune_bwd_f32", _p(Eu), _ld(Eu), _p(Ei), _ld(Ei), Eu.shape[1], _p(users), _p(pos), _p(neg),
-                  users.numel(), _p(ctx.n_valid), ctx.decay, ctx.bsz, _p(saved), _p(g), _p(dEu), _ld(dEu), _p(dEi), _ld(dEi), _stream())
+                  users.numel(), _p(ctx.n_valid), ctx.decay, ctx.bsz, _p(saved), _p(g), _p(dEu), _ld(dEu), _p(dEi), _ld(dEi), _p(plan), _stream())
         return dEu, dEi, None, None, None, None, None, None, None
 
 

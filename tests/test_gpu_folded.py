@@ -106,13 +106,14 @@ def test_scores_step_and_losses_assemble_equal_the_separate_launches(ops, drop, 
         running = torch.tensor([1.5, 2.5, 3.5], dtype=torch.float64, device=DEV)
         common = (P, arr, d, p_(idx[0]), p_(idx[1]), p_(idx[2]), cap, p_(nv))
         st = _stream()
+        plan = ops.bpr_scatter_plan(idx[0], idx[1], idx[2], nv)
         for _ in range(3):                                         # three "steps": the counters advance three times
             if folded:
                 _lib.call("llmrec_bpr_multi_scores_step_f32", *common, p_(saved), p_(stamp), p_(state), 1e-3, 0.9, 0.999, st)
             else:
                 _lib.call("llmrec_adamw_advance", p_(state), 1e-3, 0.9, 0.999, st)
                 _lib.call("llmrec_bpr_multi_scores_f32", *common, p_(saved), p_(stamp), st)
-            _lib.call("llmrec_bpr_multi_select_bwd_f32", *common, 1 - drop, 1e-5, 64.0, p_(saved), None, None, p_(stamp), st)
+            _lib.call("llmrec_bpr_multi_select_bwd_f32", *common, 1 - drop, 1e-5, 64.0, p_(saved), None, None, p_(stamp), p_(plan), st)
             if folded:
                 _lib.call("llmrec_bpr_multi_losses_assemble_f32", P, cap, p_(nv), 1 - drop, 1e-5, 64.0, p_(out), p_(saved), wc, p_(partial), partial.numel(),
                           coef, p_(scal), p_(running), st)

@@ -472,8 +472,9 @@ def test_bpr_multi_sharded_matches_oracle_on_concatenated_batch(ops):
     assert [int(blocks[r, -1]) for r in range(W)] == valid
     for r in range(W):
         call(2, r)
+        plan = ops.bpr_scatter_plan(dev_idx[r][0], dev_idx[r][1], dev_idx[r][2], nv[r])
         _lib.call("llmrec_bpr_multi_bwd_f32", P, arr, d, p_(dev_idx[r][0]), p_(dev_idx[r][1]), p_(dev_idx[r][2]), cap, p_(nv[r]),
-                  1e-5, 64.0, p_(saved[r]), st)
+                  1e-5, 64.0, p_(saved[r]), p_(plan), st)
     for i in range(P):
         mf = sum(float(outs[r][i, 0]) for r in range(W))
         assert abs(mf - want[i][0]) < 3e-6 * abs(want[i][0])
@@ -486,8 +487,9 @@ def test_bpr_multi_sharded_matches_oracle_on_concatenated_batch(ops):
 @pytest.mark.parametrize("drop,cap,valid,d", [(0.71, 1126, 1126, 64), (0.0, 1024, 1000, 64), (0.5, 2048, 1500, 128), (0.71, 96, 0, 64), (0.999, 40, 40, 16)])
 def test_bpr_select_and_backward_in_one_launch(ops, drop, cap, valid, d):
     """scores -> llmrec_bpr_multi_select_bwd_f32 -> llmrec_bpr_multi_losses_f32 (the fused step's loss path) against
-    llmrec_bpr_multi_fwd_f32 + llmrec_bpr_multi_bwd_f32: `saved` and `out` bit for bit (valid < capacity included, an empty
-    batch included), gradients to atomic-order rounding, and against the oracle's autograd."""
+    llmrec_bpr_multi_fwd_f32 + llmrec_bpr_multi_bwd_f32: `saved`, `out` AND the gradient rows bit for bit (valid < capacity included,
+    an empty batch included; round 6: the scatter is deterministic - one owner per destination row adds the duplicates in slot order),
+    and against the oracle's autograd."""
     import ctypes
     from llmrec_amd import _lib
     rng = np.random.default_rng(5)
@@ -513,13 +515,14 @@ def test_bpr_select_and_backward_in_one_launch(ops, drop, cap, valid, d):
         flag_u, flag_i = torch.full((U,), 42, dtype=torch.uint8, device=DEV), torch.zeros(I, dtype=torch.uint8, device=DEV)   # 42: a stale stamp
         stamp = torch.tensor([41 + 255 * 3], dtype=torch.int32, device=DEV)     # the scores launch advances it: stamp value (42 + 765) % 255 + 1 = 43
         common = (P, arr, d, p_(idx[0]), p_(idx[1]), p_(idx[2]), cap, p_(nv))
+        plan = ops.bpr_scatter_plan(idx[0], idx[1], idx[2], nv)
         if fused:
             _lib.call("llmrec_bpr_multi_scores_f32", *common, p_(saved), p_(stamp), st)
-            _lib.call("llmrec_bpr_multi_select_bwd_f32", *common, 1 - drop, 1e-5, 64.0, p_(saved), p_(flag_u), p_(flag_i), p_(stamp), st)
+            _lib.call("llmrec_bpr_multi_select_bwd_f32", *common, 1 - drop, 1e-5, 64.0, p_(saved), p_(flag_u), p_(flag_i), p_(stamp), p_(plan), st)
             _lib.call("llmrec_bpr_multi_losses_f32", P, cap, p_(nv), 1 - drop, 1e-5, 64.0, p_(out), p_(saved), st)
         else:
             _lib.call("llmrec_bpr_multi_fwd_f32", *common, 1 - drop, 1e-5, 64.0, p_(out), p_(saved), st)
-            _lib.call("llmrec_bpr_multi_bwd_f32", *common, 1e-5, 64.0, p_(saved), st)
+            _lib.call("llmrec_bpr_multi_bwd_f32", *common, 1e-5, 64.0, p_(saved), p_(plan), st)
         torch.cuda.synchronize()
         if fused:                                            # the rows of the valid samples carry the step's stamp, no other row changes
             assert int(stamp[0]) == 42 + 255 * 3
@@ -543,7 +546,9 @@ def test_bpr_select_and_backward_in_one_launch(ops, drop, cap, valid, d):
             assert torch.equal(a[lo + slot * cap:lo + slot * cap + valid].view(torch.int32), b[lo + slot * cap:lo + slot * cap + valid].view(torch.int32)), slot
     assert torch.equal(o0.view(torch.int32), o1.view(torch.int32))
     for i in range(P):
-        assert rel_err(g1[i][0], g0[i][0]) < 1e-6 and rel_err(g1[i][1], g0[i][1]) < 1e-6
+        assert torch.equal(g1[i][0].view(torch.int32), g0[i][0].view(torch.int32)) and torch.equal(g1[i][1].view(torch.int32), g0[i][1].view(torch.int32))
+    s2, o2, g2 = run(True)                                   # and again: the same bits (no float atomics anywhere in the scatter)
+    assert all(torch.equal(g2[i][k].view(torch.int32), g1[i][k].view(torch.int32)) for i in range(P) for k in (0, 1))
     if valid and int((1 - drop) * valid) > 0:
         cfg = O.Config(batch_size=64, decay=1e-5, prune_loss_drop_rate=drop)
         for i, (Eu, Ei) in enumerate(tabs):
@@ -553,6 +558,83 @@ def test_bpr_select_and_backward_in_one_launch(ops, drop, cap, valid, d):
             (w[i][0] * mf + w[i][1] * emb).backward()
             assert abs(float(o1[i, 0]) - float(mf)) < 3e-6 * abs(float(mf))
             assert rel_err(g1[i][0], a.grad) < 2e-5 and rel_err(g1[i][1], b.grad) < 2e-5
+
+
+def test_bpr_scatter_plan_layout(ops):
+    """llmrec_bpr_scatter_plan: sorted (id << 32 | slot) keys per side, the unused slots (id 0xffffffff) at the end, and the run
+    lengths at the first position of every run."""
+    rng = np.random.default_rng(2)
+    for cap, valid, with_count in ((37, 29, True), (37, 37, False), (1126, 1100, True), (16, 0, True)):
+        u, p, q = (torch.tensor(rng.integers(0, n, size=cap)) for n in (6, 9, 9))
+        nv = torch.tensor([valid], dtype=torch.int32, device=DEV) if with_count else None
+        plan = ops.bpr_scatter_plan(u.to(DEV), p.to(DEV), q.to(DEV), nv).cpu()
+        keys = plan[:3 * cap].numpy().astype(np.uint64)
+        runlen = plan[3 * cap:].view(torch.int32)[:3 * cap].numpy()
+        none = 0xFFFFFFFF
+        ku = sorted((int(u[b]) << 32) | b for b in range(valid)) + [(none << 32) | b for b in range(valid, cap)]
+        ki = sorted([(int(p[b]) << 32) | b for b in range(valid)] + [(int(q[b]) << 32) | (cap + b) for b in range(valid)]) + \
+            sorted([(none << 32) | b for b in range(valid, cap)] + [(none << 32) | (cap + b) for b in range(valid, cap)])
+        assert [int(x) for x in keys[:cap]] == ku and [int(x) for x in keys[cap:]] == ki
+        for side, want in ((runlen[:cap], ku), (runlen[cap:], ki)):
+            ids = [k >> 32 for k in want]
+            for j, i_ in enumerate(ids):
+                head = i_ != none and (j == 0 or ids[j - 1] != i_)
+                assert side[j] == (ids.count(i_) if head else 0), (cap, valid, j)
+
+
+@pytest.mark.parametrize("d", [64, 24, 200])
+def test_bpr_backward_is_deterministic_on_heavy_duplicates_and_shared_targets(ops, d):
+    """The loss backward's scatter (llmrec_bpr_multi_bwd_f32 through llmrec_bpr_scatter_plan): (a) a batch in which every sample hits
+    ONE user, two positives and three negatives (runs of hundreds of duplicates) against the oracle's index_put backward; (b) problems
+    that share one dEu buffer (the step's five attribute problems all scatter into d prof_u) = the sum of the same problems run into
+    buffers of their own; (c) two runs: the same bits."""
+    import ctypes
+    from llmrec_amd import _lib
+    rng = np.random.default_rng(17)
+    U, I, P, cap, valid = 40, 50, 4, 700, 613
+    tabs = [(torch.tensor((rng.standard_normal((U, d)) * 0.3).astype(np.float32)), torch.tensor((rng.standard_normal((I, d)) * 0.3).astype(np.float32)))
+            for _ in range(P)]
+    tabs = [(tabs[0][0], tabs[0][1])] + [(tabs[1][0], t[1]) for t in tabs[1:]]         # problems 1.. share their USER table (as prof_u)
+    idx = [torch.tensor(rng.choice(c, size=cap)) for c in ([7], [3, 11], [5, 6, 49])]
+    dev = [x.to(DEV) for x in idx]
+    nv = torch.tensor([valid], dtype=torch.int32, device=DEV)
+    dev_t = [(a.to(DEV), b.to(DEV)) for a, b in tabs]
+    w = [(1.0, 1.0)] + [(0.012, 0.0)] * (P - 1)
+    p_ = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = torch.cuda.current_stream().cuda_stream
+    plan = ops.bpr_scatter_plan(dev[0], dev[1], dev[2], nv)
+
+    def run(shared):
+        gu = [torch.zeros(U, d, device=DEV) for _ in range(P)]
+        if shared:
+            gu = [gu[0]] + [gu[1]] * (P - 1)
+        gi = [torch.zeros(I, d, device=DEV) for _ in range(P)]
+        arr = (ops.BprProblem * P)()
+        for i in range(P):
+            arr[i].Eu, arr[i].ldu, arr[i].Ei, arr[i].ldi = dev_t[i][0].data_ptr(), d, dev_t[i][1].data_ptr(), d
+            arr[i].dEu, arr[i].lddu, arr[i].dEi, arr[i].lddi = gu[i].data_ptr(), d, gi[i].data_ptr(), d
+            arr[i].g_mf, arr[i].g_emb = w[i]
+        saved = torch.zeros(P * ops.bpr_saved_floats(cap), device=DEV)
+        out = torch.zeros(P, 2, device=DEV)
+        common = (P, arr, d, p_(dev[0]), p_(dev[1]), p_(dev[2]), cap, p_(nv))
+        _lib.call("llmrec_bpr_multi_fwd_f32", *common, 1 - 0.71, 1e-5, 64.0, p_(out), p_(saved), st)
+        _lib.call("llmrec_bpr_multi_bwd_f32", *common, 1e-5, 64.0, p_(saved), p_(plan), st)
+        torch.cuda.synchronize()
+        return [g.cpu() for g in gu], [g.cpu() for g in gi]
+    gu_own, gi_own = run(False)
+    gu_sh, gi_sh = run(True)
+    gu_sh2, gi_sh2 = run(True)
+    assert all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(gu_sh + gi_sh, gu_sh2 + gi_sh2))
+    assert all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(gi_own, gi_sh))          # item targets: unchanged
+    assert torch.equal(gu_own[0].view(torch.int32), gu_sh[0].view(torch.int32))
+    assert rel_err(gu_sh[1], sum(gu_own[1:])) < 2e-5                            # (613 x 3 addends in another order)
+    cfg = O.Config(batch_size=64, decay=1e-5, prune_loss_drop_rate=0.71)
+    for i, (Eu, Ei) in enumerate(tabs):
+        a = Eu.clone().requires_grad_(True); b = Ei.clone().requires_grad_(True)
+        u, pp, q = (x[:valid] for x in idx)
+        mf, emb = O.bpr_loss(a[u], b[pp], b[q], cfg)
+        (w[i][0] * mf + w[i][1] * emb).backward()
+        assert rel_err(gu_own[i], a.grad) < 2e-5 and rel_err(gi_own[i], b.grad) < 2e-5
 
 
 # ------------------------------------------------------------------------------------------
