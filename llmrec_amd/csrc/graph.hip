@@ -325,16 +325,28 @@ int llmrec_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, int32_t t_wave,
     return LLMREC_OK;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of kernel `which` on the CURRENT device, set once per (kernel, device); false = refused
+static bool big_lds_ok(int which, const void* fn, int bytes) {
+    static signed char state[2][64] = {};                      // 0 unknown, 1 granted, -1 refused (a race between two first calls sets the same value twice)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = 0; }
+    if (state[which][dev] == 0) {
+        const bool ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        state[which][dev] = ok ? 1 : -1;
+    }
+    return state[which][dev] > 0;
+}
+
 int llmrec_sort_unique_ids_i32(int64_t n, const int64_t* ids, int32_t* list, int32_t* n_out, llmrec_stream_t stream_) {
     LLMREC_CHECK_ARG(n >= 0 && n <= LLMREC_SORT_UNIQUE_MAX && n_out, "sort_unique_ids: 0 <= n <= %d", LLMREC_SORT_UNIQUE_MAX);
     LLMREC_CHECK_ARG(n == 0 || (ids && list), "sort_unique_ids: null pointer");
     int n_pow2 = 2;
     while (n_pow2 < n) n_pow2 <<= 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LLMREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_unique_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       LLMREC_SORT_UNIQUE_MAX * (int)sizeof(uint32_t)));
-        attr_set = true;
+    if ((size_t)n_pow2 * sizeof(uint32_t) > 64 * 1024 && !big_lds_ok(0, reinterpret_cast<const void*>(sort_unique_block_kernel),
+                                                                      LLMREC_SORT_UNIQUE_MAX * (int)sizeof(uint32_t))) {
+        set_error("sort_unique_ids: %d ids need %zu B of LDS, which this device does not grant", (int)n, (size_t)n_pow2 * sizeof(uint32_t));
+        return LLMREC_EUNSUPPORTED;
     }
     sort_unique_block_kernel<<<1, 1024, (size_t)n_pow2 * sizeof(uint32_t), (hipStream_t)stream_>>>((int)n, n_pow2, ids, list, n_out);
     LLMREC_LAUNCH_CHECK();
@@ -365,17 +377,15 @@ int llmrec_scatter_rows_f32(int64_t n, const int64_t* ids, const float* rows, in
         int n_pow2 = 2;
         while (n_pow2 < n) n_pow2 <<= 1;
         const size_t shmem = (size_t)n_pow2 * sizeof(uint64_t);
-        static bool attr_set = false;                          // (idempotent; a race between two first calls sets the same value twice)
-        if (!attr_set) {
-            LLMREC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_sort_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           SCATTER_SORT_MAX * (int)sizeof(uint64_t)));
-            attr_set = true;
+        // more than 64 KB of LDS needs the per-DEVICE attribute (a process-wide flag skipped the second device); a part that
+        // does not grant it takes the radix-sort path below
+        if (shmem <= 64 * 1024 || big_lds_ok(1, reinterpret_cast<const void*>(scatter_sort_block_kernel), SCATTER_SORT_MAX * (int)sizeof(uint64_t))) {
+            scatter_sort_block_kernel<<<1, 1024, shmem, stream>>>((int)n, n_pow2, ids, keys_a);
+            LLMREC_LAUNCH_CHECK();
+            scatter_runs_kernel<<<(unsigned)ceil_div(n, 16), 256, 0, stream>>>(n, keys_a, rows, ldr, d, alpha, dst, ldd);
+            LLMREC_LAUNCH_CHECK();
+            return LLMREC_OK;
         }
-        scatter_sort_block_kernel<<<1, 1024, shmem, stream>>>((int)n, n_pow2, ids, keys_a);
-        LLMREC_LAUNCH_CHECK();
-        scatter_runs_kernel<<<(unsigned)ceil_div(n, 16), 256, 0, stream>>>(n, keys_a, rows, ldr, d, alpha, dst, ldd);
-        LLMREC_LAUNCH_CHECK();
-        return LLMREC_OK;
     }
     scatter_keys_kernel<<<grid_for(n, 256), 256, 0, stream>>>(n, ids, keys_a);
     LLMREC_LAUNCH_CHECK();

@@ -558,7 +558,10 @@ __device__ __forceinline__ void tk_split8(const float (&x)[8], uint4& H, uint4& 
     tk_split2(x[0], x[1], H.x, M.x); tk_split2(x[2], x[3], H.y, M.y);
     tk_split2(x[4], x[5], H.z, M.z); tk_split2(x[6], x[7], H.w, M.w);
 }
-constexpr float TK_PRE_SLACK = 0x1p-14f;                                 // ub = s' + TK_PRE_SLACK ||u|| ||i||  (both norms rounded UP by 2^-10)
+// ub = s' + slack ||u|| ||i||  (both norms rounded UP by 2^-10). slack >= 3.02 * 2^-16 (the dropped <u_m, i_m> term and the two split residuals)
+// + n * 2^-24 (fp32 accumulation of the n = 3 d products): d <= 64 -> 3.02 + 0.75 < 4 = 2^-14 * 2^16; d <= 128 -> 3.02 + 1.5 > 4, so the
+// bound doubles there (the d = 64 constant was used for every d).
+__device__ __host__ __forceinline__ float tk_pre_slack(int d) { return d <= 64 ? 0x1p-14f : 0x1p-13f; }
 constexpr float TK_NORM_UP = 1.0f + 0x1p-10f;
 
 // workspace header of the mode (first 256 bytes of the fragment area): [0] unused, [1] user tiles flagged for the exact sweep, [2] train rows swept as bitmaps
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(256) void topk_pack_items_bf16_kernel(TopkArgs a, i
     for (int j = 0; j < 8; ++j) { const int k = 8 * g + j; x[j] = k < a.d ? row[k] : 0.f; ss = fmaf(x[j], x[j], ss); }
     if (a.cn && (G & (G - 1)) == 0) {                                  // G = 4, 8, 16: an item's threads are G aligned neighbouring lanes - its
         for (int off = G >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);   // squared norm by a butterfly (fixed tree); G = 12: topk_item_norm_kernel
-        if (g == 0) a.cn[item_p] = item_p < a.n_items ? TK_PRE_SLACK * (sqrtf(ss) * TK_NORM_UP) : 0.f;
+        if (g == 0) a.cn[item_p] = item_p < a.n_items ? tk_pre_slack(a.d) * (sqrtf(ss) * TK_NORM_UP) : 0.f;
     }
     uint4 H, M;
     tk_split8(x, H, M);
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(256) void topk_pack_items_bf16_kernel(TopkArgs a, i
     pk2[base] = H; pk2[base + 64] = M;
 }
 
-// cn[item] = TK_PRE_SLACK * ||item|| rounded up: the item's factor of the score's upper bound. One 16-lane group per item; padded slots get 0.
+// cn[item] = tk_pre_slack(d) * ||item|| rounded up: the item's factor of the score's upper bound. One 16-lane group per item; padded slots get 0.
 __global__ __launch_bounds__(256) void topk_item_norm_kernel(TopkArgs a, float* __restrict__ cn, int64_t n_pad) {
     const int gl = threadIdx.x & 15;
     for (int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); item < n_pad; item += (int64_t)gridDim.x * 16) {
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(256) void topk_item_norm_kernel(TopkArgs a, float* 
             for (int k = gl; k < a.d; k += 16) ss = fmaf(row[k], row[k], ss);
         }
         ss = group_sum<16>(ss);
-        if (gl == 0) cn[item] = TK_PRE_SLACK * (sqrtf(ss) * TK_NORM_UP);
+        if (gl == 0) cn[item] = tk_pre_slack(a.d) * (sqrtf(ss) * TK_NORM_UP);
     }
 }
 

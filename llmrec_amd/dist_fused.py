@@ -40,6 +40,7 @@ from typing import List, Optional
 
 import torch
 
+from . import _lib
 from .dist import Comm, ShardedGraph
 
 
@@ -179,6 +180,12 @@ class ShardedFusedID:
         self.sparse_forward = sparse_backward and sparse_forward
         if self.sparse_forward:                                # the restricted last layer's row list (device) and its fixed-size message block
             cap = comm.world * 2 * batch_local
+            if cap > _lib.CONST["LLMREC_SORT_UNIQUE_MAX"]:      #  the one-block id sort's limit: refuse at set-up, not at the first step
+                raise RuntimeError("ShardedFusedStep: the restricted forward lists world * 2 * batch = %d item ids per step; llmrec_sort_unique_ids_i32 "
+                                   "takes at most %d - use sparse_forward=False (the dense forward) for this batch size"
+                                   % (cap, _lib.CONST["LLMREC_SORT_UNIQUE_MAX"]))
+            # (the layer's message is the FIXED-SIZE block of `cap` rows with a device-side count: with heavily duplicated batch items it
+            #  carries more bytes than the distinct rows alone would - the price of never reading the count back to the host)
             self.need_rows = torch.zeros(cap, dtype=torch.int32, device=dev)
             self.need_n = torch.zeros(1, dtype=torch.int32, device=dev)
             self.need_part = torch.zeros(cap, d, dtype=torch.float32, device=dev)

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 from tests._dropin import load_dropin, golden_argv
 from tests.conftest import GoldenCase, GOLDEN_CASES
 
-STEPS = 3
+STEPS = 6
 NAMES = ["item_trans.weight", "user_trans.bias", "image_trans.weight", "user_id_embedding.weight", "item_id_embedding.weight"]
 
 
@@ -74,8 +74,14 @@ def _worker(rank, world, port, case, out_dir, use_graph):
             losses.append(step.scal[1:4].clone().cpu().numpy())
     assert len(losses) == STEPS
     params = dict(tr.model_mm.named_parameters())
+    state = {}
+    for k, p_ in params.items():                               # EVERY parameter and both Adam moments (bitwise replicas)
+        state["p__" + k.replace(".", "_")] = p_.detach().cpu().numpy()
+        st = tr.optimizer.state.get(p_)
+        if st is not None:
+            state["m__" + k.replace(".", "_")] = st[0].detach().cpu().numpy(); state["v__" + k.replace(".", "_")] = st[1].detach().cpu().numpy()
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), losses=np.array(losses),
-             **{k.replace(".", "_"): params[k].detach().cpu().numpy() for k in NAMES})
+             **{k.replace(".", "_"): params[k].detach().cpu().numpy() for k in NAMES}, **state)
     torch.save(seen, os.path.join(out_dir, "batches%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -93,9 +99,11 @@ def test_two_process_replicas_match_single_process_global_batch(tmp_path, use_gr
     case = GOLDEN_CASES[0]
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path), use_graph), nprocs=world, join=True)
     r = [np.load(tmp_path / ("r%d.npz" % k)) for k in range(world)]
-    for k in NAMES:                                            # replicas bit-identical
+    full = [k for k in r[0].files if k[:3] in ("p__", "m__", "v__")]
+    assert sum(k.startswith("m__") for k in full) >= 10
+    for k in full:                                             # replicas bit-identical: every parameter, both Adam moments, after STEPS steps
         for j in range(1, world):
-            assert np.array_equal(r[0][k.replace(".", "_")], r[j][k.replace(".", "_")]), (k, j)
+            assert np.array_equal(r[0][k].view(np.int32), r[j][k].view(np.int32)), (k, j)
     for j in range(1, world):
         assert np.allclose(r[0]["losses"], r[j]["losses"], rtol=0, atol=0)
     # single process, global batch = the ranks' slices concatenated (valid entries of rank 0, then of rank 1, ...)

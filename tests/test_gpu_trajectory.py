@@ -23,7 +23,16 @@ from oracle import make_trajectory as MT
 
 METRIC_TOL = 0.002       # north_star's Recall@20 tolerance, applied to all 12 metric values of every evaluation
 LOSS_RTOL = 1e-3
-E_L2_TOL = 3e-3          # ||E_gpu - E_reference|| / ||E_reference|| after the LAST epoch (~1000 AdamW steps): measured 4e-7 at lr 1e-4, 3.5e-4 / 1.0e-3 at lr 1e-3
+# ||E_gpu - E_reference|| / ||E_reference|| after the LAST epoch (~1000 AdamW steps). Since round 6 the step is bitwise reproducible
+# (tests/test_gpu_reproducible.py: no float atomics in the gradient scatter), so this number is a CONSTANT of (case, path), not a sample:
+# measured (E_u, E_i), identical on every box so far -
+#   nf_mid     (lr 1e-4)  4.3e-7, 4.1e-7 on every path
+#   nf_mid_lr  (lr 1e-3)  3.5e-4, 3.0e-4 on every path
+#   ml_mid     (lr 1e-3)  4.4e-4, 6.1e-4 pre-propagated; 3.65e-3, 5.11e-3 in the reference's order of operations (graph / fused_reference_order)
+# - the per-step difference is 1e-6-class on both orders (tests/test_gpu_step.py, bench.py's gate); over 860 steps at lr 1e-3 it is amplified
+# by the trajectory itself, differently for each rounding pattern. The gate is twice the largest measured value of the case. (Round 5's single
+# 3e-3 was calibrated on ONE run of a then non-reproducible step - 1.0e-3 on the builder's box, 3.6e-3 on the driver's - and failed there.)
+E_L2_TOL = {"nf_mid": 1e-6, "nf_mid_lr": 7e-4, "ml_mid": 1.1e-2}
 
 
 @pytest.fixture(scope="module")
@@ -112,7 +121,7 @@ def test_training_trajectory_tracks_reference(case, path, datasets, monkeypatch)
     assert float(loss_rel.max()) <= LOSS_RTOL and float(mf_rel.max()) <= LOSS_RTOL and float(emb_rel.max()) <= LOSS_RTOL
     assert abs(best_recall - float(z["best_recall"])) <= METRIC_TOL
     assert _decisions(lines) == _decisions(meta["log_lines"])
-    assert all(e <= E_L2_TOL for e in e_rel), e_rel
+    assert all(e <= E_L2_TOL[case] for e in e_rel), e_rel
 
 
 def test_in_graph_sampler_path_tracks_the_oracle_over_many_steps(datasets, monkeypatch):
