@@ -181,7 +181,7 @@ class ShardedFusedID:
         if self.sparse_forward:                                # the restricted last layer's row list (device) and its fixed-size message block
             cap = comm.world * 2 * batch_local
             if cap > _lib.CONST["LLMREC_SORT_UNIQUE_MAX"]:      #  the one-block id sort's limit: refuse at set-up, not at the first step
-                raise RuntimeError("ShardedFusedStep: the restricted forward lists world * 2 * batch = %d item ids per step; llmrec_sort_unique_ids_i32 "
+                raise RuntimeError("ShardedFusedID: the restricted forward lists world * 2 * batch = %d item ids per step; llmrec_sort_unique_ids_i32 "
                                    "takes at most %d - use sparse_forward=False (the dense forward) for this batch size"
                                    % (cap, _lib.CONST["LLMREC_SORT_UNIQUE_MAX"]))
             # (the layer's message is the FIXED-SIZE block of `cap` rows with a device-side count: with heavily duplicated batch items it
