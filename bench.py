@@ -659,12 +659,20 @@ def spmm_roofline_large(device, seed, n_users=2_000_000, n_items=1_000_000, n_ed
     for name, a, X in (("ui", g.ui.fwd, Xi), ("iu", g.iu.fwd, Xu)):
         Y = torch.empty(a.n_rows, d, device=device)
         ms = event_time_ms(lambda: ops.spmm_raw(a, X, out=Y), 10, warmup=2)
+        # the same product through the operand's own CSR in row order (round 6: the plan's length-class ordered, permuted CSR is the default)
+        _, key = ops.spmm_shape(d, a.nnz)
+        keep = a.plans.get(key)
+        ms_plain = None
+        if keep is not None and keep.slot_row is not None:
+            a.plans[key] = ops.SpmmPlan.build(a.rowptr, *key)
+            ms_plain = event_time_ms(lambda: ops.spmm_raw(a, X, out=Y), 10, warmup=2)
+            a.plans[key] = keep
         alg = 4.0 * nnz + 4.0 * (a.n_rows + 1) + 4.0 * a.n_rows + 4.0 * d * a.n_cols + 4.0 * d * a.n_rows
         gather = nnz * (4.0 + 4.0 * d) + 4.0 * d * a.n_rows
         res[name] = {"ms": ms, "edges_per_s": nnz / ms * 1e3, "algorithmic_gbs": alg / ms / 1e6,
                      "frac_hbm_algorithmic": alg / ms / 1e6 / HBM_PEAK_GBS, "no_reuse_gather_gbs": gather / ms / 1e6,
                      "frac_gather_model": gather / ms / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "no_reuse_gather_bytes": gather,
-                     "n_long_rows": a.plan.n_long}
+                     "n_long_rows": a.plan.n_long, "ms_rows_in_id_order": ms_plain}
     out = {"graph": {"n_users": n_users, "n_items": n_items, "nnz": int(nnz), "d": d},
            "fractions": "frac_hbm_algorithmic = SURVEY 8(d)'s bytes (every X row read ONCE: 4 nnz + 8 rows + 4 d (rows + cols)) / time / 8 TB/s - north_star's >= 0.40 "
                         "target, UNMET on a structureless graph; frac_gather_model = the no-reuse gather model (nnz (4 + 4 d) + 4 d rows: every edge fetches "
@@ -681,6 +689,9 @@ def spmm_roofline_large(device, seed, n_users=2_000_000, n_items=1_000_000, n_ed
     cp = spmm_cache_policy_record()
     if cp is not None:
         out["cache_policy"] = cp
+    xm = spmm_xcd_map_record()
+    if xm is not None:
+        out["xcd_map"] = xm
     return out
 
 
@@ -698,6 +709,27 @@ def spmm_cache_policy_record():
                 "ui_ms": [_r(base["ui"]["ms"], 4), _r(best["ui"]["ms"], 4)], "ui_l2_hit": [_r(base["ui"].get("l2_hit_rate"), 3), _r(best["ui"].get("l2_hit_rate"), 3)],
                 "ui_traffic_gb": [_r(base["ui"].get("hbm_bytes_per_launch", 0) / 1e9, 3), _r(best["ui"].get("hbm_bytes_per_launch", 0) / 1e9, 3)],
                 "file": os.path.basename(files[-1])}
+    except Exception:
+        return None
+
+
+def spmm_xcd_map_record():
+    """The round-6 block -> row map experiment (profiles/r*_pmc_spmm_xcd.json, tools/spmm_xcd.sh): linear vs XCD-contiguous on the standard
+    generator and on the community-ordered graph, rows = users. None when absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_spmm_xcd.json")))
+    if not files:
+        return None
+    try:
+        rows = json.load(open(files[-1]))["rows"]
+        pick = lambda g, x: next(r for r in rows if r["graph"] == g and r["dir"] == "ui" and r["xcd_contiguous"] == x)
+        o = {"experiment": "xcd_contiguous_block_to_row_map", "file": os.path.basename(files[-1])}
+        for g in ("std", "comm"):
+            a_, b_ = pick(g, 0), pick(g, 1)
+            o[g] = {"ui_ms": [_r(a_["ms"], 4), _r(b_["ms"], 4)], "ui_traffic_gb": [_r(a_.get("traffic_gb"), 4), _r(b_.get("traffic_gb"), 4)],
+                    "ui_l2_hit": [_r(a_.get("l2_hit_rate"), 3), _r(b_.get("l2_hit_rate"), 3)]}
+        o["outcome"] = "positive on community-ordered ids, neutral on the standard generator; off by default (not combinable with the length-class order)"
+        return o
     except Exception:
         return None
 
@@ -1205,10 +1237,12 @@ def compact_line(line: dict) -> dict:
             out["roofline"]["second"] = roof(line["roofline"]["second"])
     sp = line.get("spmm_roofline")
     if isinstance(sp, dict):
-        out["spmm_roofline"] = {k: _pick(sp[k], ("ms", "frac_hbm_algorithmic", "frac_gather_model", "traffic_over_algorithmic", "l2_hit_rate"), 4)
+        out["spmm_roofline"] = {k: _pick(sp[k], ("ms", "ms_rows_in_id_order", "frac_hbm_algorithmic", "frac_gather_model", "traffic_over_algorithmic", "l2_hit_rate"), 4)
                                 for k in ("ui", "iu") if k in sp}
         if "cache_policy" in sp:
-            out["spmm_roofline"]["cache_policy"] = sp["cache_policy"]
+            out["spmm_roofline"]["cache_policy"] = {k: v for k, v in sp["cache_policy"].items() if k in ("experiment", "outcome", "file")}
+        if isinstance(sp.get("xcd_map"), dict):
+            out["spmm_roofline"]["xcd_map"] = {k: v for k, v in sp["xcd_map"].items() if k in ("experiment", "file", "comm")}
     cb = line.get("cpu_baseline")
     if isinstance(cb, dict):
         out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "ms_per_step", "eval_users_per_s"), 5)

@@ -105,6 +105,13 @@ typedef struct {
     int32_t n_split_rows; const int32_t* split_rows;       /* rows with nnz > t_block */
     const int32_t* split_seg_begin;                        /* [n_split_rows] first piece of each split row */
     int32_t n_segments;   const int32_t* seg_split;        /* [n_segments] index into split_rows */
+    /* Round 6 - PERMUTED CSR (pattern-only operands). slot_row != NULL: the rowptr / colidx arguments of llmrec_spmm_f32 are a copy of the operand's
+     * CSR whose rows are stored in the order they are visited (llmrec_csr_permute_rows): slots [0, n_short_rows) = the lane-group bucket (nnz <=
+     * LONG_ROW, empty rows included), then the wavefront, block and split rows; CSR row `slot` is output row slot_row[slot] (Y, Z, S, row_scale,
+     * post_scale and the row flags are addressed by OUTPUT row) and the four lists hold slots. llmrec_amd/ops.py orders every bucket by descending
+     * length class (power-of-two bucket of nnz), ascending row id within a class: a wavefront's 64 / LPR rows then have (almost) equal lengths
+     * and finish together, and the index stream stays sequential - profiles/experiments/r06_spmm_order.md. Results do not depend on the order. */
+    int32_t n_short_rows; const int32_t* slot_row;
 } llmrec_spmm_plan_t;
 
 #define LLMREC_SPMM_EPI_NONE 0
@@ -140,6 +147,10 @@ typedef struct {
      * degree (hot rows first), so that the cold 256-B rows stream through the L2 without displacing the hot set. A hint only: results are
      * bit-identical. Pattern-only, unmasked products; ignored otherwise. 0 = off. */
     int32_t x_nt_from_row;
+    /* Block -> row map (round 6 experiment, profiles/experiments/r06_spmm_order.md): xcd_contiguous != 0 gives the workgroups of one XCD (ids
+     * equal mod 8: each XCD has a private L2) a CONTIGUOUS piece of the short-row / wavefront-row / block-row tasks instead of every 8th
+     * block of them - for graphs whose row ids expose communities. Results are bit-identical. 0 = the linear map. */
+    int32_t xcd_contiguous;
 } llmrec_spmm_epilogue_t;
 /* Round 5 - "these rows of A X" with the row list AND its length in device memory (the row-restricted forward of the row-sharded step,
  * without a host read-back: llmrec_amd/dist_fused.py). Pattern-only operands (A = diag(row_scale) P).
@@ -182,6 +193,11 @@ int llmrec_spmm_plan_count(int64_t n_rows, const int32_t* rowptr, int32_t t_wave
 int llmrec_spmm_plan_fill(int64_t n_rows, const int32_t* rowptr, int32_t t_wave, int32_t t_block, int32_t segment,
                           int32_t* scratch4, int32_t* wave_rows, int32_t* block_rows, int32_t* split_rows,
                           int32_t* split_seg_begin, int32_t* seg_split, llmrec_stream_t stream);
+
+/* p_colidx[p_rowptr[s] + j] = colidx[rowptr[perm[s]] + j]: the CSR with its rows stored in the order perm (p_rowptr = the prefix sums of the
+ * permuted row lengths, computed by the caller). One lane group per row. */
+int llmrec_csr_permute_rows(int64_t n_rows, const int32_t* rowptr, const int32_t* colidx, const int32_t* perm, const int32_t* p_rowptr,
+                            int32_t* p_colidx, llmrec_stream_t stream);
 
 int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
                     const int32_t* rowptr, const int32_t* colidx, const float* val,

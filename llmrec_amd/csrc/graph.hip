@@ -193,6 +193,17 @@ __global__ __launch_bounds__(256) void scatter_runs_kernel(int64_t n, const uint
     }
 }
 
+// one 16-lane group per destination row: copies the row's index segment
+__global__ __launch_bounds__(256) void csr_permute_rows_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                               const int32_t* __restrict__ perm, const int32_t* __restrict__ p_rowptr,
+                                                               int32_t* __restrict__ p_colidx) {
+    const int gl = threadIdx.x & 15;
+    for (int64_t s = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); s < n_rows; s += (int64_t)gridDim.x * 16) {
+        const int32_t src = rowptr[perm[s]], dst = p_rowptr[s], len = p_rowptr[s + 1] - dst;
+        for (int32_t j = gl; j < len; j += 16) p_colidx[dst + j] = colidx[src + j];
+    }
+}
+
 }  // namespace llmrec
 
 using namespace llmrec;
@@ -291,6 +302,15 @@ int llmrec_csr_row_constant(int64_t n_rows, const int32_t* rowptr, const float* 
         LLMREC_LAUNCH_CHECK();
     }
     flag_finish_kernel<<<1, 1, 0, stream>>>(flag_out);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int llmrec_csr_permute_rows(int64_t n_rows, const int32_t* rowptr, const int32_t* colidx, const int32_t* perm, const int32_t* p_rowptr,
+                            int32_t* p_colidx, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_rows >= 0 && rowptr && perm && p_rowptr, "csr_permute_rows: bad argument");
+    if (n_rows == 0) return LLMREC_OK;
+    csr_permute_rows_kernel<<<grid_for(n_rows, 16, 256 * 32), 256, 0, (hipStream_t)stream_>>>(n_rows, rowptr, colidx, perm, p_rowptr, p_colidx);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

@@ -109,7 +109,10 @@ struct SpmmArgs {
     const uint8_t* y_needed;     // rows whose byte != x_active are neither computed nor written (short-row range)
     int32_t listed_only;         // no short-row range at all: only the plan's row lists are computed
     int32_t nt_from;             // (NT kernels) X rows with index >= nt_from are gathered with the non-temporal policy: cache hint only
+    int32_t xcd;                 // block -> row map of the short-row / wavefront-row / block-row ranges: XCD-contiguous (xcd_range_logical)
     // plan
+    const int32_t* slot_row;     // non-NULL: rowptr / colidx are the PERMUTED CSR of the plan - CSR row `slot` is output row slot_row[slot], the
+    int32_t n_short_rows;        // first n_short_rows slots are the lane-group bucket, the plan's lists hold slots (llmrec_spmm_plan_t)
     const int32_t* wave_rows;
     const int32_t* block_rows;
     const int32_t* split_rows;
@@ -277,12 +280,14 @@ __device__ __forceinline__ void rows_body(const SpmmArgs& a, int64_t block) {
     constexpr int GPB = TPB / LPR;
     const int gl = threadIdx.x & (LPR - 1);
     const int64_t task = block * GPB + (threadIdx.x / LPR);
-    if (task >= a.n_rows * a.n_slices) return;
-    const int64_t slice = task / a.n_rows, row = task - slice * a.n_rows;      // slice-major: neighbouring lane groups take neighbouring rows
+    const int64_t n_list = a.slot_row ? (int64_t)a.n_short_rows : a.n_rows;
+    if (task >= n_list * a.n_slices) return;
+    const int64_t slice = task / n_list, slot = task - slice * n_list;         // slice-major: neighbouring lane groups take neighbouring rows
+    const int64_t row = a.slot_row ? (int64_t)a.slot_row[slot] : slot;         // (permuted CSR: by descending length class - equal lengths side by side)
     const int64_t col0 = slice * a.d;
     if (a.y_needed && (int)a.y_needed[row] != a.x_active) return;                // (uniform per lane group) nobody reads this row
-    const int32_t s = a.rowptr[row], e = a.rowptr[row + 1];
-    if ((e - s) > LLMREC_SPMM_LONG_ROW) return;
+    const int32_t s = a.rowptr[slot], e = a.rowptr[slot + 1];
+    if (!a.slot_row && (e - s) > LLMREC_SPMM_LONG_ROW) return;
     Vec<VEC> acc[NCHUNK];
 #pragma unroll
     for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
@@ -328,10 +333,12 @@ __device__ __forceinline__ void wave_range(const SpmmArgs& a, int64_t col0, int3
 }
 
 // (row, slice) tasks of a row list, slice-major
-__device__ __forceinline__ void list_task(const SpmmArgs& a, const int32_t* list, int32_t n_list, int64_t task, int32_t& row, int64_t& col0, int32_t& slot) {
+// crow: the row of the CSR arrays (a slot of the permuted CSR when there is one), row: the output row
+__device__ __forceinline__ void list_task(const SpmmArgs& a, const int32_t* list, int32_t n_list, int64_t task, int32_t& crow, int32_t& row, int64_t& col0, int32_t& slot) {
     const int64_t slice = task / n_list;
     slot = (int32_t)(task - slice * n_list);
-    row = list[slot];
+    crow = list[slot];
+    row = a.slot_row ? a.slot_row[crow] : crow;
     col0 = slice * a.d;
 }
 
@@ -341,13 +348,13 @@ __device__ __forceinline__ void wave_rows_body(const SpmmArgs& a, int32_t block)
     const int lane = threadIdx.x & 63;
     const int64_t task = (int64_t)block * (TPB / 64) + (threadIdx.x >> 6);
     if (task >= (int64_t)a.n_wave_rows * a.n_slices) return;
-    int32_t row, slot; int64_t col0;
-    list_task(a, a.wave_rows, a.n_wave_rows, task, row, col0, slot);
+    int32_t crow, row, slot; int64_t col0;
+    list_task(a, a.wave_rows, a.n_wave_rows, task, crow, row, col0, slot);
     Vec<VEC> acc[NCHUNK];
     int any = 0;
     bool zero_row = false;
     if (MASKED) {                                                        // as in rows_body: scan the mask first, accumulate only if something is active
-        const int32_t rs = a.rowptr[row], re = a.rowptr[row + 1];
+        const int32_t rs = a.rowptr[crow], re = a.rowptr[crow + 1];
         for (int32_t base = rs; base < re; base += 64)
             if (base + lane < re) any |= (int)a.x_mask[a.colidx[base + lane]] == a.x_active;
         const bool any_w = __ballot(any != 0) != 0ull;
@@ -358,7 +365,7 @@ __device__ __forceinline__ void wave_rows_body(const SpmmArgs& a, int32_t block)
             for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
         }
     } else {
-        wave_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, col0, a.rowptr[row], a.rowptr[row + 1], lane, acc, any);
+        wave_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, col0, a.rowptr[crow], a.rowptr[crow + 1], lane, acc, any);
     }
     if (lane < LPR) finish_row<LPR, NCHUNK, VEC>(a, col0, row, lane, acc, zero_row);
 }
@@ -388,6 +395,18 @@ __device__ __forceinline__ bool block_range(const SpmmArgs& a, int64_t col0, int
     return true;
 }
 
+// Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with a private L2 (4 MB). With the linear block -> row map every XCD
+// therefore walks the WHOLE row range (every 8th block), and on a graph whose ids expose communities each community's X rows are fetched
+// into all eight L2s. xcd = 1 (llmrec_spmm_epilogue_t.xcd_contiguous): within a range [base, base + n) of block ids the blocks of XCD x
+// (ids = x mod 8) take the x-th contiguous piece of the range's tasks, in id order - neighbouring rows run on ONE XCD and each L2 holds
+// the columns of its own eighth of the rows. Only the block -> row map changes: results are bit-identical.
+__device__ __forceinline__ int32_t xcd_range_logical(int32_t b, int32_t base, int32_t n) {
+    const int x = b & 7, r0 = base & 7;
+    int32_t off = 0;
+    for (int xx = 0; xx < x; ++xx) { const int fl = (xx - r0) & 7; off += fl < n ? (n - fl + 7) >> 3 : 0; }
+    return off + ((b - base - ((x - r0) & 7)) >> 3);
+}
+
 // ONE launch: [0, blk_seg) segments of the split rows, [blk_seg, blk_block) block rows, [blk_block, blk_wave) wave
 // rows (8 per block), the rest short rows. The heavy blocks come first.
 template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED, bool NT>
@@ -395,13 +414,19 @@ __global__ __launch_bounds__(TPB) void spmm_kernel(SpmmArgs a) {
     constexpr int ROWW = NCHUNK * LPR * VEC;
     __shared__ __attribute__((aligned(16))) float red_lds[(TPB / 64 - 1) * ROWW];
     const int32_t b = blockIdx.x;
-    if (b >= a.blk_wave) { rows_body<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, (int64_t)b - a.blk_wave); return; }
-    if (b >= a.blk_block) { wave_rows_body<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, b - a.blk_block); return; }
+    if (b >= a.blk_wave) {
+        rows_body<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, a.xcd ? (int64_t)xcd_range_logical(b, a.blk_wave, (int32_t)gridDim.x - a.blk_wave) : (int64_t)b - a.blk_wave);
+        return;
+    }
+    if (b >= a.blk_block) {
+        wave_rows_body<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, a.xcd ? xcd_range_logical(b, a.blk_block, a.blk_wave - a.blk_block) : b - a.blk_block);
+        return;
+    }
     Vec<VEC> acc[NCHUNK];
-    int32_t row, slot; int64_t col0;
+    int32_t crow, row, slot; int64_t col0;
     if (b >= a.blk_seg) {
-        list_task(a, a.block_rows, a.n_block_rows, b - a.blk_seg, row, col0, slot);
-        if (block_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, col0, a.rowptr[row], a.rowptr[row + 1], red_lds, acc)) {
+        list_task(a, a.block_rows, a.n_block_rows, a.xcd ? xcd_range_logical(b, a.blk_seg, a.blk_block - a.blk_seg) : b - a.blk_seg, crow, row, col0, slot);
+        if (block_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, col0, a.rowptr[crow], a.rowptr[crow + 1], red_lds, acc)) {
             if (MASKED && col0 == 0 && threadIdx.x == 0 && a.y_flag) a.y_flag[row] = (uint8_t)a.x_active;   // conservative: "may be non-zero"
             finish_row<LPR, NCHUNK, VEC>(a, col0, row, threadIdx.x, acc);
         }
@@ -409,11 +434,12 @@ __global__ __launch_bounds__(TPB) void spmm_kernel(SpmmArgs a) {
     }
     const int32_t slice = b / a.n_segments, seg = b - slice * a.n_segments;
     slot = a.seg_split[seg];
-    row = a.split_rows[slot];
+    crow = a.split_rows[slot];
+    row = a.slot_row ? a.slot_row[crow] : crow;
     col0 = (int64_t)slice * a.d;
     const int32_t k_in_row = seg - a.split_seg_begin[slot];
-    const int32_t re = a.rowptr[row + 1];
-    const int32_t s = a.rowptr[row] + k_in_row * a.segment;
+    const int32_t re = a.rowptr[crow + 1];
+    const int32_t s = a.rowptr[crow] + k_in_row * a.segment;
     const int32_t e = min(s + a.segment, re);
     if (block_range<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, col0, s, e, red_lds, acc)) {
         if (MASKED && col0 == 0 && k_in_row == 0 && threadIdx.x == 0 && a.y_flag) a.y_flag[row] = (uint8_t)a.x_active;   // conservative
@@ -435,8 +461,9 @@ __global__ __launch_bounds__(256) void spmm_finalize_kernel(SpmmArgs a) {
     __shared__ __attribute__((aligned(16))) float fin_lds[G * ROWW];
     const int gl = threadIdx.x & (LPR - 1), g = threadIdx.x / LPR;
     const int32_t slice = blockIdx.x / a.n_split_rows, slot = blockIdx.x - slice * a.n_split_rows;
-    const int32_t row = a.split_rows[slot];
-    const int32_t deg = a.rowptr[row + 1] - a.rowptr[row];
+    const int32_t crow = a.split_rows[slot];
+    const int32_t row = a.slot_row ? a.slot_row[crow] : crow;
+    const int32_t deg = a.rowptr[crow + 1] - a.rowptr[crow];
     const int32_t nseg = (deg + a.segment - 1) / a.segment;
     const float* pr = a.partials + ((int64_t)slice * a.n_segments + a.split_seg_begin[slot]) * a.d;
     Vec<VEC> acc[NCHUNK];
@@ -540,7 +567,7 @@ static int launch_spmm(SpmmArgs& a, hipStream_t stream) {
     const bool weighted = a.val != nullptr || a.col_scale != nullptr;
     constexpr int GPB = TPB / LPR;
     const int64_t S = a.n_slices;
-    const int64_t row_blocks = a.listed_only ? 0 : ceil_div(a.n_rows * S, GPB);
+    const int64_t row_blocks = a.listed_only ? 0 : ceil_div((a.slot_row ? (int64_t)a.n_short_rows : a.n_rows) * S, GPB);
     const int64_t wave_blocks = ceil_div(a.n_wave_rows * S, TPB / 64);
     const int64_t total = a.n_segments * S + a.n_block_rows * S + wave_blocks + row_blocks;
     if (total > 0x7fffffffll) { set_error("spmm: too many rows for one launch"); return LLMREC_EUNSUPPORTED; }
@@ -594,6 +621,9 @@ extern "C" int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
     a.n_slices = slice_width > 0 ? d / slice_width : 1;
     a.wave_rows = p.wave_rows; a.block_rows = p.block_rows; a.split_rows = p.split_rows; a.split_seg_begin = p.split_seg_begin;
     a.seg_split = p.seg_split; a.partials = partials;
+    LLMREC_CHECK_ARG(p.n_short_rows >= 0 && p.n_short_rows <= n_rows, "spmm: bad short-row count");
+    LLMREC_CHECK_ARG(!p.slot_row || (!val && !(epilogue_host && epilogue_host->rows_listed_only)), "spmm: a permuted CSR is pattern-only and complete");
+    a.slot_row = p.slot_row; a.n_short_rows = p.slot_row ? p.n_short_rows : 0;
     a.n_wave_rows = p.n_wave_rows; a.n_block_rows = p.n_block_rows; a.n_split_rows = p.n_split_rows; a.n_segments = p.n_segments;
     a.segment = p.segment;
     a.epi_op = LLMREC_SPMM_EPI_NONE; a.alpha = 0.f;
@@ -608,6 +638,7 @@ extern "C" int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
         a.listed_only = e.rows_listed_only != 0;
         LLMREC_CHECK_ARG(e.x_nt_from_row >= 0, "spmm: negative x_nt_from_row");
         a.nt_from = e.x_nt_from_row;
+        a.xcd = e.xcd_contiguous != 0;
         if (e.y_row_needed) {
             LLMREC_CHECK_ARG(e.x_mask_active >= 1 && e.x_mask_active <= 255, "spmm: y_row_needed needs x_mask_active in 1..255");
             a.y_needed = e.y_row_needed; a.x_active = e.x_mask_active;

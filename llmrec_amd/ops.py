@@ -59,7 +59,7 @@ class SpmmPlanC(_c.Structure):
     _fields_ = [("t_wave", _c.c_int32), ("t_block", _c.c_int32), ("segment", _c.c_int32),
                 ("n_wave_rows", _c.c_int32), ("wave_rows", _c.c_void_p), ("n_block_rows", _c.c_int32), ("block_rows", _c.c_void_p),
                 ("n_split_rows", _c.c_int32), ("split_rows", _c.c_void_p), ("split_seg_begin", _c.c_void_p),
-                ("n_segments", _c.c_int32), ("seg_split", _c.c_void_p)]
+                ("n_segments", _c.c_int32), ("seg_split", _c.c_void_p), ("n_short_rows", _c.c_int32), ("slot_row", _c.c_void_p)]
 
 
 class SpmmEpilogueC(_c.Structure):
@@ -67,7 +67,7 @@ class SpmmEpilogueC(_c.Structure):
     _fields_ = [("op", _c.c_int32), ("alpha", _c.c_float), ("Z", _c.c_void_p), ("ldz", _c.c_int64), ("S", _c.c_void_p), ("lds", _c.c_int64),
                 ("post_scale", _c.c_void_p), ("x_row_mask", _c.c_void_p), ("x_mask_active", _c.c_int32), ("y_row_flag", _c.c_void_p),
                 ("z_row_flag", _c.c_void_p), ("y_row_gate", _c.c_void_p), ("y_row_needed", _c.c_void_p), ("rows_listed_only", _c.c_int32),
-                ("x_nt_from_row", _c.c_int32)]
+                ("x_nt_from_row", _c.c_int32), ("xcd_contiguous", _c.c_int32)]
 
 
 EPI_NONE, EPI_SOFTMAX, EPI_SOFTMAX_BWD = 0, 1, 2
@@ -109,6 +109,20 @@ class SpmmPlan:
     split_rows: Optional[torch.Tensor] = None
     split_seg_begin: Optional[torch.Tensor] = None
     seg_split: Optional[torch.Tensor] = None
+    # the permuted CSR (llmrec_spmm_plan_t.slot_row): rows stored in visiting order, slot -> output row; None = the operand's own CSR
+    n_short: int = 0
+    slot_row: Optional[torch.Tensor] = None
+    p_rowptr: Optional[torch.Tensor] = None
+    p_colidx: Optional[torch.Tensor] = None
+    colidx_src: int = 0               # data_ptr of the colidx the permuted copy was made from
+
+    def csr_of(self, a: "Csr"):
+        """(rowptr, colidx) llmrec_spmm_f32 gets with this plan: the permuted copy when the plan has one (made from THIS operand's pattern)."""
+        if self.slot_row is None:
+            return a.rowptr, a.colidx
+        if a.val is not None or a.colidx.data_ptr() != self.colidx_src:
+            raise RuntimeError("SpmmPlan: the permuted CSR of this plan belongs to another pattern (plans are shared by operands over ONE pattern)")
+        return self.p_rowptr, self.p_colidx
 
     @property
     def n_long(self) -> int:
@@ -120,7 +134,8 @@ class SpmmPlan:
             dp = lambda t, n: t.data_ptr() if n else None
             c = self._c = SpmmPlanC(self.t_wave, self.t_block, self.segment, self.n_wave, dp(self.wave_rows, self.n_wave),
                                     self.n_block, dp(self.block_rows, self.n_block), self.n_split, dp(self.split_rows, self.n_split),
-                                    dp(self.split_seg_begin, self.n_split), self.n_seg, dp(self.seg_split, self.n_split))
+                                    dp(self.split_seg_begin, self.n_split), self.n_seg, dp(self.seg_split, self.n_split),
+                                    self.n_short if self.slot_row is not None else 0, dp(self.slot_row, self.slot_row is not None))
         return c
 
     def scratch(self, d: int, device) -> Optional[torch.Tensor]:
@@ -136,23 +151,64 @@ class SpmmPlan:
         return cache[key]
 
     @staticmethod
-    def build(rowptr: torch.Tensor, t_wave: int = 128, t_block: int = 2048, segment: int = 2048) -> "SpmmPlan":
+    def by_length_class(rows: torch.Tensor, deg: torch.Tensor) -> torch.Tensor:
+        """`rows` (ascending ids) reordered by descending length class - the power-of-two bucket of the row's nnz, empty rows last - and
+        ascending id within a class (stable): rows that share a wavefront / a round of blocks then take (almost) equally long."""
+        if os.environ.get("LLMREC_SPMM_CLASS", "log2") == "exact":       # (experiment: one class per length)
+            cls = deg.to(torch.int64)
+        else:
+            cls = torch.where(deg > 0, torch.floor(torch.log2(deg.clamp(min=1).to(torch.float64))).to(torch.int64) + 1, torch.zeros_like(deg, dtype=torch.int64))
+        return rows[torch.sort(-cls, stable=True).indices].to(torch.int32).contiguous()
+
+    @staticmethod
+    def build(rowptr: torch.Tensor, t_wave: int = 128, t_block: int = 2048, segment: int = 2048, colidx: Optional[torch.Tensor] = None,
+              order_rows: Optional[bool] = None) -> "SpmmPlan":
+        """colidx (pattern-only operands) + order_rows: the plan carries a PERMUTED copy of the CSR - every bucket's rows stored in the order
+        they are visited, by descending length class (by_length_class). order_rows None = on (LLMREC_SPMM_ORDER=0: the operand's own CSR in
+        row order). Measured (profiles/experiments/r06_spmm_order.md): 2 M x 1 M x 40 M edges, d = 64: 1.65 -> 1.39 ms (rows = users),
+        1.14 -> 0.99 ms (rows = items); cfg 4 whole 57.2 -> 53.5 ms per step; the Netflix-shaped step 0.460 -> 0.447 ms. Results never
+        depend on the order (bit-identical: tests/test_gpu_ops.py)."""
         n_rows = rowptr.numel() - 1
         dev = rowptr.device
+        if order_rows is None:
+            order_rows = os.environ.get("LLMREC_SPMM_ORDER", "1") != "0"
+        order_rows = bool(order_rows) and colidx is not None and n_rows > 0
         scratch = torch.zeros(4, dtype=torch.int32, device=dev)
         counts = (_c.c_int32 * 4)()
         _lib.call("llmrec_spmm_plan_count", n_rows, _p(rowptr), t_wave, t_block, segment, _p(scratch), counts, _stream())
         nw, nb, nsp, nseg = (int(x) for x in counts)
-        if nw + nb + nsp == 0:
-            return SpmmPlan(t_wave, t_block, segment)
-        i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        wr, br, sr, sb, ss = i32(nw), i32(nb), i32(nsp), i32(nsp), i32(nseg)
-        _lib.call("llmrec_spmm_plan_fill", n_rows, _p(rowptr), t_wave, t_block, segment, _p(scratch), _p(wr), _p(br), _p(sr), _p(sb), _p(ss), _stream())
-        # the fill compacts with atomics: sort the two independent row lists so that the plan (and the order rows are
-        # visited in) is reproducible run to run; results never depend on the order
-        wr = torch.sort(wr[:nw]).values.contiguous() if nw else None
-        br = torch.sort(br[:nb]).values.contiguous() if nb else None
-        return SpmmPlan(t_wave, t_block, segment, nw, nb, nsp, nseg, wr, br, sr if nsp else None, sb if nsp else None, ss if nsp else None)
+        wr = br = sr = sb = ss = None
+        if nw + nb + nsp:
+            i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+            wr, br, sr, sb, ss = i32(nw), i32(nb), i32(nsp), i32(nsp), i32(nseg)
+            _lib.call("llmrec_spmm_plan_fill", n_rows, _p(rowptr), t_wave, t_block, segment, _p(scratch), _p(wr), _p(br), _p(sr), _p(sb), _p(ss), _stream())
+            # the fill compacts with atomics: sort the two independent row lists so that the plan (and the order rows are
+            # visited in) is reproducible run to run; results never depend on the order
+            wr = torch.sort(wr[:nw]).values.contiguous() if nw else None
+            br = torch.sort(br[:nb]).values.contiguous() if nb else None
+            sr, sb, ss = (sr, sb, ss) if nsp else (None, None, None)
+        if not order_rows:
+            return SpmmPlan(t_wave, t_block, segment, nw, nb, nsp, nseg, wr, br, sr, sb, ss)
+        deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+        ids = torch.nonzero(deg <= CONST["LLMREC_SPMM_LONG_ROW"]).flatten()
+        parts = [SpmmPlan.by_length_class(ids, deg[ids])]
+        if nw:
+            parts.append(SpmmPlan.by_length_class(wr.long(), deg[wr.long()]))
+        if nb:
+            parts.append(SpmmPlan.by_length_class(br.long(), deg[br.long()]))
+        if nsp:
+            parts.append(sr[:nsp])
+        n_short = parts[0].numel()
+        slot_row = torch.cat(parts).contiguous()                       # slot -> row
+        assert slot_row.numel() == n_rows
+        p_rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(deg[slot_row.long()], 0, out=p_rowptr[1:])
+        p_rowptr = p_rowptr.to(torch.int32)
+        p_colidx = torch.empty_like(colidx)
+        _lib.call("llmrec_csr_permute_rows", n_rows, _p(rowptr), _p(colidx), _p(slot_row), _p(p_rowptr), _p(p_colidx), _stream())
+        ar = lambda lo, n: torch.arange(lo, lo + n, dtype=torch.int32, device=dev) if n else None     # the lists hold slots
+        return SpmmPlan(t_wave, t_block, segment, nw, nb, nsp, nseg, ar(n_short, nw), ar(n_short + nw, nb), ar(n_short + nw + nb, nsp), sb, ss,
+                        n_short, slot_row, p_rowptr, p_colidx, colidx.data_ptr())
 
 
 @dataclass
@@ -184,7 +240,7 @@ class Csr:
                 # building a plan synchronises (llmrec_spmm_plan_count returns counts to the host) - illegal under capture
                 raise RuntimeError("Csr.plan_for: no row plan for (d = %d, whole_row = %s) yet and the stream is being captured; "
                                    "run the same product once eagerly (a warm-up step) before capturing" % (d, whole_row))
-            pl = self.plans[key] = SpmmPlan.build(self.rowptr, *key)
+            pl = self.plans[key] = SpmmPlan.build(self.rowptr, *key, colidx=self.colidx if self.val is None else None)
         return sw, pl
 
     @property
@@ -300,13 +356,14 @@ def spmm_epilogue(op: int = EPI_NONE, alpha: float = 0.0, Z: Optional[torch.Tens
                   post_scale: Optional[torch.Tensor] = None, x_row_mask: Optional[torch.Tensor] = None, x_mask_active: int = 0,
                   y_row_flag: Optional[torch.Tensor] = None, z_row_flag: Optional[torch.Tensor] = None,
                   y_row_gate: Optional[torch.Tensor] = None, y_row_needed: Optional[torch.Tensor] = None, rows_listed_only: bool = False,
-                  x_nt_from_row: int = 0):
+                  x_nt_from_row: int = 0, xcd_contiguous: bool = False):
     """llmrec_spmm_epilogue_t: Y = post_scale . op(alpha * Z + A X); S = forward softmax rows for EPI_SOFTMAX_BWD.
     x_row_mask (uint8 [n_cols]) / x_mask_active: X rows whose byte differs from the active value are promised all-zero and not read;
     y_row_flag (uint8 [n_rows]): receives the active value for rows whose result can be non-zero (z_row_flag: the non-zero rows of Z);
     y_row_gate (uint8 [n_rows]): rows without the active value are promised zero results and written as zeros unread;
     y_row_needed (uint8 [n_rows]): rows without the active value are neither computed nor written; rows_listed_only: compute the rows
-    in the plan's lists only (spmm_listed); x_nt_from_row > 0: X rows from that index on are gathered with non-temporal loads (cache hint)."""
+    in the plan's lists only (spmm_listed); x_nt_from_row > 0: X rows from that index on are gathered with non-temporal loads (cache hint);
+    xcd_contiguous: the workgroups of one XCD take a contiguous piece of the rows (same bits, another block -> row map)."""
     for t in (x_row_mask, y_row_flag, z_row_flag, y_row_gate, y_row_needed):
         if t is not None and (t.dtype != torch.uint8 or not t.is_contiguous()):
             raise RuntimeError("spmm_epilogue: row masks / flags are contiguous uint8 tensors")
@@ -317,7 +374,8 @@ def spmm_epilogue(op: int = EPI_NONE, alpha: float = 0.0, Z: Optional[torch.Tens
                          y_row_flag.data_ptr() if y_row_flag is not None else None,
                          z_row_flag.data_ptr() if z_row_flag is not None else None,
                          y_row_gate.data_ptr() if y_row_gate is not None else None,
-                         y_row_needed.data_ptr() if y_row_needed is not None else None, 1 if rows_listed_only else 0, int(x_nt_from_row))
+                         y_row_needed.data_ptr() if y_row_needed is not None else None, 1 if rows_listed_only else 0, int(x_nt_from_row),
+                         1 if xcd_contiguous else 0)
 
 
 def listed_plan(a: Csr, rows: torch.Tensor, d: int, whole_row: bool = False) -> SpmmPlan:
@@ -417,7 +475,8 @@ def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumu
             Xs = cache[key] = torch.empty(X.shape, dtype=torch.float32, device=X.device)
         _lib.call("llmrec_scale_rows_f32", X.shape[0], d, _p(col_scale), _p(X), _ld(X), _p(Xs), _ld(Xs), _stream())
         X, col_scale = Xs, None
-    _lib.call("llmrec_spmm_f32", a.n_rows, a.n_cols, _p(a.rowptr), _p(a.colidx), _p(a.val), _p(a.row_scale),
+    rp, ci = pl.csr_of(a)
+    _lib.call("llmrec_spmm_f32", a.n_rows, a.n_cols, _p(rp), _p(ci), _p(a.val), _p(a.row_scale),
               _p(col_scale), _p(X), _ld(X), _p(Y), _ld(Y), d, sw, _c.byref(pl.c_struct()), _p(partials),
               _c.byref(epilogue) if epilogue is not None else None, _stream())
     return Y

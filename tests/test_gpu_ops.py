@@ -142,6 +142,23 @@ def test_spmm_row_buckets_split_rows_and_epilogues(ops):
             op.fwd.plans[key] = ops.SpmmPlan.build(op.fwd.rowptr, *alt)
             assert rel_err(ops.spmm_raw(op.fwd, X).cpu(), want) < 4e-6, (d, alt)
         op.fwd.plans[key] = keep
+        # round 6: the plan's PERMUTED CSR (rows stored by descending length class, slot -> row map, lists in slots): the same bits as the
+        # operand's own CSR - with every bucket populated (lane-group rows incl. empty ones, wavefront, block and split rows), with the
+        # "+ Z" and softmax epilogues, with column slices, and with the XCD-contiguous block -> row map
+        assert op.fwd.val is None and keep.slot_row is None
+        for alt in (key, (32, 32, 64)):
+            perm = ops.SpmmPlan.build(op.fwd.rowptr, *alt, colidx=op.fwd.colidx, order_rows=True)
+            assert perm.slot_row is not None and sorted(perm.slot_row.tolist()) == list(range(n_rows))
+            plain = ops.SpmmPlan.build(op.fwd.rowptr, *alt)
+            for epi in (lambda: None, lambda: ops.spmm_epilogue(ops.EPI_NONE, 0.25, Z), lambda: ops.spmm_epilogue(ops.EPI_SOFTMAX),
+                        lambda: ops.spmm_epilogue(ops.EPI_SOFTMAX_BWD, 0.5, Z, torch.softmax(Z, dim=-1)),
+                        lambda: ops.spmm_epilogue(xcd_contiguous=True)):
+                op.fwd.plans[key] = plain
+                a_ = ops.spmm_raw(op.fwd, X, epilogue=epi())
+                op.fwd.plans[key] = perm
+                b_ = ops.spmm_raw(op.fwd, X, epilogue=epi())
+                assert torch.equal(a_.view(torch.int32), b_.view(torch.int32)), (d, alt)
+        op.fwd.plans[key] = keep
         Y2 = ops.spmm_raw(op.fwd, X, epilogue=ops.spmm_epilogue(ops.EPI_NONE, 0.25, Z))
         assert rel_err(Y2.cpu(), 0.25 * Z_cpu + want) < 4e-6, d
         Y3 = Z.clone(); ops.spmm_raw(op.fwd, X, out=Y3, accumulate=True)
