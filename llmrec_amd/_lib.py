@@ -85,6 +85,7 @@ def load():
     return lib
 
 
+_TRACE = os.environ.get("LLMREC_TRACE_CALLS", "0") == "1"
 n_calls = 0      # entry-point invocations so far (FusedStep reports the per-step delta: a launch-count proxy without a profiler)
 
 
@@ -93,7 +94,15 @@ def call(name: str, *args):
     global n_calls
     n_calls += 1
     lib = load()
-    status = getattr(lib, name)(*args)
+    if _TRACE:                                               # LLMREC_TRACE_CALLS=1 (debugging a device fault): name each entry point, synchronise behind it
+        import sys
+        import torch
+        print("[llmrec] %s" % name, file=sys.stderr, flush=True)
+        status = getattr(lib, name)(*args)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize()
+    else:
+        status = getattr(lib, name)(*args)
     if status != 0:
         raise RuntimeError("%s failed: %s (%s)" % (
             name, lib.llmrec_status_string(status).decode(), lib.llmrec_last_error().decode()))

@@ -188,6 +188,7 @@ class SpmmPlan:
             br = torch.sort(br[:nb]).values.contiguous() if nb else None
             sr, sb, ss = (sr, sb, ss) if nsp else (None, None, None)
         if not order_rows:
+            torch.cuda.current_stream().synchronize()                  # (see below: the lists are read by every stream)
             return SpmmPlan(t_wave, t_block, segment, nw, nb, nsp, nseg, wr, br, sr, sb, ss)
         deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
         ids = torch.nonzero(deg <= CONST["LLMREC_SPMM_LONG_ROW"]).flatten()
@@ -207,7 +208,12 @@ class SpmmPlan:
         p_colidx = torch.empty_like(colidx)
         _lib.call("llmrec_csr_permute_rows", n_rows, _p(rowptr), _p(colidx), _p(slot_row), _p(p_rowptr), _p(p_colidx), _stream())
         ar = lambda lo, n: torch.arange(lo, lo + n, dtype=torch.int32, device=dev) if n else None     # the lists hold slots
-        return SpmmPlan(t_wave, t_block, segment, nw, nb, nsp, nseg, ar(n_short, nw), ar(n_short + nw, nb), ar(n_short + nw + nb, nsp), sb, ss,
+        lists = (ar(n_short, nw), ar(n_short + nw, nb), ar(n_short + nw + nb, nsp))
+        # A plan is built lazily, on whatever stream runs the first product over its operand (a SIDE stream of the fused step's warm-up), and
+        # is then shared by every stream: its arrays must be complete before any other stream reads them. (Round 6: four replica processes
+        # on one GPU faulted in the first captured step - the chain's stream read a permuted CSR the profile stream was still writing.)
+        torch.cuda.current_stream().synchronize()
+        return SpmmPlan(t_wave, t_block, segment, nw, nb, nsp, nseg, lists[0], lists[1], lists[2], sb, ss,
                         n_short, slot_row, p_rowptr, p_colidx, colidx.data_ptr())
 
 

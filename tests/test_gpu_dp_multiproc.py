@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 from tests._dropin import load_dropin, golden_argv
 from tests.conftest import GoldenCase, GOLDEN_CASES
 
-STEPS = 6
+STEPS = int(os.environ.get("LLMREC_TEST_DP_STEPS", "6"))
 NAMES = ["item_trans.weight", "user_trans.bias", "image_trans.weight", "user_id_embedding.weight", "item_id_embedding.weight"]
 
 
@@ -93,7 +93,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("use_graph,world", [(False, 2), (True, 2), (True, 4)])
+@pytest.mark.parametrize("use_graph,world", [(False, 2), (True, 2), (True, 4), (False, 4)])
 def test_two_process_replicas_match_single_process_global_batch(tmp_path, use_graph, world):
     """world = 4: four replicas on the one GPU (the exchange buffers hold four slices, the prune threshold covers four local batches)."""
     case = GOLDEN_CASES[0]

@@ -145,7 +145,7 @@ def test_spmm_row_buckets_split_rows_and_epilogues(ops):
         # round 6: the plan's PERMUTED CSR (rows stored by descending length class, slot -> row map, lists in slots): the same bits as the
         # operand's own CSR - with every bucket populated (lane-group rows incl. empty ones, wavefront, block and split rows), with the
         # "+ Z" and softmax epilogues, with column slices, and with the XCD-contiguous block -> row map
-        assert op.fwd.val is None and keep.slot_row is None
+        assert op.fwd.val is None and keep.slot_row is not None          # (the default plan of a pattern-only operand is the permuted one)
         for alt in (key, (32, 32, 64)):
             perm = ops.SpmmPlan.build(op.fwd.rowptr, *alt, colidx=op.fwd.colidx, order_rows=True)
             assert perm.slot_row is not None and sorted(perm.slot_row.tolist()) == list(range(n_rows))
