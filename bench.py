@@ -224,7 +224,7 @@ class NetflixShaped:
         if not hasattr(self, "_eval_q") or self._eval_q.numel() != q.numel():
             self._eval_q = q                                    # fixed query set: the evaluation graph is captured once
         with torch.no_grad():                                   # eval-mode forward (no dropout in this config) + scoring + top-50
-            return self.fused.eval_topk(self._eval_q, self.graph.by_user, 50, use_graph=self.use_graph)
+            return self.fused.eval_topk(self._eval_q, self.graph.by_user, 50, use_graph=self.use_graph and os.environ.get("LLMREC_EVAL_GRAPH", "1") == "1")
 
     def config(self):
         return {"workload": "netflix_shaped_cfg2" if self.shape_name == "nf" else "movielens_shaped_cfg3",

@@ -682,6 +682,14 @@ int llmrec_topk_hits(int32_t n_query, const int64_t* query_users, int32_t K, con
  * instead of n x K hits). */
 int llmrec_topk_metrics(int32_t n_query, const int64_t* query_users, int32_t K, const uint8_t* hits, const int32_t* topk_idx,
                         const int32_t* test_rowptr, int32_t n_ks, const int32_t* ks_host, double* out, llmrec_stream_t stream);
+/* Round 6 - a whole evaluation's R10 in two launches (what batch_test.py:160-165 accumulates over the users): out[4][n_ks] = the SUMS over the
+ * query users of precision, recall, ndcg, hit-ratio at every cut-off (the caller divides by the number of users), from the ranked lists and the
+ * held-out CSR directly - the hit flags and the per-user values stay in registers, the users are added by fixed trees (deterministic). K <= 128.
+ * `out` may be device memory or mapped (pinned) host memory: an evaluation graph then ends with the twelve doubles already on the host. */
+int64_t llmrec_topk_eval_sums_workspace_bytes(int32_t n_query, int32_t n_ks);
+int llmrec_topk_eval_sums(int32_t n_query, const int64_t* query_users, int32_t K, const int32_t* topk_idx, const int32_t* test_rowptr,
+                          const int32_t* test_colidx, int32_t n_ks, const int32_t* ks_host, void* workspace, int64_t workspace_bytes,
+                          double* out, llmrec_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * R11  on-device BPR sampler             replaces Data.sample (reference

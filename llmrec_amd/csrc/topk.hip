@@ -939,6 +939,89 @@ __global__ void topk_metrics_kernel(int n_query, const int64_t* __restrict__ que
     }
 }
 
+// R10 in two launches for a whole evaluation (round 6): hits + per-user metrics + their sums over the users, nothing per user leaves the
+// kernel. Launch 1: one thread per user (the binary searches of topk_hits_kernel, the arithmetic of topk_metrics_kernel, in double), then the
+// block's 128 users are added by a fixed pairwise tree in LDS -> partial[block][4 n_ks]. Launch 2: one block adds the partials in block order
+// (thread t: partial[t], partial[t + 256], ...; then the pairwise tree) -> out[4 n_ks], which may be mapped host memory. Deterministic.
+constexpr int ES_THREADS = 128;
+__global__ __launch_bounds__(ES_THREADS) void topk_eval_sums_kernel(int n_query, const int64_t* __restrict__ query_users, int K,
+                                                                    const int32_t* __restrict__ topk_idx, const int32_t* __restrict__ rowptr,
+                                                                    const int32_t* __restrict__ colidx, MetricKs ks, double* __restrict__ partial) {
+    __shared__ double red[ES_THREADS];
+    const int q = blockIdx.x * ES_THREADS + threadIdx.x;
+    double val[4][8];                                                  // [metric][cut-off], statically indexed (registers)
+    const int nv = 4 * ks.n;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) val[m][t] = 0.0;
+    if (q < n_query) {
+        const int64_t u = query_users[q];
+        const int32_t r0 = rowptr[u], r1 = rowptr[u + 1];
+        const double n_pos = (double)(r1 - r0);
+        const int32_t* id = topk_idx + (int64_t)q * K;
+        unsigned long long hit_lo = 0ull, hit_hi = 0ull;              // K <= 128 hit flags
+        int total_hits = 0, list_len = 0;
+        for (int j = 0; j < K; ++j) {
+            const int32_t item = id[j];
+            int32_t lo = r0, hi = r1;
+            while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (colidx[mid] < item) lo = mid + 1; else hi = mid; }
+            const bool h = item >= 0 && lo < r1 && colidx[lo] == item;
+            if (h) { if (j < 64) hit_lo |= 1ull << j; else hit_hi |= 1ull << (j - 64); }
+            total_hits += h; list_len += item >= 0;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t < ks.n) {
+                const int kk = ks.k[t] < K ? ks.k[t] : K;
+                double s = 0.0, dcg = 0.0, idcg = 0.0;
+                for (int j = 0; j < kk; ++j) {
+                    const double disc = 1.0 / log2((double)(j + 2));
+                    const bool h = j < 64 ? ((hit_lo >> j) & 1ull) != 0ull : ((hit_hi >> (j - 64)) & 1ull) != 0ull;
+                    if (h) { s += 1.0; dcg += disc; }
+                    if (j < total_hits) idcg += disc;
+                }
+                const int denom = list_len < kk ? list_len : kk;
+                val[0][t] = s / (double)(denom > 0 ? denom : 1);
+                val[1][t] = n_pos > 0.0 ? s / n_pos : 0.0;
+                val[2][t] = idcg > 0.0 ? dcg / idcg : 0.0;
+                val[3][t] = s > 0.0 ? 1.0 : 0.0;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t < ks.n) {                                            // (block-uniform)
+                red[threadIdx.x] = val[m][t];
+                __syncthreads();
+                for (int off = ES_THREADS / 2; off > 0; off >>= 1) {
+                    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+                    __syncthreads();
+                }
+                if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * nv + m * ks.n + t] = red[0];
+                __syncthreads();
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void topk_eval_sums_finish_kernel(int n_blocks, int nv, const double* __restrict__ partial, double* __restrict__ out) {
+    __shared__ double red[256];
+    for (int i = 0; i < nv; ++i) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < n_blocks; b += 256) s += partial[(int64_t)b * nv + i];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[i] = red[0];
+        __syncthreads();
+    }
+}
+
 static int device_cus() {
     static const int n = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
                               return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }();
@@ -1156,6 +1239,33 @@ int llmrec_topk_hits(int32_t n_query, const int64_t* query_users, int32_t K, con
     LLMREC_CHECK_ARG(query_users && topk_idx && test_rowptr && test_colidx && hits, "topk_hits: null pointer");
     const int64_t n = (int64_t)n_query * K;
     topk_hits_kernel<<<(int)ceil_div(n, 256), 256, 0, (hipStream_t)stream_>>>(n_query, query_users, K, topk_idx, test_rowptr, test_colidx, hits);
+    LLMREC_LAUNCH_CHECK();
+    return LLMREC_OK;
+}
+
+int64_t llmrec_topk_eval_sums_workspace_bytes(int32_t n_query, int32_t n_ks) {
+    if (n_query < 0 || n_ks < 1 || n_ks > 8) return -1;
+    return align_up((int64_t)ceil_div(n_query > 0 ? n_query : 1, ES_THREADS) * 4 * n_ks * (int64_t)sizeof(double), 256);
+}
+
+int llmrec_topk_eval_sums(int32_t n_query, const int64_t* query_users, int32_t K, const int32_t* topk_idx, const int32_t* test_rowptr,
+                          const int32_t* test_colidx, int32_t n_ks, const int32_t* ks_host, void* workspace, int64_t workspace_bytes,
+                          double* out, llmrec_stream_t stream_) {
+    LLMREC_CHECK_ARG(n_query >= 0 && K > 0 && K <= 128 && n_ks >= 1 && n_ks <= 8 && ks_host && out, "topk_eval_sums: bad sizes (K <= 128, at most 8 cut-offs)");
+    LLMREC_CHECK_ARG(n_query == 0 || (query_users && topk_idx && test_rowptr && test_colidx), "topk_eval_sums: null pointer");
+    if (!workspace || workspace_bytes < llmrec_topk_eval_sums_workspace_bytes(n_query, n_ks)) {
+        set_error("topk_eval_sums: workspace %lld < %lld", (long long)workspace_bytes, (long long)llmrec_topk_eval_sums_workspace_bytes(n_query, n_ks));
+        return LLMREC_EWORKSPACE;
+    }
+    MetricKs ks = {};
+    ks.n = n_ks;
+    for (int i = 0; i < n_ks; ++i) { LLMREC_CHECK_ARG(ks_host[i] > 0, "topk_eval_sums: cut-offs must be positive"); ks.k[i] = ks_host[i]; }
+    const int n_blocks = (int)ceil_div(n_query, ES_THREADS);
+    if (n_blocks > 0) {
+        topk_eval_sums_kernel<<<n_blocks, ES_THREADS, 0, (hipStream_t)stream_>>>(n_query, query_users, K, topk_idx, test_rowptr, test_colidx, ks, (double*)workspace);
+        LLMREC_LAUNCH_CHECK();
+    }
+    topk_eval_sums_finish_kernel<<<1, 256, 0, (hipStream_t)stream_>>>(n_blocks, 4 * n_ks, (const double*)workspace, out);
     LLMREC_LAUNCH_CHECK();
     return LLMREC_OK;
 }

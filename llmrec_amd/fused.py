@@ -419,10 +419,14 @@ class FusedStep:
             self._spmm(self.ui.fwd, self.P_cat, self.U_cat)              # 7 streams, one adjacency pass
         self._spmm(self.iu.fwd, self.U_cat, self.I_cat)
         if not split_proj:
-            self._fork_from(ev1, self.s1)
-            with self._on(self.s1):                                      # profile stream: items first
+            if getattr(self, "profile_on_main", False):                  # (evaluation graphs: two branches instead of three, see eval_topk)
                 self._spmm(self.iu.fwd, self.P_usr, self.prof_i, tag=1)
                 self._spmm(self.ui.fwd, self.prof_i, self.prof_u, tag=1)
+            else:
+                self._fork_from(ev1, self.s1)
+                with self._on(self.s1):                                  # profile stream: items first
+                    self._spmm(self.iu.fwd, self.P_usr, self.prof_i, tag=1)
+                    self._spmm(self.ui.fwd, self.prof_i, self.prof_u, tag=1)
         if self._zero_in_forward and not self.fold:                      # training: the feature regulariser's value needs only U_cat / I_cat -
             self._fork(self.s3)                                          # captured HERE it runs beside the fusion and the BPR launches (captured
             with self._on(self.s3):                                      # after the BPR backward, round 2, the graph ran it last: the step's tail)
@@ -816,14 +820,19 @@ class FusedStep:
         """Nothing is deferred in the single-graph step (DataParallelStep defers its AdamW)."""
 
     # -- evaluation -------------------------------------------------------------------------------
-    def eval_topk(self, query_users: torch.Tensor, train: Optional[ops.Csr], K: int, use_graph: bool = False):
+    def eval_topk(self, query_users: torch.Tensor, train: Optional[ops.Csr], K: int, use_graph: bool = False, held=None, Ks=None):
         """Reference Trainer.test up to the ranked lists (main.py:297-303, batch_test.py:83-109): no-grad forward +
         scoring + masked top-K for the listed users -> (idx int32 [n, K], scores). With use_graph the whole
-        evaluation (~40 launches) is one HIP graph per (query set, K), replayed at every epoch end."""
+        evaluation (~40 launches) is one HIP graph per (query set, K), replayed at every epoch end.
+        held = (rowptr, colidx) of the held-out CSR + Ks (use_graph only): the evaluation also ends with llmrec_topk_eval_sums - hits, per-user
+        precision / recall / ndcg / hit-ratio and their sums over the users, two launches at the graph's tail writing the 4 x len(Ks)
+        doubles into PINNED host memory (self.eval_sums(...) after a stream synchronisation; batch_test.py:160-165 divided by the
+        number of users) - nothing per user leaves the device and no copy follows the replay."""
         if not use_graph:
             self.forward()
             return ops.score_topk(self.E_u, self.E_i, query_users, train, K)
-        key = (query_users.data_ptr(), query_users.numel(), K, id(train))
+        Ks = tuple(int(k) for k in Ks) if held is not None else None
+        key = (query_users.data_ptr(), query_users.numel(), K, id(train), None if held is None else (held[0].data_ptr(), Ks))
         ev = self._eval_graphs.get(key)
         if ev is None:
             q = query_users.to(torch.int64).contiguous()
@@ -831,12 +840,27 @@ class FusedStep:
             idx = torch.empty(n, K, dtype=torch.int32, device=q.device)
             sc = torch.empty(n, K, dtype=torch.float32, device=q.device)
             ws = ops.topk_workspace(n, self.I, q.device, self.d)
+            sums = sums_ws = None
+            if held is not None:
+                sums = torch.zeros(4, len(Ks), dtype=torch.float64).pin_memory()
+                sums_ws = torch.empty(_lib.query("llmrec_topk_eval_sums_workspace_bytes", n, len(Ks)), dtype=torch.uint8, device=q.device)
 
             def run():
-                self.forward()
+                # the evaluation's graph has TWO branches (the ID chain beside the projection; the profile chain stays on the main stream):
+                # 0.572 ms per replay back to back / 0.599 one at a time, against 0.73 - 0.76 / 0.595 with the training forward's three
+                # side branches - successive launches of a many-branch graph pay for their cross-queue joins (tools/eval_probe.py, round 6)
+                branches, ms = os.environ.get("LLMREC_EVAL_BRANCHES", "2"), self.multi_stream
+                self.profile_on_main = branches == "2"
+                self.multi_stream = ms and branches != "1"
+                try:
+                    self.forward()
+                finally:
+                    self.profile_on_main, self.multi_stream = False, ms
                 _call("llmrec_score_topk_mode_f32", n, _p(q), _p(self.E_u), _ld(self.E_u), _p(self.E_i), _ld(self.E_i), self.I, self.d,
                       _p(train.rowptr) if train is not None else None, _p(train.colidx) if train is not None else None,
                       K, _p(idx), _p(sc), _p(ws), ws.numel() if ws is not None else 0, ops.topk_mode(None, self.I, self.d, K))
+                if held is not None:
+                    ops.topk_eval_sums(idx, q, held[0], held[1], Ks, out=sums, ws=sums_ws)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -846,9 +870,18 @@ class FusedStep:
             g = torch.cuda.CUDAGraph()
             with _capture_without_gc(g):
                 run()
-            ev = self._eval_graphs[key] = (g, idx, sc, q, train, ws)     # keeps the captured operands alive
+            ev = self._eval_graphs[key] = (g, idx, sc, q, train, ws, sums, sums_ws, held)     # keeps the captured operands alive
         ev[0].replay()
+        self._last_eval = ev
         return ev[1], ev[2]
+
+    def eval_sums(self):
+        """The pinned [4, len(Ks)] sums of the LAST eval_topk(..., held=...) replay; synchronises the current stream first."""
+        ev = getattr(self, "_last_eval", None)
+        if ev is None or ev[6] is None:
+            raise RuntimeError("FusedStep.eval_sums: the last evaluation was not captured with a held-out set")
+        torch.cuda.current_stream().synchronize()
+        return ev[6]
 
     def drop_eval_graph(self, query_users: torch.Tensor):
         """Release every captured evaluation (graph, result lists, top-K workspace) of this query tensor."""

@@ -1106,6 +1106,24 @@ def topk_hits(topk_idx: torch.Tensor, query_users: torch.Tensor, test_rowptr: to
     return hits
 
 
+def topk_eval_sums(idx: torch.Tensor, query_users: torch.Tensor, test_rowptr: torch.Tensor, test_colidx: torch.Tensor, Ks,
+                   out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[4, len(Ks)] float64: the sums over the query users of precision / recall / ndcg / hit-ratio at every cut-off (llmrec_topk_eval_sums:
+    hits, per-user metrics and their sums in two launches). out: a device tensor or a PINNED host tensor (written by the kernel itself)."""
+    _need_gpu(idx, query_users, test_rowptr, test_colidx)
+    n, K = idx.shape
+    Ks = [int(k) for k in Ks]
+    if out is None:
+        out = torch.empty(4, len(Ks), dtype=torch.float64, device=idx.device)
+    need = _lib.query("llmrec_topk_eval_sums_workspace_bytes", n, len(Ks))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=idx.device)
+    arr = (_c.c_int32 * len(Ks))(*Ks)
+    _lib.call("llmrec_topk_eval_sums", n, _p(query_users.to(torch.int64).contiguous()), K, _p(idx.contiguous()), _p(test_rowptr), _p(test_colidx),
+              len(Ks), arr, _p(ws), ws.numel(), _c.c_void_p(out.data_ptr()), _stream())
+    return out
+
+
 def sample_bpr(seed: int, step: int, exist_users: torch.Tensor, n_items: int, train: Csr, B: int):
     dev = exist_users.device
     u = torch.empty(B, dtype=torch.int64, device=dev)

@@ -179,11 +179,16 @@ class Trainer(object):
 
     # -- evaluation -------------------------------------------------------------------------------
     def test(self, users_to_test, is_val):
-        self.model_mm.eval()
+        if self.model_mm.training:
+            self.model_mm.eval()
         fused = self._fused_step()
         with torch.no_grad():
-            if fused and USE_GRAPH() and args.test_flag == 'part':
-                # forward + scoring + masked top-K as ONE graph replay per evaluation
+            if fused and args.test_flag == 'part':
+                # forward + scoring + masked top-K as ONE graph replay per evaluation (LLMREC_EVAL_GRAPH=0: the same launches issued eagerly).
+                # Round 6, full Netflix-shaped dataset, tools/eval_probe.py, ms per evaluation [20 back to back | one at a time, host
+                # synchronised behind each, as this method runs]: graph with the forward's three side branches 0.73 - 0.76 | 0.595; graph with
+                # two branches (profile chain on the main stream: FusedStep.eval_topk's choice) 0.572 | 0.599; one-stream graph 0.601 | 0.620;
+                # eager 0.558 | 0.664 - issued onto an idle GPU the ~40 launches leave the host ~70 us behind the device.
                 # the query tensor is cached on the CONTENT of the user list (a different list of the same length
                 # must not reuse it); the evaluation graph is keyed on that tensor
                 own = getattr(self, "_eval_own", None)          # the list train() itself built once and hands in every epoch: trusted by identity
@@ -204,7 +209,14 @@ class Trainer(object):
                     if getattr(self, "_eval_own_list", None) is users_to_test:
                         self._eval_own = (users_to_test, len(users_to_test), q)
                 st = data_generator.device_state(device)
-                idx, _ = fused.eval_topk(q, st["train"], max(eval(args.Ks)), use_graph=True)
+                Ks_ = eval(args.Ks)
+                if USE_GRAPH() and os.environ.get("LLMREC_EVAL_GRAPH", "1") == "1":
+                    # ONE graph replay: forward, scoring, masked top-K AND the metrics (llmrec_topk_eval_sums: hits, per-user values and their
+                    # sums, the twelve doubles written into pinned host memory by the graph's last launch): no launch, no copy behind it
+                    fused.eval_topk(q, st["train"], max(Ks_), use_graph=True, held=st["val"] if is_val else st["test"], Ks=Ks_)
+                    sums = fused.eval_sums().numpy() / len(users_to_test)
+                    return {'precision': sums[0].copy(), 'recall': sums[1].copy(), 'ndcg': sums[2].copy(), 'hit_ratio': sums[3].copy(), 'auc': 0.}
+                idx, _ = fused.eval_topk(q, st["train"], max(Ks_), use_graph=False)
                 return test_torch(fused.E_u, fused.E_i, users_to_test, is_val, topk=(q, idx))
             if fused:                                          # same forward, ~40 launches over preallocated buffers
                 fused.forward()

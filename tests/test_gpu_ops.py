@@ -832,6 +832,17 @@ def test_topk_metrics_match_host_formulae(ops):
     want = metrics_from_hit_matrix(hits.cpu().numpy(), n_pos, Ks, (topk >= 0).sum(1))
     for j, k in enumerate(("precision", "recall", "ndcg", "hit_ratio")):
         assert np.allclose(got[:, j, :], want[k], rtol=0, atol=1e-13), k
+    # round 6: llmrec_topk_eval_sums - hits, per-user metrics and their sums over the users in two launches, into device memory or straight
+    # into pinned host memory; a permuted / partial query list; deterministic
+    sums = ops.topk_eval_sums(idx, q, csr.rowptr, csr.colidx, Ks)
+    assert np.allclose(sums.cpu().numpy(), got.sum(0), rtol=1e-14, atol=1e-12)
+    pinned = torch.zeros(4, len(Ks), dtype=torch.float64).pin_memory()
+    ops.topk_eval_sums(idx, q, csr.rowptr, csr.colidx, Ks, out=pinned)
+    torch.cuda.synchronize()
+    assert np.array_equal(pinned.numpy(), sums.cpu().numpy())
+    sel = torch.tensor(rng.permutation(U)[:77]).to(DEV)
+    part = ops.topk_eval_sums(idx[sel].contiguous(), sel, csr.rowptr, csr.colidx, Ks).cpu().numpy()
+    assert np.allclose(part, got[sel.cpu().numpy()].sum(0), rtol=1e-14, atol=1e-12)
 
 
 def test_fuse_bwd_source_mode_and_zero_rows(ops):

@@ -45,3 +45,29 @@ pr = cProfile.Profile(); sync(); pr.enable()
 for _ in range(3): tr.test(users, False)
 sync(); pr.disable()
 pstats.Stats(pr).sort_stats("cumtime").print_stats(18)
+
+# round 6: the evaluation as a graph / eagerly, with the forward's side streams or on one stream
+print("--- eval_topk variants (ms per evaluation, 20 back to back) ---")
+for ms_flag in (True, False):
+    fused.multi_stream = ms_flag
+    fused._eval_graphs.clear()
+    for g in (True, False):
+        fused.eval_topk(q, st["train"], 50, use_graph=g)
+        print("multi_stream=%s graph=%s: %.4f" % (ms_flag, g, T(lambda: fused.eval_topk(q, st["train"], 50, use_graph=g), 20)))
+fused.multi_stream = True
+fused._eval_graphs.clear()
+print("--- evaluation graph with two branches (ID chain beside the projection, the profile chain on the main stream) ---")
+fused.profile_on_main = True
+for g in (True, False):
+    fused._eval_graphs.clear()
+    fused.eval_topk(q, st["train"], 50, use_graph=g)
+    print("profile_on_main graph=%s: %.4f" % (g, T(lambda: fused.eval_topk(q, st["train"], 50, use_graph=g), 20)))
+    print("   isolated (sync per call): %.4f" % T(lambda: (fused.eval_topk(q, st["train"], 50, use_graph=g), sync()), 20))
+fused.profile_on_main = False
+for ms_flag, g in ((True, True), (False, True), (True, False)):
+    fused.multi_stream = ms_flag
+    fused._eval_graphs.clear()
+    fused.eval_topk(q, st["train"], 50, use_graph=g)
+    print("multi_stream=%s graph=%s isolated (sync per call): %.4f" % (ms_flag, g, T(lambda: (fused.eval_topk(q, st["train"], 50, use_graph=g), sync()), 20)))
+fused.multi_stream = True
+fused._eval_graphs.clear()
