@@ -639,6 +639,10 @@ int llmrec_score_topk_f32(int32_t n_query, const int64_t* query_users,
  *   - with a train CSR and at most 131 072 items: a block turns the rows of up to two of its users with more than 48 train items into
  *     bitmaps (one word per 32-item tile, in its own slice of the workspace) and reads one word per round instead of walking the row.
  * The lists and scores are the same, bit for bit. workspace == NULL behaves like llmrec_score_topk_f32. */
+/* Tuning knob of the bf16 sweep's ITEM PARTS (tables beyond the L2: every user tile is cut into parts of `items` items whose fragments fit an
+ * XCD's L2, block ids part-major; csrc/topk.hip plan_parts): 0 = the library's policy (8 MB of fragments per part for tables beyond 131 072 items),
+ * -1 = never, else a multiple of 32 >= 1024. Process-wide; set it BEFORE sizing a workspace (llmrec_score_topk_workspace_bytes depends on it). */
+int llmrec_topk_set_part_items(int32_t items);
 int64_t llmrec_score_topk_workspace_bytes(int32_t n_query, int64_t n_items, int32_t d);
 int llmrec_score_topk_ws_f32(int32_t n_query, const int64_t* query_users,
                              const float* Eu, int64_t ldu, const float* Ei, int64_t ldi,

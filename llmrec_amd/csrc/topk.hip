@@ -57,6 +57,7 @@ struct TopkArgs {
     // user tiles from split_from on are swept by n_parts blocks each (a part = a contiguous range of item tiles); their
     // 64-slot lists go to ws_idx / ws_score [(tile - split_from) * n_parts + part][16][64] and are merged by topk_merge_kernel
     int split_from, n_parts;
+    int part_major;              // block ids of the split tiles: part-major (all tiles of part 0, then part 1, ...) instead of tile-major
     int32_t* ws_idx; float* ws_score;
     // the item table re-laid in FRAGMENT order by topk_pack_items_kernel (null: the sweep loads Ei itself):
     // packed[((tile * 2 + n) * DK + c) * 64 + lane] = the float4 lane `lane` feeds to column tile n, k chunk c of item tile `tile`
@@ -303,8 +304,9 @@ __global__ __launch_bounds__(256, (DK <= 4 ? 4 : 2)) void score_topk_kernel(Topk
     int tile = blockIdx.x, part = 0, n_parts = 1;
     if ((int)blockIdx.x >= a.split_from) {                     // block-uniform
         n_parts = a.n_parts;
-        tile = a.split_from + ((int)blockIdx.x - a.split_from) / n_parts;
-        part = ((int)blockIdx.x - a.split_from) % n_parts;
+        const int r_ = (int)blockIdx.x - a.split_from, nst_ = (a.n_query + 15) / 16 - a.split_from;
+        tile = a.split_from + (a.part_major ? r_ % nst_ : r_ / n_parts);
+        part = a.part_major ? r_ / nst_ : r_ % n_parts;
     }
     const int q0 = tile * 16;
     if (q0 >= a.n_query) return;                               // block-uniform
@@ -661,8 +663,9 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     int tile = blockIdx.x, part = 0, n_parts = 1;
     if ((int)blockIdx.x >= a.split_from) {
         n_parts = a.n_parts;
-        tile = a.split_from + ((int)blockIdx.x - a.split_from) / n_parts;
-        part = ((int)blockIdx.x - a.split_from) % n_parts;
+        const int r_ = (int)blockIdx.x - a.split_from, nst_ = (a.n_query + 15) / 16 - a.split_from;
+        tile = a.split_from + (a.part_major ? r_ % nst_ : r_ / n_parts);
+        part = a.part_major ? r_ / nst_ : r_ % n_parts;
     }
     const int q0 = tile * 16;
     if (q0 >= a.n_query) return;
@@ -1039,12 +1042,38 @@ static void plan_split(int n_query, int64_t n_items, int* split_from, int* n_par
     while (parts > 1 && item_tiles / parts < 64) --parts;      // at least 16 rounds per wave of a part
     *split_from = parts > 1 ? full : n_tiles; *n_parts = parts > 1 ? parts : 1;
 }
+// ITEM PARTS for tables beyond the L2 (round 6; bf16 sweep only). At 10^6 items every 16-user tile streamed the whole
+// fragment table (256 MB at d = 64) through the L2-miss path: 4096 tiles x 256 MB at the ~7.4 TB/s of that path = 0.145 s, slower than the
+// exact sweep. Here EVERY user tile is cut into parts of TK_PART_ITEMS items - a part's fragments fit the 4 MB L2 of an XCD - and the block
+// ids are PART-MAJOR: the ~1000 blocks resident at any moment sweep the same part, so one block's fetch serves the others on its XCD from
+// the L2 instead of 4096 fetches from the fabric. The parts' 64-slot lists are merged, re-scored exactly and verified by
+// topk_merge_pre_kernel, as for the left-over tiles of the small-table plan. g_part_items: 0 = the policy below; tools set it
+// (llmrec_topk_set_part_items) to sweep the part size.
+constexpr int64_t TK_PARTS_FROM_ITEMS = 131072;                // tables up to here: the small-table plan (L2 / MALL-resident fragments)
+constexpr int64_t TK_PART_BYTES = 8 << 20;                      // fragments per part. Measured (65 536 users x 10^6 items, d = 64; exact sweep 109.5 ms,
+constexpr int TK_PART_ITEMS_MIN = 16384;                        // bf16 sweep without parts 136.0): parts of 8 192 / 16 384 / 32 768 / 65 536 items 76.9 /
+static int g_part_items = 0;                                    // 56.7 / 50.7 / 91.8 ms; d = 128, 16 384 users (exact 50.5, no parts 62.1): 27.8 / 29.8 / 50.2 / 61.9
+// d < 0: the smallest part any width gets (workspace sizing: the layout must not depend on d)
+static bool plan_parts(int n_query, int64_t n_items, int d, int* n_parts) {
+    if (g_part_items < 0 || (g_part_items == 0 && n_items <= TK_PARTS_FROM_ITEMS)) return false;
+    int64_t per = g_part_items;
+    if (per == 0) {
+        per = d < 0 ? TK_PART_ITEMS_MIN : TK_PART_BYTES / ((int64_t)ceil_div(d, 32) * 32 * 4);      // hi + mid bf16 = 4 bytes per (padded) column
+        int64_t p2 = TK_PART_ITEMS_MIN;
+        while (p2 * 2 <= per && p2 < 65536) p2 *= 2;
+        per = p2;
+    }
+    const int64_t parts = ceil_div(n_items, per);
+    if (parts < 2 || parts > 4096 || ceil_div(n_query, 16) * parts > 0x7fffffffll) return false;
+    *n_parts = (int)parts;
+    return true;
+}
 
 template <bool SELECT>
 static int launch_topk(const TopkArgs& a, hipStream_t stream) {
     const int DK = (a.d + 15) / 16;
     const int n_tiles = (int)ceil_div(a.n_query, 16);
-    const int grid = a.split_from + (n_tiles - a.split_from) * a.n_parts;
+    const int grid = (int)(a.split_from + (int64_t)(n_tiles - a.split_from) * a.n_parts);
     const bool fast = a.vec_ok && a.d == 16 * DK;
     if (SELECT && a.mode == 1) {
         const int DK32 = (a.d + 31) / 32;
@@ -1118,10 +1147,14 @@ using namespace llmrec;
 extern "C" {
 
 static int64_t topk_split_bytes(int32_t n_query, int64_t n_items) {
-    int split_from = 0, n_parts = 1;
+    int split_from = 0, n_parts = 1, wide_parts = 0;
     plan_split(n_query, n_items, &split_from, &n_parts);
-    if (n_parts == 1) return 0;
-    return ((int64_t)ceil_div(n_query, 16) - split_from) * n_parts * 16 * 64 * 8;
+    int64_t bytes = n_parts == 1 ? 0 : ((int64_t)ceil_div(n_query, 16) - split_from) * n_parts * 16 * 64 * 8;
+    if (plan_parts(n_query, n_items, -1, &wide_parts)) {       // (the bf16 sweep's item parts: every tile is split; sized for the smallest part)
+        const int64_t wide = (int64_t)ceil_div(n_query, 16) * wide_parts * 16 * 64 * 8;
+        if (wide > bytes) bytes = wide;
+    }
+    return bytes;
 }
 static int64_t topk_packed_bytes(int64_t n_items, int32_t d) {
     const int64_t exact = ceil_div(n_items, TK_TILE) * 2 * ceil_div(d, 16) * 64 * 16;      // fp32 fragments (rows padded to whole tiles, d to 16)
@@ -1138,6 +1171,12 @@ static int64_t topk_heavy_bytes(int32_t n_query, int64_t n_items) {
     const int64_t n_tiles = ceil_div(n_query, 16), grid = split_from + (n_tiles - split_from) * n_parts;
     const int64_t bytes = grid * TK_HEAVY_PER_BLOCK * words * 4;
     return (words > 4096 || bytes > (64ll << 20)) ? 0 : align_up(bytes, 256);
+}
+
+int llmrec_topk_set_part_items(int32_t items) {
+    LLMREC_CHECK_ARG(items == -1 || items == 0 || (items >= 1024 && items % TK_TILE == 0), "topk_set_part_items: -1 (off), 0 (policy) or a multiple of %d >= 1024", TK_TILE);
+    g_part_items = items;
+    return LLMREC_OK;
 }
 
 int64_t llmrec_score_topk_workspace_bytes(int32_t n_query, int64_t n_items, int32_t d) {
@@ -1187,7 +1226,7 @@ int llmrec_score_topk_mode_f32(int32_t n_query, const int64_t* query_users,
     a.n_items = n_items; a.d = d; a.train_rowptr = train_rowptr; a.train_colidx = train_colidx; a.K = K;
     a.out_idx = out_idx; a.out_score = out_score; a.S = nullptr; a.lds = 0;
     a.vec_ok = (ldu % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)Eu | (uintptr_t)Ei) % 16 == 0);
-    a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
+    a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.part_major = 0; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
     if (mode == LLMREC_TOPK_MODE_PREFILTER && K > LLMREC_TOPK_PREFILTER_MAX_K) mode = LLMREC_TOPK_MODE_EXACT_SWEEP;   // (no room to verify in 64 slots)
     a.mode = mode; a.pk2 = nullptr; a.hdr = nullptr; a.cn = nullptr; a.fb_word = nullptr; a.only_flagged = nullptr;
     a.heavy_bm = nullptr; a.heavy_words = 0;
@@ -1195,13 +1234,20 @@ int llmrec_score_topk_mode_f32(int32_t n_query, const int64_t* query_users,
         const int64_t need = llmrec_score_topk_workspace_bytes(n_query, n_items, d), split = topk_split_bytes(n_query, n_items);
         LLMREC_CHECK_ARG(workspace_bytes >= need && (uintptr_t)workspace % 16 == 0, "score_topk: workspace of %lld bytes needed (16-byte aligned)", (long long)need);
         if (split > 0) {
-            plan_split(n_query, n_items, &a.split_from, &a.n_parts);
-            a.ws_score = (float*)workspace;
-            a.ws_idx = (int32_t*)((char*)workspace + split / 2);
+            int wide_parts = 0;
+            if (mode == LLMREC_TOPK_MODE_PREFILTER && plan_parts(n_query, n_items, d, &wide_parts)) {
+                a.split_from = 0; a.n_parts = wide_parts; a.part_major = 1;
+            } else {
+                plan_split(n_query, n_items, &a.split_from, &a.n_parts);
+            }
+            if (a.n_parts > 1) {
+                a.ws_score = (float*)workspace;
+                a.ws_idx = (int32_t*)((char*)workspace + split / 2);
+            }
         }
         char* frag = (char*)workspace + align_up(split, 256);
         a.packed = (const float4*)frag;
-        if (train_rowptr && topk_heavy_bytes(n_query, n_items) > 0) {
+        if (train_rowptr && !a.part_major && topk_heavy_bytes(n_query, n_items) > 0) {      // (item parts: a block walks 1 / n_parts of a row)
             a.heavy_bm = (uint32_t*)(frag + topk_packed_bytes(n_items, d) + topk_flag_bytes(n_query));
             a.heavy_words = (int)ceil_div(n_items, TK_TILE);
         }
@@ -1226,7 +1272,7 @@ int llmrec_scores_f32(int32_t n_query, const int64_t* query_users,
     a.n_items = n_items; a.d = d; a.train_rowptr = nullptr; a.train_colidx = nullptr; a.K = 1;
     a.out_idx = nullptr; a.out_score = nullptr; a.S = S; a.lds = lds;
     a.vec_ok = (ldu % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)Eu | (uintptr_t)Ei) % 16 == 0);
-    a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
+    a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.part_major = 0; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
     a.mode = 0; a.pk2 = nullptr; a.hdr = nullptr; a.cn = nullptr; a.fb_word = nullptr; a.only_flagged = nullptr;
     a.heavy_bm = nullptr; a.heavy_words = 0;
     return launch_topk<false>(a, (hipStream_t)stream_);

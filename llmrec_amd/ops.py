@@ -1032,24 +1032,30 @@ class FusedAdamW:
 # R9/R10: scoring + top-K, R11: sampler
 # ---------------------------------------------------------------------------------------------
 TOPK_MODES = {"exact": 0, "prefilter": 1}
-TOPK_PREFILTER_MAX_TABLE_BYTES = 1 << 27      # 128 MB: where the bf16 sweep stops paying (profiles/experiments/r05_topk.md)
 
 
 def topk_mode(mode=None, n_items: int = 0, d: int = 64, K: int = 50) -> int:
     """llmrec_score_topk_mode_f32's mode: "exact" = every score by the exact-fp32 MFMA chain; "prefilter" = bf16 sweep keeping the 64 best
     by approximate score, exact re-ranking + verification, exact sweep for the tiles that fail it (bit-identical lists and scores);
-    "auto" (default; LLMREC_TOPK_MODE overrides) = prefilter while the fp32 item table (n_items x d x 4 bytes) stays within
-    TOPK_PREFILTER_MAX_TABLE_BYTES and K leaves room to verify - measured on MI355X at 16 384 users, d = 64: 1.22 x (10 K items), 1.6 x (33 K),
-    1.8 x (66 K - 131 K), 1.4 x (262 K), 1.08 x (524 K = 134 MB), 0.84 x at 10^6 items, where every 16-user tile streams a 256 MB table past the
-    Infinity Cache and the sweep is bound by that stream, not by the matrix cores."""
+    "auto" (default; LLMREC_TOPK_MODE overrides) = prefilter whenever K leaves room to verify. Measured on MI355X at 16 384 users, d = 64
+    (profiles/r06_topk_crossover.json): 1.41 x (10 K items), 1.96 x (33 K), 2.09 x (66 K), 2.03 x (131 K), 1.93 x (262 K), 1.96 x (524 K),
+    1.99 x (10^6); 65 536 users x 10^6 items 107.7 -> 46.4 ms, d = 128 50.2 -> 29.7 ms. Up to round 5 the mode stopped paying at 524 K
+    items (0.84 x at 10^6: every 16-user tile streamed the 256 MB fragment table through the L2-miss path); since round 6 tables beyond
+    131 072 items are swept in item PARTS of 8 MB of fragments with part-major block ids (csrc/topk.hip plan_parts), so that the blocks
+    resident at one time share each part through the L2."""
     if mode is None:
         mode = os.environ.get("LLMREC_TOPK_MODE", "auto")
     if mode == "auto":
-        ok = K <= CONST["LLMREC_TOPK_PREFILTER_MAX_K"] and 0 < n_items * max(d, 1) * 4 <= TOPK_PREFILTER_MAX_TABLE_BYTES
-        mode = "prefilter" if ok else "exact"
+        mode = "prefilter" if K <= CONST["LLMREC_TOPK_PREFILTER_MAX_K"] else "exact"
     if mode not in TOPK_MODES:
         raise RuntimeError("top-K mode %r (auto | exact | prefilter)" % (mode,))
     return TOPK_MODES[mode]
+
+
+def topk_set_part_items(items: int = 0):
+    """llmrec_topk_set_part_items: the bf16 sweep's item parts (0 = the library's policy, -1 = never, else items per part). Process-wide;
+    workspaces sized before a change are stale."""
+    _lib.call("llmrec_topk_set_part_items", int(items))
 
 
 def score_topk(Eu, Ei, query_users: torch.Tensor, train: Optional[Csr], K: int, mode=None, stats: Optional[dict] = None):

@@ -165,3 +165,24 @@ def test_dense_train_rows_cross_the_staged_window(ops, I, d):
         assert (i0[u, n:] == -1).all(), (u, n_free)
         tr_u = set(cols[rows == u].tolist())
         assert not (set(i0[u, :n].tolist()) & tr_u)
+
+
+@pytest.mark.parametrize("U,I,d,K,part", [(700, 9000, 64, 50, 1024), (333, 40000, 64, 50, 4096), (90, 20000, 128, 20, 2048), (50, 5000, 48, 50, 1024)])
+def test_item_parts_of_the_bf16_sweep_equal_the_exact_sweep(ops, U, I, d, K, part):
+    """Round 6: the bf16 sweep with EVERY user tile cut into item parts (part-major block ids: the plan for tables beyond the L2, forced here
+    on small tables through llmrec_topk_set_part_items) - train masks that cross part boundaries, long train rows walked inside a part,
+    a last part shorter than the others, exact ties that send tiles to the exact sweep: the same bits as the exact sweep."""
+    rng = np.random.default_rng(U + I + part)
+    Eu = torch.tensor((rng.standard_normal((U, d)) * 0.4).astype(np.float32)).to(DEV)
+    Ei = torch.tensor((rng.standard_normal((I, d)) * 0.4).astype(np.float32)).to(DEV)
+    train = _train_csr(ops, U, I, rng, 300)
+    q = torch.tensor(rng.permutation(U)).to(DEV)
+    try:
+        ops.topk_set_part_items(part)
+        _assert_same(*_both(ops, Eu, Ei, q, train, K), what="item parts")
+        assert LAST["fallback_tiles"] == 0, LAST
+        Ei_t = torch.round(Ei * 2)                                                          # integer-valued: exact ties everywhere (ordered by item id)
+        Eu_t = torch.round(Eu * 2)
+        _assert_same(*_both(ops, Eu_t, Ei_t, q, train, K), what="item parts, ties")
+    finally:
+        ops.topk_set_part_items(0)
