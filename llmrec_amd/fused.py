@@ -372,8 +372,9 @@ class FusedStep:
         return (_c.c_float * len(r))(*r)
 
     # -- forward ----------------------------------------------------------------------------------
-    def forward(self, sampler=None, after_chain=None):
-        """sampler / after_chain: launches for the ID chain's stream, ahead of / behind its SpMMs (the batch and what is derived from it)."""
+    def forward(self, sampler=None, after_chain=None, before_fusion=None):
+        """sampler / after_chain: launches for the ID chain's stream, ahead of / behind its SpMMs (the batch and what is derived from it);
+        before_fusion: called behind the join of the side chains, ahead of the fusion launch."""
         m, d = self.m, self.d
         self._fork(self.s2)
         # LLMREC_ID_FIRST=1 (experiment, profiles/experiments/r05_step_chain.md): the ID chain's SpMMs BEFORE the sampler and the row list on
@@ -432,6 +433,8 @@ class FusedStep:
             with self._on(self.s3):                                      # after the BPR backward, round 2, the graph ran it last: the step's tail)
                 self._feat_reg()
         self._join(self.s1, self.s2)
+        if before_fusion is not None:
+            before_fusion()
 
         # E_u and E_i (Models.py:185-197) in ONE launch: llmrec_fuse_fwd_multi_f32 (two independent row ranges)
         keep = []
@@ -478,6 +481,30 @@ class FusedStep:
             arr[i].g_mf, arr[i].g_emb = self.w_mf[i], self.w_emb[i]
         return arr
 
+    def _bpr_launches(self, users, pos, neg, n_valid, lo: int = 0, hi: Optional[int] = None):
+        """scores -> selection -> backward rows of the problems [lo, hi) (all: the step's three loss launches). The launch that contains
+        problem 0 begins the step (row stamp, AdamW's counter) and stamps the batch's rows."""
+        hp, B = self.hp, users.numel()
+        hi = self.n_prob if hi is None else hi
+        full = self._problems()
+        n = hi - lo
+        probs = full if (lo == 0 and hi == self.n_prob) else (ops.BprProblem * n)(*[full[i] for i in range(lo, hi)])
+        saved = self.saved if lo == 0 else self.saved[lo * ops.bpr_saved_floats(B):]
+        remember = float(1 - hp.prune_loss_drop_rate)
+        first = lo == 0
+        if self.fold and first:                                          # the scores launch begins the step: row stamp + AdamW's counter
+            o = self.opt
+            if o.dev_state is None:
+                o.dev_state = torch.zeros(3, dtype=torch.float32, device=self.E_u.device)
+            _call("llmrec_bpr_multi_scores_step_f32", n, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), _p(saved),
+                  _p(self.row_stamp), _p(o.dev_state), o.lr, o.betas[0], o.betas[1])
+        else:
+            _call("llmrec_bpr_multi_scores_f32", n, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), _p(saved),
+                  _p(self.row_stamp) if first else None)
+        _call("llmrec_bpr_multi_select_bwd_f32", n, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), remember,
+              float(hp.decay), float(hp.batch_size), _p(saved), _p(self.flag_u) if first else None, _p(self.flag_i) if first else None,
+              _p(self.row_stamp), _p(self.bpr_plan))
+
     def loss_backward(self, users, pos, neg, n_valid=None):
         B = users.numel()
         if B > self.b_max:
@@ -488,17 +515,12 @@ class FusedStep:
         # critical path: scores -> [selection + gradient rows] (two launches); the loss VALUES (one more launch) and their assembly for
         # the log line ride on the ID chain's stream (a branch of their own right behind the BPR launches: the graph ran it as the step's tail)
         self._check_scatter_targets()
-        if self.fold:                                                    # the scores launch begins the step: row stamp + AdamW's counter
-            o = self.opt
-            if o.dev_state is None:
-                o.dev_state = torch.zeros(3, dtype=torch.float32, device=self.E_u.device)
-            _call("llmrec_bpr_multi_scores_step_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), _p(self.saved),
-                  _p(self.row_stamp), _p(o.dev_state), o.lr, o.betas[0], o.betas[1])
+        if getattr(self, "_bpr_split_done", False):                      # (LLMREC_BPR_SPLIT: problems 1.. were launched beside the fusion)
+            self._bpr_launches(users, pos, neg, n_valid, lo=0, hi=1)
+            self._join(self.s1)
+            self._bpr_split_done = False
         else:
-            _call("llmrec_bpr_multi_scores_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), _p(self.saved),
-                  _p(self.row_stamp))
-        _call("llmrec_bpr_multi_select_bwd_f32", self.n_prob, probs, self.d, _p(users), _p(pos), _p(neg), B, _p(n_valid), remember,
-              float(hp.decay), float(hp.batch_size), _p(self.saved), _p(self.flag_u), _p(self.flag_i), _p(self.row_stamp), _p(self.bpr_plan))
+            self._bpr_launches(users, pos, neg, n_valid)
 
         def side():                              # (runs on the ID chain's stream, _backward places it)
             if self.fold:                        # loss values + regulariser (the fusion launch's partial sums) + assembly: one launch
@@ -723,11 +745,11 @@ class FusedStep:
         if loss_s3:
             self._join(self.s3)
 
-    def _train_forward(self, sampler=None, after_chain=None):
+    def _train_forward(self, sampler=None, after_chain=None, before_fusion=None):
         """forward() of a training step: also advances AdamW's counters (and samples the batch) on a side stream."""
         self._zero_in_forward = True
         try:
-            self.forward(sampler, after_chain)
+            self.forward(sampler, after_chain, before_fusion)
         finally:
             self._zero_in_forward = False
 
@@ -773,7 +795,17 @@ class FusedStep:
             self._stamp(0)
             if sampler is not None and not side:
                 sampler()
-            self._train_forward(sampler if side else None, late)
+            # LLMREC_BPR_SPLIT=1 (experiment, profiles/experiments/r06_step_chain.md): the seven side problems' loss launches (their tables are
+            # complete BEFORE the fusion) on the profile stream beside the fusion; only problem 0 (E_u / E_i) stays on the critical path
+            split = (os.environ.get("LLMREC_BPR_SPLIT", "0") == "1" and self.fold and self.multi_stream and self.n_prob > 1)
+            self._bpr_split_done = False
+
+            def side_problems():
+                self._fork_from(self._mark(), self.s1)
+                with self._on(self.s1):
+                    self._bpr_launches(users, pos, neg, n_valid, lo=1)
+                self._bpr_split_done = True
+            self._train_forward(sampler if side else None, late, side_problems if split else None)
             self.loss_backward(users, pos, neg, n_valid)
             if not self.inline_adamw:
                 self.opt.step(advanced=True)
