@@ -400,6 +400,43 @@ SYNTH_CONFIGS = {
 SYNTH_BLOCKS = 16
 
 
+def synth_blocks_of_rank(scaling: str, blocks: int, rank: int, world: int):
+    """(total user blocks of the job, the blocks of `rank`): strong scaling splits all SYNTH_BLOCKS over the ranks, weak gives every rank
+    `blocks` (default 2) of them."""
+    if scaling == "strong":
+        total = blocks or SYNTH_BLOCKS
+        if total % world:
+            raise SystemExit("strong scaling: %d blocks do not divide over %d ranks" % (total, world))
+        return total, list(range(rank * (total // world), (rank + 1) * (total // world)))
+    per = blocks or 2
+    return per * world, list(range(rank * per, (rank + 1) * per))
+
+
+def row_sharded_plan(name: str, scaling: str, world: int, exchange: str = "all_reduce", n_chunks: int = 0, blocks: int = 0, batch_local: int = 1024,
+                     sparse_forward: bool = False):
+    """The shape of an N-rank row-sharded line WITHOUT launching anything (tests/test_bench_line_cpu.py): per-rank
+    users / edges, the user partition (llmrec_amd.dist.user_block over the job's users), the chunks of the exchanged I x d message and the
+    bytes a step exchanges (llmrec_amd.dist_fused.plan_chunks / message_plan - the functions ShardedFusedID itself uses)."""
+    from llmrec_amd import dist as ldist
+    from llmrec_amd.dist_fused import plan_chunks, message_plan
+    cfg = SYNTH_CONFIGS[name]
+    bu, be_ = cfg["n_users"] // SYNTH_BLOCKS, cfg["n_edges"] // SYNTH_BLOCKS
+    ranks = []
+    for r in range(world):
+        total, mine = synth_blocks_of_rank(scaling, blocks, r, world)
+        u0, u1 = ldist.user_block(bu * total, r, world)
+        assert (u0, u1) == (mine[0] * bu, (mine[-1] + 1) * bu), "the block split and the contiguous user partition disagree"
+        ranks.append({"rank": r, "blocks": mine, "users": [u0, u1], "edges_nominal": be_ * len(mine)})
+    n_aug = int(batch_local * cfg["aug_rate"])
+    chunks = plan_chunks(cfg["n_items"], cfg["d"], world, n_chunks or None, exchange)
+    return {"config": {"workload": "synthetic_%s_shape_row_sharded_id_path" % name, "scaling": scaling, "n_users_global": bu * total,
+                       "n_items": cfg["n_items"], "users_per_gpu": bu * len(ranks[0]["blocks"]), "edges_per_gpu_nominal": be_ * len(ranks[0]["blocks"]),
+                       "embed_size": cfg["d"], "prop_layers": cfg["layers"], "batch_per_gpu": batch_local, "augmented_triples_per_gpu": n_aug,
+                       "global_batch": (batch_local + n_aug) * world, "user_blocks_total": total},
+            "ranks": ranks, "chunks": chunks,
+            "messages": message_plan(cfg["n_items"], cfg["d"], cfg["layers"], batch_local + n_aug, len(chunks), exchange, sparse_forward)}
+
+
 class RowSharded:
     """llmrec_amd/dist_fused.ShardedFusedID on cfg-4 / cfg-5-shaped synthetic graphs. The graph is generated in 16
     user blocks with per-block seeds, so the GLOBAL graph does not depend on the number of ranks: weak scaling gives
@@ -413,15 +450,7 @@ class RowSharded:
         cfg = SYNTH_CONFIGS[name]
         self.name, self.cfg, self.scaling, self.device, self.rank, self.world = name, cfg, scaling, device, rank, world
         bu, be_ = cfg["n_users"] // SYNTH_BLOCKS, cfg["n_edges"] // SYNTH_BLOCKS
-        if scaling == "strong":
-            total = blocks or SYNTH_BLOCKS
-            if total % world:
-                raise SystemExit("strong scaling: %d blocks do not divide over %d ranks" % (total, world))
-            mine = list(range(rank * (total // world), (rank + 1) * (total // world)))
-        else:
-            per = blocks or 2
-            total = per * world
-            mine = list(range(rank * per, (rank + 1) * per))
+        total, mine = synth_blocks_of_rank(scaling, blocks, rank, world)
         self.blocks_total, self.blocks_mine = total, len(mine)
         self.comm, self.backend = ldist.Comm(single=single), ldist.HipBackend()
         t0 = time.perf_counter()

@@ -104,6 +104,28 @@ def all_reduce_start(comm: Comm, t: torch.Tensor):
     return comm.dist.all_reduce(t, async_op=True)
 
 
+def plan_chunks(n_items: int, d: int, world: int, n_chunks=None, exchange: str = "all_reduce", force: bool = False):
+    """The item-row chunks [(r0, r1)] of an exchanged I x d message (pure arithmetic: bench.py composes an N-rank line's fields from it
+    without launching). None = the policy: one chunk in a world of one rank (nothing to overlap), else pieces of >= 32 MB, at most 8;
+    rs_ag: every chunk but possibly the last splits evenly over the ranks."""
+    if n_chunks is None:
+        n_chunks = 1 if (world == 1 and not force) else max(1, min(8, (4 * n_items * d) // (32 << 20)))
+    n_chunks = max(1, min(int(n_chunks), n_items))
+    per = (n_items + n_chunks - 1) // n_chunks
+    if exchange == "rs_ag":
+        per = (per + world - 1) // world * world
+    return [(r0, min(r0 + per, n_items)) for r0 in range(0, n_items, per)]
+
+
+def message_plan(n_items: int, d: int, n_layers: int, batch: int, n_chunks: int, exchange: str = "all_reduce", sparse_forward: bool = False) -> dict:
+    """What one step of the row-sharded ID path exchanges (one I x d message per layer and direction), from the shapes alone."""
+    n_msg = 2 * n_layers - (1 if sparse_forward else 0)
+    return {"exchange": exchange, "allreduce_I_x_d_bytes": 4 * n_items * d * n_msg,
+            "last_forward_message": "a fixed block of 2 B world rows (the batches' item rows, zeros behind the list's end)" if sparse_forward else "I x d",
+            "allreduce_messages": n_msg * n_chunks + (1 if sparse_forward else 0), "chunk_bytes": 4 * d * ((n_items + n_chunks - 1) // n_chunks),
+            "bpr_rows_allgather_bytes_per_rank": 2 * batch * (4 * d + 8), "prune_allgather_bytes_per_rank": 4 * batch}
+
+
 class ShardedFusedID:
     """One rank's part of the fused ID-path training step."""
 
@@ -193,13 +215,7 @@ class ShardedFusedID:
         self.flag_u = torch.zeros(U, dtype=torch.uint8, device=dev)
         self.flag_i = torch.zeros(I, dtype=torch.uint8, device=dev)
         # item-row chunks of the two SpMMs whose output is all-reduced (>= 32 MB per message unless told otherwise)
-        if n_chunks is None:                                  # nothing to overlap in a world of one rank
-            n_chunks = 1 if (comm.world == 1 and not comm.force) else max(1, min(8, (4 * I * d) // (32 << 20)))
-        n_chunks = max(1, min(n_chunks, I))
-        per = (I + n_chunks - 1) // n_chunks
-        if exchange == "rs_ag":                               # every chunk but possibly the last splits evenly over the ranks
-            per = (per + comm.world - 1) // comm.world * comm.world
-        self.chunks = [(r0, min(r0 + per, I)) for r0 in range(0, I, per)]
+        self.chunks = plan_chunks(I, d, comm.world, n_chunks, exchange, force=comm.force)
         # rs_ag: one staging piece per chunk (the rows this rank reduces and owns between the two halves of the exchange)
         self.shards = [f((r1 - r0) // comm.world, d) if (exchange == "rs_ag" and (r1 - r0) % comm.world == 0) else None
                        for r0, r1 in self.chunks]
@@ -409,8 +425,6 @@ class ShardedFusedID:
 
     # -- accounting for bench.py -------------------------------------------------------------------------
     def message_bytes_per_step(self) -> dict:
-        return {"exchange": self.exchange, "allreduce_I_x_d_bytes": 4 * self.I * self.d * (2 * self.L - (1 if self.sparse_forward else 0)),
-                "last_forward_message": "a fixed block of 2 B world rows (the batches' item rows, zeros behind the list's end)" if self.sparse_forward else "I x d",
-                "exchanged_bytes_last_step": int(self.allreduce_bytes),
-                "allreduce_messages": (2 * self.L - (1 if self.sparse_forward else 0)) * len(self.chunks) + (1 if self.sparse_forward else 0),
-                "bpr_rows_allgather_bytes_per_rank": 2 * self.B * (4 * self.d + 8), "prune_allgather_bytes_per_rank": 4 * self.B}
+        out = message_plan(self.I, self.d, self.L, self.B, len(self.chunks), self.exchange, self.sparse_forward)
+        out["exchanged_bytes_last_step"] = int(self.allreduce_bytes)
+        return out

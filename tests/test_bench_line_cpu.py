@@ -110,12 +110,41 @@ def test_headline_vs_reference_comparison_is_a_pure_function_of_the_two_records(
 
 
 def test_topk_mode_policy():
-    """ops.topk_mode: "auto" = the bf16 sweep while the fp32 item table fits 128 MB and K leaves room for the verification."""
+    """ops.topk_mode: "auto" = the bf16 sweep whenever K leaves room for the verification (round 6: at every table size - tables beyond
+    131 072 items are swept in item parts)."""
     from llmrec_amd import ops
     assert ops.topk_mode("auto", 17366, 64, 50) == 1 and ops.topk_mode("auto", 10322, 64, 50) == 1
-    assert ops.topk_mode("auto", 524288, 64, 50) == 1 and ops.topk_mode("auto", 524289, 64, 50) == 0      # 128 MB
-    assert ops.topk_mode("auto", 1_000_000, 64, 50) == 0 and ops.topk_mode("auto", 200_000, 128, 50) == 1
+    assert ops.topk_mode("auto", 524288, 64, 50) == 1 and ops.topk_mode("auto", 524289, 64, 50) == 1
+    assert ops.topk_mode("auto", 1_000_000, 64, 50) == 1 and ops.topk_mode("auto", 5_000_000, 128, 50) == 1
     assert ops.topk_mode("auto", 17366, 64, 57) == 0 and ops.topk_mode("auto", 17366, 64, 56) == 1       # K <= LLMREC_TOPK_PREFILTER_MAX_K
     assert ops.topk_mode("exact", 17366, 64, 50) == 0 and ops.topk_mode("prefilter", 10**7, 64, 50) == 1
     with pytest.raises(RuntimeError):
         ops.topk_mode("fast")
+
+
+def test_eight_rank_cfg4_line_is_composed_without_launching():
+    """what `python bench.py --gpus 8` (cfg 4, strong scaling) will report as its shape and its exchanged bytes, from
+    bench.row_sharded_plan - pure arithmetic over llmrec_amd.dist.user_block and llmrec_amd.dist_fused.plan_chunks / message_plan, the
+    functions the ranks themselves use. No multi-GPU run exists; this pins the plan."""
+    import bench
+    p = bench.row_sharded_plan("cfg4", "strong", 8)
+    c = p["config"]
+    assert c["n_users_global"] == 10_000_000 and c["users_per_gpu"] == 1_250_000 and c["edges_per_gpu_nominal"] == 25_000_000
+    assert c["global_batch"] == 8 * 1024 and c["user_blocks_total"] == 16
+    assert [r["blocks"] for r in p["ranks"]] == [[2 * k, 2 * k + 1] for k in range(8)]
+    assert [r["users"] for r in p["ranks"]] == [[1_250_000 * k, 1_250_000 * (k + 1)] for k in range(8)]          # contiguous, complete
+    # one I x d message per layer and direction: 4 x 256 MB per step, each in 7 chunks (>= 32 MiB) queued behind the chunk's SpMM
+    assert len(p["chunks"]) == 7 and p["chunks"][0] == (0, 142_858) and p["chunks"][-1] == (857_148, 1_000_000)
+    assert all(a[1] == b[0] for a, b in zip(p["chunks"], p["chunks"][1:]))
+    m = p["messages"]
+    assert m["allreduce_I_x_d_bytes"] == 4 * 1_000_000 * 64 * 4 and m["allreduce_messages"] == 28 and m["chunk_bytes"] == 4 * 64 * 142_858
+    assert m["bpr_rows_allgather_bytes_per_rank"] == 2 * 1024 * (256 + 8)
+    # rs_ag: chunks that split evenly over the 8 ranks; the restricted forward: one message fewer, one fixed-size block more
+    q = bench.row_sharded_plan("cfg4", "strong", 8, exchange="rs_ag", sparse_forward=True)
+    assert all((r1 - r0) % 8 == 0 for r0, r1 in q["chunks"][:-1]) and q["messages"]["allreduce_messages"] == 3 * len(q["chunks"]) + 1
+    # cfg 5 at 8 ranks, weak scaling (2 of the 16 blocks per GPU = the whole config): 2.56 GB messages, + 5 % triples
+    w = bench.row_sharded_plan("cfg5", "weak", 8)
+    assert w["config"]["n_users_global"] == 50_000_000 and w["config"]["augmented_triples_per_gpu"] == 51
+    assert w["messages"]["allreduce_I_x_d_bytes"] == 4 * 5_000_000 * 128 * 4 and len(w["chunks"]) == 8
+    # a world of one rank: nothing to overlap, one chunk
+    assert len(bench.row_sharded_plan("cfg4", "strong", 1)["chunks"]) == 1
