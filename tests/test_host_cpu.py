@@ -36,7 +36,9 @@ def test_workspace_queries_run_without_gpu():
     # + the bitmaps of long train rows: two rows of one word per item tile for every block of the sweep (off beyond 131 072 items / 64 MB)
     heavy = lambda blocks, n_items: up(blocks * 2 * -(-n_items // 32) * 4)
     assert _lib.query("llmrec_score_topk_workspace_bytes", 13187, 17366, 64) == 57 * 4 * 16 * 64 * 8 + packed(17366, 64, 13187) + heavy(768 + 57 * 4, 17366)
-    assert _lib.query("llmrec_score_topk_workspace_bytes", 4096 * 16, 1_000_000, 64) == packed(1_000_000, 64, 4096 * 16)      # whole rounds: nothing is split
+    # beyond 131 072 items the bf16 sweep cuts EVERY user tile into item parts (round 6): part lists for the smallest part (16 384 items) of any width
+    assert _lib.query("llmrec_score_topk_workspace_bytes", 4096 * 16, 1_000_000, 64) == 4096 * 62 * 16 * 64 * 8 + packed(1_000_000, 64, 4096 * 16)
+    assert _lib.query("llmrec_score_topk_workspace_bytes", 4096 * 16, 1_000_000, 128) == 4096 * 62 * 16 * 64 * 8 + packed(1_000_000, 128, 4096 * 16)
     assert _lib.query("llmrec_score_topk_workspace_bytes", 100, 500, 20) == packed(500, 20, 100) + heavy(7, 500)        # too few items to cut
     assert _lib.query("llmrec_score_topk_workspace_bytes", 16 * 4096, 131_072, 64) == packed(131_072, 64, 16 * 4096)      # 128 MB of slices: off
     assert _lib.query("llmrec_score_topk_workspace_bytes", -1, 10, 64) == -1
@@ -175,7 +177,7 @@ def test_bench_finds_its_committed_profile_data():
         avg = bench.rocprof_avg_us([(key, 1)])
         assert avg is not None and avg["avg_us"] > 0, key
     shares = bench.kernel_time_shares()
-    assert shares is not None and "spmm_kernel" in shares["classes"] and shares["file"].startswith("r05_")
+    assert shares is not None and "spmm_kernel" in shares["classes"] and shares["file"].startswith("r06_")
     # and the kernels exist under these names in the library's source
     csrc = open(os.path.join(os.path.dirname(_lib.HEADER), "..", "llmrec_amd", "csrc", "dense.hip")).read()
     for key in names:
