@@ -323,8 +323,8 @@ __global__ __launch_bounds__(256) void bpr_pack_kernel(int n_prob, int B_max, co
 //                          runlen[3 B_max]           at a run's first position: the number of keys with that id; 0 elsewhere (and for id 0xffffffff)
 //   bpr_bwd_runs_kernel  one 16-lane group per sorted position and problem; the HEAD of a run of equal ids owns the destination row
 //                        and adds, in ascending problem index (problems whose target POINTER is the same - the five attribute problems
-//                        of a step share d prof_u - are summed by the first of them) and ascending slot, what bpr_bwd_multi_kernel's
-//                        atomics added; a dropped sample (coefficient 0) of a problem without a regulariser share is skipped, its
+//                        of a step share d prof_u - are summed by the first of them) and ascending slot, what rounds 1 - 5
+//                        added with atomics; a dropped sample (coefficient 0) of a problem without a regulariser share is skipped, its
 //                        contribution being exactly zero. The (problem, member) pairs of a run are taken 16 at a time: lane l fetches
 //                        pair l's slot, coefficient and row ids (ONE round of dependent loads for 16 pairs), the pairs that contribute are
 //                        compacted into LDS records, and the group then streams the records' rows four at a time.
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void bpr_select_kernel(const int64_t* __restri
     }
 }
 
-// the rows bpr_bwd_multi_kernel added into are cleared again (same grid): the scatter targets stay all-zero between steps
+// the rows the loss backward added into are cleared again (one lane group per sample): the scatter targets stay all-zero between steps
 // without a dense memset
 __global__ __launch_bounds__(256) void bpr_zero_rows_kernel(BprTables t, int d, const int64_t* __restrict__ users,
                                                             const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
