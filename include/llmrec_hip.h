@@ -151,6 +151,10 @@ typedef struct {
      * equal mod 8: each XCD has a private L2) a CONTIGUOUS piece of the short-row / wavefront-row / block-row tasks instead of every 8th
      * block of them - for graphs whose row ids expose communities. Results are bit-identical. 0 = the linear map. */
     int32_t xcd_contiguous;
+    /* Round 6: the tasks of the lane-group bucket run as software pipelines - a lane group takes several tasks and keeps the next task's indices
+     * and the one after's row pointers in flight while it gathers (one memory round trip per task instead of three; results bit-identical).
+     * no_pipeline != 0 restores one task per lane group (A/B switch). */
+    int32_t no_pipeline;
 } llmrec_spmm_epilogue_t;
 /* Round 5 - "these rows of A X" with the row list AND its length in device memory (the row-restricted forward of the row-sharded step,
  * without a host read-back: llmrec_amd/dist_fused.py). Pattern-only operands (A = diag(row_scale) P).

@@ -109,6 +109,8 @@ struct SpmmArgs {
     const uint8_t* y_needed;     // rows whose byte != x_active are neither computed nor written (short-row range)
     int32_t listed_only;         // no short-row range at all: only the plan's row lists are computed
     int32_t nt_from;             // (NT kernels) X rows with index >= nt_from are gathered with the non-temporal policy: cache hint only
+    int32_t no_pipeline;         // llmrec_spmm_epilogue_t.no_pipeline
+    int32_t pipe;                // > 1: tasks per lane group of the short-row range, run as a software pipeline (rows_body_pipe)
     int32_t xcd;                 // block -> row map of the short-row / wavefront-row / block-row ranges: XCD-contiguous (xcd_range_logical)
     // plan
     const int32_t* slot_row;     // non-NULL: rowptr / colidx are the PERMUTED CSR of the plan - CSR row `slot` is output row slot_row[slot], the
@@ -125,10 +127,59 @@ struct SpmmArgs {
 
 // Accumulate sum_{j in [s, e)} w_j * X[col_j, chunk columns] into acc, in ascending j order. MASKED: rows of X that are not active
 // (a.x_mask) are known to be all-zero and are not fetched; `any` collects whether this lane saw an active column.
-template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED, bool NT>
-__device__ __forceinline__ void accumulate_range(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, int gl, Vec<VEC> (&acc)[NCHUNK], int& any) {
+// unmasked ranges (round 6): the NEXT chunk's column indices (and adjacency values) are fetched while the current chunk's rows are gathered, the
+// col_scale factors of the current chunk ride beside its gathers - one memory round trip per chunk of LPR non-zeros instead of two or three.
+// Same gathers, same order of additions: bit-identical to the loop it replaces.
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool NT>
+__device__ __forceinline__ void accumulate_range_plain(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, int gl, Vec<VEC> (&acc)[NCHUNK]) {
+    int32_t c_next = 0;
+    float v_next = 1.0f;
+    if (s + gl < e) { c_next = a.colidx[s + gl]; if (WEIGHTED && a.val) v_next = a.val[s + gl]; }
     for (int32_t base = s; base < e; base += LPR) {
         const int n = min(LPR, e - base);
+        const int32_t myc = c_next;
+        float myw = v_next;
+        const int32_t nb = base + LPR;
+        if (nb + gl < e) { c_next = a.colidx[nb + gl]; if (WEIGHTED && a.val) v_next = a.val[nb + gl]; }
+        float cs = 1.0f;
+        if (WEIGHTED && a.col_scale && gl < n) cs = a.col_scale[myc];        // (in flight beside the gathers below)
+        for (int t = 0; t < n; t += UNROLL) {
+            Vec<VEC> v[UNROLL][NCHUNK];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int tt = t + u;
+                const int32_t c = __shfl(myc, tt & (LPR - 1), LPR);
+                const float* xr = a.X + (int64_t)c * a.ldx + col0;
+#pragma unroll
+                for (int k = 0; k < NCHUNK; ++k) {
+                    const int col = (k * LPR + gl) * VEC;
+                    if (tt < n && col < a.d) {
+                        if (NT && c >= a.nt_from) v[u][k].load_nt(xr + col);     // (uniform per lane group) cold row: do not displace the hot set
+                        else v[u][k].load(xr + col);
+                    } else v[u][k].zero();
+                }
+            }
+            if (WEIGHTED && t == 0) myw = gl < n ? myw * cs : 0.f;            // val[e] * col_scale[c], as the loop it replaces forms it
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                float w = 0.f;
+                if (WEIGHTED) w = __shfl(myw, (t + u) & (LPR - 1), LPR);
+#pragma unroll
+                for (int k = 0; k < NCHUNK; ++k) {
+                    if (WEIGHTED) acc[k].fma(w, v[u][k]);
+                    else acc[k].add(v[u][k]);
+                }
+            }
+        }
+    }
+}
+
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED, bool NT>
+__device__ __forceinline__ void accumulate_range(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, int gl, Vec<VEC> (&acc)[NCHUNK], int& any) {
+    if constexpr (!MASKED) {
+        if (!a.no_pipeline) { accumulate_range_plain<LPR, NCHUNK, VEC, WEIGHTED, NT>(a, col0, s, e, gl, acc); return; }
+    }
+    for (int32_t base = s; base < e; base += LPR) {        const int n = min(LPR, e - base);
         int32_t myc = 0;
         float myw = 0.f;
         int myact = 0;
@@ -315,6 +366,99 @@ __device__ __forceinline__ void rows_body(const SpmmArgs& a, int64_t block) {
     finish_row<LPR, NCHUNK, VEC>(a, col0, row, gl, acc, zero_row);
 }
 
+// PIPELINED short rows (round 6). A (row, slice) task of the lane-group bucket is three DEPENDENT memory round trips - {slot -> output row,
+// row pointers} -> column indices -> X rows - for a handful of gathers, and a launch-bound product (the step's [rows, 7 x 64] side products:
+// 121 k tasks, ~32 k lane groups resident) pays them once per round of resident blocks: 4 rounds x 3 latencies. Here a lane group takes
+// `pipe` tasks (task, task + G, task + 2 G, ...: neighbouring groups keep neighbouring slots) and runs them as a software pipeline: while the
+// rows of task i are gathered, the indices of task i + 1 and the row pointers of task i + 2 are already in flight - ONE round trip per task
+// after a two-deep prologue, and pipe x fewer blocks to schedule. Same gathers in the same order: bit-identical sums. (The other shape tried -
+// one task per row looping over the slices, indices loaded once - was no faster in the step and slower alone: 29.4 vs 28.3 us.)
+template <int LPR, int NCHUNK, int VEC, bool WEIGHTED>
+__device__ __forceinline__ void rows_body_pipe(const SpmmArgs& a, int64_t block, int64_t n_blocks) {
+    constexpr int GPB = TPB / LPR;
+    constexpr int NI = (LLMREC_SPMM_LONG_ROW + LPR - 1) / LPR;         // index registers per lane
+    const int gl = threadIdx.x & (LPR - 1);
+    const int64_t n_list = a.slot_row ? (int64_t)a.n_short_rows : a.n_rows;
+    const int64_t n_tasks = n_list * a.n_slices, G = n_blocks * GPB;
+    int64_t t0 = block * GPB + (threadIdx.x / LPR);
+    if (t0 >= n_tasks) return;
+    auto level1 = [&](int64_t t, int64_t& row, int32_t& s_, int32_t& n_, int64_t& col0) {    // slot -> output row, row pointers (independent loads)
+        const int64_t slice = t / n_list, slot = t - slice * n_list;
+        row = a.slot_row ? (int64_t)a.slot_row[slot] : slot;
+        s_ = a.rowptr[slot]; n_ = a.rowptr[slot + 1] - s_;
+        col0 = slice * a.d;
+    };
+    auto level2 = [&](int32_t s_, int32_t n_, int32_t (&c)[NI]) {                              // the row's column indices (<= LONG_ROW of them)
+#pragma unroll
+        for (int k = 0; k < NI; ++k) { const int j = k * LPR + gl; c[k] = (j < n_ && n_ <= LLMREC_SPMM_LONG_ROW) ? a.colidx[s_ + j] : 0; }
+    };
+    int64_t row0, col00, row1 = 0, col01 = 0;
+    int32_t s0, n0, s1 = 0, n1 = 0, c0[NI], c1[NI];
+    level1(t0, row0, s0, n0, col00);
+    level2(s0, n0, c0);
+    int64_t t1 = t0 + G;
+    bool has1 = t1 < n_tasks;
+    if (has1) level1(t1, row1, s1, n1, col01);
+    for (;;) {
+        int64_t row2 = 0, col02 = 0;
+        int32_t s2 = 0, n2 = 0;
+        const int64_t t2 = t1 + G;
+        const bool has2 = has1 && t2 < n_tasks;
+        if (has1) level2(s1, n1, c1);                                   // in flight while task 0's rows are gathered
+        if (has2) level1(t2, row2, s2, n2, col02);
+        if (n0 <= LLMREC_SPMM_LONG_ROW && !(a.y_needed && (int)a.y_needed[row0] != a.x_active)) {   // (longer: a row of another bucket, plain plans only)
+            float w0[NI];
+            if (WEIGHTED) {
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    const int j = k * LPR + gl;
+                    w0[k] = 0.f;
+                    if (j < n0) { w0[k] = a.val ? a.val[s0 + j] : 1.0f; if (a.col_scale) w0[k] *= a.col_scale[c0[k]]; }
+                }
+            }
+            Vec<VEC> acc[NCHUNK];
+#pragma unroll
+            for (int k = 0; k < NCHUNK; ++k) acc[k].zero();
+#pragma unroll
+            for (int ki = 0; ki < NI; ++ki) {
+                const int nk = min(LPR, n0 - ki * LPR);                 // indices of this register that are in the row (uniform per lane group)
+                for (int t = 0; t < nk; t += UNROLL) {
+                    Vec<VEC> v[UNROLL][NCHUNK];
+                    float w[UNROLL];
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) {
+                        const int tt = t + u;
+                        const int32_t c = __shfl(c0[ki], tt & (LPR - 1), LPR);
+                        const float* xr = a.X + (int64_t)c * a.ldx + col00;
+#pragma unroll
+                        for (int k = 0; k < NCHUNK; ++k) {
+                            const int col = (k * LPR + gl) * VEC;
+                            if (tt < nk && col < a.d) v[u][k].load(xr + col);
+                            else v[u][k].zero();
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) {
+                        if (WEIGHTED) w[u] = __shfl(w0[ki], (t + u) & (LPR - 1), LPR);
+#pragma unroll
+                        for (int k = 0; k < NCHUNK; ++k) {
+                            if (WEIGHTED) acc[k].fma(w[u], v[u][k]);
+                            else acc[k].add(v[u][k]);
+                        }
+                    }
+                }
+            }
+            finish_row<LPR, NCHUNK, VEC>(a, col00, row0, gl, acc, false);
+        }
+        if (!has1) break;
+        row0 = row1; col00 = col01; s0 = s1; n0 = n1;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) c0[k] = c1[k];
+        row1 = row2; col01 = col02; s1 = s2; n1 = n2;
+        t1 = t2; has1 = has2;
+    }
+}
+
 // one wavefront over [s, e): the 64/LPR lane groups take contiguous parts, butterfly sum -> every group holds the total
 template <int LPR, int NCHUNK, int VEC, bool WEIGHTED, bool MASKED, bool NT>
 __device__ __forceinline__ void wave_range(const SpmmArgs& a, int64_t col0, int32_t s, int32_t e, int lane, Vec<VEC> (&acc)[NCHUNK], int& any) {
@@ -415,7 +559,9 @@ __global__ __launch_bounds__(TPB) void spmm_kernel(SpmmArgs a) {
     __shared__ __attribute__((aligned(16))) float red_lds[(TPB / 64 - 1) * ROWW];
     const int32_t b = blockIdx.x;
     if (b >= a.blk_wave) {
-        rows_body<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, a.xcd ? (int64_t)xcd_range_logical(b, a.blk_wave, (int32_t)gridDim.x - a.blk_wave) : (int64_t)b - a.blk_wave);
+        const int64_t lb = a.xcd ? (int64_t)xcd_range_logical(b, a.blk_wave, (int32_t)gridDim.x - a.blk_wave) : (int64_t)b - a.blk_wave;
+        if (!MASKED && !NT && a.pipe > 1) rows_body_pipe<LPR, NCHUNK, VEC, WEIGHTED>(a, lb, (int64_t)gridDim.x - a.blk_wave);     // (block-uniform)
+        else rows_body<LPR, NCHUNK, VEC, WEIGHTED, MASKED, NT>(a, lb);
         return;
     }
     if (b >= a.blk_block) {
@@ -567,7 +713,16 @@ static int launch_spmm(SpmmArgs& a, hipStream_t stream) {
     const bool weighted = a.val != nullptr || a.col_scale != nullptr;
     constexpr int GPB = TPB / LPR;
     const int64_t S = a.n_slices;
-    const int64_t row_blocks = a.listed_only ? 0 : ceil_div((a.slot_row ? (int64_t)a.n_short_rows : a.n_rows) * S, GPB);
+    // unmasked products: the short rows' tasks as software pipelines (rows_body_pipe) - as many tasks per lane group as keep ~4 blocks per CU
+    const int64_t short_tasks = a.listed_only ? 0 : (a.slot_row ? (int64_t)a.n_short_rows : a.n_rows) * S;
+    int64_t pipe = 1;
+    if (!a.x_mask && !(a.nt_from > 0 && !weighted) && !a.no_pipeline) {
+        pipe = ceil_div(short_tasks, (int64_t)GPB * 1024);
+        if (pipe > 8) pipe = 8;
+        if (pipe < 1) pipe = 1;
+    }
+    a.pipe = (int32_t)pipe;
+    const int64_t row_blocks = ceil_div(short_tasks, GPB * pipe);
     const int64_t wave_blocks = ceil_div(a.n_wave_rows * S, TPB / 64);
     const int64_t total = a.n_segments * S + a.n_block_rows * S + wave_blocks + row_blocks;
     if (total > 0x7fffffffll) { set_error("spmm: too many rows for one launch"); return LLMREC_EUNSUPPORTED; }
@@ -639,6 +794,7 @@ extern "C" int llmrec_spmm_f32(int64_t n_rows, int64_t n_cols,
         LLMREC_CHECK_ARG(e.x_nt_from_row >= 0, "spmm: negative x_nt_from_row");
         a.nt_from = e.x_nt_from_row;
         a.xcd = e.xcd_contiguous != 0;
+        a.no_pipeline = e.no_pipeline != 0;
         if (e.y_row_needed) {
             LLMREC_CHECK_ARG(e.x_mask_active >= 1 && e.x_mask_active <= 255, "spmm: y_row_needed needs x_mask_active in 1..255");
             a.y_needed = e.y_row_needed; a.x_active = e.x_mask_active;

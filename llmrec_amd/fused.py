@@ -282,6 +282,8 @@ class FusedStep:
                 partials = self._partials[key] = torch.empty(pl.n_seg * d, dtype=torch.float32, device=X.device)
         if accumulate:
             epilogue = ops.spmm_epilogue(ops.EPI_NONE, 1.0, Y)
+        if epilogue is None and os.environ.get("LLMREC_SPMM_PIPELINE", "1") == "0":      # (A/B switch: one task per lane group)
+            epilogue = ops.spmm_epilogue()
         rp, ci = pl.csr_of(a)
         _call("llmrec_spmm_f32", a.n_rows, a.n_cols, _p(rp), _p(ci), _p(a.val), _p(a.row_scale), _p(a.col_scale),
               _p(X), _ld(X), _p(Y), _ld(Y), d, sw, _c.byref(pl.c_struct()), _p(partials),

@@ -67,7 +67,7 @@ class SpmmEpilogueC(_c.Structure):
     _fields_ = [("op", _c.c_int32), ("alpha", _c.c_float), ("Z", _c.c_void_p), ("ldz", _c.c_int64), ("S", _c.c_void_p), ("lds", _c.c_int64),
                 ("post_scale", _c.c_void_p), ("x_row_mask", _c.c_void_p), ("x_mask_active", _c.c_int32), ("y_row_flag", _c.c_void_p),
                 ("z_row_flag", _c.c_void_p), ("y_row_gate", _c.c_void_p), ("y_row_needed", _c.c_void_p), ("rows_listed_only", _c.c_int32),
-                ("x_nt_from_row", _c.c_int32), ("xcd_contiguous", _c.c_int32)]
+                ("x_nt_from_row", _c.c_int32), ("xcd_contiguous", _c.c_int32), ("no_pipeline", _c.c_int32)]
 
 
 EPI_NONE, EPI_SOFTMAX, EPI_SOFTMAX_BWD = 0, 1, 2
@@ -362,7 +362,7 @@ def spmm_epilogue(op: int = EPI_NONE, alpha: float = 0.0, Z: Optional[torch.Tens
                   post_scale: Optional[torch.Tensor] = None, x_row_mask: Optional[torch.Tensor] = None, x_mask_active: int = 0,
                   y_row_flag: Optional[torch.Tensor] = None, z_row_flag: Optional[torch.Tensor] = None,
                   y_row_gate: Optional[torch.Tensor] = None, y_row_needed: Optional[torch.Tensor] = None, rows_listed_only: bool = False,
-                  x_nt_from_row: int = 0, xcd_contiguous: bool = False):
+                  x_nt_from_row: int = 0, xcd_contiguous: bool = False, no_pipeline: Optional[bool] = None):
     """llmrec_spmm_epilogue_t: Y = post_scale . op(alpha * Z + A X); S = forward softmax rows for EPI_SOFTMAX_BWD.
     x_row_mask (uint8 [n_cols]) / x_mask_active: X rows whose byte differs from the active value are promised all-zero and not read;
     y_row_flag (uint8 [n_rows]): receives the active value for rows whose result can be non-zero (z_row_flag: the non-zero rows of Z);
@@ -381,7 +381,8 @@ def spmm_epilogue(op: int = EPI_NONE, alpha: float = 0.0, Z: Optional[torch.Tens
                          z_row_flag.data_ptr() if z_row_flag is not None else None,
                          y_row_gate.data_ptr() if y_row_gate is not None else None,
                          y_row_needed.data_ptr() if y_row_needed is not None else None, 1 if rows_listed_only else 0, int(x_nt_from_row),
-                         1 if xcd_contiguous else 0)
+                         1 if xcd_contiguous else 0,
+                         1 if (no_pipeline if no_pipeline is not None else os.environ.get("LLMREC_SPMM_PIPELINE", "1") == "0") else 0)
 
 
 def listed_plan(a: Csr, rows: torch.Tensor, d: int, whole_row: bool = False) -> SpmmPlan:
@@ -481,6 +482,8 @@ def spmm_raw(a: Csr, X: torch.Tensor, out: Optional[torch.Tensor] = None, accumu
             Xs = cache[key] = torch.empty(X.shape, dtype=torch.float32, device=X.device)
         _lib.call("llmrec_scale_rows_f32", X.shape[0], d, _p(col_scale), _p(X), _ld(X), _p(Xs), _ld(Xs), _stream())
         X, col_scale = Xs, None
+    if epilogue is None and os.environ.get("LLMREC_SPMM_PIPELINE", "1") == "0":          # (A/B switch: one task per lane group)
+        epilogue = spmm_epilogue()
     rp, ci = pl.csr_of(a)
     _lib.call("llmrec_spmm_f32", a.n_rows, a.n_cols, _p(rp), _p(ci), _p(a.val), _p(a.row_scale),
               _p(col_scale), _p(X), _ld(X), _p(Y), _ld(Y), d, sw, _c.byref(pl.c_struct()), _p(partials),

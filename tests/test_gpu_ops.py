@@ -577,6 +577,42 @@ def test_bpr_select_and_backward_in_one_launch(ops, drop, cap, valid, d):
             assert rel_err(g1[i][0], a.grad) < 2e-5 and rel_err(g1[i][1], b.grad) < 2e-5
 
 
+@pytest.mark.parametrize("d,weighted,n_rows", [(448, False, 30000), (448, True, 30000), (64, False, 150000), (192, True, 25000), (20, False, 70000)])
+def test_spmm_pipelined_short_rows_equal_one_task_per_lane_group(ops, d, weighted, n_rows):
+    """Round 6: the lane-group bucket's tasks as software pipelines (a lane group takes up to 8 tasks and keeps the next task's indices and
+    the one after's row pointers in flight) against one task per lane group (epilogue.no_pipeline): the same bits - plain and with the
+    "+ Z" epilogue, pattern-only and weighted (col_scale: the transposed products of the step's backward), sliced and unsliced operands,
+    float4 and scalar rows (d = 20), with and without the plan's permuted CSR, empty rows and every long-row bucket included."""
+    rng = np.random.default_rng(d + int(weighted))
+    n_cols = 5000
+    degs = rng.integers(0, 34, size=n_rows)
+    for k, dg in enumerate([0, 0, 1, 31, 32, 33, 100, 129, 600, 2049, 4000]):
+        degs[(k * 17 + 3) % n_rows] = dg
+    rows = np.repeat(np.arange(n_rows), degs)
+    cols = rng.integers(0, n_cols, size=rows.size)
+    key64 = np.unique(rows.astype(np.int64) * n_cols + cols)                   # (distinct (row, col) pairs)
+    rows, cols = key64 // n_cols, key64 % n_cols
+    rp, ci, _ = ops.csr_from_coo(torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV), None, n_rows, n_cols)
+    rs = torch.tensor(rng.random(n_rows).astype(np.float32)).to(DEV)
+    cs = torch.tensor(rng.random(n_cols).astype(np.float32)).to(DEV) if weighted else None
+    a = ops.Csr(n_rows, n_cols, rp, ci, None, rs, cs, {})
+    X = torch.tensor(rng.standard_normal((n_cols, d)).astype(np.float32)).to(DEV)
+    Z = torch.tensor(rng.standard_normal((n_rows, d)).astype(np.float32)).to(DEV)
+    sw, pl = a.plan_for(d)
+    assert pl.slot_row is not None and n_rows * (d // sw if sw else 1) > 2 * 32 * 1024         # enough tasks for several per lane group
+    _, key = ops.spmm_shape(d, a.nnz)
+    for plan in (pl, ops.SpmmPlan.build(rp, *key)):
+        a.plans[key] = plan
+        for z in (None, Z):
+            mk = lambda off: ops.spmm_epilogue(ops.EPI_NONE, 0.5 if z is not None else 0.0, z, no_pipeline=off)
+            y_pipe = ops.spmm_raw(a, X, epilogue=mk(False))
+            y_task = ops.spmm_raw(a, X, epilogue=mk(True))
+            assert torch.equal(y_pipe.view(torch.int32), y_task.view(torch.int32)), (d, weighted, plan is pl, z is not None)
+    A64 = torch.sparse_coo_tensor(torch.tensor(np.vstack([rows, cols])), torch.ones(len(rows), dtype=torch.float64), (n_rows, n_cols))
+    want = torch.sparse.mm(A64, X.cpu().double() * (cs.cpu().double()[:, None] if weighted else 1.0)) * rs.cpu().double()[:, None]
+    assert rel_err(ops.spmm_raw(a, X).cpu(), want.float()) < 4e-6
+
+
 def test_bpr_scatter_plan_layout(ops):
     """llmrec_bpr_scatter_plan: sorted (id << 32 | slot) keys per side, the unused slots (id 0xffffffff) at the end, and the run
     lengths at the first position of every run."""
