@@ -378,13 +378,14 @@ __device__ __forceinline__ void rows_body_pipe(const SpmmArgs& a, int64_t block,
     constexpr int GPB = TPB / LPR;
     constexpr int NI = (LLMREC_SPMM_LONG_ROW + LPR - 1) / LPR;         // index registers per lane
     const int gl = threadIdx.x & (LPR - 1);
-    const int64_t n_list = a.slot_row ? (int64_t)a.n_short_rows : a.n_rows;
-    const int64_t n_tasks = n_list * a.n_slices, G = n_blocks * GPB;
-    int64_t t0 = block * GPB + (threadIdx.x / LPR);
+    // (32-bit task arithmetic: the host enables the pipeline only below 2^31 tasks - fewer registers, no 64-bit divisions)
+    const int32_t n_list = (int32_t)(a.slot_row ? (int64_t)a.n_short_rows : a.n_rows);
+    const int32_t n_tasks = n_list * a.n_slices, G = (int32_t)n_blocks * GPB;
+    int32_t t0 = (int32_t)block * GPB + (int32_t)(threadIdx.x / LPR);
     if (t0 >= n_tasks) return;
-    auto level1 = [&](int64_t t, int64_t& row, int32_t& s_, int32_t& n_, int64_t& col0) {    // slot -> output row, row pointers (independent loads)
-        const int64_t slice = t / n_list, slot = t - slice * n_list;
-        row = a.slot_row ? (int64_t)a.slot_row[slot] : slot;
+    auto level1 = [&](int32_t t, int32_t& row, int32_t& s_, int32_t& n_, int32_t& col0) {    // slot -> output row, row pointers (independent loads)
+        const int32_t slice = t / n_list, slot = t - slice * n_list;
+        row = a.slot_row ? a.slot_row[slot] : slot;
         s_ = a.rowptr[slot]; n_ = a.rowptr[slot + 1] - s_;
         col0 = slice * a.d;
     };
@@ -392,17 +393,17 @@ __device__ __forceinline__ void rows_body_pipe(const SpmmArgs& a, int64_t block,
 #pragma unroll
         for (int k = 0; k < NI; ++k) { const int j = k * LPR + gl; c[k] = (j < n_ && n_ <= LLMREC_SPMM_LONG_ROW) ? a.colidx[s_ + j] : 0; }
     };
-    int64_t row0, col00, row1 = 0, col01 = 0;
+    int32_t row0, col00, row1 = 0, col01 = 0;
     int32_t s0, n0, s1 = 0, n1 = 0, c0[NI], c1[NI];
     level1(t0, row0, s0, n0, col00);
     level2(s0, n0, c0);
-    int64_t t1 = t0 + G;
+    int32_t t1 = t0 + G;
     bool has1 = t1 < n_tasks;
     if (has1) level1(t1, row1, s1, n1, col01);
     for (;;) {
-        int64_t row2 = 0, col02 = 0;
+        int32_t row2 = 0, col02 = 0;
         int32_t s2 = 0, n2 = 0;
-        const int64_t t2 = t1 + G;
+        const int32_t t2 = t1 + G;
         const bool has2 = has1 && t2 < n_tasks;
         if (has1) level2(s1, n1, c1);                                   // in flight while task 0's rows are gathered
         if (has2) level1(t2, row2, s2, n2, col02);
@@ -717,7 +718,7 @@ static int launch_spmm(SpmmArgs& a, hipStream_t stream) {
     const int64_t short_tasks = a.listed_only ? 0 : (a.slot_row ? (int64_t)a.n_short_rows : a.n_rows) * S;
     int64_t pipe = 1;
     if (!a.x_mask && !(a.nt_from > 0 && !weighted) && !a.no_pipeline) {
-        pipe = ceil_div(short_tasks, (int64_t)GPB * 1024);
+        pipe = short_tasks + (int64_t)GPB * 8192 < (1ll << 31) ? ceil_div(short_tasks, (int64_t)GPB * 1024) : 1;      // (32-bit task ids in the kernel)
         if (pipe > 8) pipe = 8;
         if (pipe < 1) pipe = 1;
     }
