@@ -401,7 +401,8 @@ class FusedStep:
                 i_prev = self.Il[l]
             if sampler is not None and self.multi_stream and id_first:
                 sampler()
-            if after_chain is not None:
+            self._ev_chain = self._mark() if after_chain is not None else None   # the chain's SpMMs are done; what follows on this stream
+            if after_chain is not None:                                          # is not needed by the fusion
                 after_chain()
         self._stamp(1)
         split_proj = os.environ.get("LLMREC_SPLIT_PROJ", "0") == "1" and self.multi_stream and self.d <= 64
@@ -434,7 +435,11 @@ class FusedStep:
             self._fork(self.s3)                                          # captured HERE it runs beside the fusion and the BPR launches (captured
             with self._on(self.s3):                                      # after the BPR backward, round 2, the graph ran it last: the step's tail)
                 self._feat_reg()
-        self._join(self.s1, self.s2)
+        if getattr(self, "_ev_chain", None) is not None and self.multi_stream:
+            self._join(self.s1)
+            torch.cuda.current_stream().wait_event(self._ev_chain)               # (not the stream's tail: after_chain's launches are joined later)
+        else:
+            self._join(self.s1, self.s2)
         if before_fusion is not None:
             before_fusion()
 
@@ -517,6 +522,8 @@ class FusedStep:
         # critical path: scores -> [selection + gradient rows] (two launches); the loss VALUES (one more launch) and their assembly for
         # the log line ride on the ID chain's stream (a branch of their own right behind the BPR launches: the graph ran it as the step's tail)
         self._check_scatter_targets()
+        if getattr(self, "_ev_plan", None) is not None:                  # (LLMREC_PLAN_STREAM=late: the plan was built behind the ID chain)
+            torch.cuda.current_stream().wait_event(self._ev_plan)
         if getattr(self, "_bpr_split_done", False):                      # (LLMREC_BPR_SPLIT: problems 1.. were launched beside the fusion)
             self._bpr_launches(users, pos, neg, n_valid, lo=0, hi=1)
             self._join(self.s1)
@@ -707,6 +714,8 @@ class FusedStep:
                 self.ws_wgrad_multi = torch.empty(max(need, 0), dtype=torch.uint8, device=dY_cat.device) if need >= 0 else False
             if self.ws_wgrad_multi is not False:
                 self._stamp(3)
+                if getattr(self, "_ev_reach", None) is not None:                 # (LLMREC_REACH_LATE: the row list was built behind the ID chain)
+                    torch.cuda.current_stream().wait_event(self._ev_reach)
                 lins = (m.item_trans, m.user_trans, m.text_trans, m.image_trans)              # (wgrad_targets' order)
                 if split_wgrad:
                     # the three item-side Linears first - their only late parent is the transposed side product on THIS stream - then,
@@ -775,22 +784,39 @@ class FusedStep:
         side = self.multi_stream                                 # the sampler rides beside the projection (forward())
         # (Built on the regulariser's stream instead - forked from the main stream, waiting for the sampler's event of the ID chain's stream,
         #  its own event awaited by the weight gradient - hipGraphInstantiate of this image recursed until the stack ran out: not kept.)
-        # right behind the sampler, on the ID chain's stream: the scatter plan of the loss backward (needed ~200 us later) and the row list
-        # (needed by the weight gradient only, at the far end of the step). Measured on one box, 300 steps each, twice (round 6):
-        # here 0.452 / 0.455 ms per step; LLMREC_PLAN_STREAM=late (behind the chain's SpMMs, where the launch takes 16 us instead of the
-        # ~60 us its blocks wait for LDS beside the projection) 0.463 / 0.463; on a branch of its own forked from the sampler and joined
-        # ahead of the loss launches 0.534 / 0.534 - the graph runtime then runs the PROJECTION behind the ID chain (not kept).
+        # The scatter plan of the loss backward (needed ~200 us later) and the row list (needed by the weight gradient only, at the far end of
+        # the step) ride on the ID chain's stream BEHIND its SpMMs; the fusion waits for the chain's event (self._ev_chain), the loss launches
+        # for the plan's (self._ev_plan), the weight gradient for the list's (self._ev_reach). Measured on one box, 300 steps each, twice
+        # (round 6, profiles/experiments/r06_step_chain.md): both right behind the sampler, ahead of the SpMMs (LLMREC_PLAN_STREAM=early
+        # LLMREC_REACH_LATE=0, the state until then) 0.4539 / 0.4539 ms per step; here 0.4470 / 0.4481. With the plan behind the chain but the
+        # fusion joining the whole stream (the first form of "late") 0.460 / 0.461; the plan on a branch of its own forked from the sampler
+        # 0.534 / 0.534 - the graph runtime then runs the PROJECTION behind the ID chain (not kept).
         fill = sampler
-        late = self.multi_stream and os.environ.get("LLMREC_PLAN_STREAM", "early") == "late"
+        plan_late = self.multi_stream and os.environ.get("LLMREC_PLAN_STREAM", "late") == "late"
+        reach_late = self.multi_stream and self.wgrad_rows and os.environ.get("LLMREC_REACH_LATE", "1") == "1"
+        self._ev_reach = None
+
+        def reach():
+            ops.batch_reach_rows(users, pos, neg, n_valid, self.iu.fwd, self.act_flags, self.act_rows, self.act_n)
 
         def sampler():
             if fill is not None:
                 fill()
-            if not late:
+            if not plan_late:
                 self.build_scatter_plan(users, pos, neg, n_valid)
-            if self.wgrad_rows:
-                ops.batch_reach_rows(users, pos, neg, n_valid, self.iu.fwd, self.act_flags, self.act_rows, self.act_n)
-        late = (lambda: self.build_scatter_plan(users, pos, neg, n_valid)) if late else None
+            if self.wgrad_rows and not reach_late:
+                reach()
+
+        self._ev_plan = None
+
+        def late_work():
+            if plan_late:
+                self.build_scatter_plan(users, pos, neg, n_valid)
+                self._ev_plan = self._mark()                             # (the loss launches wait for this event, the fusion only for the chain's)
+            if reach_late:
+                reach()
+                self._ev_reach = self._mark()
+        late = late_work if (plan_late or reach_late) else None
         self.spmm_edge_units = 0.0
         calls0 = _lib.n_calls
         try:
