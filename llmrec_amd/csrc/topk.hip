@@ -566,7 +566,7 @@ __device__ __forceinline__ void tk_split8(const float (&x)[8], uint4& H, uint4& 
 __device__ __host__ __forceinline__ float tk_pre_slack(int d) { return d <= 64 ? 0x1p-14f : 0x1p-13f; }
 constexpr float TK_NORM_UP = 1.0f + 0x1p-10f;
 
-// workspace header of the mode (first 256 bytes of the fragment area): [0] unused, [1] user tiles flagged for the exact sweep, [2] train rows swept as bitmaps
+// workspace header of the mode (first 256 bytes of the fragment area): [0] drains of the bf16 sweep (all blocks), [1] user tiles flagged for the exact sweep, [2] train rows swept as bitmaps
 // the item table as bf16 (hi, mid) MFMA fragments: pk2[(((tile * 2 + n) * DK32 + c) * 2 + hm) * 64 + lane], lane = 16 (k group) + item-in-tile;
 // one thread per (item, 8 consecutive k). Also clears the header and the fallback flags (the norm kernel and the sweep follow on the stream).
 __global__ __launch_bounds__(256) void topk_pack_items_bf16_kernel(TopkArgs a, int DK32, uint4* __restrict__ pk2) {
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void topk_pack_items_bf16_kernel(TopkArgs a, i
     for (int j = 0; j < 8; ++j) { const int k = 8 * g + j; x[j] = k < a.d ? row[k] : 0.f; ss = fmaf(x[j], x[j], ss); }
     if (a.cn && (G & (G - 1)) == 0) {                                  // G = 4, 8, 16: an item's threads are G aligned neighbouring lanes - its
         for (int off = G >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);   // squared norm by a butterfly (fixed tree); G = 12: topk_item_norm_kernel
-        if (g == 0) a.cn[item_p] = item_p < a.n_items ? tk_pre_slack(a.d) * (sqrtf(ss) * TK_NORM_UP) : 0.f;
+        if (g == 0) a.cn[item_p] = item_p < a.n_items ? tk_pre_slack(a.d) * (sqrtf(ss) * TK_NORM_UP) : __builtin_nanf("");   // (NaN: a padded slot's bound never passes a filter)
     }
     uint4 H, M;
     tk_split8(x, H, M);
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void topk_pack_items_bf16_kernel(TopkArgs a, i
     pk2[base] = H; pk2[base + 64] = M;
 }
 
-// cn[item] = tk_pre_slack(d) * ||item|| rounded up: the item's factor of the score's upper bound. One 16-lane group per item; padded slots get 0.
+// cn[item] = tk_pre_slack(d) * ||item|| rounded up: the item's factor of the score's upper bound. One 16-lane group per item; padded slots get NaN.
 __global__ __launch_bounds__(256) void topk_item_norm_kernel(TopkArgs a, float* __restrict__ cn, int64_t n_pad) {
     const int gl = threadIdx.x & 15;
     for (int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); item < n_pad; item += (int64_t)gridDim.x * 16) {
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void topk_item_norm_kernel(TopkArgs a, float* 
             for (int k = gl; k < a.d; k += 16) ss = fmaf(row[k], row[k], ss);
         }
         ss = group_sum<16>(ss);
-        if (gl == 0) cn[item] = tk_pre_slack(a.d) * (sqrtf(ss) * TK_NORM_UP);
+        if (gl == 0) cn[item] = item < a.n_items ? tk_pre_slack(a.d) * (sqrtf(ss) * TK_NORM_UP) : __builtin_nanf("");
     }
 }
 
@@ -649,13 +649,49 @@ __device__ __forceinline__ void tk_finalize_user(const TopkArgs& a, const float*
     }
 }
 
+// ---- the bf16 sweep's candidate pools ----
+// One UNSORTED pool of TK_POOL (ub, item) entries per user, shared by the block's four wavefronts (slots from one LDS counter per user). A round appends
+// every score that reaches the user's filter. When some pool may not hold another round of all four waves (4 x TK_TILE appends), the block
+// drains: the owner wave of a user finds the 64th largest ub of the pool by BISECTION over the 32 bits of the order-preserving key - one compare per
+// held entry and bit, the counts from the compares' lane masks on the scalar unit - keeps the 64 entries at or above it (entries above it first, then
+// entries equal to it in slot order: which of several EQUAL bounds stays cannot change the output, the list is re-ranked by exact score and verified against the
+// bound), and that value is the user's new filter. ~170 vector instructions per user and drain whatever the pool holds - the sorted lists of
+// rounds 2 - 5 (bitonic sort of every 64 buffered entries + merge into a register list: ~200 instructions per 64 entries, ~12 x per user and sweep) were
+// ~40 % of the sweep's vector instructions. The ONE sort per user happens after the sweep, on the 64 survivors.
+constexpr int TK_POOL = 256;
+
+// A separator of the 64 largest of the wave's 4 x 64 keys e[j] (0 = no entry, below every key; every entry >= lo, the user's filter so far; at least 64
+// entries): the largest P the search reaches with #{e >= P} >= 64 - it stops at the first P with EXACTLY 64 keys at or above it (P is then a lower bound
+// of the 64th largest key, which is all a filter needs), else it ends at the 64th largest key itself (ties). The bits above the highest bit in which the
+// largest key differs from lo are common to every key and skipped: ~10 steps instead of 32 on scores of one binade. Wave-uniform.
+__device__ __forceinline__ uint32_t tk_select64(const uint32_t (&e)[4], uint32_t lo) {
+    uint32_t hi = max(max(e[0], e[1]), max(e[2], e[3]));
+    hi = max(hi, (uint32_t)xor_lane_i<1>((int)hi, 0)); hi = max(hi, (uint32_t)xor_lane_i<2>((int)hi, 0));
+    hi = max(hi, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x124, 0xf, 0xf, true));      // row_ror:4
+    hi = max(hi, (uint32_t)xor_lane_i<8>((int)hi, 0));
+    hi = max(hi, (uint32_t)xor_lane_i<16>((int)hi, 0));
+    hi = max((uint32_t)__builtin_amdgcn_readlane((int)hi, 0), (uint32_t)__builtin_amdgcn_readlane((int)hi, 32));
+    const uint32_t diff = hi ^ lo;
+    if (diff == 0u) return hi;                                 // every key equal
+    const int top = 31 - __builtin_clz(diff);
+    uint32_t P = top == 31 ? 0u : hi & ~((2u << top) - 1u);
+#pragma unroll 1
+    for (int b = top; b >= 0; --b) {
+        const uint32_t c = P | (1u << b);
+        const int n = __popcll(__ballot(e[0] >= c)) + __popcll(__ballot(e[1] >= c)) + __popcll(__ballot(e[2] >= c)) + __popcll(__ballot(e[3] >= c));
+        P = n >= 64 ? c : P;
+        if (n == 64) break;
+    }
+    return P;
+}
+__device__ __forceinline__ int tk_mbcnt(uint64_t m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
 template <int DK32>
 __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kernel(TopkArgs a, const uint4* __restrict__ pk2, const float* __restrict__ cn) {
-    __shared__ float buf_s[4][16][TK_CAP];                             // upper bounds ub of the buffered candidates
-    __shared__ int32_t buf_i[4][16][TK_CAP];
-    __shared__ __attribute__((aligned(16))) int32_t cnt_s[4][16];     // fill of buffer (wave, user): LDS atomics (the appends are lane-local)
-    __shared__ float thr_s[16];                                        // the filter: the 64th ub of the user's list so far
-    __shared__ int32_t flag_s[2];
+    __shared__ __attribute__((aligned(8))) float2 pool[16][TK_POOL];   // the user's candidates: (upper bound ub, item id as bits) - one 8-byte store per append
+    __shared__ __attribute__((aligned(16))) int32_t cnt_s[16];        // fill of the user's pool: LDS atomics (the appends are lane-local)
+    __shared__ __attribute__((aligned(16))) float thr_s[16];          // the filter: the 64th ub of the user's pool at the last drain (+inf: no such user)
+    __shared__ int32_t flag_s[1];                                      // waves that finished their quarter
     __shared__ int32_t train_s[4][16][TK_TRAIN_STAGE];
     __shared__ __attribute__((aligned(16))) uint32_t mask_s[4][16];   // train masks of an event round (zero between rounds)
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -669,9 +705,9 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     }
     const int q0 = tile * 16;
     if (q0 >= a.n_query) return;
-    if (threadIdx.x < 16) thr_s[threadIdx.x] = -INFINITY;
-    if (threadIdx.x < 64) { (&cnt_s[0][0])[threadIdx.x] = 0; (&mask_s[0][0])[threadIdx.x] = 0u; }
-    if (threadIdx.x < 2) flag_s[threadIdx.x] = 0;
+    if (threadIdx.x < 16) { thr_s[threadIdx.x] = q0 + (int)threadIdx.x < a.n_query ? -INFINITY : INFINITY; cnt_s[threadIdx.x] = 0; }
+    if (threadIdx.x < 64) (&mask_s[0][0])[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) flag_s[0] = 0;
     __syncthreads();
 
     // A operand: row li of the block's users, k = 32 c + 8 lq + j -> (hi, mid) fragments
@@ -717,9 +753,6 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     const int hoff = tk_heavy_setup(a, lane, q0 + lane < a.n_query, row_begin, end);               // >= 0: this lane's row is a bitmap
     if (hoff >= 0) nxt = INT_MAX;
     uint32_t hm = 0u;                                                                              // the bitmap word of the round's tile
-    uint64_t lk[4];                                                    // the block's lists of users 4 w + rr by upper bound, as 64-bit keys, slot = lane
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) lk[rr] = TK_KEY_EMPTY;
 
     const int64_t my_rounds = t_end > t_begin ? t_end - t_begin : 0;
     uint4 bH[2][DK32], bM[2][DK32];
@@ -739,39 +772,51 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     bool counted = false;
     for (;;) {
         const bool fin = round >= my_rounds;
-        // a buffer must keep room for the next round's TK_TILE candidates: this wave's four counters of the lane's user group, straight from LDS
-        const int4 c4 = *reinterpret_cast<const int4*>(&cnt_s[w][lq * 4]);
+        // the round's view of the block state, ONE LDS round trip: the fills of the pools of the lane's user group (a pool must keep room for the next
+        // round's 4 x TK_TILE candidates) and the four rows' filters (they change at drains only). The pools and their counters are shared by the four
+        // waves and the counters only grow between drains: a wave that finds a pool too full waits at the barrier, and every other wave finds the
+        // same at the top of its next round - no drain-request flag (the per-wave buffers of rounds 2 - 5 needed one, and a second LDS round trip).
+        const int4 c4 = *reinterpret_cast<const int4*>(&cnt_s[lq * 4]);
+        const float4 t4 = *reinterpret_cast<const float4*>(&thr_s[lq * 4]);
         const int fill = max(max(c4.x, c4.y), max(c4.z, c4.w));
-        bool drain = fin || __ballot(fill > TK_CAP - TK_TILE) != 0ull;
-        if (!drain) drain = __hip_atomic_load(&flag_s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+        const bool drain = fin || __ballot(fill > TK_POOL - 4 * TK_TILE) != 0ull;
         if (drain) {
-            if (fin && !counted) { counted = true; if (lane == 0) atomicAdd(&flag_s[1], 1); }
-            if (!fin && lane == 0) __hip_atomic_store(&flag_s[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (fin && !counted) { counted = true; if (lane == 0) atomicAdd(&flag_s[0], 1); }
             __syncthreads();                                   // (every wave's appends - LDS atomics and stores - are complete and visible)
-            const int done_quarters = flag_s[1];
-#pragma unroll
+            const int done_quarters = flag_s[0];
+            if (a.hdr && threadIdx.x == 0) atomicAdd(&a.hdr[0], 1u);   // (statistics: drains, over all blocks)
+#pragma unroll 1
             for (int rr = 0; rr < 4; ++rr) {
                 const int u = 4 * w + rr;
-                const int p1 = cnt_s[0][u], p2 = p1 + cnt_s[1][u], p3 = p2 + cnt_s[2][u], total = p3 + cnt_s[3][u];
-                uint64_t k1 = lk[rr];
-                for (int j0 = 0; j0 < total; j0 += 64) {
-                    const int j = j0 + lane;
-                    const int ww = (j >= p1) + (j >= p2) + (j >= p3);
-                    const int start = ww == 0 ? 0 : (ww == 1 ? p1 : (ww == 2 ? p2 : p3));
-                    uint64_t bk = TK_KEY_EMPTY;
-                    if (j < total) bk = tk_key(buf_s[ww][u][j - start], buf_i[ww][u][j - start]);
-                    sort64k(bk, lane);
-                    merge64k(k1, bk, lane);
+                const int n = __builtin_amdgcn_readfirstlane(cnt_s[u]);
+                if (n <= 64) continue;                         // (wave-uniform) nothing to drop yet / nothing new since the last drain
+                int32_t id[4]; uint32_t e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int idx = lane + 64 * j;
+                    const float2 en = pool[u][idx];
+                    id[j] = __float_as_int(en.y);
+                    e[j] = idx < n ? tk_ord(en.x) : 0u;            // (every held key is >= tk_ord(-inf) > 0)
                 }
-                lk[rr] = k1;
-                if (total > 0) {
-                    const float nthr = tk_unord((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k1 >> 32), 63));   // the 64th: the whole list is exact-by-ub
-                    if (lane == 0) thr_s[u] = nthr;
+                const uint32_t P = tk_select64(e, tk_ord(thr_s[u]));
+                // (LDS operations of one wave are performed in order: every slot was read above)
+                int base = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint64_t mg = __ballot(e[j] > P);
+                    if (e[j] > P) { const int pos = base + tk_mbcnt(mg); pool[u][pos] = make_float2(tk_unord(e[j]), __int_as_float(id[j])); }
+                    base += __popcll(mg);
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (base >= 64) break;                     // (wave-uniform)
+                    const uint64_t me = __ballot(e[j] == P);
+                    const int pos = base + tk_mbcnt(me);
+                    if (e[j] == P && pos < 64) { pool[u][pos] = make_float2(tk_unord(P), __int_as_float(id[j])); }
+                    base += __popcll(me);
+                }
+                if (lane == 0) { cnt_s[u] = 64; thr_s[u] = tk_unord(P); }
             }
-            __syncthreads();                                   // (every owner has read the counters)
-            if (threadIdx.x < 64) (&cnt_s[0][0])[threadIdx.x] = 0;
-            if (threadIdx.x == 0) flag_s[0] = 0;
             __syncthreads();
             if (done_quarters == 4) break;
             continue;
@@ -820,37 +865,41 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float rthr = (q0 + lq * 4 + r < a.n_query) ? thr_s[lq * 4 + r] : INFINITY;
+            const float rthr = cmp4(t4, r);
             const uint32_t rm = rm4[r];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const float v = fmaf(unr[r], cn_now[n], acc[n][r]);        // ub = s' + 2^-14 ||u|| ||i||
+                // the common case is ONE compare and one scalar branch: the sweep is bound by the instructions it issues (~1 per 4 cycles and SIMD, every
+                // type counted: profiles/experiments/r06_topk_pool.md), and the compiler folded the train-mask test and the exec juggling of the
+                // append into the straight line (11 instructions per (row, column tile) instead of 3) until the scheduling barrier pinned them here
                 if (__ballot(v >= rthr) == 0ull) continue;
+                __builtin_amdgcn_sched_barrier(0);
                 const int col = 16 * n + li;
-                const bool pass = (v >= rthr) && (base + col < a.n_items) && !((rm >> col) & 1u);
-                if (pass) {                                    // lane-local append: a slot from the buffer's LDS counter (the order inside a
-                    const int off = atomicAdd(&cnt_s[w][lq * 4 + r], 1);   // buffer is irrelevant: it is sorted by (ub, id) at the drain)
-                    buf_s[w][lq * 4 + r][off] = v;
-                    buf_i[w][lq * 4 + r][off] = (int32_t)(base + col);
+                const bool pass = (v >= rthr) && !((rm >> col) & 1u);       // (slots past the table's end: cn = NaN, so v is NaN and never passes)
+                if (pass) {                                    // lane-local append: a slot from the pool's LDS counter (the order inside a
+                    const int off = atomicAdd(&cnt_s[lq * 4 + r], 1);      // pool is irrelevant)
+                    pool[lq * 4 + r][off] = make_float2(v, __int_as_float((int32_t)base + col));
                 }
             }
         }
         ++round;
     }
-    if (n_parts > 1) {                                         // a part's lists (approximate scores): merged and finalised by topk_merge_pre_kernel
-        const int64_t base = ((int64_t)(tile - a.split_from) * n_parts + part) * 16;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            a.ws_idx[(base + 4 * w + rr) * 64 + lane] = tk_key_id(lk[rr]);
-            a.ws_score[(base + 4 * w + rr) * 64 + lane] = tk_key_ub(lk[rr]);
-        }
-        return;
-    }
+    // the users' survivors (<= 64 each: the last drain ran after every wave's last round) -> ONE sorted list per user, slot = lane, as 64-bit keys
 #pragma unroll 1
     for (int rr = 0; rr < 4; ++rr) {
-        const int q = q0 + 4 * w + rr;
-        if (q >= a.n_query) continue;                          // wave-uniform
-        tk_finalize_user(a, a.Eu + a.query_users[q] * a.ldu, q, tile, tk_key_ub(lk[rr]), tk_key_id(lk[rr]), lane);
+        const int u = 4 * w + rr, q = q0 + u;
+        const int n = cnt_s[u];
+        const float2 en = pool[u][lane];
+        uint64_t k1 = lane < n ? tk_key(en.x, __float_as_int(en.y)) : TK_KEY_EMPTY;
+        sort64k(k1, lane);
+        if (n_parts > 1) {                                     // a part's lists (approximate scores): merged and finalised by topk_merge_pre_kernel
+            const int64_t row = ((int64_t)(tile - a.split_from) * n_parts + part) * 16 + u;
+            a.ws_idx[row * 64 + lane] = tk_key_id(k1);
+            a.ws_score[row * 64 + lane] = tk_key_ub(k1);
+        } else if (q < a.n_query) {                            // wave-uniform
+            tk_finalize_user(a, a.Eu + a.query_users[q] * a.ldu, q, tile, tk_key_ub(k1), tk_key_id(k1), lane);
+        }
     }
 }
 

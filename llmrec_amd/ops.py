@@ -1079,6 +1079,7 @@ def score_topk(Eu, Ei, query_users: torch.Tensor, train: Optional[Csr], K: int, 
         stats["tiles"] = (n + 15) // 16
         pre = topk_mode(mode, Ei.shape[0], Eu.shape[1], K) == 1 and K <= CONST["LLMREC_TOPK_PREFILTER_MAX_K"]
         stats["fallback_tiles"] = int(ws[off + 4:off + 8].view(torch.int32).item()) if pre else 0
+        stats["drains"] = int(ws[off:off + 4].view(torch.int32).item()) if pre else None                # pool drains of the bf16 sweep, summed over its blocks
         stats["bitmap_rows"] = int(ws[off + 8:off + 12].view(torch.int32).item()) if pre else None     # long train rows swept as per-block bitmaps (bf16 mode's launch)
     return idx, sc
 
