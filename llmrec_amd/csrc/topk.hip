@@ -72,6 +72,9 @@ struct TopkArgs {
     // users with long train rows: a block builds bitmaps (one word per item tile) of up to TK_HEAVY_PER_BLOCK of its users in its own
     // slice of this area and reads one word per round instead of walking the row (NULL: every row is walked)
     uint32_t* heavy_bm; int heavy_words;
+    // heavy_all != 0 (bf16 sweep): EVERY row of the block is a bitmap and the block's slice is tile-major - word [tile][16 users], one 64-byte line per
+    // item tile - so a lane reads the masks of its four rows with 16 bytes and no row is walked (tk_rows_setup)
+    int heavy_all;
 };
 
 template <int DK>
@@ -196,11 +199,13 @@ __device__ __forceinline__ void tk_train_refill(const int32_t* __restrict__ coli
 // the tile prefetch) instead. Further long rows of the same block are walked. Called by all 256 threads (every wave holds the same 16 rows
 // in its lanes 0..15); returns this lane's word offset inside the block's slice, -1: walk the row.
 constexpr int TK_HEAVY_PER_BLOCK = 2, TK_HEAVY_DEG = 48;
+// rows of heavy_words words a block's slice holds: 16 where the workspace is laid out for tk_rows_setup (a block may still choose the two-row form)
+__device__ __forceinline__ int tk_heavy_stride(const TopkArgs& a) { return a.heavy_all ? 16 : TK_HEAVY_PER_BLOCK; }
 __device__ __forceinline__ int tk_heavy_setup(const TopkArgs& a, int lane, bool row_valid, int32_t row_begin, int32_t row_end) {
     if (!a.heavy_bm) return -1;                                // uniform
     unsigned hb = (unsigned)__ballot(lane < 16 && row_valid && row_end - row_begin > TK_HEAVY_DEG) & 0xffffu;
     if (hb == 0u) return -1;                                   // block-uniform: every wave sees the same rows
-    uint32_t* const slice = a.heavy_bm + (size_t)blockIdx.x * TK_HEAVY_PER_BLOCK * a.heavy_words;
+    uint32_t* const slice = a.heavy_bm + (size_t)blockIdx.x * tk_heavy_stride(a) * a.heavy_words;
     int mine = -1;
     for (int s = 0; s < TK_HEAVY_PER_BLOCK && hb != 0u; ++s) {
         const int u = __builtin_ctz(hb);
@@ -222,12 +227,70 @@ __device__ __forceinline__ int tk_heavy_setup(const TopkArgs& a, int lane, bool 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the atomics are performed at the L2 before any wave reads a word back)
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // (the L1 drops what it holds: the words are read with plain loads)
     return mine;
 }
-// (an agent-scope atomic load: served by the L2, where the atomics above landed)
+// (a plain load: the set-up ended with an acquire fence - this CU's L1 holds no line of the slice from before the atomics - and the slice is written by
+//  this block alone. The agent-scope atomic load used until round 6 is served beyond the XCD's L2 on this part: ~0.5 us per round, measured as + 70 us per
+//  sweep when every block read two such words per round.)
 __device__ __forceinline__ uint32_t tk_heavy_word(const TopkArgs& a, int off, int64_t tile) {
-    return __hip_atomic_load(a.heavy_bm + (size_t)blockIdx.x * TK_HEAVY_PER_BLOCK * a.heavy_words + off + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return a.heavy_bm[(size_t)blockIdx.x * tk_heavy_stride(a) * a.heavy_words + off + tile];
 }
+// ---- every train row of the block as a bitmap, tile-major (bf16 sweep, tables of up to 131 072 items while the slices fit 64 MB) ----
+// The row walk of the sweep - compare the row's next item with the tile, step the cursor through the LDS stage, exchange the masks through LDS - was
+// ~45 of the ~200 instructions a wave issues per round, and the sweep is bound by exactly that count. Here the block turns ALL its rows into bitmaps
+// once (a few hundred train items, one LDS atomicOr each) in a slice of its own laid out [item tile][16 users]: the masks a lane needs for a round - the
+// words of its four rows - are 16 consecutive bytes, ONE load issued with the tile's fragments one round ahead. Called by all 256 threads.
+__device__ __forceinline__ void tk_rows_setup(const TopkArgs& a, int lane, bool row_valid, int32_t row_begin, int32_t row_end, uint32_t* lds, int lds_words) {
+    // Built in LDS (the candidate pools' 32 KB, unused until the sweep starts), TK_ROWS_STAGE tiles of all 16 rows at a time, and copied out with
+    // 16-byte stores: zeroing the slice in global memory and one global atomicOr per train item - the first form - cost 49 us of a 0.31 ms sweep
+    // (all blocks start together: 36 MB of zeroes, then 0.66 M atomics at the L2).
+    uint32_t* const slice = a.heavy_bm + (size_t)blockIdx.x * 16 * a.heavy_words;
+    // the first 256 items of every row: 16 independent loads per thread, in flight together (one row after the other - load, wait, atomic - was a chain
+    // of 16 memory latencies per pass: 28 us of set-up); what a row holds beyond 256 items is read in the passes
+    int32_t first[16];
+    unsigned long_rows = 0u;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int32_t rb = __builtin_amdgcn_readlane(row_begin, u), re = __builtin_amdgcn_readlane(row_valid ? row_end : row_begin, u);
+        const int e = rb + (int)threadIdx.x;
+        first[u] = e < re ? a.train_colidx[e] : -1;
+        if (re - rb > 256) long_rows |= 1u << u;
+    }
+    const int stage = lds_words / 16;                           // item tiles per pass
+    for (int t0 = 0; t0 < a.heavy_words; t0 += stage) {
+        const int nt = a.heavy_words - t0 < stage ? a.heavy_words - t0 : stage;
+        for (int i = threadIdx.x; i < nt * 4; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int32_t it = first[u];
+            const int t = (it >> 5) - t0;
+            if ((uint32_t)it < (uint32_t)a.n_items && (uint32_t)t < (uint32_t)nt) atomicOr(&lds[t * 16 + u], 1u << (it & 31));
+        }
+        for (unsigned r = long_rows; r != 0u; r &= r - 1u) {      // (block-uniform)
+            const int u = __builtin_ctz(r);
+            const int32_t rb = __builtin_amdgcn_readlane(row_begin, u), re = __builtin_amdgcn_readlane(row_end, u);
+            for (int e = rb + 256 + (int)threadIdx.x; e < re; e += 256) {
+                const int32_t it = a.train_colidx[e];
+                const int t = (it >> 5) - t0;
+                if ((uint32_t)it < (uint32_t)a.n_items && (uint32_t)t < (uint32_t)nt) atomicOr(&lds[t * 16 + u], 1u << (it & 31));
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nt * 4; i += 256) reinterpret_cast<uint4*>(slice + (size_t)t0 * 16)[i] = reinterpret_cast<const uint4*>(lds)[i];
+        __syncthreads();                                       // (the stage is reused - by the next pass or by the sweep's pools)
+    }
+    if (a.hdr && threadIdx.x == 0) atomicAdd(&a.hdr[2], 16u);     // (statistics: train rows swept as bitmaps)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the words are at the L2 before any wave reads one back)
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // (the L1 drops what it holds: the words are read with plain loads)
+}
+// the words of rows 4 lq .. 4 lq + 3 for one item tile: 16 bytes, one load (plain: see tk_heavy_word)
+__device__ __forceinline__ uint4 tk_rows_words(const TopkArgs& a, int lq, int64_t tile) {
+    return *reinterpret_cast<const uint4*>(a.heavy_bm + ((size_t)blockIdx.x * a.heavy_words + tile) * 16 + lq * 4);
+}
+constexpr int TK_ROWS_BM_MIN = 16 * 12;   // train items of a block's 16 rows from which tk_rows_setup pays
 constexpr int TK_CAP = 64;    // buffer slots per (wave, user): drained before a round could overflow it
 
 // scores only (llmrec_scores_f32): S[q][item], same MFMA chain as the selection kernel
@@ -740,6 +803,15 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     if (lane < 16 && a.train_rowptr) {
         cur = a.train_rowptr[user_a]; end = a.train_rowptr[user_a + 1];
         row_begin = cur;
+    }
+    // (block-uniform: every wave holds the same 16 rows) every train row of the block as a bitmap, no row walked - when the rows are long enough to pay
+    // for the slice's set-up and the two loads per round: measured at the Netflix shape, 4.2 train items per user: walking 0.283 ms, bitmaps 0.296; ~50 per
+    // user: 0.381 / 0.321
+    int row_items = lane < 16 && q0 + lane < a.n_query ? end - row_begin : 0;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) row_items += __shfl_xor(row_items, off, 64);
+    const bool all_bm = a.heavy_all != 0 && __builtin_amdgcn_readfirstlane(row_items) > TK_ROWS_BM_MIN;
+    if (lane < 16 && a.train_rowptr && !all_bm) {
         const int64_t first = t_begin * TK_TILE;
         int32_t lo = cur, hi = end;
         while (lo < hi) {
@@ -750,8 +822,11 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
         tk_train_stage(a.train_colidx, cur & ~(TK_TRAIN_STAGE - 1), end, &train_s[w][lane][0]);   // (the window is aligned in colidx positions:
         nxt = train_s[w][lane][cur & (TK_TRAIN_STAGE - 1)];                                       //  slots before cur are never read)
     }
-    const int hoff = tk_heavy_setup(a, lane, q0 + lane < a.n_query, row_begin, end);               // >= 0: this lane's row is a bitmap
+    int hoff = -1;
+    if (all_bm) tk_rows_setup(a, lane, q0 + lane < a.n_query, row_begin, end, reinterpret_cast<uint32_t*>(&pool[0][0]), 16 * TK_POOL * 2);
+    else hoff = tk_heavy_setup(a, lane, q0 + lane < a.n_query, row_begin, end);                    // >= 0: this lane's row is a bitmap
     if (hoff >= 0) nxt = INT_MAX;
+    uint4 rmw = make_uint4(0u, 0u, 0u, 0u);                                                        // all_bm: the words of the lane's four rows, one round ahead
     uint32_t hm = 0u;                                                                              // the bitmap word of the round's tile
 
     const int64_t my_rounds = t_end > t_begin ? t_end - t_begin : 0;
@@ -767,61 +842,63 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
         cnv[0] = cnp[0]; cnv[1] = cnp[16];
         pk += 2 * DK32 * 2 * 64; cnp += TK_TILE;
     };
-    if (my_rounds > 0) { load_tile(); if (hoff >= 0) hm = tk_heavy_word(a, hoff, t_begin); }
-    int64_t round = 0;
-    bool counted = false;
-    for (;;) {
-        const bool fin = round >= my_rounds;
+    if (my_rounds > 0) { load_tile(); if (hoff >= 0) hm = tk_heavy_word(a, hoff, t_begin); if (all_bm) rmw = tk_rows_words(a, lq, t_begin); }
+    // One drain of the block's pools (every wave of the block calls it at the same point of its program: a barrier on each side). Returns the
+    // number of waves that have finished their quarter of the items.
+    auto drain_pools = [&]() -> int {
+        __syncthreads();                                   // (every wave's appends - LDS atomics and stores - are complete and visible)
+        const int done_quarters = flag_s[0];
+        if (a.hdr && threadIdx.x == 0) atomicAdd(&a.hdr[0], 1u);   // (statistics: drains, over all blocks)
+#pragma unroll 1
+        for (int rr = 0; rr < 4; ++rr) {
+            const int u = 4 * w + rr;
+            const int n = __builtin_amdgcn_readfirstlane(cnt_s[u]);
+            if (n <= 64) continue;                         // (wave-uniform) nothing to drop yet / nothing new since the last drain
+            int32_t id[4]; uint32_t e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = lane + 64 * j;
+                const float2 en = pool[u][idx];
+                id[j] = __float_as_int(en.y);
+                e[j] = idx < n ? tk_ord(en.x) : 0u;            // (every held key is >= tk_ord(-inf) > 0)
+            }
+            const uint32_t P = tk_select64(e, tk_ord(thr_s[u]));
+            // (LDS operations of one wave are performed in order: every slot was read above)
+            int base = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t mg = __ballot(e[j] > P);
+                if (e[j] > P) { const int pos = base + tk_mbcnt(mg); pool[u][pos] = make_float2(tk_unord(e[j]), __int_as_float(id[j])); }
+                base += __popcll(mg);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (base >= 64) break;                     // (wave-uniform)
+                const uint64_t me = __ballot(e[j] == P);
+                const int pos = base + tk_mbcnt(me);
+                if (e[j] == P && pos < 64) { pool[u][pos] = make_float2(tk_unord(P), __int_as_float(id[j])); }
+                base += __popcll(me);
+            }
+            if (lane == 0) { cnt_s[u] = 64; thr_s[u] = tk_unord(P); }
+        }
+        __syncthreads();
+        return done_quarters;
+    };
+    const int n_rounds = (int)my_rounds;
+    for (int round = 0; round < n_rounds; ++round) {
         // the round's view of the block state, ONE LDS round trip: the fills of the pools of the lane's user group (a pool must keep room for the next
         // round's 4 x TK_TILE candidates) and the four rows' filters (they change at drains only). The pools and their counters are shared by the four
         // waves and the counters only grow between drains: a wave that finds a pool too full waits at the barrier, and every other wave finds the
         // same at the top of its next round - no drain-request flag (the per-wave buffers of rounds 2 - 5 needed one, and a second LDS round trip).
         const int4 c4 = *reinterpret_cast<const int4*>(&cnt_s[lq * 4]);
-        const float4 t4 = *reinterpret_cast<const float4*>(&thr_s[lq * 4]);
+        float4 t4 = *reinterpret_cast<const float4*>(&thr_s[lq * 4]);
+        asm volatile("" : "+v"(t4.x), "+v"(t4.y), "+v"(t4.z), "+v"(t4.w));      // (both reads in flight together: the compiler sank this one to its use - a second round trip)
         const int fill = max(max(c4.x, c4.y), max(c4.z, c4.w));
-        const bool drain = fin || __ballot(fill > TK_POOL - 4 * TK_TILE) != 0ull;
-        if (drain) {
-            if (fin && !counted) { counted = true; if (lane == 0) atomicAdd(&flag_s[0], 1); }
-            __syncthreads();                                   // (every wave's appends - LDS atomics and stores - are complete and visible)
-            const int done_quarters = flag_s[0];
-            if (a.hdr && threadIdx.x == 0) atomicAdd(&a.hdr[0], 1u);   // (statistics: drains, over all blocks)
-#pragma unroll 1
-            for (int rr = 0; rr < 4; ++rr) {
-                const int u = 4 * w + rr;
-                const int n = __builtin_amdgcn_readfirstlane(cnt_s[u]);
-                if (n <= 64) continue;                         // (wave-uniform) nothing to drop yet / nothing new since the last drain
-                int32_t id[4]; uint32_t e[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int idx = lane + 64 * j;
-                    const float2 en = pool[u][idx];
-                    id[j] = __float_as_int(en.y);
-                    e[j] = idx < n ? tk_ord(en.x) : 0u;            // (every held key is >= tk_ord(-inf) > 0)
-                }
-                const uint32_t P = tk_select64(e, tk_ord(thr_s[u]));
-                // (LDS operations of one wave are performed in order: every slot was read above)
-                int base = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint64_t mg = __ballot(e[j] > P);
-                    if (e[j] > P) { const int pos = base + tk_mbcnt(mg); pool[u][pos] = make_float2(tk_unord(e[j]), __int_as_float(id[j])); }
-                    base += __popcll(mg);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (base >= 64) break;                     // (wave-uniform)
-                    const uint64_t me = __ballot(e[j] == P);
-                    const int pos = base + tk_mbcnt(me);
-                    if (e[j] == P && pos < 64) { pool[u][pos] = make_float2(tk_unord(P), __int_as_float(id[j])); }
-                    base += __popcll(me);
-                }
-                if (lane == 0) { cnt_s[u] = 64; thr_s[u] = tk_unord(P); }
-            }
-            __syncthreads();
-            if (done_quarters == 4) break;
-            continue;
+        if (__ballot(fill > TK_POOL - 4 * TK_TILE) != 0ull) {
+            drain_pools();
+            t4 = *reinterpret_cast<const float4*>(&thr_s[lq * 4]);
         }
-        const int64_t base = (t_begin + round) * TK_TILE;
+        const int32_t base = ((int32_t)t_begin + round) * TK_TILE;      // (item ids are int32)
         f32x4 acc[2];
         acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
 #pragma unroll
@@ -834,28 +911,29 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
             }
         const float cn_now[2] = {cnv[0], cnv[1]};                       // (this tile's factors: the prefetch below overwrites cnv)
         const uint32_t hm_now = hm;
+        const uint4 rmw_now = rmw;
         __builtin_amdgcn_sched_barrier(0);
-        if (round + 1 < my_rounds) { load_tile(); if (hoff >= 0) hm = tk_heavy_word(a, hoff, t_begin + round + 1); }
+        if (round + 1 < n_rounds) { load_tile(); if (hoff >= 0) hm = tk_heavy_word(a, hoff, t_begin + round + 1); if (all_bm) rmw = tk_rows_words(a, lq, t_begin + round + 1); }
         __builtin_amdgcn_sched_barrier(0);
-        // 32-bit mask of this tile's train items, by the row-owner lanes; the items come from the LDS stage (tk_train_stage)
-        uint32_t m = hm_now;
-        for (;;) {
-            const int32_t base32 = (int32_t)base;
-            bool need = false;
-            while ((uint32_t)(nxt - base32) < (uint32_t)TK_TILE) {      // lanes >= 16 hold INT_MAX; nxt >= base (sorted rows)
-                m |= 1u << (nxt - base32);
-                if ((++cur & (TK_TRAIN_STAGE - 1)) == 0) { need = true; break; }    // window consumed
-                nxt = train_s[w][lane & 15][cur & (TK_TRAIN_STAGE - 1)];
+        uint32_t rm4[4] = {rmw_now.x, rmw_now.y, rmw_now.z, rmw_now.w};
+        // rows that are walked: only in rounds whose tile holds a train item of some row (or a set bitmap word) - wave-uniform, one compare otherwise
+        if (!all_bm && __ballot((uint32_t)(nxt - base) < (uint32_t)TK_TILE || hm_now != 0u) != 0ull) {
+            __builtin_amdgcn_sched_barrier(0);
+            // 32-bit mask of this tile's train items, by the row-owner lanes; the items come from the LDS stage (tk_train_stage)
+            uint32_t m = hm_now;
+            for (;;) {
+                bool need = false;
+                while ((uint32_t)(nxt - base) < (uint32_t)TK_TILE) {        // lanes >= 16 hold INT_MAX; nxt >= base (sorted rows)
+                    m |= 1u << (nxt - base);
+                    if ((++cur & (TK_TRAIN_STAGE - 1)) == 0) { need = true; break; }    // window consumed
+                    nxt = train_s[w][lane & 15][cur & (TK_TRAIN_STAGE - 1)];
+                }
+                const unsigned nb = (unsigned)__ballot(need);
+                if (nb == 0u) break;                                       // (wave-uniform; the usual case)
+                tk_train_refill(a.train_colidx, nb, cur, end, train_s[w], lane);
+                if (need) nxt = train_s[w][lane & 15][0];
             }
-            const unsigned nb = (unsigned)__ballot(need);
-            if (nb == 0u) break;                                       // (wave-uniform; the usual case)
-            tk_train_refill(a.train_colidx, nb, cur, end, train_s[w], lane);
-            if (need) nxt = train_s[w][lane & 15][0];
-        }
-
-        // event rounds only (wave-uniform): the owners' masks go through LDS - one 16-byte read gives a lane the masks of its four rows
-        uint32_t rm4[4] = {0u, 0u, 0u, 0u};
-        if (__ballot(m != 0u) != 0ull) {
+            // the owners' masks go through LDS - one 16-byte read gives a lane the masks of its four rows
             if (m != 0u) mask_s[w][lane & 15] = m;
             __builtin_amdgcn_wave_barrier();
             const uint4 t = *reinterpret_cast<const uint4*>(&mask_s[w][lq * 4]);
@@ -879,12 +957,14 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
                 const bool pass = (v >= rthr) && !((rm >> col) & 1u);       // (slots past the table's end: cn = NaN, so v is NaN and never passes)
                 if (pass) {                                    // lane-local append: a slot from the pool's LDS counter (the order inside a
                     const int off = atomicAdd(&cnt_s[lq * 4 + r], 1);      // pool is irrelevant)
-                    pool[lq * 4 + r][off] = make_float2(v, __int_as_float((int32_t)base + col));
+                    pool[lq * 4 + r][off] = make_float2(v, __int_as_float(base + col));
                 }
             }
         }
-        ++round;
     }
+    // this wave's quarter is swept: it keeps draining with the block until all four are (the last drain leaves <= 64 entries per pool)
+    if (lane == 0) atomicAdd(&flag_s[0], 1);
+    while (drain_pools() != 4) {}
     // the users' survivors (<= 64 each: the last drain ran after every wave's last round) -> ONE sorted list per user, slot = lane, as 64-bit keys
 #pragma unroll 1
     for (int rr = 0; rr < 4; ++rr) {
@@ -1213,13 +1293,17 @@ static int64_t topk_packed_bytes(int64_t n_items, int32_t d) {
 static int64_t topk_flag_bytes(int32_t n_query) { return align_up(4 * ceil_div(n_query, 16), 256); }   // one word per user tile (bf16 mode)
 // bitmaps of long train rows: TK_HEAVY_PER_BLOCK rows of one word per item tile for every block of the sweep; 0 = off (item tables beyond
 // 131 072 items, or more than 64 MB of slices)
-static int64_t topk_heavy_bytes(int32_t n_query, int64_t n_items) {
+static int64_t topk_heavy_bytes(int32_t n_query, int64_t n_items, int* all_rows = nullptr) {
     const int64_t words = ceil_div(n_items, TK_TILE);
     int split_from = 0, n_parts = 1;
     plan_split(n_query, n_items, &split_from, &n_parts);
     const int64_t n_tiles = ceil_div(n_query, 16), grid = split_from + (n_tiles - split_from) * n_parts;
-    const int64_t bytes = grid * TK_HEAVY_PER_BLOCK * words * 4;
-    return (words > 4096 || bytes > (64ll << 20)) ? 0 : align_up(bytes, 256);
+    // every row of a block as a bitmap (tile-major slices, bf16 sweep: tk_rows_setup) while 16 rows per block fit the budget, else the long rows only
+    const int64_t all = grid * 16 * words * 4, bytes = grid * TK_HEAVY_PER_BLOCK * words * 4;
+    if (all_rows) *all_rows = 0;
+    if (words > 4096) return 0;
+    if (all <= (64ll << 20)) { if (all_rows) *all_rows = 1; return align_up(all, 256); }
+    return bytes > (64ll << 20) ? 0 : align_up(bytes, 256);
 }
 
 int llmrec_topk_set_part_items(int32_t items) {
@@ -1278,7 +1362,7 @@ int llmrec_score_topk_mode_f32(int32_t n_query, const int64_t* query_users,
     a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.part_major = 0; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
     if (mode == LLMREC_TOPK_MODE_PREFILTER && K > LLMREC_TOPK_PREFILTER_MAX_K) mode = LLMREC_TOPK_MODE_EXACT_SWEEP;   // (no room to verify in 64 slots)
     a.mode = mode; a.pk2 = nullptr; a.hdr = nullptr; a.cn = nullptr; a.fb_word = nullptr; a.only_flagged = nullptr;
-    a.heavy_bm = nullptr; a.heavy_words = 0;
+    a.heavy_bm = nullptr; a.heavy_words = 0; a.heavy_all = 0;
     if (workspace) {                                           // without a workspace: one block per user tile, fragments straight from Ei
         const int64_t need = llmrec_score_topk_workspace_bytes(n_query, n_items, d), split = topk_split_bytes(n_query, n_items);
         LLMREC_CHECK_ARG(workspace_bytes >= need && (uintptr_t)workspace % 16 == 0, "score_topk: workspace of %lld bytes needed (16-byte aligned)", (long long)need);
@@ -1296,9 +1380,11 @@ int llmrec_score_topk_mode_f32(int32_t n_query, const int64_t* query_users,
         }
         char* frag = (char*)workspace + align_up(split, 256);
         a.packed = (const float4*)frag;
-        if (train_rowptr && !a.part_major && topk_heavy_bytes(n_query, n_items) > 0) {      // (item parts: a block walks 1 / n_parts of a row)
+        int all_rows = 0;
+        if (train_rowptr && !a.part_major && topk_heavy_bytes(n_query, n_items, &all_rows) > 0) {      // (item parts: a block walks 1 / n_parts of a row)
             a.heavy_bm = (uint32_t*)(frag + topk_packed_bytes(n_items, d) + topk_flag_bytes(n_query));
             a.heavy_words = (int)ceil_div(n_items, TK_TILE);
+            a.heavy_all = all_rows;                            // (the slices' stride; the exact sweep keeps to the two-row form inside them)
         }
         if (mode == LLMREC_TOPK_MODE_PREFILTER) {
             a.hdr = (uint32_t*)frag;                           // (the first 256 bytes of the fragment area)
@@ -1323,7 +1409,7 @@ int llmrec_scores_f32(int32_t n_query, const int64_t* query_users,
     a.vec_ok = (ldu % 4 == 0) && (ldi % 4 == 0) && (((uintptr_t)Eu | (uintptr_t)Ei) % 16 == 0);
     a.split_from = (int)ceil_div(n_query, 16); a.n_parts = 1; a.part_major = 0; a.ws_idx = nullptr; a.ws_score = nullptr; a.packed = nullptr;
     a.mode = 0; a.pk2 = nullptr; a.hdr = nullptr; a.cn = nullptr; a.fb_word = nullptr; a.only_flagged = nullptr;
-    a.heavy_bm = nullptr; a.heavy_words = 0;
+    a.heavy_bm = nullptr; a.heavy_words = 0; a.heavy_all = 0;
     return launch_topk<false>(a, (hipStream_t)stream_);
 }
 

@@ -57,7 +57,11 @@ def test_prefilter_equals_exact_on_random_tables(ops, U, I, d, K):
     _assert_same(*_both(ops, Eu, Ei, q, train, K), what="random")
     if K <= 50 and I >= 1000:
         assert LAST["fallback_tiles"] == 0, LAST                   # well-separated scores: the verification holds everywhere
-        assert LAST["bitmap_rows"] == 0, LAST                      # rows of at most 40 train items are walked
+        # rows of at most 40 train items: no long row; a block whose 16 rows hold more than 192 items sweeps them ALL as bitmaps (tile-major slice)
+        assert LAST["bitmap_rows"] % 16 == 0 and LAST["bitmap_rows"] > 0, LAST
+        sparse = _train_csr(ops, U, I, rng, 6)                     # ~3 items per row: every block walks its rows
+        _assert_same(*_both(ops, Eu, Ei, q, sparse, K), what="random, sparse train rows")
+        assert LAST["bitmap_rows"] == 0, LAST
     _assert_same(*_both(ops, Eu, Ei, q, None, K), what="random, no mask")
     _assert_same(*_both(ops, Eu, Ei, q[:7], train, K), what="7 queries")
 
@@ -152,8 +156,8 @@ def test_dense_train_rows_cross_the_staged_window(ops, I, d):
     q = torch.arange(U, device=DEV)
     i0, s0, i1, s1 = _both(ops, Eu, Ei, q, train, K)
     _assert_same(i0, s0, i1, s1, what="dense train rows")
-    # the long rows went through the bitmap path (up to two per block - the others of a block are walked; 54 users = 4 user tiles, each
-    # swept by one block or, at 20 000 items, by eight blocks of an item range each)
+    # the long rows went through a bitmap path (all 16 rows of a block as one tile-major slice, or - item parts, slices beyond the budget - up to
+    # two per block with the others walked; 54 users = 4 user tiles, each swept by one block or, at 20 000 items, by eight blocks of an item range each)
     assert LAST["bitmap_rows"] >= 4, LAST
     S = (Eu.double() @ Ei.double().T)
     S[torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV)] = -float("inf")
@@ -186,3 +190,34 @@ def test_item_parts_of_the_bf16_sweep_equal_the_exact_sweep(ops, U, I, d, K, par
         _assert_same(*_both(ops, Eu_t, Ei_t, q, train, K), what="item parts, ties")
     finally:
         ops.topk_set_part_items(0)
+
+
+def test_blocks_of_both_bitmap_forms_in_one_call(ops):
+    """One call whose blocks choose differently: user tiles with dense train rows sweep all 16 rows as bitmaps (tile-major slice), tiles with sparse rows
+    walk them - and turn their one long row into a bitmap of the two-row form INSIDE the same slice layout. (A stride mismatch between the two forms let
+    the sparse tiles' slices land in the dense tiles' ones: one user of 13 187 lost an item - found by a timing script, not by the suite.)"""
+    rng = np.random.default_rng(77)
+    I, d, K = 3000, 64, 50
+    degs = []
+    for t in range(8):
+        if t % 2 == 0:
+            degs += list(rng.integers(20, 60, size=16))                        # dense tile: all rows as bitmaps
+        else:
+            row = list(rng.integers(0, 4, size=16)); row[int(rng.integers(0, 16))] = 110   # sparse tile with one long row (<= 192 items in all: walked)
+            degs += row
+    degs = np.array(degs + [2, 150, 1])                                        # a partial last tile
+    U = len(degs)
+    rows = np.repeat(np.arange(U), degs)
+    cols = np.concatenate([np.sort(rng.choice(I, size=int(dg), replace=False)) for dg in degs]).astype(np.int64)
+    rp, ci, _ = ops.csr_from_coo(torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV), None, U, I)
+    train = ops.Csr(U, I, rp, ci, None, None, None, ops.SpmmPlan())
+    Eu = torch.tensor((rng.standard_normal((U, d)) * 0.4).astype(np.float32)).to(DEV)
+    Ei = torch.tensor((rng.standard_normal((I, d)) * 0.4).astype(np.float32)).to(DEV)
+    q = torch.arange(U, device=DEV)
+    for rep in range(3):                                                       # (the workspace is reused: stale slices of the call before)
+        i0, s0, i1, s1 = _both(ops, Eu, Ei, q, train, K)
+        _assert_same(i0, s0, i1, s1, what="mixed bitmap forms, call %d" % rep)
+    assert LAST["bitmap_rows"] >= 4 * 16 + 4, LAST                             # four dense tiles + the long rows of the sparse ones
+    S = Eu.double() @ Ei.double().T
+    S[torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV)] = -float("inf")
+    assert not torch.isinf(S.gather(1, i1.long())).any()                       # no train item in any list
