@@ -1179,9 +1179,10 @@ static void plan_split(int n_query, int64_t n_items, int* split_from, int* n_par
 // topk_merge_pre_kernel, as for the left-over tiles of the small-table plan. g_part_items: 0 = the policy below; tools set it
 // (llmrec_topk_set_part_items) to sweep the part size.
 constexpr int64_t TK_PARTS_FROM_ITEMS = 131072;                // tables up to here: the small-table plan (L2 / MALL-resident fragments)
-constexpr int64_t TK_PART_BYTES = 8 << 20;                      // fragments per part. Measured (65 536 users x 10^6 items, d = 64; exact sweep 109.5 ms,
-constexpr int TK_PART_ITEMS_MIN = 16384;                        // bf16 sweep without parts 136.0): parts of 8 192 / 16 384 / 32 768 / 65 536 items 76.9 /
-static int g_part_items = 0;                                    // 56.7 / 50.7 / 91.8 ms; d = 128, 16 384 users (exact 50.5, no parts 62.1): 27.8 / 29.8 / 50.2 / 61.9
+constexpr int64_t TK_PART_BYTES = 4 << 20;                      // fragments per part: one XCD's L2. Measured with the pool sweep (65 536 users x 10^6 items, d = 64;
+constexpr int TK_PART_ITEMS_MIN = 8192;                         // exact sweep 112.3 ms, bf16 sweep without parts 129.2): parts of 8 192 / 16 384 / 32 768 / 65 536 items
+static int g_part_items = 0;                                    // 59.5 / 44.4 / 58.3 / 98.2 ms; d = 128, 16 384 users (exact 51.1, no parts 60.7): 23.7 / 31.0 / 50.8 / 61.2.
+                                                                // (The sorted-list sweep of rounds 2 - 5 had its optimum at 8 MB: 76.9 / 56.7 / 50.7 / 91.8 and 27.8 / 29.8 / 50.2 / 61.9.)
 // d < 0: the smallest part any width gets (workspace sizing: the layout must not depend on d)
 static bool plan_parts(int n_query, int64_t n_items, int d, int* n_parts) {
     if (g_part_items < 0 || (g_part_items == 0 && n_items <= TK_PARTS_FROM_ITEMS)) return false;

@@ -37,9 +37,9 @@ def test_workspace_queries_run_without_gpu():
     # else the two longest rows of a block (off beyond 131 072 items / 64 MB)
     heavy = lambda blocks, n_items, rows=16: up(blocks * rows * -(-n_items // 32) * 4)
     assert _lib.query("llmrec_score_topk_workspace_bytes", 13187, 17366, 64) == 57 * 4 * 16 * 64 * 8 + packed(17366, 64, 13187) + heavy(768 + 57 * 4, 17366)
-    # beyond 131 072 items the bf16 sweep cuts EVERY user tile into item parts (round 6): part lists for the smallest part (16 384 items) of any width
-    assert _lib.query("llmrec_score_topk_workspace_bytes", 4096 * 16, 1_000_000, 64) == 4096 * 62 * 16 * 64 * 8 + packed(1_000_000, 64, 4096 * 16)
-    assert _lib.query("llmrec_score_topk_workspace_bytes", 4096 * 16, 1_000_000, 128) == 4096 * 62 * 16 * 64 * 8 + packed(1_000_000, 128, 4096 * 16)
+    # beyond 131 072 items the bf16 sweep cuts EVERY user tile into item parts (round 6): part lists for the smallest part (8 192 items) of any width
+    assert _lib.query("llmrec_score_topk_workspace_bytes", 4096 * 16, 1_000_000, 64) == 4096 * 123 * 16 * 64 * 8 + packed(1_000_000, 64, 4096 * 16)
+    assert _lib.query("llmrec_score_topk_workspace_bytes", 4096 * 16, 1_000_000, 128) == 4096 * 123 * 16 * 64 * 8 + packed(1_000_000, 128, 4096 * 16)
     assert _lib.query("llmrec_score_topk_workspace_bytes", 100, 500, 20) == packed(500, 20, 100) + heavy(7, 500)        # too few items to cut
     assert _lib.query("llmrec_score_topk_workspace_bytes", 16 * 4096, 131_072, 64) == packed(131_072, 64, 16 * 4096)      # 128 MB of two-row slices: off
     assert _lib.query("llmrec_score_topk_workspace_bytes", 16 * 1024, 65_536, 64) == packed(65_536, 64, 16 * 1024) + heavy(1024, 65_536, rows=2)   # 16 rows: 128 MB; two rows: 16 MB
