@@ -27,6 +27,7 @@
 // into a 32-bit tile mask.
 #include "common.h"
 #include <limits.h>
+#include <type_traits>
 
 namespace llmrec {
 
@@ -727,8 +728,11 @@ constexpr int TK_POOL = 256;
 // entries): the largest P the search reaches with #{e >= P} >= 64 - it stops at the first P with EXACTLY 64 keys at or above it (P is then a lower bound
 // of the 64th largest key, which is all a filter needs), else it ends at the 64th largest key itself (ties). The bits above the highest bit in which the
 // largest key differs from lo are common to every key and skipped: ~10 steps instead of 32 on scores of one binade. Wave-uniform.
+template <int NJ>                                              // NJ: registers of e that hold entries (the pool's fill / 64, rounded up)
 __device__ __forceinline__ uint32_t tk_select64(const uint32_t (&e)[4], uint32_t lo) {
-    uint32_t hi = max(max(e[0], e[1]), max(e[2], e[3]));
+    uint32_t hi = max(e[0], e[1]);
+    if (NJ > 2) hi = max(hi, e[2]);
+    if (NJ > 3) hi = max(hi, e[3]);
     hi = max(hi, (uint32_t)xor_lane_i<1>((int)hi, 0)); hi = max(hi, (uint32_t)xor_lane_i<2>((int)hi, 0));
     hi = max(hi, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x124, 0xf, 0xf, true));      // row_ror:4
     hi = max(hi, (uint32_t)xor_lane_i<8>((int)hi, 0));
@@ -741,7 +745,9 @@ __device__ __forceinline__ uint32_t tk_select64(const uint32_t (&e)[4], uint32_t
 #pragma unroll 1
     for (int b = top; b >= 0; --b) {
         const uint32_t c = P | (1u << b);
-        const int n = __popcll(__ballot(e[0] >= c)) + __popcll(__ballot(e[1] >= c)) + __popcll(__ballot(e[2] >= c)) + __popcll(__ballot(e[3] >= c));
+        int n = __popcll(__ballot(e[0] >= c)) + __popcll(__ballot(e[1] >= c));
+        if (NJ > 2) n += __popcll(__ballot(e[2] >= c));
+        if (NJ > 3) n += __popcll(__ballot(e[3] >= c));
         P = n >= 64 ? c : P;
         if (n == 64) break;
     }
@@ -854,31 +860,38 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
             const int u = 4 * w + rr;
             const int n = __builtin_amdgcn_readfirstlane(cnt_s[u]);
             if (n <= 64) continue;                         // (wave-uniform) nothing to drop yet / nothing new since the last drain
-            int32_t id[4]; uint32_t e[4];
+            // (wave-uniform) the pool's entries in NJ registers per lane, slot = lane + 64 j: most drains find 130 - 190 entries, i.e. three
+            auto drain_user = [&](auto nj_tag) -> uint32_t {
+                constexpr int NJ = decltype(nj_tag)::value;
+                int32_t id[4]; uint32_t e[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int idx = lane + 64 * j;
-                const float2 en = pool[u][idx];
-                id[j] = __float_as_int(en.y);
-                e[j] = idx < n ? tk_ord(en.x) : 0u;            // (every held key is >= tk_ord(-inf) > 0)
-            }
-            const uint32_t P = tk_select64(e, tk_ord(thr_s[u]));
-            // (LDS operations of one wave are performed in order: every slot was read above)
-            int base = 0;
+                for (int j = 0; j < NJ; ++j) {
+                    const int idx = lane + 64 * j;
+                    const float2 en = pool[u][idx];
+                    id[j] = __float_as_int(en.y);
+                    e[j] = idx < n ? tk_ord(en.x) : 0u;        // (every held key is >= tk_ord(-inf) > 0)
+                }
+                const uint32_t P = tk_select64<NJ>(e, tk_ord(thr_s[u]));
+                // (LDS operations of one wave are performed in order: every slot was read above)
+                int base = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint64_t mg = __ballot(e[j] > P);
-                if (e[j] > P) { const int pos = base + tk_mbcnt(mg); pool[u][pos] = make_float2(tk_unord(e[j]), __int_as_float(id[j])); }
-                base += __popcll(mg);
-            }
+                for (int j = 0; j < NJ; ++j) {
+                    const uint64_t mg = __ballot(e[j] > P);
+                    if (e[j] > P) { const int pos = base + tk_mbcnt(mg); pool[u][pos] = make_float2(tk_unord(e[j]), __int_as_float(id[j])); }
+                    base += __popcll(mg);
+                }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (base >= 64) break;                     // (wave-uniform)
-                const uint64_t me = __ballot(e[j] == P);
-                const int pos = base + tk_mbcnt(me);
-                if (e[j] == P && pos < 64) { pool[u][pos] = make_float2(tk_unord(P), __int_as_float(id[j])); }
-                base += __popcll(me);
-            }
+                for (int j = 0; j < NJ; ++j) {
+                    if (base >= 64) break;                     // (wave-uniform)
+                    const uint64_t me = __ballot(e[j] == P);
+                    const int pos = base + tk_mbcnt(me);
+                    if (e[j] == P && pos < 64) { pool[u][pos] = make_float2(tk_unord(P), __int_as_float(id[j])); }
+                    base += __popcll(me);
+                }
+                return P;
+            };
+            const uint32_t P = n <= 128 ? drain_user(std::integral_constant<int, 2>()) : n <= 192 ? drain_user(std::integral_constant<int, 3>())
+                                                                                                  : drain_user(std::integral_constant<int, 4>());
             if (lane == 0) { cnt_s[u] = 64; thr_s[u] = tk_unord(P); }
         }
         __syncthreads();
