@@ -954,26 +954,32 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
             __builtin_amdgcn_wave_barrier();
             if (m != 0u) mask_s[w][lane & 15] = 0u;
         }
+        // MASKED = false: no row of the wave has a train item in this tile (the usual round of sparse rows) - the append skips the mask test
+        auto select_round = [&](auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float rthr = cmp4(t4, r);
-            const uint32_t rm = rm4[r];
+            for (int r = 0; r < 4; ++r) {
+                const float rthr = cmp4(t4, r);
+                const uint32_t rm = rm4[r];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const float v = fmaf(unr[r], cn_now[n], acc[n][r]);        // ub = s' + 2^-14 ||u|| ||i||
-                // the common case is ONE compare and one scalar branch: the sweep is bound by the instructions it issues (~1 per 4 cycles and SIMD, every
-                // type counted: profiles/experiments/r06_topk_pool.md), and the compiler folded the train-mask test and the exec juggling of the
-                // append into the straight line (11 instructions per (row, column tile) instead of 3) until the scheduling barrier pinned them here
-                if (__ballot(v >= rthr) == 0ull) continue;
-                __builtin_amdgcn_sched_barrier(0);
-                const int col = 16 * n + li;
-                const bool pass = (v >= rthr) && !((rm >> col) & 1u);       // (slots past the table's end: cn = NaN, so v is NaN and never passes)
-                if (pass) {                                    // lane-local append: a slot from the pool's LDS counter (the order inside a
-                    const int off = atomicAdd(&cnt_s[lq * 4 + r], 1);      // pool is irrelevant)
-                    pool[lq * 4 + r][off] = make_float2(v, __int_as_float(base + col));
+                for (int n = 0; n < 2; ++n) {
+                    const float v = fmaf(unr[r], cn_now[n], acc[n][r]);    // ub = s' + 2^-14 ||u|| ||i||
+                    // the common case is ONE compare and one scalar branch: the sweep is bound by the instructions it issues (~1 per 4 cycles and SIMD,
+                    // every type counted: profiles/experiments/r06_topk_pool.md), and the compiler folded the train-mask test and the exec juggling of
+                    // the append into the straight line (11 instructions per (row, column tile) instead of 3) until the scheduling barrier pinned them here
+                    if (__ballot(v >= rthr) == 0ull) continue;
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int col = 16 * n + li;
+                    const bool pass = (v >= rthr) && !(MASKED && ((rm >> col) & 1u));   // (slots past the table's end: cn = NaN, so v is NaN and never passes)
+                    if (pass) {                                // lane-local append: a slot from the pool's LDS counter (the order inside a
+                        const int off = atomicAdd(&cnt_s[lq * 4 + r], 1);  // pool is irrelevant)
+                        pool[lq * 4 + r][off] = make_float2(v, __int_as_float(base + col));
+                    }
                 }
             }
-        }
+        };
+        if (__ballot((rm4[0] | rm4[1] | rm4[2] | rm4[3]) != 0u) != 0ull) select_round(std::true_type());
+        else select_round(std::false_type());
     }
     // this wave's quarter is swept: it keeps draining with the block until all four are (the last drain leaves <= 64 entries per pool)
     if (lane == 0) atomicAdd(&flag_s[0], 1);
