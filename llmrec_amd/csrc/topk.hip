@@ -242,10 +242,13 @@ __device__ __forceinline__ uint32_t tk_heavy_word(const TopkArgs& a, int off, in
 // ~45 of the ~200 instructions a wave issues per round, and the sweep is bound by exactly that count. Here the block turns ALL its rows into bitmaps
 // once (a few hundred train items, one LDS atomicOr each) in a slice of its own laid out [item tile][16 users]: the masks a lane needs for a round - the
 // words of its four rows - are 16 consecutive bytes, ONE load issued with the tile's fragments one round ahead. Called by all 256 threads.
-__device__ __forceinline__ void tk_rows_setup(const TopkArgs& a, int lane, bool row_valid, int32_t row_begin, int32_t row_end, uint32_t* lds, int lds_words) {
-    // Built in LDS (the candidate pools' 32 KB, unused until the sweep starts), TK_ROWS_STAGE tiles of all 16 rows at a time, and copied out with
+__device__ __forceinline__ void tk_rows_setup(const TopkArgs& a, int lane, bool row_valid, int32_t row_begin, int32_t row_end, uint32_t* lds, int lds_words,
+                                              int blk_t0, int blk_t1, int wave_t0, int wave_t1) {
+    // Built in LDS (the candidate pools' 32 KB, unused until the sweep starts), lds_words / 16 tiles of all 16 rows at a time, and copied out with
     // 16-byte stores: zeroing the slice in global memory and one global atomicOr per train item - the first form - cost 49 us of a 0.31 ms sweep
-    // (all blocks start together: 36 MB of zeroes, then 0.66 M atomics at the L2).
+    // (all blocks start together: 36 MB of zeroes, then 0.66 M atomics at the L2). Only the tiles the block sweeps [blk_t0, blk_t1) are built, and every
+    // wave copies out the tiles of ITS quarter [wave_t0, wave_t1): it is the only reader of those words, a wave's loads follow its own stores to the
+    // same address in order, so the sweep starts without waiting for the stores (no s_waitcnt vmcnt(0) + barrier + L1 invalidate behind the copy).
     uint32_t* const slice = a.heavy_bm + (size_t)blockIdx.x * 16 * a.heavy_words;
     // the first 256 items of every row: 16 independent loads per thread, in flight together (one row after the other - load, wait, atomic - was a chain
     // of 16 memory latencies per pass: 28 us of set-up); what a row holds beyond 256 items is read in the passes
@@ -259,8 +262,8 @@ __device__ __forceinline__ void tk_rows_setup(const TopkArgs& a, int lane, bool 
         if (re - rb > 256) long_rows |= 1u << u;
     }
     const int stage = lds_words / 16;                           // item tiles per pass
-    for (int t0 = 0; t0 < a.heavy_words; t0 += stage) {
-        const int nt = a.heavy_words - t0 < stage ? a.heavy_words - t0 : stage;
+    for (int t0 = blk_t0; t0 < blk_t1; t0 += stage) {
+        const int nt = blk_t1 - t0 < stage ? blk_t1 - t0 : stage;
         for (int i = threadIdx.x; i < nt * 4; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
 #pragma unroll
@@ -279,19 +282,21 @@ __device__ __forceinline__ void tk_rows_setup(const TopkArgs& a, int lane, bool 
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < nt * 4; i += 256) reinterpret_cast<uint4*>(slice + (size_t)t0 * 16)[i] = reinterpret_cast<const uint4*>(lds)[i];
+        const int c0 = wave_t0 > t0 ? wave_t0 : t0, c1 = wave_t1 < t0 + nt ? wave_t1 : t0 + nt;      // this wave's tiles of the pass
+        for (int i = (c0 - t0) * 4 + lane; i < (c1 - t0) * 4; i += 64)
+            reinterpret_cast<uint4*>(slice + (size_t)t0 * 16)[i] = reinterpret_cast<const uint4*>(lds)[i];
         __syncthreads();                                       // (the stage is reused - by the next pass or by the sweep's pools)
     }
     if (a.hdr && threadIdx.x == 0) atomicAdd(&a.hdr[2], 16u);     // (statistics: train rows swept as bitmaps)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the words are at the L2 before any wave reads one back)
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // (the L1 drops what it holds: the words are read with plain loads)
 }
 // the words of rows 4 lq .. 4 lq + 3 for one item tile: 16 bytes, one load (plain: see tk_heavy_word)
 __device__ __forceinline__ uint4 tk_rows_words(const TopkArgs& a, int lq, int64_t tile) {
     return *reinterpret_cast<const uint4*>(a.heavy_bm + ((size_t)blockIdx.x * a.heavy_words + tile) * 16 + lq * 4);
 }
-constexpr int TK_ROWS_BM_MIN = 16 * 12;   // train items of a block's 16 rows from which tk_rows_setup pays
+#ifndef TK_ROWS_BM_MIN_N
+#define TK_ROWS_BM_MIN_N (16 * 12)
+#endif
+constexpr int TK_ROWS_BM_MIN = TK_ROWS_BM_MIN_N;   // train items of a block's 16 rows from which tk_rows_setup pays
 constexpr int TK_CAP = 64;    // buffer slots per (wave, user): drained before a round could overflow it
 
 // scores only (llmrec_scores_f32): S[q][item], same MFMA chain as the selection kernel
@@ -812,7 +817,7 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     }
     // (block-uniform: every wave holds the same 16 rows) every train row of the block as a bitmap, no row walked - when the rows are long enough to pay
     // for the slice's set-up and the two loads per round: measured at the Netflix shape, 4.2 train items per user: walking 0.283 ms, bitmaps 0.296; ~50 per
-    // user: 0.381 / 0.321
+    // user: 0.381 / 0.321. (All 16 rows as bitmaps whenever ONE row is long, instead of the two-row form beside walked rows: 0.2645 against 0.262 - no gain.)
     int row_items = lane < 16 && q0 + lane < a.n_query ? end - row_begin : 0;
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) row_items += __shfl_xor(row_items, off, 64);
@@ -829,7 +834,8 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
         nxt = train_s[w][lane][cur & (TK_TRAIN_STAGE - 1)];                                       //  slots before cur are never read)
     }
     int hoff = -1;
-    if (all_bm) tk_rows_setup(a, lane, q0 + lane < a.n_query, row_begin, end, reinterpret_cast<uint32_t*>(&pool[0][0]), 16 * TK_POOL * 2);
+    if (all_bm) tk_rows_setup(a, lane, q0 + lane < a.n_query, row_begin, end, reinterpret_cast<uint32_t*>(&pool[0][0]), 16 * TK_POOL * 2,
+                              (int)part_begin, (int)tiles_total, (int)t_begin, (int)t_end);
     else hoff = tk_heavy_setup(a, lane, q0 + lane < a.n_query, row_begin, end);                    // >= 0: this lane's row is a bitmap
     if (hoff >= 0) nxt = INT_MAX;
     uint4 rmw = make_uint4(0u, 0u, 0u, 0u);                                                        // all_bm: the words of the lane's four rows, one round ahead
