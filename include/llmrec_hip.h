@@ -663,8 +663,9 @@ int llmrec_score_topk_ws_f32(int32_t n_query, const int64_t* query_users,
  *                                 score) proves that no other item can be in the top K. User tiles that fail the proof are swept again by the
  *                                 exact kernel (second launch; the other tiles' blocks exit at once). Needs the workspace;
  *                                 K <= LLMREC_TOPK_PREFILTER_MAX_K (else the exact sweep runs). llmrec_score_topk_stats_offset: byte offset inside
- *                                 the workspace of three uint32 words the mode leaves behind - [1] = the number of user tiles the exact sweep
- *                                 had to redo, [2] = the number of long train rows the blocks swept as bitmaps. */
+ *                                 the workspace of three uint32 words the mode leaves behind - [0] = the drains of the sweep's candidate
+ *                                 pools, summed over its blocks (round 6), [1] = the number of user tiles the exact sweep had to redo, [2] = the
+ *                                 number of train rows the blocks swept as bitmaps (long rows; all 16 rows of a user tile with dense rows). */
 #define LLMREC_TOPK_PREFILTER_MAX_K 56
 #define LLMREC_TOPK_MODE_EXACT_SWEEP 0
 #define LLMREC_TOPK_MODE_PREFILTER 1
