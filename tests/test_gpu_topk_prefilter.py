@@ -66,12 +66,13 @@ def test_prefilter_equals_exact_on_random_tables(ops, U, I, d, K):
     _assert_same(*_both(ops, Eu, Ei, q[:7], train, K), what="7 queries")
 
 
-@pytest.mark.parametrize("kind", ["near_identical_rows", "softmax_rows", "tiny_spread", "huge_norm_outlier", "integers", "ascending", "few_candidates"])
+@pytest.mark.parametrize("kind", ["near_identical_rows", "softmax_rows", "tiny_spread", "huge_norm_outlier", "integers", "ascending", "few_candidates",
+                                  "all_negative", "zeros_and_signs", "strictly_ascending"])
 def test_prefilter_equals_exact_where_the_filter_is_loose_or_ties_abound(ops, kind):
     # fixed seeds (hash(str) changes from process to process; 35 of the 1000 seeds it produced leave the "integers" case without a single
     # tile for the exact sweep - all 1000 give bit-identical, reference-equal lists in both modes, swept on the GPU)
     rng = np.random.default_rng({"near_identical_rows": 101, "softmax_rows": 102, "tiny_spread": 103, "huge_norm_outlier": 104, "integers": 105,
-                                 "ascending": 106, "few_candidates": 107}[kind])
+                                 "ascending": 106, "few_candidates": 107, "all_negative": 108, "zeros_and_signs": 109, "strictly_ascending": 110}[kind])
     U, I, d, K = 200, 6000, 64, 50
     if kind == "near_identical_rows":        # scores within ~1e-4 relative of one another: the slack admits many false positives
         base = rng.standard_normal(d).astype(np.float32)
@@ -94,6 +95,15 @@ def test_prefilter_equals_exact_where_the_filter_is_loose_or_ties_abound(ops, ki
     elif kind == "ascending":                # item scores grow with the id: the threshold rises all sweep long
         Eu = np.abs(rng.standard_normal((U, d))).astype(np.float32)
         Ei = (np.abs(rng.standard_normal((I, d))) * np.linspace(0.1, 2.0, I)[:, None]).astype(np.float32)
+    elif kind == "all_negative":             # every score (and every filter of the pool sweep) below zero: the order-preserving keys of negative floats
+        Eu = np.abs(rng.standard_normal((U, d))).astype(np.float32)
+        Ei = (-np.abs(rng.standard_normal((I, d))) * 0.3).astype(np.float32)
+    elif kind == "zeros_and_signs":          # scores of both signs around exact zeros (+0 / -0 bounds; a third of the items and a few users are all-zero rows)
+        Eu = (rng.standard_normal((U, d)) * 0.2).astype(np.float32); Eu[::9] = 0.0
+        Ei = (rng.standard_normal((I, d)) * 0.2).astype(np.float32); Ei[::3] = 0.0; Ei[1::7] *= -0.0
+    elif kind == "strictly_ascending":       # every item beats all items before it, for every user: every candidate passes every filter, the pools refill
+        Eu = (np.abs(rng.standard_normal((U, d))) + 0.5).astype(np.float32)     # each round and a drain follows each round
+        Ei = (np.full((I, d), 0.25) * (1.0 + np.arange(I)[:, None] * 1e-3)).astype(np.float32)
     else:                                    # few_candidates: most items are train items
         Ei = rng.standard_normal((I, d)).astype(np.float32); Eu = rng.standard_normal((U, d)).astype(np.float32)
     Eu, Ei = torch.tensor(Eu).to(DEV), torch.tensor(Ei).to(DEV)
