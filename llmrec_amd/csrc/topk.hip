@@ -683,7 +683,11 @@ __global__ __launch_bounds__(256) void topk_item_norm_kernel(TopkArgs a, float* 
 
 // One user's 64 kept items (lane = slot, sorted by approximate score; id INT_MAX = empty slot) -> the exact ranking, the verification, the
 // output. `urow` = the user's fp32 row (LDS or global). Wave-uniform control flow.
-__device__ __forceinline__ void tk_finalize_user(const TopkArgs& a, const float* urow, int q, int tile, float ub, int32_t id, int lane) {
+// BATCH: 16-column chunks of the item rows loaded together (64 B per lane and chunk). 1: one chunk at a time - a chain of d / 16 dependent memory round
+// trips per user, but only 16 registers; 4: d <= 64 in ONE round trip (the sweep's tail: its fragment registers are dead by then - 28 us of a 0.243 ms
+// sweep were these chains, four users per wave one after the other). ulen: length of urow (the staged LDS copy is zero-padded to whole chunks).
+template <int BATCH>
+__device__ __forceinline__ void tk_finalize_user(const TopkArgs& a, const float* urow, int ulen, int q, int tile, float ub, int32_t id, int lane) {
     const float ub64 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ub), 63));   // bounds every item outside the list (-inf: list not full)
     float e = -INFINITY;
     {
@@ -692,14 +696,24 @@ __device__ __forceinline__ void tk_finalize_user(const TopkArgs& a, const float*
         float acc = 0.f;
         const int nc = (a.d + 15) / 16;
 #pragma unroll 1
-        for (int c = 0; c < nc; ++c) {                                   // the k-ordered chain: c, then s, then q; k = 16 c + 4 q + s
-            float4 iv[4], uv[4];
+        for (int c0 = 0; c0 < nc; c0 += BATCH) {                         // the k-ordered chain: c, then s, then q; k = 16 c + 4 q + s
+            float4 iv[BATCH][4];
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) { iv[qq] = ld4g(ir, 16 * c + 4 * qq, a.d, a.vec_ok); uv[qq] = ld4g(urow, 16 * c + 4 * qq, a.d, false); }
+            for (int b = 0; b < BATCH; ++b)
 #pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_)
+                for (int qq = 0; qq < 4; ++qq) iv[b][qq] = ld4g(ir, 16 * (c0 + b) + 4 * qq, a.d, a.vec_ok);   // (zeros past d)
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) acc = __builtin_fmaf(cmp4(uv[qq], s_), cmp4(iv[qq], s_), acc);
+            for (int b = 0; b < BATCH; ++b) {
+                float4 uv[4];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) uv[qq] = ld4g(urow, 16 * (c0 + b) + 4 * qq, ulen, BATCH > 1);
+                if (c0 + b < nc) {                                       // (wave-uniform; chunks past d stay out of the chain: fma(0, 0, -0.0f) is +0.0f)
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) acc = __builtin_fmaf(cmp4(uv[qq], s_), cmp4(iv[b][qq], s_), acc);
+                }
+            }
         }
         if (id != INT_MAX) e = acc;
     }
@@ -991,20 +1005,42 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     if (lane == 0) atomicAdd(&flag_s[0], 1);
     while (drain_pools() != 4) {}
     // the users' survivors (<= 64 each: the last drain ran after every wave's last round) -> ONE sorted list per user, slot = lane, as 64-bit keys
-#pragma unroll 1
+    uint64_t kk[4];
+#pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-        const int u = 4 * w + rr, q = q0 + u;
+        const int u = 4 * w + rr;
         const int n = cnt_s[u];
         const float2 en = pool[u][lane];
-        uint64_t k1 = lane < n ? tk_key(en.x, __float_as_int(en.y)) : TK_KEY_EMPTY;
-        sort64k(k1, lane);
-        if (n_parts > 1) {                                     // a part's lists (approximate scores): merged and finalised by topk_merge_pre_kernel
-            const int64_t row = ((int64_t)(tile - a.split_from) * n_parts + part) * 16 + u;
-            a.ws_idx[row * 64 + lane] = tk_key_id(k1);
-            a.ws_score[row * 64 + lane] = tk_key_ub(k1);
-        } else if (q < a.n_query) {                            // wave-uniform
-            tk_finalize_user(a, a.Eu + a.query_users[q] * a.ldu, q, tile, tk_key_ub(k1), tk_key_id(k1), lane);
+        kk[rr] = lane < n ? tk_key(en.x, __float_as_int(en.y)) : TK_KEY_EMPTY;
+        sort64k(kk[rr], lane);
+    }
+    if (n_parts > 1) {                                         // a part's lists (approximate scores): merged and finalised by topk_merge_pre_kernel
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t row = ((int64_t)(tile - a.split_from) * n_parts + part) * 16 + 4 * w + rr;
+            a.ws_idx[row * 64 + lane] = tk_key_id(kk[rr]);
+            a.ws_score[row * 64 + lane] = tk_key_ub(kk[rr]);
         }
+        return;
+    }
+    // exact re-ranking + verification. The wave's four user rows are staged in LDS (the pools are read: their area is free once every wave is here), so
+    // the item rows of a user's 64 candidates can be loaded four 16-column chunks at a time without the user's row taking registers beside them
+    __syncthreads();
+    float* const urows = reinterpret_cast<float*>(&pool[0][0]);
+    const int ulen = ((a.d + 15) / 16) * 16;                   // <= 128 floats per row
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        int qq = q0 + 4 * w + rr;
+        if (qq > a.n_query - 1) qq = a.n_query - 1;
+        const float* src = a.Eu + a.query_users[qq] * a.ldu;
+        for (int k0 = lane; k0 < ulen; k0 += 64) urows[(4 * w + rr) * ulen + k0] = k0 < a.d ? src[k0] : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();                           // (this wave's rows only: LDS operations of one wave are performed in order)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int q = q0 + 4 * w + rr;
+        if (q >= a.n_query) continue;                          // wave-uniform
+        tk_finalize_user<4>(a, urows + (4 * w + rr) * ulen, ulen, q, tile, tk_key_ub(kk[rr]), tk_key_id(kk[rr]), lane);
     }
 }
 
@@ -1021,7 +1057,7 @@ __global__ __launch_bounds__(1024) void topk_merge_pre_kernel(TopkArgs a) {
         const int64_t row = ((int64_t)blockIdx.x * a.n_parts + p) * 16 + w;
         merge64k(k1, tk_key(a.ws_score[row * 64 + lane], a.ws_idx[row * 64 + lane]), lane);
     }
-    tk_finalize_user(a, a.Eu + a.query_users[q] * a.ldu, q, tile, tk_key_ub(k1), tk_key_id(k1), lane);
+    tk_finalize_user<1>(a, a.Eu + a.query_users[q] * a.ldu, a.d, q, tile, tk_key_ub(k1), tk_key_id(k1), lane);
 }
 
 // the lists of a split tile's parts -> the tile's top K (one wave per four users, as in the sweep)
