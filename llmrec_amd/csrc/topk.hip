@@ -685,9 +685,10 @@ __global__ __launch_bounds__(256) void topk_item_norm_kernel(TopkArgs a, float* 
 // output. `urow` = the user's fp32 row (LDS or global). Wave-uniform control flow.
 // BATCH: 16-column chunks of the item rows loaded together (64 B per lane and chunk). 1: one chunk at a time - a chain of d / 16 dependent memory round
 // trips per user, but only 16 registers; 4: d <= 64 in ONE round trip (the sweep's tail: its fragment registers are dead by then - 28 us of a 0.243 ms
-// sweep were these chains, four users per wave one after the other). ulen: length of urow (the staged LDS copy is zero-padded to whole chunks).
+// sweep were these chains, four users per wave one after the other). ulen: length of urow (the staged LDS copy is zero-padded to whole chunks);
+// u_vec: urow + 4 j is 16-byte aligned for every j.
 template <int BATCH>
-__device__ __forceinline__ void tk_finalize_user(const TopkArgs& a, const float* urow, int ulen, int q, int tile, float ub, int32_t id, int lane) {
+__device__ __forceinline__ void tk_finalize_user(const TopkArgs& a, const float* urow, int ulen, bool u_vec, int q, int tile, float ub, int32_t id, int lane) {
     const float ub64 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ub), 63));   // bounds every item outside the list (-inf: list not full)
     float e = -INFINITY;
     {
@@ -706,7 +707,7 @@ __device__ __forceinline__ void tk_finalize_user(const TopkArgs& a, const float*
             for (int b = 0; b < BATCH; ++b) {
                 float4 uv[4];
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) uv[qq] = ld4g(urow, 16 * (c0 + b) + 4 * qq, ulen, BATCH > 1);
+                for (int qq = 0; qq < 4; ++qq) uv[qq] = ld4g(urow, 16 * (c0 + b) + 4 * qq, ulen, u_vec);
                 if (c0 + b < nc) {                                       // (wave-uniform; chunks past d stay out of the chain: fma(0, 0, -0.0f) is +0.0f)
 #pragma unroll
                     for (int s_ = 0; s_ < 4; ++s_)
@@ -776,7 +777,7 @@ __device__ __forceinline__ int tk_mbcnt(uint64_t m) { return (int)__builtin_amdg
 
 template <int DK32>
 __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kernel(TopkArgs a, const uint4* __restrict__ pk2, const float* __restrict__ cn) {
-    __shared__ __attribute__((aligned(8))) float2 pool[16][TK_POOL];   // the user's candidates: (upper bound ub, item id as bits) - one 8-byte store per append
+    __shared__ __attribute__((aligned(16))) float2 pool[16][TK_POOL];   // the user's candidates: (upper bound ub, item id as bits) - one 8-byte store per append
     __shared__ __attribute__((aligned(16))) int32_t cnt_s[16];        // fill of the user's pool: LDS atomics (the appends are lane-local)
     __shared__ __attribute__((aligned(16))) float thr_s[16];          // the filter: the 64th ub of the user's pool at the last drain (+inf: no such user)
     __shared__ int32_t flag_s[1];                                      // waves that finished their quarter
@@ -1040,7 +1041,7 @@ __global__ __launch_bounds__(256, (DK32 <= 2 ? 4 : 2)) void score_topk_pre_kerne
     for (int rr = 0; rr < 4; ++rr) {
         const int q = q0 + 4 * w + rr;
         if (q >= a.n_query) continue;                          // wave-uniform
-        tk_finalize_user<4>(a, urows + (4 * w + rr) * ulen, ulen, q, tile, tk_key_ub(kk[rr]), tk_key_id(kk[rr]), lane);
+        tk_finalize_user<4>(a, urows + (4 * w + rr) * ulen, ulen, true, q, tile, tk_key_ub(kk[rr]), tk_key_id(kk[rr]), lane);
     }
 }
 
@@ -1057,7 +1058,7 @@ __global__ __launch_bounds__(1024) void topk_merge_pre_kernel(TopkArgs a) {
         const int64_t row = ((int64_t)blockIdx.x * a.n_parts + p) * 16 + w;
         merge64k(k1, tk_key(a.ws_score[row * 64 + lane], a.ws_idx[row * 64 + lane]), lane);
     }
-    tk_finalize_user<1>(a, a.Eu + a.query_users[q] * a.ldu, a.d, q, tile, tk_key_ub(k1), tk_key_id(k1), lane);
+    tk_finalize_user<4>(a, a.Eu + a.query_users[q] * a.ldu, a.d, a.vec_ok != 0, q, tile, tk_key_ub(k1), tk_key_id(k1), lane);
 }
 
 // the lists of a split tile's parts -> the tile's top K (one wave per four users, as in the sweep)
