@@ -1063,7 +1063,8 @@ def topk_set_part_items(items: int = 0):
 
 def score_topk(Eu, Ei, query_users: torch.Tensor, train: Optional[Csr], K: int, mode=None, stats: Optional[dict] = None):
     """Masked top-K item ids (int32 [n_query, K], -1 = none) and scores for the listed users. stats (a dict; synchronises): receives
-    "fallback_tiles" / "tiles" - the user tiles the bf16 mode's verification sent to the exact sweep."""
+    "fallback_tiles" / "tiles" - the user tiles the bf16 mode's verification sent to the exact sweep -, "drains" - the pool drains of the bf16
+    sweep, summed over its blocks - and "bitmap_rows" - the train rows its blocks swept as bitmaps (None outside the bf16 mode)."""
     _need_gpu(Eu, Ei, query_users)
     Eu, Ei = _rowmajor(Eu.detach()), _rowmajor(Ei.detach())
     q = query_users.to(torch.int64).contiguous()
