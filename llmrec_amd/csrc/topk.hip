@@ -247,8 +247,8 @@ __device__ __forceinline__ void tk_rows_setup(const TopkArgs& a, int lane, bool 
     // Built in LDS (the candidate pools' 32 KB, unused until the sweep starts), lds_words / 16 tiles of all 16 rows at a time, and copied out with
     // 16-byte stores: zeroing the slice in global memory and one global atomicOr per train item - the first form - cost 49 us of a 0.31 ms sweep
     // (all blocks start together: 36 MB of zeroes, then 0.66 M atomics at the L2). Only the tiles the block sweeps [blk_t0, blk_t1) are built, and every
-    // wave copies out the tiles of ITS quarter [wave_t0, wave_t1): it is the only reader of those words, a wave's loads follow its own stores to the
-    // same address in order, so the sweep starts without waiting for the stores (no s_waitcnt vmcnt(0) + barrier + L1 invalidate behind the copy).
+    // wave copies out the tiles of ITS quarter [wave_t0, wave_t1): it is the only reader of those words, so it waits for its own stores only (no
+    // barrier and no L1 invalidate behind the copy: the words were never read before and the L1 is write-through).
     uint32_t* const slice = a.heavy_bm + (size_t)blockIdx.x * 16 * a.heavy_words;
     // the first 256 items of every row: 16 independent loads per thread, in flight together (one row after the other - load, wait, atomic - was a chain
     // of 16 memory latencies per pass: 28 us of set-up); what a row holds beyond 256 items is read in the passes
@@ -288,6 +288,7 @@ __device__ __forceinline__ void tk_rows_setup(const TopkArgs& a, int lane, bool 
         __syncthreads();                                       // (the stage is reused - by the next pass or by the sweep's pools)
     }
     if (a.hdr && threadIdx.x == 0) atomicAdd(&a.hdr[2], 16u);     // (statistics: train rows swept as bitmaps)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (this wave's own stores only: no barrier, no L1 invalidate - it wrote what it will read)
 }
 // the words of rows 4 lq .. 4 lq + 3 for one item tile: 16 bytes, one load (plain: see tk_heavy_word)
 __device__ __forceinline__ uint4 tk_rows_words(const TopkArgs& a, int lq, int64_t tile) {
